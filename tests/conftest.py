@@ -1,0 +1,24 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def fixtures():
+    import base64
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "fixtures.json")) as f:
+        ents = json.load(f)["entries"]
+    for e in ents:
+        e["payload"] = base64.b64decode(e["payload"])
+    return ents

@@ -1,0 +1,141 @@
+"""CPU tests: pin the oracle restatement (oracle/*.c) against
+(a) the golden (payload, bytes, CRC) triples of the reference's own fixture archives and
+(b) the compiled reference itself (oracle/_ref: mz_strm_zlib.c / mz_strm_lzma.c / mz_crypt.c over
+    zlib 1.2.11 / liblzma 5.2.5)."""
+import hashlib
+import lzma
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+
+needs_ref = pytest.mark.skipif(not (oracle.have_ref() or os.path.exists("/root/reference/mz_zip.c")),
+                               reason="oracle/_ref not built and /root/reference absent")
+
+
+def test_crc32_known_answers():
+    # appnote.txt:837-847 polynomial; the classic check value
+    assert oracle.crc32(b"123456789") == 0xCBF43926
+    assert oracle.crc32(b"") == 0
+    assert oracle.crc32(b"a") == 0xE8B7BE43
+
+
+def test_crc32_chaining_and_combine():
+    rnd = np.random.RandomState(1)
+    data = rnd.bytes(100000)
+    whole = oracle.crc32(data)
+    assert whole == zlib.crc32(data)
+    for cut in (0, 1, 7, 4096, 65535, 99999, 100000):
+        a, b = data[:cut], data[cut:]
+        assert oracle.crc32(b, oracle.crc32(a)) == whole            # mz_zip.c:2049 chaining
+        assert oracle.crc32_combine(oracle.crc32(a), oracle.crc32(b), len(b)) == whole
+    # 1-byte calls with inverted state, as mz_strm_pkcrypt.c:79,86 issues them
+    v = 0x12345678
+    for byte in data[:64]:
+        v2 = ~oracle.crc32(bytes([byte]), ~v & 0xFFFFFFFF) & 0xFFFFFFFF
+        v = v2
+    assert v == (~zlib.crc32(data[:64], ~0x12345678 & 0xFFFFFFFF)) & 0xFFFFFFFF
+
+
+def test_fixtures_golden(fixtures):
+    """Every fixture entry decodes to the size and CRC its archive pins."""
+    seen = {0: 0, 8: 0, 14: 0}
+    for e in fixtures:
+        if e["method"] == 0:
+            data = e["payload"]
+        elif e["method"] == 8:
+            st, used, data = oracle.inflate_raw(e["payload"], e["usize"] + 16)
+            assert st == 0 and used == e["csize"], (e["archive"], e["entry"], st, used)
+            assert used == e["ref"]["total_in"]
+        else:
+            st, used, data = oracle.lzma_zip_decode(e["payload"], e["usize"] + 16, e["usize"])
+            assert st == 0 and used == e["csize"], (e["archive"], e["entry"], st, used)
+            assert used == e["ref"]["total_in"]
+        assert len(data) == e["usize"]
+        assert oracle.crc32(data) == e["crc"], (e["archive"], e["entry"])
+        assert hashlib.sha256(data).hexdigest() == e["sha256"]
+        seen[e["method"]] += 1
+    assert seen[0] >= 10 and seen[8] >= 10 and seen[14] >= 1
+
+
+def test_inflate_edges_vs_zlib():
+    for name, data, z in synth.edge_payloads():
+        st, used, out = oracle.inflate_raw(z + b"\x00garbage", len(data) + 8)
+        assert st == 0, name
+        assert used == len(z), name
+        assert out == data, name
+
+
+@needs_ref
+def test_inflate_status_parity_with_reference():
+    """Error class and exact TOTAL_IN for malformed streams, against the live reference."""
+    ref = oracle.ref()
+    n = 0
+    for name, data, z in synth.edge_payloads():
+        if len(z) < 16:
+            continue
+        for cname, bad in synth.corruptions(z):
+            r = ref.stream_decode(8, bad, len(data) + 70000)
+            st, used, out = oracle.inflate_raw(bad, len(data) + 70000)
+            last = r["rets"][-1] if r["rets"] else 0
+            ref_status = last if last < 0 else 0
+            assert st == ref_status, (name, cname, st, r["rets"], r["error"])
+            if st == 0:
+                assert out == r["out"], (name, cname)
+                assert used == r["total_in"], (name, cname)
+            n += 1
+    assert n > 100
+
+
+@needs_ref
+def test_crc32_matches_reference():
+    ref = oracle.ref()
+    rnd = np.random.RandomState(5)
+    for n in (0, 1, 2, 3, 255, 256, 65535, 65536, 1 << 20):
+        d = rnd.bytes(n)
+        assert oracle.crc32(d) == ref.crc32(d)
+        assert oracle.crc32(d, 0xDEADBEEF) == ref.crc32(d, 0xDEADBEEF)
+
+
+def _zip_lzma(data, preset=6, eos=True):
+    """ZIP method-14 payload as mz_stream_lzma writes it (mz_strm_lzma.c:94-104,250-265)."""
+    filt = [dict(id=lzma.FILTER_LZMA1, preset=preset)]
+    raw = lzma.compress(data, format=lzma.FORMAT_ALONE, filters=filt)
+    # .lzma alone = props(5) + size(8) + stream; python writes size = -1 + EOS marker
+    assert raw[5:13] == b"\xff" * 8
+    return bytes([5, 2, 5, 0]) + raw[:5] + raw[13:]
+
+
+@needs_ref
+def test_lzma_parity_with_reference():
+    ref = oracle.ref()
+    c = synth.corpus()
+    rnd = np.random.RandomState(11)
+    cases = [b"", b"a", c[:1000], c[:150000], rnd.bytes(5000), b"A" * 100000, c[1000:70000] + rnd.bytes(3000) + c[:50000]]
+    for i, data in enumerate(cases):
+        z = _zip_lzma(data)
+        r = ref.stream_decode(14, z, len(data) + 64, max_in=len(z), max_out=len(data))
+        assert r["out"] == data and r["error"] == 0, i
+        st, used, out = oracle.lzma_zip_decode(z, len(data) + 64, len(data))
+        assert st == 0 and out == data, i
+        assert used == r["total_in"] == len(z), (i, used, r["total_in"], len(z))
+        # reference-encoded (mz_stream_lzma WRITE) payloads too
+        z2, info = ref.stream_encode(14, data)
+        st, used, out = oracle.lzma_zip_decode(z2, len(data) + 64, len(data))
+        assert st == 0 and out == data and used == len(z2), i
+        # malformed variants: status class only
+        if len(z) > 40:
+            for bad in (z[:len(z) // 2], z[:20], z[:9], z[:5],
+                        z[:len(z) // 3] + bytes([z[len(z) // 3] ^ 0x55]) + z[len(z) // 3 + 1:],
+                        z[:9] + b"\x01" + z[10:]):
+                r = ref.stream_decode(14, bad, len(data) + 70000)
+                last = r["rets"][-1] if r["rets"] else r["open"]
+                st, used, out = oracle.lzma_zip_decode(bad, len(data) + 70000, -1)
+                if last < 0:
+                    assert st == -3, (i, len(bad), st, r)
+                else:
+                    assert st == 0 and out == r["out"], (i, len(bad), st)
