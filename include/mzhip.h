@@ -1,0 +1,108 @@
+/* mzhip.h -- C ABI of the MI355X codec backend for minizip-ng.
+ *
+ * Two groups of entry points live in libmzhip.so:
+ *
+ * (1) The DROP-IN symbols.  They are declared by the reference's own headers
+ *     and are re-implemented here with identical names, signatures and error
+ *     behaviour, so that mz_zip.c / mz_zip_rw.c / compat/ are compiled
+ *     unmodified and linked against this library instead of mz_strm_zlib.o,
+ *     mz_strm_lzma.o and the CRC symbol of mz_crypt.o (link-time substitution,
+ *     SURVEY 8b):
+ *         mz_stream_zlib_{open,is_open,read,write,tell,seek,close,error,
+ *                         get_prop_int64,set_prop_int64,create,delete,
+ *                         get_interface}          (mz_strm_zlib.h:20-35)
+ *         mz_stream_lzma_{...same 13...}          (mz_strm_lzma.h:20-35)
+ *         mz_crypt_crc32_update                   (mz_crypt.h:20)
+ *     They are declared in include/mz_strm_hip.h.
+ *
+ * (2) The BATCH entry points below -- the data-parallel path that has no
+ *     analogue in the (strictly one-entry-at-a-time) reference: thousands of
+ *     independent entries per launch, inputs and outputs resident in HBM.
+ *     Plain pointers and sizes only; `stream` is a hipStream_t passed as
+ *     void* (NULL = the default stream).  All d_* pointers are device pointers.
+ *
+ * Status words are numerically the reference's (mz.h:21-26): 0 OK,
+ * -3 MZ_DATA_ERROR, -5 MZ_BUF_ERROR (input ended early), plus
+ * MZHIP_OUT_FULL (-200) when an entry produces more than its out_cap.
+ */
+#ifndef MZHIP_H
+#define MZHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZHIP_API __attribute__((visibility("default")))
+
+#define MZHIP_STATUS_OK 0
+#define MZHIP_STATUS_DATA_ERROR (-3)
+#define MZHIP_STATUS_BUF_ERROR (-5)
+#define MZHIP_STATUS_OUT_FULL (-200)
+
+/* Library / device ------------------------------------------------------ */
+
+/* Number of visible HIP devices, or <0 (no HIP runtime / no GPU): callers must
+ * treat that as fatal -- there is no CPU fallback in this library. */
+MZHIP_API int32_t mzhip_device_count(void);
+/* Bind the calling thread to `device` and create its constant tables.
+ * Idempotent.  0 or a negative MZ_* code. */
+MZHIP_API int32_t mzhip_init(int32_t device);
+MZHIP_API const char *mzhip_last_error(void);
+MZHIP_API const char *mzhip_version(void);
+
+/* K1+K2: raw-DEFLATE decode with fused CRC-32 ---------------------------- */
+
+/* Replaces, for n entries at once, the per-entry loop
+ *   mz_stream_zlib_read (mz_strm_zlib.c:116-193) + mz_crypt_crc32_update (mz_zip.c:2049).
+ * Entry i reads   d_in  + d_in_off[i]  .. + d_in_len[i]   (raw DEFLATE, appnote.txt:2030-2166)
+ * and writes      d_out + d_out_off[i] .. at most d_out_cap[i] bytes.
+ * Results per entry: d_out_len (== PROP_TOTAL_OUT), d_in_used (== PROP_TOTAL_IN,
+ * exact compressed bytes consumed, mz_zip.c:2090,2116), d_crc (CRC-32 of the
+ * output, what mz_zip.c:2122 compares with the central directory), d_status.
+ * Asynchronous on `stream`. */
+MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                      void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,
+                                      uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status,
+                                      void *stream);
+
+/* K2 alone: CRC-32 of n buffers (STORE entries, mz_zip.c:2049 with the raw
+ * stream).  d_init may be NULL (all zero) or hold the chaining value of each
+ * buffer (mz_crypt_crc32_update's `value`). */
+MZHIP_API int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
+                                    const uint32_t *d_init, uint32_t *d_crc, void *stream);
+
+/* K3: raw-LZMA1 range decode with fused CRC-32 ---------------------------- */
+
+/* Replaces, for n method-14 entries at once, mz_stream_lzma_read (mz_strm_lzma.c:147-241 ->
+ * liblzma lzma_alone_decoder/lzma_code) + mz_crypt_crc32_update (mz_zip.c:2049).
+ * Entry i's input starts at the ZIP-LZMA header (2 B version, 2 B props size, 5 B
+ * lc/lp/pb + dictionary size; appnote.txt:2232-2275) -- exactly the entry payload as
+ * it sits in the archive -- and ends at the end-of-stream marker.  d_max_out (may be
+ * NULL) carries PROP_TOTAL_OUT_MAX per entry (mz_zip.c:1845; <0 = none): d_out_len and
+ * d_crc are clamped to it like mz_strm_lzma.c:214-215.  d_in_used counts the 9 header
+ * bytes (ZIP accounting, mz_strm_lzma.c:124,198).  Status: 0, -3 data error, -5 input
+ * ended early (mz_stream_lzma_read reports both as MZ_DATA_ERROR), -200 out_cap hit,
+ * -109 for lc+lp > 3 (model does not fit the per-wave LDS slice). */
+MZHIP_API int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                                   const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out,
+                                   uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,
+                                   int32_t *d_status, void *stream);
+
+/* Host-buffer conveniences (H2D + kernel + D2H, synchronous); these are what the
+ * vtbl shim uses for one-entry-at-a-time callers. */
+MZHIP_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
+                                     uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                                  uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size);
+
+/* Geometry the last launch used (for reports): workgroups, waves per workgroup, LDS bytes per workgroup. */
+MZHIP_API void mzhip_inflate_launch_geometry(uint32_t n, uint32_t *grid, uint32_t *waves_per_wg, uint32_t *lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,158 @@
+/* crc32_core.h -- wave-parallel CRC-32 (replaces mz_crypt_crc32_update,
+ * reference mz_crypt.c:35-92: reflected 0xEDB88320, register inverted on
+ * entry and exit).
+ *
+ * CRC is GF(2)-linear, so a buffer is folded 1 KiB (one "tile") at a time by a
+ * whole wavefront: lane l owns the 16 bytes at tile*1024 + 16*l (a coalesced
+ * 16 B/lane read) and keeps its own 32-bit accumulator.  Between tiles the
+ * accumulator is advanced over the 1008 bytes owned by the other lanes by one
+ * multiplication with the constant x^(8*1008) mod P; at the end lane l is
+ * advanced by x^(128*(63-l)), the 64 accumulators are XOR-reduced, and the
+ * <1 KiB tail is folded the same way with per-lane byte counts.  The initial
+ * 0xFFFFFFFF rides in lane 0's accumulator, so no length-dependent fix-up is
+ * needed.  Polynomials are held bit-reflected (bit 31 = x^0) like the
+ * reference's table (mz_crypt.c:52).
+ */
+#ifndef MZHIP_CRC32_CORE_H
+#define MZHIP_CRC32_CORE_H
+
+#include "wave.h"
+
+#define MZ_CRC_POLY 0xEDB88320u
+#define MZ_CRC_TILE 1024u
+
+/* constants generated once on the host (mzhip_crc_tables_init) and handed to
+ * the kernels; byte_tab is staged into LDS per workgroup. */
+typedef struct mzhip_crc_tables {
+    uint32_t byte_tab[256]; /* mz_crypt.c:52-80 equivalent, generated */
+    uint32_t kx[32];        /* x^(8*1008) * x^j  mod P, j = 0..31       */
+    uint32_t x16[64];       /* x^(128*j) mod P                          */
+    uint32_t x1[16];        /* x^(8*j) mod P                            */
+} mzhip_crc_tables;
+
+/* host-side generation (plain arithmetic on 32-bit polynomials) */
+static inline uint32_t mzhip_gf2_mul_host(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b & 1) ? ((b >> 1) ^ MZ_CRC_POLY) : (b >> 1);
+    }
+    return p;
+}
+static inline uint32_t mzhip_xpow8_host(uint64_t nbytes) {
+    uint32_t r = 0x80000000u, sq = 0x00800000u; /* x^0, x^8 */
+    while (nbytes) {
+        if (nbytes & 1) r = mzhip_gf2_mul_host(r, sq);
+        sq = mzhip_gf2_mul_host(sq, sq);
+        nbytes >>= 1;
+    }
+    return r;
+}
+static inline void mzhip_crc_tables_init(mzhip_crc_tables *t) {
+    for (uint32_t n = 0; n < 256; n++) {
+        uint32_t c = n;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? (MZ_CRC_POLY ^ (c >> 1)) : (c >> 1);
+        t->byte_tab[n] = c;
+    }
+    uint32_t k = mzhip_xpow8_host(MZ_CRC_TILE - 16);
+    for (int j = 0; j < 32; j++) {
+        t->kx[j] = k;
+        k = (k & 1) ? ((k >> 1) ^ MZ_CRC_POLY) : (k >> 1); /* times x */
+    }
+    for (int j = 0; j < 64; j++) t->x16[j] = mzhip_xpow8_host(16u * (uint32_t)j);
+    for (int j = 0; j < 16; j++) t->x1[j] = mzhip_xpow8_host((uint32_t)j);
+}
+/* crc(A||B) from crc(A), crc(B), |B| -- 32-bit arithmetic on checksums only */
+static inline uint32_t mzhip_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    return mzhip_gf2_mul_host(mzhip_xpow8_host(len_b), crc_a) ^ crc_b;
+}
+
+/* a * b mod P, both per-lane */
+MZ_DEV uint32_t mz_gf2_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        p ^= b & (0u - (a >> 31));
+        a <<= 1;
+        b = (b >> 1) ^ (MZ_CRC_POLY & (0u - (b & 1)));
+    }
+    return p;
+}
+
+/* a * K mod P for the compile-time-fixed K whose shifted copies are kx[] */
+MZ_DEV uint32_t mz_gf2_mul_kx(uint32_t a, const uint32_t *kx) {
+    uint32_t p = 0;
+#pragma unroll
+    for (int j = 0; j < 32; j++)
+        p ^= kx[j] & (0u - ((a >> (31 - j)) & 1u));
+    return p;
+}
+
+MZ_DEV uint32_t mz_load_u32(const uint8_t *p) {
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+/* fold one little-endian dword into a raw (non-inverted) register */
+MZ_DEV uint32_t mz_crc_dword(uint32_t r, uint32_t d, const uint32_t *tab) {
+    r ^= d;
+    r = tab[r & 255] ^ (r >> 8);
+    r = tab[r & 255] ^ (r >> 8);
+    r = tab[r & 255] ^ (r >> 8);
+    r = tab[r & 255] ^ (r >> 8);
+    return r;
+}
+
+/* Fold every complete tile of buf[*done .. upto) into the per-lane
+ * accumulators.  `tab` = byte table in LDS, `kx` = constants (uniform). */
+#define MZ_CRC_FOLD_TILES(acc, done, buf, upto, tab, kx)                                   \
+    while ((uint64_t)(done) + MZ_CRC_TILE <= (uint64_t)(upto)) {                           \
+        MZ_LANES {                                                                         \
+            const uint8_t *_p = (buf) + (done) + 16u * (uint32_t)lane;                     \
+            uint32_t _r = P(acc);                                                          \
+            if ((done) != 0) _r = mz_gf2_mul_kx(_r, (kx));                                 \
+            _r = mz_crc_dword(_r, mz_load_u32(_p), (tab));                                 \
+            _r = mz_crc_dword(_r, mz_load_u32(_p + 4), (tab));                             \
+            _r = mz_crc_dword(_r, mz_load_u32(_p + 8), (tab));                             \
+            _r = mz_crc_dword(_r, mz_load_u32(_p + 12), (tab));                            \
+            P(acc) = _r;                                                                   \
+        }                                                                                  \
+        (done) += MZ_CRC_TILE;                                                             \
+    }
+
+/* Finish: buf[0..n) has had its floor(n/1024) tiles folded.  Returns the
+ * finished CRC-32 in `result` (uniform). `tmp` is a PV(uint32_t) scratch. */
+#define MZ_CRC_FINISH_FROM(result, acc, tmp, done, buf, n, tab, tabs, reg0)                \
+    do {                                                                                   \
+        uint32_t _reg = (reg0);                                                            \
+        if ((done) != 0) {                                                                 \
+            MZ_LANES { P(tmp) = mz_gf2_mul(P(acc), (tabs)->x16[63 - lane]); }              \
+            MZ_WAVE_XOR(_reg, tmp);                                                        \
+        }                                                                                  \
+        uint32_t _r = (uint32_t)((n) - (done)); /* tail bytes, < 1024 */                   \
+        if (_r != 0) {                                                                     \
+            MZ_LANES {                                                                     \
+                uint32_t _o = 16u * (uint32_t)lane;                                        \
+                uint32_t _v = _r > _o ? (_r - _o > 16u ? 16u : _r - _o) : 0u;              \
+                uint32_t _c = (lane == 0) ? _reg : 0u;                                     \
+                const uint8_t *_p = (buf) + (done) + _o;                                   \
+                for (uint32_t _i = 0; _i < _v; _i++)                                       \
+                    _c = (tab)[(_c ^ _p[_i]) & 255] ^ (_c >> 8);                           \
+                uint32_t _rem = _r - _o - _v; /* bytes after this lane's piece */          \
+                if (_v == 0) { _c = 0; _rem = 0; }                                         \
+                _c = mz_gf2_mul(_c, (tabs)->x16[_rem >> 4]);                               \
+                _c = mz_gf2_mul(_c, (tabs)->x1[_rem & 15]);                                \
+                P(tmp) = _c;                                                               \
+            }                                                                              \
+            MZ_WAVE_XOR(_reg, tmp);                                                        \
+        }                                                                                  \
+        (result) = ~_reg;                                                                  \
+    } while (0)
+
+/* reg0 = the raw register before byte 0 (0xFFFFFFFF for a fresh CRC, ~value when chaining) */
+#define MZ_CRC_FINISH(result, acc, tmp, done, buf, n, tab, tabs) \
+    MZ_CRC_FINISH_FROM(result, acc, tmp, done, buf, n, tab, tabs, 0xFFFFFFFFu)
+
+#endif

@@ -1,0 +1,403 @@
+/* lzma_core.h -- raw-LZMA1 range decode of ONE entry by ONE wavefront, CRC-32
+ * fused (kernel K3 of SURVEY 2.1).
+ *
+ * Replaces what the reference does for a method-14 entry through
+ * mz_stream_lzma_read (mz_strm_lzma.c:147-241 -> liblzma lzma_alone_decoder /
+ * lzma_code): input starts at the ZIP-LZMA header (2 B version, 2 B props size,
+ * 5 B props: appnote.txt:2232-2275), uncompressed size unknown, stream ends at
+ * the end-of-stream marker, TOTAL_OUT clamped to TOTAL_OUT_MAX
+ * (mz_strm_lzma.c:214-215).  Algorithm: the public-domain LZMA specification
+ * (11-bit adaptive bit models, 12 states, rep0-3, two length coders, 6-bit
+ * position slots, aligned bits).  liblzma 5.2.5 behaviours kept: first coder
+ * byte must be 0x00; lazy normalisation (before each bit); distance valid iff
+ * < min(produced, dict size rounded up to >=4096, multiple of 16); code == 0
+ * required after the EOS marker.
+ *
+ * MI355X mapping: the adaptive model makes a stream strictly serial, so the
+ * parallel axis is entries.  One wave = one entry; the whole probability model
+ * (7 990 x u16 = 15.6 KiB for lc+lp <= 3) lives in that wave's LDS slice, ten
+ * waves per CU; the range coder state is wave-uniform (scalar unit); compressed
+ * bytes are fetched 256 at a time into VGPRs (one coalesced load) and handed to
+ * the scalar side by v_readlane; match copies and the CRC tiles use all 64
+ * lanes; the dictionary is the output buffer itself.
+ */
+#ifndef MZHIP_LZMA_CORE_H
+#define MZHIP_LZMA_CORE_H
+
+#include "crc32_core.h"
+#include "wave.h"
+
+#define MZ_LZMA_MAX_LCLP 3
+#define MZ_LZMA_LIT_PROBS (0x300u << MZ_LZMA_MAX_LCLP)
+
+/* probability model layout inside the per-wave LDS slice (u16 indices) */
+#define LZ_IS_MATCH 0                      /* [12][16] */
+#define LZ_IS_REP (LZ_IS_MATCH + 192)      /* [12] */
+#define LZ_IS_REP_G0 (LZ_IS_REP + 12)      /* [12] */
+#define LZ_IS_REP_G1 (LZ_IS_REP_G0 + 12)   /* [12] */
+#define LZ_IS_REP_G2 (LZ_IS_REP_G1 + 12)   /* [12] */
+#define LZ_IS_REP0_LONG (LZ_IS_REP_G2 + 12) /* [12][16] */
+#define LZ_POS_SLOT (LZ_IS_REP0_LONG + 192) /* [4][64] */
+#define LZ_POS_DEC (LZ_POS_SLOT + 256)     /* [115] */
+#define LZ_ALIGN (LZ_POS_DEC + 115)        /* [16] */
+#define LZ_LEN (LZ_ALIGN + 16)             /* choice, choice2, low[16][8], mid[16][8], high[256] = 514 */
+#define LZ_REP_LEN (LZ_LEN + 514)
+#define LZ_LIT (LZ_REP_LEN + 514)
+#define LZ_NUM_PROBS (LZ_LIT + MZ_LZMA_LIT_PROBS)
+
+typedef struct mz_lzma_lds {
+    uint16_t probs[(LZ_NUM_PROBS + 1) & ~1u];
+} mz_lzma_lds;
+
+typedef struct mz_lzma_result {
+    int32_t status;
+    uint32_t out_len;
+    uint32_t in_used;
+    uint32_t crc;
+} mz_lzma_result;
+
+/* ---- wave-uniform range coder; the 256-byte input window lives one dword per lane ---- */
+#define LZ_REFILL()                                                                     \
+    do {                                                                                \
+        MZ_LANES {                                                                      \
+            uint32_t _o = in_base + 4u * (uint32_t)lane;                                \
+            uint32_t _d = 0;                                                            \
+            for (uint32_t _b = 0; _b < 4; _b++)                                         \
+                if (_o + _b < in_len) _d |= (uint32_t)in[_o + _b] << (8 * _b);          \
+            P(win) = _d;                                                                \
+        }                                                                               \
+    } while (0)
+
+#define LZ_NEXT_BYTE(dst)                                                               \
+    do {                                                                                \
+        if (in_pos >= in_len) {                                                         \
+            eof = 1;                                                                    \
+            (dst) = 0;                                                                  \
+        } else {                                                                        \
+            if (in_pos - in_base >= 256u) {                                             \
+                in_base = in_pos;                                                       \
+                LZ_REFILL();                                                            \
+            }                                                                           \
+            uint32_t _rel = in_pos - in_base;                                           \
+            uint32_t _dw = MZ_READLANE(win, _rel >> 2);                                 \
+            (dst) = (_dw >> (8u * (_rel & 3u))) & 0xFFu;                                \
+            in_pos++;                                                                   \
+        }                                                                               \
+    } while (0)
+
+#define LZ_NORM()                                                                       \
+    do {                                                                                \
+        if (range < (1u << 24)) {                                                       \
+            uint32_t _nb;                                                               \
+            LZ_NEXT_BYTE(_nb);                                                          \
+            range <<= 8;                                                                \
+            code = (code << 8) | _nb;                                                   \
+        }                                                                               \
+    } while (0)
+
+/* decode one bit with the adaptive model at probs[idx]; result in `bit` */
+#define LZ_BIT(bit, idx)                                                                \
+    do {                                                                                \
+        LZ_NORM();                                                                      \
+        uint32_t _pi = (idx);                                                           \
+        uint32_t _p = MZ_UNIFORM(pr[_pi]);                                              \
+        uint32_t _bound = (range >> 11) * _p;                                           \
+        if (code < _bound) {                                                            \
+            range = _bound;                                                             \
+            _p += (2048u - _p) >> 5;                                                    \
+            (bit) = 0;                                                                  \
+        } else {                                                                        \
+            range -= _bound;                                                            \
+            code -= _bound;                                                             \
+            _p -= _p >> 5;                                                              \
+            (bit) = 1;                                                                  \
+        }                                                                               \
+        MZ_LANES {                                                                      \
+            if (lane == 0) pr[_pi] = (uint16_t)_p;                                      \
+        }                                                                               \
+        MZ_WAVE_SYNC();                                                                 \
+    } while (0)
+
+#define LZ_BITTREE(sym, base, nbits)                                                    \
+    do {                                                                                \
+        uint32_t _m = 1;                                                                \
+        for (int _i = 0; _i < (nbits); _i++) {                                          \
+            uint32_t _b;                                                                \
+            LZ_BIT(_b, (base) + _m);                                                    \
+            _m = (_m << 1) + _b;                                                        \
+        }                                                                               \
+        (sym) = _m - (1u << (nbits));                                                   \
+    } while (0)
+
+#define LZ_BITTREE_REV(sym, base, nbits)                                                \
+    do {                                                                                \
+        uint32_t _m = 1, _s = 0;                                                        \
+        for (int _i = 0; _i < (int)(nbits); _i++) {                                     \
+            uint32_t _b;                                                                \
+            LZ_BIT(_b, (base) + _m);                                                    \
+            _m = (_m << 1) + _b;                                                        \
+            _s |= _b << _i;                                                             \
+        }                                                                               \
+        (sym) = _s;                                                                     \
+    } while (0)
+
+#define LZ_LEN_DECODE(len, lbase, ps)                                                   \
+    do {                                                                                \
+        uint32_t _c;                                                                    \
+        LZ_BIT(_c, (lbase));                                                            \
+        if (!_c) {                                                                      \
+            LZ_BITTREE(len, (lbase) + 2 + (ps) * 8, 3);                                 \
+        } else {                                                                        \
+            LZ_BIT(_c, (lbase) + 1);                                                    \
+            if (!_c) {                                                                  \
+                LZ_BITTREE(len, (lbase) + 2 + 128 + (ps) * 8, 3);                       \
+                (len) += 8;                                                             \
+            } else {                                                                    \
+                LZ_BITTREE(len, (lbase) + 2 + 256, 8);                                  \
+                (len) += 16;                                                            \
+            }                                                                           \
+        }                                                                               \
+    } while (0)
+
+/* Decode one ZIP-LZMA entry.  All arguments wave-uniform.  max_out < 0: no clamp. */
+MZ_DEV void mz_lzma_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                          mz_lzma_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
+                          mz_lzma_result *res) {
+    MZ_LANE_DECL
+    uint16_t *pr = L->probs;
+    int32_t status = MZHIP_DATA_ERROR;
+    uint32_t opos = 0;
+    uint32_t in_pos = 9, in_base = 9, eof = 0;
+    uint32_t range = 0xFFFFFFFFu, code = 0;
+    PV(uint32_t, win);
+    PV(uint32_t, crc_acc);
+    PV(uint32_t, crc_tmp);
+    uint32_t crc_done = 0;
+    MZ_LANES {
+        P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u;
+        P(win) = 0;
+    }
+
+    if (in_len < 9) {
+        in_pos = in_len;
+        goto finish;
+    }
+    {
+        uint32_t d = MZ_UNIFORM(in[4]);
+        if (d >= 9 * 5 * 5) goto finish; /* LZMA_FORMAT_ERROR -> MZ_DATA_ERROR (mz_strm_lzma.c:236) */
+        const uint32_t lc = d % 9;
+        d /= 9;
+        const uint32_t lp = d % 5, pb = d / 5;
+        if (lc + lp > MZ_LZMA_MAX_LCLP) {
+            status = MZHIP_UNSUPPORTED;
+            goto finish;
+        }
+        uint64_t dict = MZ_UNIFORM((uint32_t)in[5] | ((uint32_t)in[6] << 8) | ((uint32_t)in[7] << 16) |
+                                   ((uint32_t)in[8] << 24));
+        if (dict < 4096) dict = 4096;
+        dict = (dict + 15) & ~(uint64_t)15;
+
+        MZ_LANES {
+            for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64)
+                ((uint32_t *)pr)[i] = 0x04000400u; /* every model starts at 1024/2048 */
+        }
+        MZ_WAVE_SYNC();
+
+        if (in_len > 9 && MZ_UNIFORM(in[9]) != 0) goto finish; /* liblzma: first coder byte must be 0 */
+        LZ_REFILL();
+        for (int i = 0; i < 5; i++) {
+            uint32_t b;
+            LZ_NEXT_BYTE(b);
+            code = (code << 8) | b;
+        }
+        if (eof) goto finish;
+
+        uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0;
+        uint32_t prev_byte = 0, match_byte = 0;
+        const uint32_t pb_mask = (1u << pb) - 1, lp_mask = (1u << lp) - 1;
+
+        for (;;) {
+            if (eof) goto finish; /* truncated input */
+            const uint32_t ps = opos & pb_mask;
+            uint32_t bit;
+            LZ_BIT(bit, LZ_IS_MATCH + state * 16 + ps);
+            if (!bit) {
+                /* literal */
+                const uint32_t lbase = LZ_LIT + 0x300u * (((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));
+                uint32_t sym = 1;
+                if (state >= 7) {
+                    uint32_t mb = match_byte;
+                    do {
+                        uint32_t mbit = (mb >> 7) & 1u;
+                        mb <<= 1;
+                        uint32_t b;
+                        LZ_BIT(b, lbase + ((1u + mbit) << 8) + sym);
+                        sym = (sym << 1) | b;
+                        if (mbit != b) break;
+                    } while (sym < 0x100);
+                }
+                while (sym < 0x100) {
+                    uint32_t b;
+                    LZ_BIT(b, lbase + sym);
+                    sym = (sym << 1) | b;
+                }
+                if (eof) goto finish;
+                if (opos == out_cap) {
+                    status = MZHIP_OUT_FULL;
+                    goto finish;
+                }
+                MZ_LANES {
+                    if (lane == 0) out[opos] = (uint8_t)sym;
+                }
+                MZ_WAVE_SYNC();
+                prev_byte = sym & 0xFFu;
+                opos++;
+                state = state < 4 ? 0 : (state < 10 ? state - 3 : state - 6);
+                if ((opos & (MZ_CRC_TILE - 1)) == 0) MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
+                continue;
+            }
+            uint32_t len;
+            LZ_BIT(bit, LZ_IS_REP + state);
+            if (bit) {
+                if (opos == 0) goto finish; /* rep with an empty dictionary */
+                LZ_BIT(bit, LZ_IS_REP_G0 + state);
+                if (!bit) {
+                    LZ_BIT(bit, LZ_IS_REP0_LONG + state * 16 + ps);
+                    if (!bit) {
+                        /* short rep: one byte from rep0 */
+                        if (eof) goto finish;
+                        if (rep0 >= opos || rep0 >= dict) goto finish;
+                        if (opos == out_cap) {
+                            status = MZHIP_OUT_FULL;
+                            goto finish;
+                        }
+                        uint32_t b = MZ_UNIFORM(out[opos - rep0 - 1]);
+                        MZ_LANES {
+                            if (lane == 0) out[opos] = (uint8_t)b;
+                        }
+                        MZ_WAVE_SYNC();
+                        prev_byte = b;
+                        opos++;
+                        match_byte = MZ_UNIFORM(out[opos - rep0 - 1]);
+                        state = state < 7 ? 9 : 11;
+                        if ((opos & (MZ_CRC_TILE - 1)) == 0)
+                            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
+                        continue;
+                    }
+                } else {
+                    uint32_t dist;
+                    LZ_BIT(bit, LZ_IS_REP_G1 + state);
+                    if (!bit) {
+                        dist = rep1;
+                    } else {
+                        LZ_BIT(bit, LZ_IS_REP_G2 + state);
+                        if (!bit) {
+                            dist = rep2;
+                        } else {
+                            dist = rep3;
+                            rep3 = rep2;
+                        }
+                        rep2 = rep1;
+                    }
+                    rep1 = rep0;
+                    rep0 = dist;
+                }
+                LZ_LEN_DECODE(len, LZ_REP_LEN, ps);
+                state = state < 7 ? 8 : 11;
+            } else {
+                rep3 = rep2;
+                rep2 = rep1;
+                rep1 = rep0;
+                LZ_LEN_DECODE(len, LZ_LEN, ps);
+                state = state < 7 ? 7 : 10;
+                uint32_t slot;
+                LZ_BITTREE(slot, LZ_POS_SLOT + (len < 4 ? len : 3u) * 64, 6);
+                if (slot < 4) {
+                    rep0 = slot;
+                } else {
+                    const uint32_t nb = (slot >> 1) - 1;
+                    rep0 = (2u | (slot & 1u)) << nb;
+                    uint32_t low;
+                    if (slot < 14) {
+                        LZ_BITTREE_REV(low, LZ_POS_DEC + rep0 - slot, nb);
+                        rep0 += low;
+                    } else {
+                        uint32_t direct = 0;
+                        for (uint32_t i = 0; i < nb - 4; i++) {
+                            LZ_NORM();
+                            range >>= 1;
+                            code -= range;
+                            uint32_t t = 0u - (code >> 31);
+                            code += range & t;
+                            direct = (direct << 1) + (t + 1);
+                        }
+                        rep0 += direct << 4;
+                        LZ_BITTREE_REV(low, LZ_ALIGN, 4);
+                        rep0 += low;
+                    }
+                }
+                if (rep0 == 0xFFFFFFFFu) {
+                    /* end-of-stream marker */
+                    if (eof) goto finish;
+                    LZ_NORM();
+                    if (eof) goto finish;
+                    status = (code == 0) ? MZHIP_OK : MZHIP_DATA_ERROR;
+                    goto finish;
+                }
+            }
+            if (eof) goto finish;
+            len += 2;
+            if (rep0 >= opos || rep0 >= dict) goto finish; /* distance beyond the dictionary */
+            {
+                uint32_t n = len;
+                int full = 0;
+                if (n > out_cap - opos) {
+                    n = out_cap - opos;
+                    full = 1;
+                }
+                const uint32_t dist = rep0 + 1;
+                const uint8_t *src = out + (opos - dist);
+                if (dist >= n) {
+                    MZ_LANES {
+                        for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = src[i];
+                    }
+                } else {
+                    MZ_LANES {
+                        for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = src[i % dist];
+                    }
+                }
+                MZ_WAVE_SYNC();
+                opos += n;
+                if (full) {
+                    status = MZHIP_OUT_FULL;
+                    goto finish;
+                }
+                prev_byte = MZ_UNIFORM(out[opos - 1]);
+                match_byte = MZ_UNIFORM(out[opos - dist]);
+                MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
+            }
+        }
+    }
+
+finish:
+    {
+        uint32_t olen = opos;
+        if (max_out >= 0 && (int64_t)olen > max_out) olen = (uint32_t)max_out; /* mz_strm_lzma.c:214-215 */
+        if (status == MZHIP_DATA_ERROR && eof) status = MZHIP_BUF_ERROR;       /* input ended early */
+        res->status = status;
+        res->out_len = olen;
+        res->in_used = in_pos > in_len ? in_len : in_pos;
+        uint32_t crc;
+        /* the CRC covers the clamped length; tiles folded so far never exceed opos */
+        if (crc_done > olen) {
+            /* clamp fell inside folded tiles: restart the fold (rare: only when max_out < produced) */
+            crc_done = 0;
+            MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
+        }
+        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, olen, crc_tab, tabs->kx);
+        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, out, olen, crc_tab, tabs);
+        res->crc = crc;
+    }
+}
+
+#endif

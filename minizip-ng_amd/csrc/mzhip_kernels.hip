@@ -1,0 +1,451 @@
+// mzhip_kernels.hip -- gfx950 kernels + host runtime of libmzhip.so (the batch C ABI of
+// include/mzhip.h).  The per-entry algorithms live in inflate_core.h / crc32_core.h; this file
+// owns launch geometry, work distribution and the device context.
+//
+// Launch shape (MI355X: 256 CUs x 4 SIMDs, 160 KiB LDS/CU, 8 XCDs):
+//   - one wavefront per ZIP entry, 4 wavefronts per workgroup, ~4.7 KiB LDS per wave
+//     (Huffman tables only -- the LZ77 window is the output buffer itself), so 8 workgroups =
+//     32 waves fit per CU;
+//   - persistent waves: the grid is sized to the chip (CUs x 8 workgroups) and every wave pulls
+//     its next entry index from one device-scope counter, so short and long entries balance and
+//     a 100k-entry batch is a single launch with no host involvement.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mzhip.h"
+#include "inflate_core.h"
+#include "lzma_core.h"
+
+#define MZ_WAVES_PER_WG 4
+#define MZ_CRC_TAB_BYTES 1024
+#define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
+#define MZ_NUM_COUNTERS 64
+
+struct InflateArgs {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    const uint32_t *in_len;
+    uint8_t *out;
+    const uint64_t *out_off;
+    const uint32_t *out_cap;
+    uint32_t n;
+    uint32_t *out_len;
+    uint32_t *in_used;
+    uint32_t *crc;
+    int32_t *status;
+    uint32_t *counter;
+    const mzhip_crc_tables *tabs;
+};
+
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_inflate_batch(InflateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *crc_tab = (uint32_t *)smem;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    const int wave = threadIdx.x >> 6;
+    mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
+    for (;;) {
+        uint32_t e = 0;
+        if (lane == 0) e = atomicAdd(a.counter, 1u);
+        e = MZ_UNIFORM(e);
+        if (e >= a.n) break;
+        mz_inflate_result r;
+        mz_inflate_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e], L, crc_tab, a.tabs, &r);
+        if (lane == 0) {
+            a.out_len[e] = r.out_len;
+            a.in_used[e] = r.in_used;
+            a.crc[e] = r.crc;
+            a.status[e] = r.status;
+        }
+    }
+}
+
+struct CrcArgs {
+    const uint8_t *buf;
+    const uint64_t *off;
+    const uint32_t *len;
+    uint32_t n;
+    const uint32_t *init;
+    uint32_t *crc;
+    uint32_t *counter;
+    const mzhip_crc_tables *tabs;
+};
+
+// K2 stand-alone: one wave per buffer, same tile folding as the fused epilogue.
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_crc32_batch(CrcArgs a) {
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    for (;;) {
+        uint32_t e = 0;
+        if (lane == 0) e = atomicAdd(a.counter, 1u);
+        e = MZ_UNIFORM(e);
+        if (e >= a.n) break;
+        const uint8_t *buf = a.buf + a.off[e];
+        const uint32_t n = a.len[e];
+        const uint32_t init = a.init ? a.init[e] : 0u;
+        uint32_t acc = (lane == 0) ? ~init : 0u; // register = ~value on entry (mz_crypt.c:81)
+        uint32_t tmp, done = 0, result;
+        const mzhip_crc_tables *tabs = a.tabs;
+        MZ_CRC_FOLD_TILES(acc, done, buf, n, crc_tab, tabs->kx);
+        MZ_CRC_FINISH_FROM(result, acc, tmp, done, buf, n, crc_tab, tabs, ~init);
+        if (lane == 0) a.crc[e] = result;
+    }
+}
+
+struct LzmaArgs {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    const uint32_t *in_len;
+    uint8_t *out;
+    const uint64_t *out_off;
+    const uint32_t *out_cap;
+    const int64_t *max_out; // may be null: no TOTAL_OUT_MAX clamp
+    uint32_t n;
+    uint32_t *out_len;
+    uint32_t *in_used;
+    uint32_t *crc;
+    int32_t *status;
+    uint32_t *counter;
+    const mzhip_crc_tables *tabs;
+};
+
+// K3: one wave per workgroup, the wave's whole probability model (15.6 KiB) in LDS -> 10 waves per CU.
+__global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
+    __shared__ __attribute__((aligned(16))) mz_lzma_lds lds;
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    for (;;) {
+        uint32_t e = 0;
+        if (lane == 0) e = atomicAdd(a.counter, 1u);
+        e = MZ_UNIFORM(e);
+        if (e >= a.n) break;
+        mz_lzma_result r;
+        mz_lzma_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
+                      a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs, &r);
+        if (lane == 0) {
+            a.out_len[e] = r.out_len;
+            a.in_used[e] = r.in_used;
+            a.crc[e] = r.crc;
+            a.status[e] = r.status;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- host
+
+namespace {
+
+struct DeviceCtx {
+    bool ready = false;
+    mzhip_crc_tables *d_tabs = nullptr;
+    uint32_t *d_counters = nullptr;
+    uint32_t next_counter = 0;
+    int cu_count = 0;
+};
+
+constexpr int kMaxDevices = 16;
+DeviceCtx g_ctx[kMaxDevices];
+std::mutex g_mu;
+thread_local char g_err[256] = "";
+
+int32_t fail(const char *what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -104; /* MZ_INTERNAL_ERROR */
+}
+
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) return fail(#expr, _e); \
+    } while (0)
+
+int32_t ctx_for_current(DeviceCtx **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) {
+        snprintf(g_err, sizeof(g_err), "device index %d out of range", dev);
+        return -102;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx &c = g_ctx[dev];
+    if (!c.ready) {
+        mzhip_crc_tables h;
+        mzhip_crc_tables_init(&h);
+        HIP_TRY(hipMalloc((void **)&c.d_tabs, sizeof(h)));
+        HIP_TRY(hipMemcpy(c.d_tabs, &h, sizeof(h), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&c.d_counters, MZ_NUM_COUNTERS * sizeof(uint32_t)));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        c.cu_count = prop.multiProcessorCount;
+        c.ready = true;
+    }
+    *out = &c;
+    return 0;
+}
+
+uint32_t *take_counter(DeviceCtx *c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    uint32_t *p = c->d_counters + (c->next_counter % MZ_NUM_COUNTERS);
+    c->next_counter++;
+    return p;
+}
+
+uint32_t grid_for(const DeviceCtx *c, uint32_t n) {
+    uint32_t wgs_needed = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
+    uint32_t resident = (uint32_t)c->cu_count * 8u; /* 8 workgroups of 4 waves per CU */
+    if (wgs_needed < 1) wgs_needed = 1;
+    return wgs_needed < resident ? wgs_needed : resident;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mzhip_last_error(void) { return g_err; }
+const char *mzhip_version(void) { return "mzhip 0.1 (gfx950)"; }
+
+int32_t mzhip_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        fail("hipGetDeviceCount", e);
+        return -1;
+    }
+    return n;
+}
+
+int32_t mzhip_init(int32_t device) {
+    HIP_TRY(hipSetDevice(device));
+    DeviceCtx *c = nullptr;
+    return ctx_for_current(&c);
+}
+
+void mzhip_inflate_launch_geometry(uint32_t n, uint32_t *grid, uint32_t *waves_per_wg, uint32_t *lds_bytes) {
+    DeviceCtx *c = nullptr;
+    uint32_t g = 0;
+    if (ctx_for_current(&c) == 0) g = grid_for(c, n);
+    if (grid) *grid = g;
+    if (waves_per_wg) *waves_per_wg = MZ_WAVES_PER_WG;
+    if (lds_bytes) *lds_bytes = (uint32_t)(MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE);
+}
+
+int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                            const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n, uint32_t *d_out_len,
+                            uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    if (n == 0) return 0;
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    InflateArgs a;
+    a.in = (const uint8_t *)d_in;
+    a.in_off = d_in_off;
+    a.in_len = d_in_len;
+    a.out = (uint8_t *)d_out;
+    a.out_off = d_out_off;
+    a.out_cap = d_out_cap;
+    a.n = n;
+    a.out_len = d_out_len;
+    a.in_used = d_in_used;
+    a.crc = d_crc;
+    a.status = d_status;
+    a.counter = take_counter(c);
+    a.tabs = c->d_tabs;
+    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
+    const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE;
+    hipLaunchKernelGGL(k_inflate_batch, dim3(grid_for(c, n)), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
+                          const uint32_t *d_init, uint32_t *d_crc, void *stream) {
+    if (n == 0) return 0;
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    CrcArgs a;
+    a.buf = (const uint8_t *)d_buf;
+    a.off = d_off;
+    a.len = d_len;
+    a.n = n;
+    a.init = d_init;
+    a.crc = d_crc;
+    a.counter = take_counter(c);
+    a.tabs = c->d_tabs;
+    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_crc32_batch, dim3(grid_for(c, n)), dim3(MZ_WAVES_PER_WG * 64), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                         const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out, uint32_t n,
+                         uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    if (n == 0) return 0;
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    LzmaArgs a;
+    a.in = (const uint8_t *)d_in;
+    a.in_off = d_in_off;
+    a.in_len = d_in_len;
+    a.out = (uint8_t *)d_out;
+    a.out_off = d_out_off;
+    a.out_cap = d_out_cap;
+    a.max_out = d_max_out;
+    a.n = n;
+    a.out_len = d_out_len;
+    a.in_used = d_in_used;
+    a.crc = d_crc;
+    a.status = d_status;
+    a.counter = take_counter(c);
+    a.tabs = c->d_tabs;
+    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
+    uint32_t resident = (uint32_t)c->cu_count * 10u; /* 16 KiB LDS per wave -> 10 single-wave workgroups per CU */
+    uint32_t grid = n < resident ? n : resident;
+    hipLaunchKernelGGL(k_lzma_batch, dim3(grid), dim3(64), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- host-buffer conveniences (synchronous): staging through one scratch allocation per call
+
+namespace {
+struct Scratch {
+    void *p = nullptr;
+    ~Scratch() {
+        if (p) (void)hipFree(p);
+    }
+};
+} // namespace
+
+int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                           uint32_t *in_used, uint32_t *crc) {
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    // layout: [meta 64 B][in (16-aligned)][out]
+    const size_t in_pad = ((size_t)in_len + 15) & ~(size_t)15;
+    const size_t total = 64 + in_pad + out_cap + 16;
+    Scratch sc;
+    HIP_TRY(hipMalloc(&sc.p, total));
+    uint8_t *base = (uint8_t *)sc.p;
+    struct Meta {
+        uint64_t in_off, out_off;
+        uint32_t in_len, out_cap, out_len, in_used, crc;
+        int32_t status;
+    } m;
+    memset(&m, 0, sizeof(m));
+    m.in_off = 64;
+    m.out_off = 64 + in_pad;
+    m.in_len = in_len;
+    m.out_cap = out_cap;
+    HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
+    if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
+    Meta *dm = (Meta *)base;
+    rc = mzhip_inflate_batch(base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, 1, &dm->out_len,
+                             &dm->in_used, &dm->crc, &dm->status, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
+    if (m.out_len && out) HIP_TRY(hipMemcpy(out, base + m.out_off, m.out_len, hipMemcpyDeviceToHost));
+    if (out_len) *out_len = m.out_len;
+    if (in_used) *in_used = m.in_used;
+    if (crc) *crc = m.crc;
+    return m.status;
+}
+
+int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                        uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    const size_t in_pad = ((size_t)in_len + 15) & ~(size_t)15;
+    const size_t total = 64 + in_pad + out_cap + 16;
+    Scratch sc;
+    HIP_TRY(hipMalloc(&sc.p, total));
+    uint8_t *base = (uint8_t *)sc.p;
+    struct Meta {
+        uint64_t in_off, out_off;
+        int64_t max_out;
+        uint32_t in_len, out_cap, out_len, in_used, crc;
+        int32_t status;
+    } m;
+    memset(&m, 0, sizeof(m));
+    m.in_off = 64;
+    m.out_off = 64 + in_pad;
+    m.max_out = max_out;
+    m.in_len = in_len;
+    m.out_cap = out_cap;
+    HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
+    if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
+    Meta *dm = (Meta *)base;
+    rc = mzhip_lzma_batch(base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, &dm->max_out, 1,
+                          &dm->out_len, &dm->in_used, &dm->crc, &dm->status, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
+    if (m.out_len && out) HIP_TRY(hipMemcpy(out, base + m.out_off, m.out_len, hipMemcpyDeviceToHost));
+    if (out_len) *out_len = m.out_len;
+    if (in_used) *in_used = m.in_used;
+    if (crc) *crc = m.crc;
+    return m.status;
+}
+
+uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
+    if (size == 0) return value;
+    DeviceCtx *c = nullptr;
+    if (ctx_for_current(&c)) {
+        fprintf(stderr, "mzhip: no usable HIP device for mz_crypt_crc32_update (%s)\n", g_err);
+        abort(); /* the CRC symbol has no error channel (mz_crypt.h:20); never fall back silently */
+    }
+    // segments of 256 KiB, one wave each; segment CRCs are chained with x^(8*len) shifts
+    // (32-bit arithmetic on checksums only, no byte is touched on the host).
+    const uint32_t seg = 256u << 10;
+    const uint32_t nseg = (uint32_t)((size + seg - 1) / seg);
+    const size_t meta = (size_t)nseg * (8 + 4 + 4);
+    const size_t meta_pad = (meta + 63) & ~(size_t)63;
+    Scratch sc;
+    if (hipMalloc(&sc.p, meta_pad + size) != hipSuccess) {
+        fprintf(stderr, "mzhip: hipMalloc failed in mz_crypt_crc32_update\n");
+        abort();
+    }
+    uint8_t *base = (uint8_t *)sc.p;
+    uint64_t *h_off = (uint64_t *)malloc(meta_pad);
+    uint32_t *h_len = (uint32_t *)(h_off + nseg);
+    uint32_t *h_crc = h_len + nseg;
+    for (uint32_t i = 0; i < nseg; i++) {
+        h_off[i] = meta_pad + (uint64_t)i * seg;
+        size_t left = size - (size_t)i * seg;
+        h_len[i] = (uint32_t)(left < seg ? left : seg);
+    }
+    bool ok = hipMemcpy(base, h_off, meta, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(base + meta_pad, buf, size, hipMemcpyHostToDevice) == hipSuccess;
+    uint64_t *d_off = (uint64_t *)base;
+    uint32_t *d_len = (uint32_t *)(d_off + nseg);
+    uint32_t *d_crc = d_len + nseg;
+    ok = ok && mzhip_crc32_batch(base, d_off, d_len, nseg, nullptr, d_crc, nullptr) == 0;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    ok = ok && hipMemcpy(h_crc, d_crc, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "mzhip: device failure in mz_crypt_crc32_update (%s)\n", g_err);
+        abort();
+    }
+    uint32_t v = value;
+    for (uint32_t i = 0; i < nseg; i++) v = mzhip_crc32_combine_host(v, h_crc[i], h_len[i]);
+    free(h_off);
+    return v;
+}
+
+} // extern "C"

@@ -1,0 +1,17 @@
+/* shim_crc32.c -- mz_crypt_crc32_update re-implemented over the HIP backend.
+ *
+ * Drop-in for the CRC symbol of the reference's mz_crypt.c:35-92 (declared at
+ * mz_crypt.h:20; called from mz_zip.c:2049,2064 and mz_os.c:340).  Same
+ * chaining contract: crc(crc(0,A),B) == crc(0,A||B); size <= 0 returns `value`
+ * unchanged, as every reference back-end does for an empty buffer.
+ * The bytes are reduced on the device (k_crc32_batch, wave-parallel tile
+ * folding); there is no table-driven CPU loop in this file.
+ */
+#include "mz_strm_hip.h"
+#include "mzhip.h"
+
+uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int32_t size) {
+    if (size <= 0 || !buf)
+        return value;
+    return mzhip_crc32_host(value, buf, (size_t)size);
+}

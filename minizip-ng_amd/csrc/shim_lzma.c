@@ -1,0 +1,329 @@
+/* shim_lzma.c -- mz_stream_lzma re-implemented over the HIP backend.
+ *
+ * Drop-in for the reference's mz_strm_lzma.c (13 exported symbols,
+ * mz_strm_lzma.h:20-35).  READ of method 14 (raw LZMA1 behind the ZIP-LZMA
+ * header) is decoded by the device range decoder (K3, lzma_core.h) through
+ * mzhip_lzma_host(); method 95 (XZ/LZMA2) and WRITE answer MZ_SUPPORT_ERROR,
+ * which is what a reference build without that codec answers
+ * (mz_strm_lzma.c:71-75,111-115).
+ *
+ * Contract mirrored from the reference (file:line = mz_strm_lzma.c):
+ *   create :429-438  method LZMA, preset default, max_total_out -1
+ *   open   :52-138   READ/LZMA consumes the 4-byte magic from base and counts
+ *                    it in TOTAL_IN (:118-124)
+ *   read   :147-241  staging pulls <=32767 B clamped by TOTAL_IN_MAX (:170-174);
+ *                    TOTAL_OUT clamped by TOTAL_OUT_MAX (:214-215); ANY decoder
+ *                    error is returned as MZ_DATA_ERROR (:236-237); error()
+ *                    keeps the decoder's own code (here: 9 data / 10 buf, the
+ *                    lzma_ret values LZMA_DATA_ERROR / LZMA_BUF_ERROR)
+ *   props  :380-428  adds COMPRESS_METHOD, TOTAL_OUT_MAX (>= -1), HEADER_SIZE=4
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "mz_strm_hip.h"
+#include "mzhip.h"
+
+#define LZMA_MAGIC_SIZE 4 /* mz_strm_lzma.c:19 */
+
+typedef struct mzhip_lzma_s {
+    mzhip_stream stream;
+    int32_t mode;
+    int32_t error;
+    int8_t initialized;
+    int16_t method;
+    uint32_t preset;
+    int64_t total_in, total_out, max_total_in, max_total_out;
+    uint8_t *in;
+    int64_t in_len, in_cap;
+    int8_t base_eof;
+    uint8_t *out;
+    int64_t out_len, out_cap, out_served;
+    int8_t decoded;
+    int32_t dev_status;
+    int64_t dev_in_used;
+    int64_t next_attempt;
+} mzhip_lzma;
+
+static mzhip_stream_vtbl mzhip_lzma_vtbl = {
+    mz_stream_lzma_open,   mz_stream_lzma_is_open, mz_stream_lzma_read,           mz_stream_lzma_write,
+    mz_stream_lzma_tell,   mz_stream_lzma_seek,    mz_stream_lzma_close,          mz_stream_lzma_error,
+    mz_stream_lzma_create, mz_stream_lzma_delete,  mz_stream_lzma_get_prop_int64, mz_stream_lzma_set_prop_int64};
+
+static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
+    if (!base || !base->vtbl || !base->vtbl->read)
+        return MZH_PARAM_ERROR;
+    if (!base->vtbl->is_open || base->vtbl->is_open(base) != MZH_OK)
+        return MZH_STREAM_ERROR;
+    return base->vtbl->read(base, buf, size);
+}
+
+static int32_t grow_in(mzhip_lzma *z, int64_t need) {
+    if (need <= z->in_cap)
+        return MZH_OK;
+    int64_t ncap = z->in_cap ? z->in_cap * 2 : 65536;
+    while (ncap < need)
+        ncap *= 2;
+    uint8_t *p = (uint8_t *)realloc(z->in, (size_t)ncap);
+    if (!p)
+        return MZH_MEM_ERROR;
+    z->in = p;
+    z->in_cap = ncap;
+    return MZH_OK;
+}
+
+int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    (void)path;
+    z->total_in = z->total_out = 0;
+    z->error = 0;
+    free(z->in);
+    free(z->out);
+    z->in = z->out = NULL;
+    z->in_len = z->in_cap = z->out_len = z->out_cap = z->out_served = 0;
+    z->base_eof = z->decoded = 0;
+    z->dev_status = 0;
+    z->dev_in_used = 0;
+    z->next_attempt = 0;
+    if (mode & MZH_OPEN_MODE_WRITE)
+        return MZH_SUPPORT_ERROR;
+    if (mode & MZH_OPEN_MODE_READ) {
+        if (z->method != MZH_COMPRESS_METHOD_LZMA)
+            return MZH_SUPPORT_ERROR;
+        if (mzhip_device_count() <= 0) {
+            z->error = 1;
+            return MZH_OPEN_ERROR;
+        }
+        /* the 4 magic bytes are consumed at open and kept as the front of the
+         * device input, which starts at the ZIP-LZMA header (mz_strm_lzma.c:118-124) */
+        if (grow_in(z, 65536) != MZH_OK)
+            return MZH_OPEN_ERROR;
+        for (int i = 0; i < LZMA_MAGIC_SIZE; i++) {
+            uint8_t b = 0;
+            if (base_read(z->stream.base, &b, 1) == 1)
+                z->in[z->in_len++] = b;
+            else
+                z->in[z->in_len++] = 0; /* the reference ignores short reads here too */
+        }
+        z->total_in += LZMA_MAGIC_SIZE;
+    }
+    z->initialized = 1;
+    z->mode = mode;
+    return MZH_OK;
+}
+
+int32_t mz_stream_lzma_is_open(void *stream) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    return z->initialized == 1 ? MZH_OK : MZH_OPEN_ERROR;
+}
+
+static int32_t pull_chunk(mzhip_lzma *z) {
+    int32_t want = MZH_STAGING_BYTES;
+    if (z->max_total_in > 0) {
+        int64_t left = z->max_total_in - z->in_len;
+        if (left < want)
+            want = (int32_t)(left < 0 ? 0 : left);
+    }
+    if (want == 0) {
+        z->base_eof = 1;
+        return 0;
+    }
+    if (grow_in(z, z->in_len + want) != MZH_OK)
+        return MZH_MEM_ERROR;
+    int32_t rd = base_read(z->stream.base, z->in + z->in_len, want);
+    if (rd < 0)
+        return rd;
+    if (rd == 0)
+        z->base_eof = 1;
+    z->in_len += rd;
+    return rd;
+}
+
+static int32_t attempt_decode(mzhip_lzma *z) {
+    for (;;) {
+        if (z->out_cap == 0) {
+            z->out_cap = z->max_total_out >= 0 ? z->max_total_out + 16 : z->in_len * 6 + 65536;
+            z->out = (uint8_t *)malloc((size_t)z->out_cap);
+            if (!z->out)
+                return MZH_MEM_ERROR;
+        }
+        uint32_t out_len = 0, in_used = 0, crc = 0;
+        int32_t st = mzhip_lzma_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, z->max_total_out,
+                                     &out_len, &in_used, &crc);
+        if (st == MZHIP_STATUS_OUT_FULL) {
+            if (z->out_cap >= 0x7FFFFFFF)
+                return MZH_MEM_ERROR;
+            int64_t ncap = z->out_cap * 4;
+            if (ncap > 0x7FFFFFFF)
+                ncap = 0x7FFFFFFF;
+            free(z->out);
+            z->out = (uint8_t *)malloc((size_t)ncap);
+            if (!z->out)
+                return MZH_MEM_ERROR;
+            z->out_cap = ncap;
+            continue;
+        }
+        if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof)
+            return 1;
+        z->dev_status = st;
+        z->out_len = out_len;
+        z->dev_in_used = in_used;
+        z->decoded = 1;
+        return 0;
+    }
+}
+
+int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    if (z->error != 0)
+        return MZH_DATA_ERROR; /* mz_strm_lzma.c:236-237 */
+    while (!z->decoded) {
+        int32_t rd = pull_chunk(z);
+        if (rd < 0)
+            return rd;
+        if (!z->base_eof && z->in_len < z->next_attempt)
+            continue;
+        int32_t r = attempt_decode(z);
+        if (r < 0) {
+            z->error = 5; /* LZMA_MEM_ERROR */
+            return MZH_DATA_ERROR;
+        }
+        if (r == 1)
+            z->next_attempt = z->in_len * 2;
+    }
+    int64_t avail = z->out_len - z->out_served;
+    if (z->dev_status != 0 && avail < size) {
+        z->error = z->dev_status == MZHIP_STATUS_BUF_ERROR ? 10 : 9; /* LZMA_BUF_ERROR : LZMA_DATA_ERROR */
+        z->total_in = z->dev_in_used;
+        z->total_out = z->out_len;
+        return MZH_DATA_ERROR;
+    }
+    int32_t n = (int32_t)(avail < size ? avail : size);
+    if (n > 0) {
+        memcpy(buf, z->out + z->out_served, (size_t)n);
+        z->out_served += n;
+        z->total_out += n;
+    }
+    if (z->out_served == z->out_len) {
+        z->total_in = z->dev_in_used;
+    } else {
+        int64_t est = z->out_len ? (z->dev_in_used * z->out_served) / z->out_len : 0;
+        if (est >= z->dev_in_used)
+            est = z->dev_in_used - 1;
+        if (est < LZMA_MAGIC_SIZE)
+            est = LZMA_MAGIC_SIZE;
+        z->total_in = est;
+    }
+    return n;
+}
+
+int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
+    (void)stream;
+    (void)buf;
+    (void)size;
+    return MZH_SUPPORT_ERROR;
+}
+
+int64_t mz_stream_lzma_tell(void *stream) {
+    (void)stream;
+    return MZH_TELL_ERROR;
+}
+
+int32_t mz_stream_lzma_seek(void *stream, int64_t offset, int32_t origin) {
+    (void)stream;
+    (void)offset;
+    (void)origin;
+    return MZH_SEEK_ERROR;
+}
+
+int32_t mz_stream_lzma_close(void *stream) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    z->initialized = 0;
+    free(z->in);
+    free(z->out);
+    z->in = z->out = NULL;
+    z->in_cap = z->out_cap = 0;
+    if (z->error != 0)
+        return MZH_CLOSE_ERROR;
+    return MZH_OK;
+}
+
+int32_t mz_stream_lzma_error(void *stream) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    return z->error;
+}
+
+int32_t mz_stream_lzma_get_prop_int64(void *stream, int32_t prop, int64_t *value) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    switch (prop) {
+    case MZH_PROP_TOTAL_IN:
+        *value = z->total_in;
+        break;
+    case MZH_PROP_TOTAL_IN_MAX:
+        *value = z->max_total_in;
+        break;
+    case MZH_PROP_TOTAL_OUT:
+        *value = z->total_out;
+        break;
+    case MZH_PROP_TOTAL_OUT_MAX:
+        *value = z->max_total_out;
+        break;
+    case MZH_PROP_HEADER_SIZE:
+        *value = LZMA_MAGIC_SIZE;
+        break;
+    default:
+        return MZH_EXIST_ERROR;
+    }
+    return MZH_OK;
+}
+
+int32_t mz_stream_lzma_set_prop_int64(void *stream, int32_t prop, int64_t value) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    switch (prop) {
+    case MZH_PROP_COMPRESS_LEVEL:
+        z->preset = value == -1 ? 6u : (uint32_t)value; /* LZMA_PRESET_DEFAULT == 6 */
+        break;
+    case MZH_PROP_COMPRESS_METHOD:
+        z->method = (int16_t)value;
+        break;
+    case MZH_PROP_TOTAL_IN_MAX:
+        z->max_total_in = value;
+        break;
+    case MZH_PROP_TOTAL_OUT_MAX:
+        if (value < -1)
+            return MZH_PARAM_ERROR;
+        z->max_total_out = value;
+        break;
+    default:
+        return MZH_EXIST_ERROR;
+    }
+    return MZH_OK;
+}
+
+void *mz_stream_lzma_create(void) {
+    mzhip_lzma *z = (mzhip_lzma *)calloc(1, sizeof(mzhip_lzma));
+    if (z) {
+        z->stream.vtbl = &mzhip_lzma_vtbl;
+        z->method = MZH_COMPRESS_METHOD_LZMA;
+        z->preset = 6;
+        z->max_total_out = -1;
+    }
+    return z;
+}
+
+void mz_stream_lzma_delete(void **stream) {
+    mzhip_lzma *z;
+    if (!stream)
+        return;
+    z = (mzhip_lzma *)*stream;
+    if (z) {
+        free(z->in);
+        free(z->out);
+        free(z);
+    }
+    *stream = NULL;
+}
+
+void *mz_stream_lzma_get_interface(void) {
+    return (void *)&mzhip_lzma_vtbl;
+}

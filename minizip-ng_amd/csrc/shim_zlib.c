@@ -1,0 +1,341 @@
+/* shim_zlib.c -- mz_stream_zlib re-implemented over the HIP backend.
+ *
+ * Drop-in for the reference's mz_strm_zlib.c (same 13 exported symbols,
+ * mz_strm_zlib.h:20-35).  Host side stays C; the DEFLATE arithmetic runs in the
+ * gfx950 kernels behind mzhip_inflate_host() (include/mzhip.h).  There is no
+ * CPU codec in here: if the device is unusable, read() fails with an MZ error.
+ *
+ * Contract mirrored from the reference (file:line = mz_strm_zlib.c):
+ *   create   :357-365  calloc, vtbl first, level -1, window_bits -15
+ *   open     :65-107   resets totals; WRITE -> deflate, READ -> inflate
+ *   read     :116-193  pulls <=32767-byte chunks from base (:132,146), clamps to
+ *                      TOTAL_IN_MAX (:141-144), negative base reads returned
+ *                      verbatim (:148-149), zlib-numbered error returned instead
+ *                      of a byte count once an error is latched (:186-189)
+ *   close    :280-305  MZ_CLOSE_ERROR if an error is latched
+ *   props    :312-355  TOTAL_IN / TOTAL_IN_MAX / TOTAL_OUT / HEADER_SIZE(0) /
+ *                      COMPRESS_WINDOW get; COMPRESS_LEVEL / TOTAL_IN_MAX /
+ *                      COMPRESS_WINDOW set; everything else MZ_EXIST_ERROR
+ *   tell/seek:266-278  MZ_TELL_ERROR / MZ_SEEK_ERROR
+ *
+ * How a pull-mode byte stream meets a batch device: the shim pulls staging
+ * chunks exactly like the reference, hands everything pulled so far to the
+ * device, and asks it to decode the entry; when the device answers "input ended
+ * early" (-5) the shim pulls more (doubling the attempt size, so total device
+ * work stays within 2x) until the stream ends or base is exhausted.  Decoded
+ * bytes are then served to read() calls from the host copy.  TOTAL_IN is the
+ * exact number of compressed bytes the stream occupies (what mz_zip.c:2090,2116
+ * need); it is only reported once every decoded byte has been served, so a
+ * caller that stops early does not trip the CRC comparison at mz_zip.c:2116.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "mz_strm_hip.h"
+#include "mzhip.h"
+
+typedef struct mzhip_zlib_s {
+    mzhip_stream stream; /* must be first (mz_strm.h:69-72) */
+    int32_t mode;
+    int32_t error;
+    int8_t initialized;
+    int16_t level;
+    int32_t window_bits;
+    int64_t total_in;
+    int64_t total_out;
+    int64_t max_total_in;
+    /* read side */
+    uint8_t *in;       /* compressed bytes pulled from base so far */
+    int64_t in_len, in_cap;
+    int8_t base_eof;   /* base returned 0 */
+    uint8_t *out;      /* decoded bytes (host copy) */
+    int64_t out_len, out_cap, out_served;
+    int8_t decoded;    /* device produced a final verdict */
+    int32_t dev_status;
+    int64_t dev_in_used;
+    int64_t next_attempt; /* try the device again once in_len reaches this */
+    /* write side */
+    uint8_t *wbuf;
+    int64_t wlen, wcap;
+} mzhip_zlib;
+
+static mzhip_stream_vtbl mzhip_zlib_vtbl = {
+    mz_stream_zlib_open,   mz_stream_zlib_is_open, mz_stream_zlib_read,           mz_stream_zlib_write,
+    mz_stream_zlib_tell,   mz_stream_zlib_seek,    mz_stream_zlib_close,          mz_stream_zlib_error,
+    mz_stream_zlib_create, mz_stream_zlib_delete,  mz_stream_zlib_get_prop_int64, mz_stream_zlib_set_prop_int64};
+
+/* what mz_stream_read does before dispatching (mz_strm.c:34-41) */
+static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
+    if (!base || !base->vtbl || !base->vtbl->read)
+        return MZH_PARAM_ERROR;
+    if (!base->vtbl->is_open || base->vtbl->is_open(base) != MZH_OK)
+        return MZH_STREAM_ERROR;
+    return base->vtbl->read(base, buf, size);
+}
+
+static void free_buffers(mzhip_zlib *z) {
+    free(z->in);
+    free(z->out);
+    free(z->wbuf);
+    z->in = z->out = z->wbuf = NULL;
+    z->in_len = z->in_cap = z->out_len = z->out_cap = z->out_served = 0;
+    z->wlen = z->wcap = 0;
+}
+
+int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    (void)path;
+    z->total_in = 0;
+    z->total_out = 0;
+    z->error = 0;
+    free_buffers(z);
+    z->base_eof = 0;
+    z->decoded = 0;
+    z->dev_status = 0;
+    z->dev_in_used = 0;
+    z->next_attempt = 0;
+    if (mode & MZH_OPEN_MODE_WRITE) {
+        /* K4 (device DEFLATE encode) is not wired into the stream yet; same answer as a
+         * reference build with MZ_ZIP_NO_COMPRESSION (mz_strm_zlib.c:80-82). */
+        return MZH_SUPPORT_ERROR;
+    } else if (mode & MZH_OPEN_MODE_READ) {
+        if (z->window_bits != -15) /* zlib / gzip wrappers: SURVEY 8(f) rank 2 */
+            return MZH_SUPPORT_ERROR;
+        if (mzhip_device_count() <= 0) {
+            z->error = MZH_STREAM_ERROR;
+            return MZH_OPEN_ERROR; /* mz_strm_zlib.c:101-102 */
+        }
+    }
+    z->initialized = 1;
+    z->mode = mode;
+    return MZH_OK;
+}
+
+int32_t mz_stream_zlib_is_open(void *stream) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    return z->initialized == 1 ? MZH_OK : MZH_OPEN_ERROR;
+}
+
+/* pull one staging chunk; returns bytes read (0 = base exhausted) or <0 */
+static int32_t pull_chunk(mzhip_zlib *z) {
+    int32_t want = MZH_STAGING_BYTES;
+    if (z->max_total_in > 0) {
+        int64_t left = z->max_total_in - z->in_len;
+        if (left < want)
+            want = (int32_t)(left < 0 ? 0 : left);
+    }
+    if (want == 0) {
+        z->base_eof = 1;
+        return 0;
+    }
+    if (z->in_len + want > z->in_cap) {
+        int64_t ncap = z->in_cap ? z->in_cap * 2 : 65536;
+        while (ncap < z->in_len + want)
+            ncap *= 2;
+        uint8_t *p = (uint8_t *)realloc(z->in, (size_t)ncap);
+        if (!p)
+            return MZH_MEM_ERROR;
+        z->in = p;
+        z->in_cap = ncap;
+    }
+    int32_t rd = base_read(z->stream.base, z->in + z->in_len, want);
+    if (rd < 0)
+        return rd;
+    if (rd == 0)
+        z->base_eof = 1;
+    z->in_len += rd;
+    return rd;
+}
+
+/* run the device over everything pulled so far; 0 = verdict reached, 1 = wants more input */
+static int32_t attempt_decode(mzhip_zlib *z) {
+    for (;;) {
+        if (z->out_cap == 0) {
+            z->out_cap = z->in_len * 4 + 65536;
+            z->out = (uint8_t *)malloc((size_t)z->out_cap);
+            if (!z->out)
+                return MZH_MEM_ERROR;
+        }
+        uint32_t out_len = 0, in_used = 0, crc = 0;
+        int32_t st = mzhip_inflate_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &out_len, &in_used,
+                                        &crc);
+        if (st == MZHIP_STATUS_OUT_FULL) {
+            if (z->out_cap >= 0x7FFFFFFF)
+                return MZH_MEM_ERROR;
+            int64_t ncap = z->out_cap * 4;
+            if (ncap > 0x7FFFFFFF)
+                ncap = 0x7FFFFFFF;
+            free(z->out);
+            z->out = (uint8_t *)malloc((size_t)ncap);
+            if (!z->out)
+                return MZH_MEM_ERROR;
+            z->out_cap = ncap;
+            continue;
+        }
+        if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof)
+            return 1; /* input ended early, but base may have more */
+        if (st != MZHIP_STATUS_OK && st != MZHIP_STATUS_BUF_ERROR && st != MZHIP_STATUS_DATA_ERROR) {
+            /* device/runtime failure: never substitute a CPU result */
+            z->dev_status = MZH_STREAM_ERROR;
+        } else {
+            z->dev_status = st;
+        }
+        z->out_len = out_len;
+        z->dev_in_used = in_used;
+        z->decoded = 1;
+        return 0;
+    }
+}
+
+int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    if (z->error != 0)
+        return z->error; /* mz_strm_zlib.c:186-189 */
+
+    while (!z->decoded) {
+        int32_t rd = pull_chunk(z);
+        if (rd < 0)
+            return rd; /* mz_strm_zlib.c:148-149 */
+        if (!z->base_eof && z->in_len < z->next_attempt)
+            continue;
+        int32_t r = attempt_decode(z);
+        if (r < 0) {
+            z->error = r;
+            return r;
+        }
+        if (r == 1)
+            z->next_attempt = z->in_len * 2;
+    }
+
+    int64_t avail = z->out_len - z->out_served;
+    if (z->dev_status != 0 && avail < size) {
+        /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189) */
+        z->error = z->dev_status;
+        z->total_in = z->dev_in_used;
+        z->total_out = z->out_len;
+        return z->error;
+    }
+    int32_t n = (int32_t)(avail < size ? avail : size);
+    if (n > 0) {
+        memcpy(buf, z->out + z->out_served, (size_t)n);
+        z->out_served += n;
+        z->total_out += n;
+    }
+    if (z->out_served == z->out_len) {
+        z->total_in = z->dev_in_used; /* the stream end has been reached: exact TOTAL_IN */
+    } else {
+        /* mid-stream: the reference would have consumed only part of the input */
+        int64_t est = z->out_len ? (z->dev_in_used * z->out_served) / z->out_len : 0;
+        if (est >= z->dev_in_used)
+            est = z->dev_in_used - 1;
+        z->total_in = est;
+    }
+    return n;
+}
+
+int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
+    (void)stream;
+    (void)buf;
+    (void)size;
+    return MZH_SUPPORT_ERROR;
+}
+
+int64_t mz_stream_zlib_tell(void *stream) {
+    (void)stream;
+    return MZH_TELL_ERROR;
+}
+
+int32_t mz_stream_zlib_seek(void *stream, int64_t offset, int32_t origin) {
+    (void)stream;
+    (void)offset;
+    (void)origin;
+    return MZH_SEEK_ERROR;
+}
+
+int32_t mz_stream_zlib_close(void *stream) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    z->initialized = 0;
+    free(z->in);
+    free(z->out);
+    free(z->wbuf);
+    z->in = z->out = z->wbuf = NULL;
+    z->in_cap = z->out_cap = z->wcap = 0;
+    if (z->error != 0)
+        return MZH_CLOSE_ERROR; /* mz_strm_zlib.c:302-303 */
+    return MZH_OK;
+}
+
+int32_t mz_stream_zlib_error(void *stream) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    return z->error;
+}
+
+int32_t mz_stream_zlib_get_prop_int64(void *stream, int32_t prop, int64_t *value) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    switch (prop) {
+    case MZH_PROP_TOTAL_IN:
+        *value = z->total_in;
+        break;
+    case MZH_PROP_TOTAL_IN_MAX:
+        *value = z->max_total_in;
+        break;
+    case MZH_PROP_TOTAL_OUT:
+        *value = z->total_out;
+        break;
+    case MZH_PROP_HEADER_SIZE:
+        *value = 0;
+        break;
+    case MZH_PROP_COMPRESS_WINDOW:
+        *value = z->window_bits;
+        break;
+    default:
+        return MZH_EXIST_ERROR;
+    }
+    return MZH_OK;
+}
+
+int32_t mz_stream_zlib_set_prop_int64(void *stream, int32_t prop, int64_t value) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    switch (prop) {
+    case MZH_PROP_COMPRESS_LEVEL:
+        z->level = (int16_t)value; /* -1 stays -1 == Z_DEFAULT_COMPRESSION (mz_strm_zlib.c:339-343) */
+        break;
+    case MZH_PROP_TOTAL_IN_MAX:
+        z->max_total_in = value;
+        break;
+    case MZH_PROP_COMPRESS_WINDOW:
+        z->window_bits = (int32_t)value;
+        break;
+    default:
+        return MZH_EXIST_ERROR;
+    }
+    return MZH_OK;
+}
+
+void *mz_stream_zlib_create(void) {
+    mzhip_zlib *z = (mzhip_zlib *)calloc(1, sizeof(mzhip_zlib));
+    if (z) {
+        z->stream.vtbl = &mzhip_zlib_vtbl;
+        z->level = -1;
+        z->window_bits = -15;
+    }
+    return z;
+}
+
+void mz_stream_zlib_delete(void **stream) {
+    mzhip_zlib *z;
+    if (!stream)
+        return;
+    z = (mzhip_zlib *)*stream;
+    if (z) {
+        free(z->in);
+        free(z->out);
+        free(z->wbuf);
+        free(z);
+    }
+    *stream = NULL;
+}
+
+void *mz_stream_zlib_get_interface(void) {
+    return (void *)&mzhip_zlib_vtbl;
+}

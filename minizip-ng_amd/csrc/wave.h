@@ -1,0 +1,102 @@
+/* wave.h -- wave64 SIMT vocabulary for the gfx950 kernels.
+ *
+ * The codec kernels are written "wave-synchronously": one 64-lane wavefront
+ * owns one ZIP entry; code is either wave-uniform (bit cursor, block state,
+ * chain walk -- lands on the scalar unit) or per-lane (candidate token decode,
+ * literal scatter, cooperative match copy, CRC folding).
+ *
+ * The same source compiles two ways:
+ *   - hipcc --offload-arch=gfx950 : the product.  A per-lane region is just
+ *     straight-line code executed by all 64 lanes; cross-lane traffic uses
+ *     v_readlane / ballot / LDS.
+ *   - g++ -DMZHIP_HOST_EMUL       : a debugging emulation used ONLY by the CPU
+ *     test-suite (tests/test_kernel_emul.py); a per-lane region becomes a loop
+ *     over lane = 0..63 and per-lane variables become 64-element arrays.  It
+ *     lets the kernels' control flow be checked against the oracle in a
+ *     container without a GPU.  It is never linked into libmzhip.so.
+ *
+ * Rule that keeps the two modes equivalent: inside one MZ_LANES region a lane
+ * only reads memory that no other lane writes in that same region; regions
+ * that communicate through LDS / global memory are separated by MZ_WAVE_SYNC().
+ */
+#ifndef MZHIP_WAVE_H
+#define MZHIP_WAVE_H
+
+#include <stdint.h>
+
+#if defined(MZHIP_HOST_EMUL)
+
+#include <string.h>
+#define MZ_DEV static inline
+#define MZ_LANE_DECL
+#define MZ_LANES for (int lane = 0; lane < 64; ++lane)
+#define PV(type, name) type name[64]
+#define P(name) name[lane]
+#define MZ_READLANE(name, idx) (name[(idx)])
+#define MZ_UNIFORM(x) (x)
+#define MZ_WAVE_SYNC() ((void)0)
+#define MZ_BALLOT(dst, cond)                         \
+    do {                                             \
+        uint64_t _bal_acc = 0;                       \
+        for (int lane = 0; lane < 64; ++lane)        \
+            if (cond) _bal_acc |= 1ull << lane;      \
+        (dst) = _bal_acc;                            \
+    } while (0)
+#define MZ_WAVE_XOR(dst, name)                       \
+    do {                                             \
+        uint32_t _xor_acc = 0;                       \
+        for (int lane = 0; lane < 64; ++lane)        \
+            _xor_acc ^= name[lane];                  \
+        (dst) = _xor_acc;                            \
+    } while (0)
+#define MZ_LDS_ATOMIC_INC(ptr) (++*(ptr))
+MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
+MZ_DEV uint32_t mz_brev32(uint32_t v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(v);
+}
+
+#else /* ---------------------------------------------------- gfx950 device */
+
+#include <hip/hip_runtime.h>
+#define MZ_DEV __device__ __forceinline__
+#define MZ_LANE_DECL const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#define MZ_LANES
+#define PV(type, name) type name
+#define P(name) name
+#define MZ_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
+#define MZ_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+/* orders this wave's memory operations for the compiler; the hardware already
+ * executes one wave's LDS (and vector-memory) instructions in issue order. */
+#define MZ_WAVE_SYNC()                                        \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+#define MZ_BALLOT(dst, cond) ((dst) = __ballot(cond))
+#define MZ_WAVE_XOR(dst, name)                                          \
+    do {                                                                \
+        uint32_t _xor_acc = (name);                                     \
+        for (int _xo = 32; _xo > 0; _xo >>= 1)                          \
+            _xor_acc ^= (uint32_t)__shfl_xor((int)_xor_acc, _xo, 64);   \
+        (dst) = MZ_UNIFORM(_xor_acc);                                   \
+    } while (0)
+#define MZ_LDS_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
+MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__popcll(v); }
+MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
+MZ_DEV uint32_t mz_brev32(uint32_t v) { return __brev(v); }
+
+#endif
+
+/* status words shared by every kernel; numerically the zlib / MZ_* codes the
+ * reference surfaces (mz.h:20-26, mz_strm_zlib.c:186-189). */
+#define MZHIP_OK 0
+#define MZHIP_DATA_ERROR (-3)
+#define MZHIP_BUF_ERROR (-5)
+#define MZHIP_OUT_FULL (-200)
+#define MZHIP_UNSUPPORTED (-109) /* MZ_SUPPORT_ERROR */
+
+#endif

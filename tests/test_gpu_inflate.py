@@ -1,0 +1,138 @@
+"""GPU parity tests for K1+K2 (raw-DEFLATE decode + fused CRC-32) through the C ABI
+(mzhip_inflate_batch / mzhip_inflate_host), checked against the oracle (oracle/*.c), zlib-made
+expected bytes, the golden fixtures, and -- where oracle/_ref travelled -- the compiled reference."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from tests import gpu_util
+
+    gpu_util.mz.require_gpu()
+    return gpu_util
+
+
+def test_edge_payloads_batch(gpu):
+    cases = synth.edge_payloads()
+    batch = gpu.make_batch([z + b"\x00trailing-garbage" for _, _, z in cases], [len(d) + 8 for _, d, _ in cases])
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    h_out = batch["d_out"].cpu().numpy()
+    for i, (name, data, z) in enumerate(cases):
+        st, used, ref_out = oracle.inflate_raw(z + b"\x00trailing-garbage", len(data) + 8)
+        assert status[i] == st == 0, name
+        assert in_used[i] == used == len(z), name
+        assert out_len[i] == len(data), name
+        assert gpu.entry_bytes(batch, h_out, i, len(data)) == data, name
+        assert crc[i] == oracle.crc32(data) == zlib.crc32(data), name
+
+
+def test_fixtures_golden(gpu, fixtures):
+    ents = [e for e in fixtures if e["method"] == 8]
+    batch = gpu.make_batch([e["payload"] for e in ents], [e["usize"] + 4 for e in ents], align=1)
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    for i, e in enumerate(ents):
+        assert status[i] == 0 and out_len[i] == e["usize"] and in_used[i] == e["csize"], (e["archive"], e["entry"])
+        assert crc[i] == e["crc"], (e["archive"], e["entry"])          # the CRC the archive's CD pins
+        assert in_used[i] == e["ref"]["total_in"] and out_len[i] == e["ref"]["total_out"]
+
+
+def test_status_parity_malformed(gpu):
+    """Error class (and exact in_used on success) for truncated / bit-flipped streams vs the oracle."""
+    names, pays, caps = [], [], []
+    for name, data, z in synth.edge_payloads():
+        if len(z) < 16:
+            continue
+        for cname, bad in synth.corruptions(z):
+            names.append((name, cname))
+            pays.append(bad)
+            caps.append(len(data) + 70000)
+    batch = gpu.make_batch(pays, caps)
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    h_out = batch["d_out"].cpu().numpy()
+    for i, nm in enumerate(names):
+        st, used, out = oracle.inflate_raw(pays[i], caps[i])
+        assert status[i] == st, (nm, status[i], st)
+        if st == 0:
+            assert in_used[i] == used and out_len[i] == len(out), nm
+            assert gpu.entry_bytes(batch, h_out, i, len(out)) == out, nm
+            assert crc[i] == oracle.crc32(out), nm
+
+
+def test_out_cap_exceeded(gpu):
+    data = synth.corpus()[:50000]
+    z = synth.deflate_raw(data)
+    batch = gpu.make_batch([z, z], [len(data) - 1, len(data)])
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    assert status[0] == -200 and status[1] == 0 and crc[1] == zlib.crc32(data)
+
+
+def test_many_entries_64k_and_8k(gpu):
+    """A few thousand corpus slices (configs 2 and 3 shapes), every byte and CRC compared."""
+    for size, n, seed in ((65536, 1500, 1234), (8192, 4000, 1235)):
+        datas = synth.slices(n, size, seed)
+        pays = [synth.deflate_raw(d) for d in datas]
+        batch = gpu.make_batch(pays, [size] * n)
+        out_len, in_used, crc, status = gpu.run_inflate(batch)
+        h_out = batch["d_out"].cpu().numpy()
+        assert (status == 0).all()
+        assert (out_len == size).all()
+        assert (in_used == np.array([len(p) for p in pays])).all()
+        want = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)
+        assert (crc == want).all()
+        for i in range(0, n, 7):
+            assert gpu.entry_bytes(batch, h_out, i, size) == datas[i]
+        # oracle spot-check (the restatement is slow: a sample)
+        for i in range(0, n, 211):
+            st, used, out = oracle.inflate_raw(pays[i], size)
+            assert st == 0 and out == datas[i] and used == in_used[i] and oracle.crc32(out) == crc[i]
+
+
+def test_unaligned_offsets(gpu):
+    datas = synth.slices(64, 5000, 99)
+    pays = [synth.deflate_raw(d) for d in datas]
+    batch = gpu.make_batch(pays, [5000 + (i % 5) for i in range(64)], align=1)
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    h_out = batch["d_out"].cpu().numpy()
+    for i in range(64):
+        assert status[i] == 0 and gpu.entry_bytes(batch, h_out, i, 5000) == datas[i] and crc[i] == zlib.crc32(datas[i])
+
+
+def test_inflate_host_entry_point(gpu):
+    data = synth.corpus()[7000:7000 + 65536]
+    z = synth.deflate_raw(data)
+    st, used, out, crc = gpu.mz.inflate_host(z + b"xx", len(data))
+    assert (st, used, out, crc) == (0, len(z), data, zlib.crc32(data))
+    st, used, out, crc = gpu.mz.inflate_host(z[:len(z) // 2], len(data))
+    assert st == -5
+
+
+def test_crc32_batch_and_host(gpu):
+    import torch
+
+    rnd = np.random.RandomState(3)
+    sizes = [0, 1, 2, 15, 16, 17, 1023, 1024, 1025, 4096, 65535, 65536, 300001]
+    bufs = [rnd.bytes(s) for s in sizes]
+    off = np.cumsum([0] + [len(b) + 3 for b in bufs[:-1]]).astype(np.int64)
+    blob = np.zeros(int(off[-1]) + sizes[-1] + 16, dtype=np.uint8)
+    for o, b in zip(off, bufs):
+        blob[o:o + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    d = torch.from_numpy(blob).cuda()
+    init = rnd.randint(0, 2**31, size=len(sizes)).astype(np.int32)
+    crc = gpu.mz.crc32_batch(d, torch.from_numpy(off).cuda(), torch.tensor(sizes, dtype=torch.int32).cuda(),
+                             torch.from_numpy(init).cuda())
+    torch.cuda.synchronize()
+    got = gpu.mz.u32(crc)
+    for i, b in enumerate(bufs):
+        assert got[i] == zlib.crc32(b, int(init[i])) == oracle.crc32(b, int(init[i])), sizes[i]
+    big = rnd.bytes(3 * (1 << 20) + 12345)
+    assert gpu.mz.crc32_host(big) == zlib.crc32(big)
+    assert gpu.mz.crc32_host(big[:1000], 0xDEADBEEF) == zlib.crc32(big[:1000], 0xDEADBEEF)
+    assert gpu.mz.crc32_host(b"123456789") == 0xCBF43926

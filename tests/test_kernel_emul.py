@@ -1,0 +1,130 @@
+"""CPU tests of the DEVICE code's control flow via the 64-lane host emulation (tests/emul/emul.cpp
+compiles minizip-ng_amd/csrc/*_core.h with -DMZHIP_HOST_EMUL).  This is debugging infrastructure
+for a container without a GPU -- the product path is the HIP build of the same headers, exercised
+by the -m gpu tests through the C ABI.  Checked against the oracle on the same inputs."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+from tests.test_oracle import _zip_lzma
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_u8p = C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    out = os.path.join(ROOT, "tests", "emul", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libemul.so")
+    subprocess.run(["g++", "-O1", "-g", "-Wno-unknown-pragmas", "-DMZHIP_HOST_EMUL",
+                    "-I" + os.path.join(ROOT, "minizip-ng_amd", "csrc"), "-shared", "-fPIC",
+                    os.path.join(ROOT, "tests", "emul", "emul.cpp"), "-o", so], check=True)
+    L = C.CDLL(so)
+    L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_lzma.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_crc32.restype = C.c_uint32
+    L.emul_crc32.argtypes = [_u8p, C.c_uint32]
+    return L
+
+
+def _run(fn, z, cap, *extra):
+    a = np.frombuffer(z, dtype=np.uint8).copy() if len(z) else np.zeros(1, np.uint8)
+    out = np.zeros(cap + 1, np.uint8)
+    ol, iu, crc = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    st = fn(a.ctypes.data_as(_u8p), len(z), out.ctypes.data_as(_u8p), cap, *extra, C.byref(ol), C.byref(iu),
+            C.byref(crc))
+    return st, iu.value, out[:ol.value].tobytes(), crc.value
+
+
+def test_lds_budget(emu):
+    # 4 waves x inflate slice + CRC table must allow 8 workgroups per 160 KiB CU
+    assert (4 * ((emu.emul_lds_bytes() + 15) // 16 * 16) + 1024) * 8 <= 160 * 1024
+    assert emu.emul_lzma_lds_bytes() + 1024 <= 16 * 1024 + 1024
+
+
+def test_crc_tiles_and_tail(emu):
+    rnd = np.random.RandomState(0)
+    for n in (0, 1, 15, 16, 17, 1023, 1024, 1025, 2047, 2048, 5000, 65535, 65536, 100001):
+        d = rnd.bytes(n)
+        a = np.frombuffer(d, dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+        assert emu.emul_crc32(a.ctypes.data_as(_u8p), n) == zlib.crc32(d) == oracle.crc32(d), n
+
+
+def test_inflate_edges(emu):
+    for name, data, z in synth.edge_payloads():
+        st, used, out, crc = _run(emu.emul_inflate, z + b"\x00junk", len(data) + 8)
+        so, uo, oo = oracle.inflate_raw(z + b"\x00junk", len(data) + 8)
+        assert (st, used, out) == (so, uo, oo) == (0, len(z), data), name
+        assert crc == oracle.crc32(data), name
+
+
+def test_inflate_fixtures(emu, fixtures):
+    for e in fixtures:
+        if e["method"] != 8:
+            continue
+        st, used, out, crc = _run(emu.emul_inflate, e["payload"], e["usize"] + 4)
+        assert (st, used, len(out), crc) == (0, e["csize"], e["usize"], e["crc"]), (e["archive"], e["entry"])
+
+
+def test_inflate_malformed_status(emu):
+    n = 0
+    for name, data, z in synth.edge_payloads():
+        if len(z) < 16:
+            continue
+        for cname, bad in synth.corruptions(z):
+            cap = len(data) + 70000
+            st, used, out, crc = _run(emu.emul_inflate, bad, cap)
+            so, uo, oo = oracle.inflate_raw(bad, cap)
+            assert st == so, (name, cname, st, so)
+            if so == 0:
+                assert (used, out) == (uo, oo), (name, cname)
+            n += 1
+    assert n > 100
+
+
+def test_inflate_out_cap(emu):
+    data = synth.corpus()[:30000]
+    z = synth.deflate_raw(data)
+    st, used, out, crc = _run(emu.emul_inflate, z, len(data) - 1)
+    assert st == -200
+
+
+def test_lzma_cases(emu):
+    c = synth.corpus()
+    rnd = np.random.RandomState(11)
+    cases = [b"", b"a", c[:1000], c[:150000], rnd.bytes(5000), b"A" * 100000, c[1000:70000] + rnd.bytes(3000) + c[:50000]]
+    for i, d in enumerate(cases):
+        z = _zip_lzma(d)
+        st, used, out, crc = _run(emu.emul_lzma, z, len(d) + 64, C.c_int64(len(d)))
+        so, uo, oo = oracle.lzma_zip_decode(z, len(d) + 64, len(d))
+        assert (st, used, out) == (so, uo, oo) == (0, len(z), d), i
+        assert crc == oracle.crc32(d)
+        if len(z) > 40:
+            third = len(z) // 3
+            for bad in (z[:len(z) // 2], z[:20], z[:9], z[:5], z[:third] + bytes([z[third] ^ 0x55]) + z[third + 1:],
+                        z[:9] + b"\x01" + z[10:]):
+                st, used, out, crc = _run(emu.emul_lzma, bad, len(d) + 70000, C.c_int64(-1))
+                so, uo, oo = oracle.lzma_zip_decode(bad, len(d) + 70000, -1)
+                if so == 0:
+                    assert st == 0 and out == oo
+                else:
+                    assert st in (-3, -5), (i, len(bad), st)   # mz_stream_lzma_read maps both to MZ_DATA_ERROR
+    # TOTAL_OUT_MAX clamp (mz_strm_lzma.c:214-215)
+    z = _zip_lzma(c[:5000])
+    st, used, out, crc = _run(emu.emul_lzma, z, 6000, C.c_int64(3000))
+    assert st == 0 and out == c[:3000] and crc == zlib.crc32(c[:3000])
+
+
+def test_lzma_fixture(emu, fixtures):
+    for e in fixtures:
+        if e["method"] != 14:
+            continue
+        st, used, out, crc = _run(emu.emul_lzma, e["payload"], e["usize"] + 4, C.c_int64(e["usize"]))
+        assert (st, used, len(out), crc) == (0, e["csize"], e["usize"], e["crc"])
