@@ -211,12 +211,10 @@ MZ_DEV void mz_decode_token(uint64_t w, const mz_inflate_lds *t, uint32_t *bits,
             uint32_t _c = MZ_UNIFORM((L_)->hist[_l]);                                                          \
             _left = (_left << 1) - (int32_t)_c;                                                                \
             if (_left < 0) _over = 1;                                                                          \
-            MZ_LANES {                                                                                         \
-                if (lane == 0) {                                                                               \
-                    (first_)[_l] = (uint16_t)_code;                                                            \
-                    (count_)[_l] = (uint16_t)_c;                                                               \
-                    (offs_)[_l] = (uint16_t)_off;                                                              \
-                }                                                                                              \
+            MZ_LANES { /* uniform store: every lane writes the same value (no lane-0 branch) */              \
+                (first_)[_l] = (uint16_t)_code;                                                                \
+                (count_)[_l] = (uint16_t)_c;                                                                   \
+                (offs_)[_l] = (uint16_t)_off;                                                                  \
             }                                                                                                  \
             _code = (_code + _c) << 1;                                                                         \
             _off += _c;                                                                                        \
@@ -242,7 +240,7 @@ MZ_DEV void mz_decode_token(uint64_t w, const mz_inflate_lds *t, uint32_t *bits,
                     uint32_t _rb = MZ_UNIFORM((L_)->rank_base[_lt]);                                           \
                     MZ_LANES {                                                                                 \
                         if (P(_len) == _lt) P(_rank) = _rb + mz_popc64(_m & ((1ull << lane) - 1));            \
-                        if (lane == 0) (L_)->rank_base[_lt] = (uint16_t)(_rb + mz_popc64(_m));                 \
+                        (L_)->rank_base[_lt] = (uint16_t)(_rb + mz_popc64(_m)); /* uniform store */          \
                     }                                                                                          \
                     MZ_WAVE_SYNC();                                                                            \
                     _pending &= ~_m;                                                                           \
@@ -414,9 +412,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     uint32_t xb = (uint32_t)(wu >> (used + nb)) & ((1u << ext) - 1);
                     used += nb + ext;
                     if (sym < 16) {
-                        MZ_LANES {
-                            if (lane == 0) L->cl[idx] = (uint8_t)sym;
-                        }
+                        MZ_LANES { L->cl[idx] = (uint8_t)sym; } /* uniform store */
                         prev = sym;
                         idx++;
                     } else {

@@ -112,9 +112,7 @@ typedef struct mz_lzma_result {
             _p -= _p >> 5;                                                              \
             (bit) = 1;                                                                  \
         }                                                                               \
-        MZ_LANES {                                                                      \
-            if (lane == 0) pr[_pi] = (uint16_t)_p;                                      \
-        }                                                                               \
+        MZ_LANES { pr[_pi] = (uint16_t)_p; } /* uniform store, no lane-0 branch */      \
         MZ_WAVE_SYNC();                                                                 \
     } while (0)
 
@@ -246,9 +244,7 @@ MZ_DEV void mz_lzma_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
                     status = MZHIP_OUT_FULL;
                     goto finish;
                 }
-                MZ_LANES {
-                    if (lane == 0) out[opos] = (uint8_t)sym;
-                }
+                MZ_LANES { out[opos] = (uint8_t)sym; } /* uniform store */
                 MZ_WAVE_SYNC();
                 prev_byte = sym & 0xFFu;
                 opos++;
@@ -272,9 +268,7 @@ MZ_DEV void mz_lzma_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
                             goto finish;
                         }
                         uint32_t b = MZ_UNIFORM(out[opos - rep0 - 1]);
-                        MZ_LANES {
-                            if (lane == 0) out[opos] = (uint8_t)b;
-                        }
+                        MZ_LANES { out[opos] = (uint8_t)b; } /* uniform store */
                         MZ_WAVE_SYNC();
                         prev_byte = b;
                         opos++;

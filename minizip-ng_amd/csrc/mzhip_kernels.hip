@@ -49,18 +49,16 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_inflate_batch(InflateA
     const int wave = threadIdx.x >> 6;
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
     for (;;) {
-        uint32_t e = 0;
-        if (lane == 0) e = atomicAdd(a.counter, 1u);
-        e = MZ_UNIFORM(e);
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
         if (e >= a.n) break;
         mz_inflate_result r;
         mz_inflate_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e], L, crc_tab, a.tabs, &r);
-        if (lane == 0) {
-            a.out_len[e] = r.out_len;
-            a.in_used[e] = r.in_used;
-            a.crc[e] = r.crc;
-            a.status[e] = r.status;
-        }
+        // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
+        a.out_len[e] = r.out_len;
+        a.in_used[e] = r.in_used;
+        a.crc[e] = r.crc;
+        a.status[e] = r.status;
     }
 }
 
@@ -82,9 +80,8 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_crc32_batch(CrcArgs a)
     __syncthreads();
     MZ_LANE_DECL
     for (;;) {
-        uint32_t e = 0;
-        if (lane == 0) e = atomicAdd(a.counter, 1u);
-        e = MZ_UNIFORM(e);
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
         if (e >= a.n) break;
         const uint8_t *buf = a.buf + a.off[e];
         const uint32_t n = a.len[e];
@@ -94,7 +91,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_crc32_batch(CrcArgs a)
         const mzhip_crc_tables *tabs = a.tabs;
         MZ_CRC_FOLD_TILES(acc, done, buf, n, crc_tab, tabs->kx);
         MZ_CRC_FINISH_FROM(result, acc, tmp, done, buf, n, crc_tab, tabs, ~init);
-        if (lane == 0) a.crc[e] = result;
+        a.crc[e] = result; // uniform store
     }
 }
 
@@ -123,19 +120,17 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
     __syncthreads();
     MZ_LANE_DECL
     for (;;) {
-        uint32_t e = 0;
-        if (lane == 0) e = atomicAdd(a.counter, 1u);
-        e = MZ_UNIFORM(e);
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
         if (e >= a.n) break;
         mz_lzma_result r;
         mz_lzma_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
                       a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs, &r);
-        if (lane == 0) {
-            a.out_len[e] = r.out_len;
-            a.in_used[e] = r.in_used;
-            a.crc[e] = r.crc;
-            a.status[e] = r.status;
-        }
+        // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
+        a.out_len[e] = r.out_len;
+        a.in_used[e] = r.in_used;
+        a.crc[e] = r.crc;
+        a.status[e] = r.status;
     }
 }
 

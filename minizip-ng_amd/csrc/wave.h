@@ -77,6 +77,20 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
         __builtin_amdgcn_wave_barrier();                      \
     } while (0)
 #define MZ_BALLOT(dst, cond) ((dst) = __ballot(cond))
+/* One device-scope fetch-add per WAVE, result broadcast to every lane.  The wave barriers pin the
+ * lane-0 branch: without them LLVM's jump threading fuses this `lane == 0` test with a neighbouring
+ * one across the loop back-edge, lane 0 and lanes 1..63 then run different trips of the persistent
+ * loop, and readfirstlane hands lanes 1..63 a stale index forever (observed on gfx950, ROCm 7.2).
+ * Rule for the kernels: `if (lane == 0)` appears nowhere else -- wave-uniform values are stored by
+ * all lanes (same address, same value) instead. */
+#define MZ_WAVE_FETCH_ADD(dst, ptr)                                        \
+    do {                                                                   \
+        uint32_t _fa = 0;                                                  \
+        __builtin_amdgcn_wave_barrier();                                   \
+        if (lane == 0) _fa = atomicAdd((ptr), 1u);                         \
+        __builtin_amdgcn_wave_barrier();                                   \
+        (dst) = MZ_UNIFORM(_fa);                                           \
+    } while (0)
 #define MZ_WAVE_XOR(dst, name)                                          \
     do {                                                                \
         uint32_t _xor_acc = (name);                                     \
