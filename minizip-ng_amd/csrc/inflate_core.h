@@ -38,20 +38,32 @@
 #define MZ_CROOT 7  /* code-length-code table bits (== max)  */
 
 /* per-wave LDS scratch */
+typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed */
+    uint16_t clc_fast[1 << MZ_CROOT];
+    uint16_t clc_sym[20];
+    uint16_t clc_first[16], clc_count[16], clc_offs[16];
+    uint8_t cl[320];     /* code lengths of the current block (nlen + ndist <= 316; fixed: 288 + 32) */
+    uint8_t clc_len[20]; /* lengths of the code-length code */
+} mz_inflate_hdr_scratch;
+
+typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
+    uint32_t ring[128]; /* 512 B of compressed stream: aligned dword j of the entry at ring[j & 127] */
+    uint8_t mslot[64];  /* lane ids of this step's match tokens, compacted */
+} mz_inflate_body_scratch;
+
 typedef struct mz_inflate_lds {
     uint16_t lit_fast[1 << MZ_LROOT]; /* (symbol << 4) | code length, 0 = not a short code */
     uint16_t dist_fast[1 << MZ_DROOT];
-    uint16_t clc_fast[1 << MZ_CROOT];
     uint16_t lit_sym[288]; /* symbols sorted by (length, value): canonical order */
     uint16_t dist_sym[32];
-    uint16_t clc_sym[20];
     uint16_t lit_first[16], lit_count[16], lit_offs[16];
     uint16_t dist_first[16], dist_count[16], dist_offs[16];
-    uint16_t clc_first[16], clc_count[16], clc_offs[16];
     uint16_t rank_base[16];
     uint32_t hist[16];
-    uint8_t cl[320]; /* code lengths of the current block (nlen + ndist <= 316; fixed: 288 + 32) */
-    uint8_t clc_len[20]; /* lengths of the code-length code */
+    union {
+        mz_inflate_hdr_scratch h;
+        mz_inflate_body_scratch b;
+    } u;
 } mz_inflate_lds;
 
 typedef struct mz_inflate_result {
@@ -277,6 +289,18 @@ MZ_DEV void mz_decode_token(uint64_t w, const mz_inflate_lds *t, uint32_t *bits,
         bitpos += (n);                                                        \
     } while (0)
 
+/* Aligned dword j of the compressed stream (dword 0 = the aligned dword holding in[0]); bytes outside
+ * [in, in + in_len) read as zero, and no byte outside that range is ever touched except inside an
+ * aligned dword that also holds a valid byte. */
+MZ_DEV uint32_t mz_load_stream_dword(const uint8_t *in_al, uint32_t in_mis, uint32_t in_len, uint32_t j) {
+    const uint64_t lo = (uint64_t)j * 4u, end = (uint64_t)in_mis + in_len;
+    if (lo >= end) return 0u;
+    uint32_t d = *(const uint32_t *)(in_al + lo);
+    if (lo < in_mis) d &= 0xFFFFFFFFu << (8u * (in_mis - (uint32_t)lo)); /* bytes before in[0] */
+    if (lo + 4u > end) d &= 0xFFFFFFFFu >> (8u * (uint32_t)(lo + 4u - end)); /* bytes past the end */
+    return d;
+}
+
 /* transmission order of the code-length-code lengths, appnote.txt:2083-2090 */
 #if defined(MZHIP_HOST_EMUL)
 static const uint8_t mz_k_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -290,6 +314,8 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                              mz_inflate_result *res) {
     MZ_LANE_DECL
     const uint64_t total_bits = (uint64_t)in_len * 8u;
+    const uint32_t in_mis = (uint32_t)((uintptr_t)in & 3u);
+    const uint8_t *in_al = in - in_mis;
     uint64_t bitpos = 0;
     uint32_t out_pos = 0;
     int32_t status = MZHIP_OK;
@@ -350,12 +376,12 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             /* fixed code, appnote.txt:2050-2059 */
             MZ_LANES {
                 for (int s = lane; s < 288 + 32; s += 64)
-                    L->cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+                    L->u.h.cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
             }
             MZ_WAVE_SYNC();
-            MZ_BUILD_HUFF(left, maxlen, L, L->cl, 288, L->lit_fast, MZ_LROOT, L->lit_sym, L->lit_first, L->lit_count,
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, 288, L->lit_fast, MZ_LROOT, L->lit_sym, L->lit_first, L->lit_count,
                           L->lit_offs);
-            MZ_BUILD_HUFF(left, maxlen, L, L->cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
                           L->dist_count, L->dist_offs);
         } else {
             /* dynamic code, appnote.txt:2060-2106 */
@@ -371,19 +397,19 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 goto finish;
             }
             MZ_LANES {
-                if (lane < 19) L->clc_len[lane] = 0;
+                if (lane < 19) L->u.h.clc_len[lane] = 0;
             }
             MZ_WAVE_SYNC();
             MZ_LANES {
                 if ((uint32_t)lane < ncode) {
                     uint64_t w = mz_bits_at(in, in_len, bitpos + 3u * (uint32_t)lane);
-                    L->clc_len[mz_k_order[lane]] = (uint8_t)((uint32_t)w & 7u);
+                    L->u.h.clc_len[mz_k_order[lane]] = (uint8_t)((uint32_t)w & 7u);
                 }
             }
             bitpos += 3ull * ncode;
             MZ_WAVE_SYNC();
-            MZ_BUILD_HUFF(left, maxlen, L, L->clc_len, 19, L->clc_fast, MZ_CROOT, L->clc_sym, L->clc_first, L->clc_count,
-                          L->clc_offs);
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.clc_len, 19, L->u.h.clc_fast, MZ_CROOT, L->u.h.clc_sym, L->u.h.clc_first, L->u.h.clc_count,
+                          L->u.h.clc_offs);
             if (left != 0) {
                 status = MZHIP_DATA_ERROR; /* invalid code lengths set */
                 goto finish;
@@ -398,7 +424,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 uint64_t wu = ((uint64_t)whi << 32) | wlo;
                 uint32_t used = 0;
                 while (idx < ntot && used + 14 <= 64) {
-                    uint32_t e = MZ_UNIFORM(L->clc_fast[(uint32_t)(wu >> used) & 127u]);
+                    uint32_t e = MZ_UNIFORM(L->u.h.clc_fast[(uint32_t)(wu >> used) & 127u]);
                     uint32_t nb = e & 15u, sym = e >> 4;
                     if (nb == 0) {
                         status = (bitpos + used + 7 > total_bits) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
@@ -412,7 +438,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     uint32_t xb = (uint32_t)(wu >> (used + nb)) & ((1u << ext) - 1);
                     used += nb + ext;
                     if (sym < 16) {
-                        MZ_LANES { L->cl[idx] = (uint8_t)sym; } /* uniform store */
+                        MZ_LANES { L->u.h.cl[idx] = (uint8_t)sym; } /* uniform store */
                         prev = sym;
                         idx++;
                     } else {
@@ -434,7 +460,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                             goto finish;
                         }
                         MZ_LANES {
-                            for (uint32_t k = (uint32_t)lane; k < rep; k += 64) L->cl[idx + k] = (uint8_t)val;
+                            for (uint32_t k = (uint32_t)lane; k < rep; k += 64) L->u.h.cl[idx + k] = (uint8_t)val;
                         }
                         prev = val;
                         idx += rep;
@@ -443,17 +469,17 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 bitpos += used;
             }
             MZ_WAVE_SYNC();
-            if (MZ_UNIFORM(L->cl[256]) == 0) {
+            if (MZ_UNIFORM(L->u.h.cl[256]) == 0) {
                 status = MZHIP_DATA_ERROR; /* invalid code -- missing end-of-block */
                 goto finish;
             }
-            MZ_BUILD_HUFF(left, maxlen, L, L->cl, nlen, L->lit_fast, MZ_LROOT, L->lit_sym, L->lit_first,
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, nlen, L->lit_fast, MZ_LROOT, L->lit_sym, L->lit_first,
                           L->lit_count, L->lit_offs);
             if (left < 0 || (left > 0 && maxlen != 1)) {
                 status = MZHIP_DATA_ERROR; /* invalid literal/lengths set */
                 goto finish;
             }
-            MZ_BUILD_HUFF(left, maxlen, L, L->cl + nlen, ndist, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + nlen, ndist, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
                           L->dist_count, L->dist_offs);
             if (left < 0 || (left > 0 && maxlen > 1)) {
                 status = MZHIP_DATA_ERROR; /* invalid distances set */
@@ -461,105 +487,259 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
         }
 
-        /* ---- compressed block body: speculative 64-offset decode ---- */
-        for (;;) {
-            PV(uint32_t, tbits);
-            PV(uint32_t, tolen);
-            PV(uint32_t, tval);
-            MZ_LANES {
-                uint64_t w = mz_bits_at(in, in_len, bitpos + (uint32_t)lane);
-                uint32_t b, o, v;
-                mz_decode_token(w, L, &b, &o, &v);
-                P(tbits) = b;
-                P(tolen) = o;
-                P(tval) = v;
+        /* ---- compressed block body: speculative 64-offset decode ----
+         * Compressed bytes are staged through a 512-byte LDS ring (two 256-byte blocks, the next
+         * block prefetched into a VGPR one block ahead), so the per-step window fetch is three
+         * ds_read_b32 and no global-memory latency sits on the critical path. */
+        {
+            uint32_t *ring = L->u.b.ring;
+            const uint32_t pbase = 8u * in_mis; /* bit offset of `in` inside its aligned dword */
+            uint32_t ring_hi;                   /* blocks < ring_hi are in the ring; block ring_hi is in wpre */
+            PV(uint32_t, wpre);
+            {
+                const uint32_t blk = ((uint32_t)bitpos + pbase) >> 11; /* 2048 bits per block */
+                MZ_LANES {
+                    ring[((blk & 1u) << 6) + (uint32_t)lane] = mz_load_stream_dword(in_al, in_mis, in_len, blk * 64u + (uint32_t)lane);
+                    ring[(((blk + 1u) & 1u) << 6) + (uint32_t)lane] =
+                        mz_load_stream_dword(in_al, in_mis, in_len, (blk + 1u) * 64u + (uint32_t)lane);
+                    P(wpre) = mz_load_stream_dword(in_al, in_mis, in_len, (blk + 2u) * 64u + (uint32_t)lane);
+                }
+                ring_hi = blk + 2u;
+                MZ_WAVE_SYNC();
             }
-            /* chain walk from offset 0: which lanes hold real tokens */
-            const uint64_t avail = total_bits - bitpos;
-            uint32_t pos = 0, eob = 0;
-            uint64_t sel = 0;
-            int32_t chain_err = MZHIP_OK;
-            while (pos < 64) {
-                uint32_t nb = MZ_READLANE(tbits, pos);
-                if (nb == 0) {
-                    uint32_t need = MZ_READLANE(tval, pos);
-                    chain_err = ((uint64_t)pos + need > avail) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
-                    break;
-                }
-                if ((uint64_t)pos + nb > avail) {
-                    chain_err = MZHIP_BUF_ERROR;
-                    break;
-                }
-                sel |= 1ull << pos;
-                uint32_t ol = MZ_READLANE(tolen, pos);
-                pos += nb;
-                if (ol == 0) {
-                    eob = 1;
-                    break;
-                }
-            }
-            bitpos += pos;
 
-            /* output offsets: literals by popcount, matches by a uniform walk */
-            uint64_t litm, matm;
-            MZ_BALLOT(litm, ((sel >> lane) & 1) && P(tolen) == 1);
-            MZ_BALLOT(matm, ((sel >> lane) & 1) && P(tolen) > 1);
-            PV(uint32_t, oofs);
-            MZ_LANES { P(oofs) = mz_popc64(litm & ((1ull << lane) - 1)); }
-            uint32_t total = mz_popc64(litm);
-            {
-                uint64_t mm = matm;
-                while (mm) {
-                    uint32_t t = mz_ctz64(mm);
-                    mm &= mm - 1;
-                    uint32_t ln = MZ_READLANE(tolen, t);
+            for (;;) {
+                const uint32_t pbit = (uint32_t)bitpos + pbase;
+                if ((pbit >> 11) + 1u >= ring_hi) {
+                    /* the cursor entered the newest block: retire the oldest, start the next fetch */
                     MZ_LANES {
-                        if ((uint32_t)lane > t) P(oofs) += ln;
+                        ring[((ring_hi & 1u) << 6) + (uint32_t)lane] = P(wpre);
+                        P(wpre) = mz_load_stream_dword(in_al, in_mis, in_len, (ring_hi + 1u) * 64u + (uint32_t)lane);
                     }
-                    total += ln;
-                }
-            }
-            if (total > out_cap - out_pos) {
-                status = MZHIP_OUT_FULL;
-                goto finish;
-            }
-            MZ_LANES {
-                if ((litm >> lane) & 1) out[out_pos + P(oofs)] = (uint8_t)P(tval);
-            }
-            MZ_WAVE_SYNC();
-            {
-                uint64_t mm = matm;
-                while (mm) {
-                    uint32_t t = mz_ctz64(mm);
-                    mm &= mm - 1;
-                    uint32_t ln = MZ_READLANE(tolen, t);
-                    uint32_t dist = MZ_READLANE(tval, t);
-                    uint32_t dst = out_pos + MZ_READLANE(oofs, t);
-                    if (dist > dst) {
-                        status = MZHIP_DATA_ERROR; /* invalid distance too far back */
-                        goto finish;
-                    }
-                    const uint8_t *src = out + (dst - dist);
-                    if (dist >= ln) {
-                        MZ_LANES {
-                            for (uint32_t i = (uint32_t)lane; i < ln; i += 64) out[dst + i] = src[i];
-                        }
-                    } else {
-                        /* overlapping run: byte i repeats with period dist */
-                        MZ_LANES {
-                            for (uint32_t i = (uint32_t)lane; i < ln; i += 64) out[dst + i] = src[i % dist];
-                        }
-                    }
+                    ring_hi++;
                     MZ_WAVE_SYNC();
                 }
+
+                /* phase 1: every lane decodes the token that would start at bit cursor + lane */
+                PV(uint64_t, win);
+                PV(uint32_t, nbl);
+                PV(uint32_t, syml);
+                MZ_LANES {
+                    const uint32_t pl = pbit + (uint32_t)lane;
+                    const uint32_t j = pl >> 5, sh = pl & 31u;
+                    const uint32_t d0 = ring[j & 127u], d1 = ring[(j + 1u) & 127u], d2 = ring[(j + 2u) & 127u];
+                    uint64_t w = ((((uint64_t)d1) << 32) | d0) >> sh;
+                    w |= ((uint64_t)d2 << 1) << (63u - sh);
+                    const uint32_t e = L->lit_fast[(uint32_t)w & ((1u << MZ_LROOT) - 1)];
+                    P(win) = w;
+                    P(nbl) = e & 15u;
+                    P(syml) = e >> 4;
+                }
+                uint64_t slow;
+                MZ_BALLOT(slow, P(nbl) == 0);
+                if (slow) { /* some lane looks at a code longer than the fast table: canonical search */
+                    MZ_LANES {
+                        if (P(nbl) == 0) {
+                            uint32_t nb;
+                            P(syml) = mz_canon_slow((uint32_t)P(win), MZ_LROOT, L->lit_first, L->lit_count, L->lit_offs,
+                                                    L->lit_sym, &nb);
+                            P(nbl) = nb;
+                        }
+                    }
+                }
+                PV(uint32_t, lenl);
+                PV(uint32_t, nb2l);
+                PV(uint32_t, dnl);
+                PV(uint32_t, dsyml);
+                MZ_LANES {
+                    /* length base / extra bits, branch-free (appnote.txt:2107-2120) */
+                    const uint32_t s = (P(syml) - 257u) & 31u;
+                    const uint32_t ex = (s < 8u || s >= 28u) ? 0u : ((s - 4u) >> 2);
+                    uint32_t lbase = (s < 8u) ? (3u + s) : (3u + ((4u + (s & 3u)) << ex));
+                    lbase = (s == 28u) ? 258u : lbase;
+                    const uint32_t wl = (uint32_t)(P(win) >> P(nbl));
+                    P(lenl) = lbase + (wl & ((1u << ex) - 1u));
+                    const uint32_t nb2 = P(nbl) + ex;
+                    const uint32_t d = L->dist_fast[(uint32_t)(P(win) >> nb2) & ((1u << MZ_DROOT) - 1)];
+                    P(nb2l) = nb2;
+                    P(dnl) = d & 15u;
+                    P(dsyml) = d >> 4;
+                }
+                MZ_BALLOT(slow, P(syml) > 256u && P(dnl) == 0);
+                if (slow) {
+                    MZ_LANES {
+                        if (P(syml) > 256u && P(dnl) == 0) {
+                            uint32_t dn;
+                            P(dsyml) = mz_canon_slow((uint32_t)(P(win) >> P(nb2l)), MZ_DROOT, L->dist_first, L->dist_count,
+                                                     L->dist_offs, L->dist_sym, &dn);
+                            P(dnl) = dn;
+                        }
+                    }
+                }
+                /* packed token: [5:0] bits (0 = invalid), [6] end-of-block, [15:7] bytes produced,
+                 * [31:16] literal byte | match distance | (invalid) bits the verdict needed */
+                PV(uint32_t, tk);
+                MZ_LANES {
+                    const uint32_t sym = P(syml), nb = P(nbl);
+                    const uint32_t ds = P(dsyml), dn = P(dnl);
+                    const uint32_t dex = (ds < 4u) ? 0u : ((ds - 2u) >> 1);
+                    const uint32_t dbase = (ds < 4u) ? (1u + ds) : (1u + ((2u + (ds & 1u)) << dex));
+                    const uint32_t dlo = (uint32_t)(P(win) >> P(nb2l));
+                    const uint32_t dist = dbase + ((dlo >> dn) & ((1u << dex) - 1u));
+                    uint32_t t;
+                    if (nb == 0u) {
+                        t = 15u << 16; /* invalid literal/length code: verdict needed 15 bits */
+                    } else if (sym < 256u) {
+                        t = nb | (1u << 7) | (sym << 16);
+                    } else if (sym == 256u) {
+                        t = nb | 64u;
+                    } else if (sym > 285u) {
+                        t = nb << 16; /* 286, 287 */
+                    } else if (dn == 0u) {
+                        t = (P(nb2l) + 15u) << 16; /* invalid distance code */
+                    } else if (ds > 29u) {
+                        t = (P(nb2l) + dn) << 16; /* 30, 31 */
+                    } else {
+                        t = (P(nb2l) + dn + dex) | (P(lenl) << 7) | (dist << 16);
+                    }
+                    P(tk) = t;
+                }
+
+                /* phase 2: chain walk from offset 0 -- which lanes hold real tokens (scalar unit) */
+                const uint64_t avail = total_bits - bitpos;
+                uint32_t pos = 0, eob = 0;
+                uint64_t sel = 0;
+                int32_t chain_err = MZHIP_OK;
+                if (avail >= 64u + 48u) {
+                    while (pos < 64u) {
+                        const uint32_t t = MZ_READLANE(tk, pos);
+                        const uint32_t nb = t & 63u;
+                        if (nb == 0u) {
+                            chain_err = MZHIP_DATA_ERROR;
+                            break;
+                        }
+                        sel |= 1ull << pos;
+                        pos += nb;
+                        if (t & 64u) {
+                            eob = 1;
+                            break;
+                        }
+                    }
+                } else { /* within 14 bytes of the end of input: also police every token's extent */
+                    while (pos < 64u) {
+                        const uint32_t t = MZ_READLANE(tk, pos);
+                        const uint32_t nb = t & 63u;
+                        if (nb == 0u) {
+                            chain_err = ((uint64_t)pos + (t >> 16) > avail) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
+                            break;
+                        }
+                        if ((uint64_t)pos + nb > avail) {
+                            chain_err = MZHIP_BUF_ERROR;
+                            break;
+                        }
+                        sel |= 1ull << pos;
+                        pos += nb;
+                        if (t & 64u) {
+                            eob = 1;
+                            break;
+                        }
+                    }
+                }
+                bitpos += pos;
+
+                /* phase 3: output offsets by a DPP prefix sum; literals scatter in one store */
+                PV(uint32_t, olen);
+                PV(uint32_t, oend);
+                MZ_LANES { P(olen) = ((sel >> lane) & 1u) ? ((P(tk) >> 7) & 511u) : 0u; }
+                MZ_INCL_SCAN(oend, olen);
+                const uint32_t total = MZ_READLANE(oend, 63);
+                if (total > out_cap - out_pos) {
+                    status = MZHIP_OUT_FULL;
+                    goto finish;
+                }
+                uint64_t matm;
+                MZ_BALLOT(matm, P(olen) > 1u);
+                MZ_LANES {
+                    if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tk) >> 16);
+                }
+                MZ_WAVE_SYNC();
+
+                /* phase 4: LZ77 back-references.  Four matches at a time, 16 lanes each: one gather of the
+                 * match descriptors, one load, one store, while every source lies before this step's output.
+                 * Anything that reads bytes produced in this same step (or overlaps itself) takes the
+                 * in-order cooperative path below. */
+                if (matm) {
+                    const uint32_t nmatch = mz_popc64(matm);
+                    uint32_t done_m = 0;
+                    MZ_LANES {
+                        if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                    }
+                    MZ_WAVE_SYNC();
+                    while (done_m < nmatch) {
+                        PV(uint32_t, msrc);
+                        PV(uint32_t, mtk);
+                        PV(uint32_t, mend);
+                        MZ_LANES {
+                            const uint32_t g = done_m + ((uint32_t)lane >> 4);
+                            P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 64u;
+                        }
+                        MZ_GATHER(mtk, tk, P(msrc));
+                        MZ_GATHER(mend, oend, P(msrc));
+                        uint64_t bad, dep;
+                        MZ_LANES {
+                            if (P(msrc) >= 64u) { P(mtk) = 0; P(mend) = 0; }
+                        }
+                        MZ_BALLOT(bad, P(msrc) < 64u && (P(mtk) >> 16) > out_pos + P(mend) - ((P(mtk) >> 7) & 511u));
+                        if (bad) {
+                            status = MZHIP_DATA_ERROR; /* invalid distance too far back */
+                            goto finish;
+                        }
+                        /* independent iff the source ends at or before this step's first output byte:
+                         * out_pos + mend - dist <= out_pos  (which also implies dist >= len, no self-overlap) */
+                        MZ_BALLOT(dep, P(msrc) < 64u && P(mend) > (P(mtk) >> 16));
+                        if (dep) { break; }
+                        MZ_LANES {
+                            if (P(msrc) < 64u) {
+                                const uint32_t ln = (P(mtk) >> 7) & 511u, dist = P(mtk) >> 16;
+                                const uint32_t dst = out_pos + P(mend) - ln;
+                                for (uint32_t i = (uint32_t)lane & 15u; i < ln; i += 16u) out[dst + i] = out[dst - dist + i];
+                            }
+                        }
+                        MZ_WAVE_SYNC();
+                        done_m += 4u;
+                    }
+                    /* in-order cooperative path for what is left (64 bytes per instruction) */
+                    while (done_m < nmatch) {
+                        const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]);
+                        const uint32_t t = MZ_READLANE(tk, tl);
+                        const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;
+                        const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;
+                        if (dist > dst) {
+                            status = MZHIP_DATA_ERROR; /* invalid distance too far back */
+                            goto finish;
+                        }
+                        const uint8_t *src = out + (dst - dist);
+                        if (dist >= ln) {
+                            MZ_LANES {
+                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i];
+                            }
+                        } else { /* overlapping run: byte i repeats with period dist */
+                            MZ_LANES {
+                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i % dist];
+                            }
+                        }
+                        MZ_WAVE_SYNC();
+                        done_m++;
+                    }
+                }
+                out_pos += total;
+                MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);
+                if (chain_err != MZHIP_OK) {
+                    status = chain_err;
+                    goto finish;
+                }
+                if (eob) break;
             }
-            out_pos += total;
-            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);
-            if (chain_err != MZHIP_OK) {
-                status = chain_err;
-                goto finish;
-            }
-            if (eob) break;
         }
     }
 

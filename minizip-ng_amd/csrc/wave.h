@@ -50,6 +50,24 @@
         (dst) = _xor_acc;                            \
     } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) (++*(ptr))
+/* dst[lane] = src[idx(lane)] -- a cross-lane gather (ds_bpermute on the device) */
+#define MZ_GATHER(dst, src, idx_expr)                                \
+    do {                                                             \
+        uint32_t _gt[64];                                            \
+        for (int lane = 0; lane < 64; ++lane)                        \
+            _gt[lane] = src[(uint32_t)(idx_expr) & 63u];             \
+        for (int lane = 0; lane < 64; ++lane)                        \
+            dst[lane] = _gt[lane];                                   \
+    } while (0)
+/* inclusive prefix sum across the wave */
+#define MZ_INCL_SCAN(dst, src)                                       \
+    do {                                                             \
+        uint32_t _sc = 0;                                            \
+        for (int lane = 0; lane < 64; ++lane) {                      \
+            _sc += src[lane];                                        \
+            dst[lane] = _sc;                                         \
+        }                                                            \
+    } while (0)
 MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 MZ_DEV uint32_t mz_brev32(uint32_t v) {
@@ -99,6 +117,21 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
         (dst) = MZ_UNIFORM(_xor_acc);                                   \
     } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
+#define MZ_GATHER(dst, src, idx_expr) ((dst) = (uint32_t)__shfl((int)(src), (int)(idx_expr), 64))
+/* inclusive wave64 prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes
+ * (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 to carry row totals (gfx9 DPP controls). */
+#define MZ_DPP(x, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xf, 0xf, false))
+__device__ __forceinline__ uint32_t mz_wave_incl_scan(uint32_t x, int lane) {
+    uint32_t t;
+    t = MZ_DPP(x, 0x111); x += ((lane & 15) >= 1) ? t : 0u;
+    t = MZ_DPP(x, 0x112); x += ((lane & 15) >= 2) ? t : 0u;
+    t = MZ_DPP(x, 0x114); x += ((lane & 15) >= 4) ? t : 0u;
+    t = MZ_DPP(x, 0x118); x += ((lane & 15) >= 8) ? t : 0u;
+    t = MZ_DPP(x, 0x142); x += ((lane & 31) >= 16) ? t : 0u;
+    t = MZ_DPP(x, 0x143); x += (lane >= 32) ? t : 0u;
+    return x;
+}
+#define MZ_INCL_SCAN(dst, src) ((dst) = mz_wave_incl_scan((src), lane))
 MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__popcll(v); }
 MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 MZ_DEV uint32_t mz_brev32(uint32_t v) { return __brev(v); }
