@@ -33,8 +33,8 @@
 #include "crc32_core.h"
 #include "wave.h"
 
-#define MZ_LROOT 10 /* literal/length fast-table index bits */
-#define MZ_DROOT 9  /* distance fast-table index bits        */
+#define MZ_LROOT 11 /* literal/length fast-table index bits */
+#define MZ_DROOT 8  /* distance fast-table index bits        */
 #define MZ_CROOT 7  /* code-length-code table bits (== max)  */
 
 /* per-wave LDS scratch */
@@ -59,6 +59,8 @@ typedef struct mz_inflate_lds {
     uint16_t lit_first[16], lit_count[16], lit_offs[16];
     uint16_t dist_first[16], dist_count[16], dist_offs[16];
     uint16_t rank_base[16];
+    uint16_t lit_lim[16];  /* left-justified 15-bit upper bound of the codes of each length */
+    int16_t lit_delta[16]; /* lit_offs[L] - lit_first[L] */
     uint32_t hist[16];
     union {
         mz_inflate_hdr_scratch h;
@@ -76,7 +78,7 @@ typedef struct mz_inflate_result {
 /* 64 bits of the stream starting at bit `bitpos`, LSB first, zero-padded past
  * the end.  Aligned dword loads; the slow path assembles bytes near the end so
  * no byte outside [in, in+in_len) is ever touched. */
-MZ_DEV uint64_t mz_bits_at(const uint8_t *in, uint32_t in_len, uint64_t bitpos) {
+MZ_DEV uint64_t mz_bits_at(const uint8_t *in, uint32_t in_len, uint32_t bitpos) {
     uint32_t byte = (uint32_t)(bitpos >> 3);
     uint32_t sh = (uint32_t)bitpos & 7u;
     const uint8_t *p = in + byte;
@@ -277,10 +279,23 @@ MZ_DEV void mz_decode_token(uint64_t w, const mz_inflate_lds *t, uint32_t *bits,
         (maxlen_out) = _max;                                                                                   \
     } while (0)
 
+/* per-length limits for the long-code (> MZ_LROOT bits) search: a 15-bit left-justified stream value v
+ * carries a code of length L iff lim[L-1] <= v < lim[L]; the symbol is lit_sym[delta[L] + (v >> (15-L))]. */
+#define MZ_LIT_LIMITS(L_)                                                                                   \
+    do {                                                                                                    \
+        MZ_LANES {                                                                                          \
+            if (lane >= 1 && lane < 16) {                                                                   \
+                (L_)->lit_lim[lane] = (uint16_t)(((uint32_t)(L_)->lit_first[lane] + (L_)->lit_count[lane]) << (15 - lane)); \
+                (L_)->lit_delta[lane] = (int16_t)((int32_t)(L_)->lit_offs[lane] - (int32_t)(L_)->lit_first[lane]); \
+            }                                                                                               \
+        }                                                                                                   \
+        MZ_WAVE_SYNC();                                                                                     \
+    } while (0)
+
 /* uniform n-bit read at the block-header level */
 #define MZ_HDR_BITS(dst, n)                                                   \
     do {                                                                      \
-        if (bitpos + (uint64_t)(n) > total_bits) {                            \
+        if (bitpos + (uint32_t)(n) > total_bits) {                            \
             status = MZHIP_BUF_ERROR;                                         \
             goto finish;                                                      \
         }                                                                     \
@@ -313,10 +328,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
                              mz_inflate_result *res) {
     MZ_LANE_DECL
-    const uint64_t total_bits = (uint64_t)in_len * 8u;
+    const uint32_t total_bits = in_len * 8u; /* in_len < 2^28, checked below */
     const uint32_t in_mis = (uint32_t)((uintptr_t)in & 3u);
     const uint8_t *in_al = in - in_mis;
-    uint64_t bitpos = 0;
+    uint32_t bitpos = 0;
     uint32_t out_pos = 0;
     int32_t status = MZHIP_OK;
     uint32_t last = 0;
@@ -325,6 +340,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     uint32_t crc_done = 0;
     MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
 
+    if (in_len >= (1u << 28)) { /* bit cursor is 32-bit: one entry's compressed stream must be < 256 MiB */
+        status = MZHIP_UNSUPPORTED;
+        goto finish;
+    }
     while (!last) {
         uint32_t hdr;
         MZ_HDR_BITS(hdr, 3);
@@ -341,7 +360,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             uint32_t len = MZ_UNIFORM((uint32_t)in[byte] | ((uint32_t)in[byte + 1] << 8));
             uint32_t nlen = MZ_UNIFORM((uint32_t)in[byte + 2] | ((uint32_t)in[byte + 3] << 8));
             byte += 4;
-            bitpos = (uint64_t)byte * 8u;
+            bitpos = byte * 8u;
             if (len != (~nlen & 0xFFFFu)) {
                 status = MZHIP_DATA_ERROR; /* invalid stored block lengths */
                 goto finish;
@@ -357,7 +376,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
             MZ_WAVE_SYNC();
             out_pos += n;
-            bitpos += (uint64_t)n * 8u;
+            bitpos += n * 8u;
             if (n < len) {
                 status = MZHIP_BUF_ERROR;
                 goto finish;
@@ -381,6 +400,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_WAVE_SYNC();
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, 288, L->lit_fast, MZ_LROOT, L->lit_sym, L->lit_first, L->lit_count,
                           L->lit_offs);
+            MZ_LIT_LIMITS(L);
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
                           L->dist_count, L->dist_offs);
         } else {
@@ -392,7 +412,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 status = MZHIP_DATA_ERROR; /* too many length or distance symbols */
                 goto finish;
             }
-            if (bitpos + 3ull * ncode > total_bits) {
+            if (bitpos + 3u * ncode > total_bits) {
                 status = MZHIP_BUF_ERROR;
                 goto finish;
             }
@@ -406,7 +426,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     L->u.h.clc_len[mz_k_order[lane]] = (uint8_t)((uint32_t)w & 7u);
                 }
             }
-            bitpos += 3ull * ncode;
+            bitpos += 3u * ncode;
             MZ_WAVE_SYNC();
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.clc_len, 19, L->u.h.clc_fast, MZ_CROOT, L->u.h.clc_sym, L->u.h.clc_first, L->u.h.clc_count,
                           L->u.h.clc_offs);
@@ -479,6 +499,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 status = MZHIP_DATA_ERROR; /* invalid literal/lengths set */
                 goto finish;
             }
+            MZ_LIT_LIMITS(L);
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + nlen, ndist, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
                           L->dist_count, L->dist_offs);
             if (left < 0 || (left > 0 && maxlen > 1)) {
@@ -497,7 +518,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             uint32_t ring_hi;                   /* blocks < ring_hi are in the ring; block ring_hi is in wpre */
             PV(uint32_t, wpre);
             {
-                const uint32_t blk = ((uint32_t)bitpos + pbase) >> 11; /* 2048 bits per block */
+                const uint32_t blk = (bitpos + pbase) >> 11; /* 2048 bits per block */
                 MZ_LANES {
                     ring[((blk & 1u) << 6) + (uint32_t)lane] = mz_load_stream_dword(in_al, in_mis, in_len, blk * 64u + (uint32_t)lane);
                     ring[(((blk + 1u) & 1u) << 6) + (uint32_t)lane] =
@@ -509,7 +530,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
 
             for (;;) {
-                const uint32_t pbit = (uint32_t)bitpos + pbase;
+                const uint32_t pbit = bitpos + pbase;
                 if ((pbit >> 11) + 1u >= ring_hi) {
                     /* the cursor entered the newest block: retire the oldest, start the next fetch */
                     MZ_LANES {
@@ -537,13 +558,18 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
                 uint64_t slow;
                 MZ_BALLOT(slow, P(nbl) == 0);
-                if (slow) { /* some lane looks at a code longer than the fast table: canonical search */
+                if (slow) { /* some lane looks at a code longer than the fast table: branch-free limit search */
                     MZ_LANES {
+                        const uint32_t v15 = mz_brev32((uint32_t)P(win)) >> 17;
+                        uint32_t len = MZ_LROOT + 1;
+#pragma unroll
+                        for (int k = MZ_LROOT + 1; k < 15; k++) len += (v15 >= L->lit_lim[k]) ? 1u : 0u;
+                        const uint32_t ok = (v15 < L->lit_lim[15]) ? 1u : 0u;
+                        const uint32_t idx = (uint32_t)((int32_t)L->lit_delta[len] + (int32_t)(v15 >> (15u - len)));
+                        const uint32_t sy = L->lit_sym[ok ? (idx < 288u ? idx : 0u) : 0u];
                         if (P(nbl) == 0) {
-                            uint32_t nb;
-                            P(syml) = mz_canon_slow((uint32_t)P(win), MZ_LROOT, L->lit_first, L->lit_count, L->lit_offs,
-                                                    L->lit_sym, &nb);
-                            P(nbl) = nb;
+                            P(syml) = sy;
+                            P(nbl) = ok ? len : 0u;
                         }
                     }
                 }
@@ -586,54 +612,48 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     const uint32_t dbase = (ds < 4u) ? (1u + ds) : (1u + ((2u + (ds & 1u)) << dex));
                     const uint32_t dlo = (uint32_t)(P(win) >> P(nb2l));
                     const uint32_t dist = dbase + ((dlo >> dn) & ((1u << dex) - 1u));
-                    uint32_t t;
-                    if (nb == 0u) {
-                        t = 15u << 16; /* invalid literal/length code: verdict needed 15 bits */
-                    } else if (sym < 256u) {
-                        t = nb | (1u << 7) | (sym << 16);
-                    } else if (sym == 256u) {
-                        t = nb | 64u;
-                    } else if (sym > 285u) {
-                        t = nb << 16; /* 286, 287 */
-                    } else if (dn == 0u) {
-                        t = (P(nb2l) + 15u) << 16; /* invalid distance code */
-                    } else if (ds > 29u) {
-                        t = (P(nb2l) + dn) << 16; /* 30, 31 */
-                    } else {
-                        t = (P(nb2l) + dn + dex) | (P(lenl) << 7) | (dist << 16);
-                    }
+                    const uint32_t nb2 = P(nb2l);
+                    const uint32_t t_match = (nb2 + dn + dex) | (P(lenl) << 7) | (dist << 16);
+                    const uint32_t t_badd = ((dn == 0u) ? (nb2 + 15u) : (nb2 + dn)) << 16; /* invalid distance code */
+                    const uint32_t t_len = (dn == 0u || ds > 29u) ? t_badd : t_match;
+                    const uint32_t t_hi = (sym > 285u) ? (nb << 16) /* 286, 287 */ : t_len;
+                    const uint32_t t_lo = (sym < 256u) ? (nb | (1u << 7) | (sym << 16)) : (nb | 64u);
+                    uint32_t t = (sym <= 256u) ? t_lo : t_hi;
+                    t = (nb == 0u) ? (15u << 16) /* invalid literal/length code: verdict needed 15 bits */ : t;
                     P(tk) = t;
                 }
 
                 /* phase 2: chain walk from offset 0 -- which lanes hold real tokens (scalar unit) */
-                const uint64_t avail = total_bits - bitpos;
+                const uint32_t avail = total_bits - bitpos;
                 uint32_t pos = 0, eob = 0;
                 uint64_t sel = 0;
                 int32_t chain_err = MZHIP_OK;
                 if (avail >= 64u + 48u) {
-                    while (pos < 64u) {
-                        const uint32_t t = MZ_READLANE(tk, pos);
+                    /* single-exit hop loop: an invalid token or the end-of-block code pushes `cur` past 63 */
+                    uint32_t cur = 0, t = 0;
+                    do {
+                        pos = cur;
+                        t = MZ_READLANE(tk, cur);
                         const uint32_t nb = t & 63u;
-                        if (nb == 0u) {
-                            chain_err = MZHIP_DATA_ERROR;
-                            break;
-                        }
-                        sel |= 1ull << pos;
-                        pos += nb;
-                        if (t & 64u) {
-                            eob = 1;
-                            break;
-                        }
+                        sel |= 1ull << cur;
+                        cur += (nb != 0u) ? nb + (t & 64u) : 64u;
+                    } while (cur < 64u);
+                    if ((t & 63u) == 0u) {
+                        sel &= ~(1ull << pos); /* the walk stopped ON an invalid token: it is not selected */
+                        chain_err = MZHIP_DATA_ERROR;
+                    } else {
+                        pos += t & 63u;
+                        eob = (t >> 6) & 1u;
                     }
                 } else { /* within 14 bytes of the end of input: also police every token's extent */
                     while (pos < 64u) {
                         const uint32_t t = MZ_READLANE(tk, pos);
                         const uint32_t nb = t & 63u;
                         if (nb == 0u) {
-                            chain_err = ((uint64_t)pos + (t >> 16) > avail) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
+                            chain_err = (pos + (t >> 16) > avail) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
                             break;
                         }
-                        if ((uint64_t)pos + nb > avail) {
+                        if (pos + nb > avail) {
                             chain_err = MZHIP_BUF_ERROR;
                             break;
                         }
@@ -685,18 +705,15 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         }
                         MZ_GATHER(mtk, tk, P(msrc));
                         MZ_GATHER(mend, oend, P(msrc));
-                        uint64_t bad, dep;
+                        uint64_t dep;
                         MZ_LANES {
                             if (P(msrc) >= 64u) { P(mtk) = 0; P(mend) = 0; }
                         }
-                        MZ_BALLOT(bad, P(msrc) < 64u && (P(mtk) >> 16) > out_pos + P(mend) - ((P(mtk) >> 7) & 511u));
-                        if (bad) {
-                            status = MZHIP_DATA_ERROR; /* invalid distance too far back */
-                            goto finish;
-                        }
-                        /* independent iff the source ends at or before this step's first output byte:
-                         * out_pos + mend - dist <= out_pos  (which also implies dist >= len, no self-overlap) */
-                        MZ_BALLOT(dep, P(msrc) < 64u && P(mend) > (P(mtk) >> 16));
+                        /* independent iff the source ends at or before this step's first output byte
+                         * (out_pos + mend - dist <= out_pos, which also rules out self-overlap) and the distance
+                         * stays inside the entry; everything else takes the in-order path below */
+                        MZ_BALLOT(dep, P(mend) > (P(mtk) >> 16) ||
+                                           (P(mtk) >> 16) > out_pos + P(mend) - ((P(mtk) >> 7) & 511u));
                         if (dep) { break; }
                         MZ_LANES {
                             if (P(msrc) < 64u) {
@@ -746,7 +763,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
 finish:
     res->status = status;
     res->out_len = out_pos;
-    res->in_used = (uint32_t)((bitpos + 7) >> 3);
+    res->in_used = (bitpos + 7u) >> 3;
     if (res->in_used > in_len) res->in_used = in_len;
     {
         uint32_t crc;

@@ -3,10 +3,10 @@
 // owns launch geometry, work distribution and the device context.
 //
 // Launch shape (MI355X: 256 CUs x 4 SIMDs, 160 KiB LDS/CU, 8 XCDs):
-//   - one wavefront per ZIP entry, 4 wavefronts per workgroup, ~4.7 KiB LDS per wave
-//     (Huffman tables only -- the LZ77 window is the output buffer itself), so 8 workgroups =
-//     32 waves fit per CU;
-//   - persistent waves: the grid is sized to the chip (CUs x 8 workgroups) and every wave pulls
+//   - one wavefront per ZIP entry, 4 wavefronts per workgroup, ~6.2 KiB LDS per wave
+//     (Huffman tables + a 512 B input ring -- the LZ77 window is the output buffer itself), so 6
+//     workgroups = 24 waves fit per CU by LDS; registers (96 VGPRs) allow 5 waves per SIMD;
+//   - persistent waves: the grid is sized to the chip (CUs x resident workgroups) and every wave pulls
 //     its next entry index from one device-scope counter, so short and long entries balance and
 //     a 100k-entry batch is a single launch with no host involvement.
 #include <hip/hip_runtime.h>
@@ -23,6 +23,9 @@
 #define MZ_CRC_TAB_BYTES 1024
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
+#ifndef MZ_MIN_WAVES_PER_SIMD
+#define MZ_MIN_WAVES_PER_SIMD 6 /* register budget: 80 VGPRs -> 6 waves per SIMD, 24 per CU (matches the LDS budget) */
+#endif
 
 struct InflateArgs {
     const uint8_t *in;
@@ -40,7 +43,7 @@ struct InflateArgs {
     const mzhip_crc_tables *tabs;
 };
 
-__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_inflate_batch(InflateArgs a) {
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_batch(InflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *crc_tab = (uint32_t *)smem;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
@@ -144,6 +147,7 @@ struct DeviceCtx {
     uint32_t *d_counters = nullptr;
     uint32_t next_counter = 0;
     int cu_count = 0;
+    int inflate_wgs_per_cu = 1;
 };
 
 constexpr int kMaxDevices = 16;
@@ -180,6 +184,11 @@ int32_t ctx_for_current(DeviceCtx **out) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         c.cu_count = prop.multiProcessorCount;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_inflate_batch, MZ_WAVES_PER_WG * 64,
+                                                         MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE) == hipSuccess &&
+            nb > 0)
+            c.inflate_wgs_per_cu = nb;
         c.ready = true;
     }
     *out = &c;
@@ -195,7 +204,7 @@ uint32_t *take_counter(DeviceCtx *c) {
 
 uint32_t grid_for(const DeviceCtx *c, uint32_t n) {
     uint32_t wgs_needed = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
-    uint32_t resident = (uint32_t)c->cu_count * 8u; /* 8 workgroups of 4 waves per CU */
+    uint32_t resident = (uint32_t)(c->cu_count * c->inflate_wgs_per_cu); /* persistent waves: fill the chip once */
     if (wgs_needed < 1) wgs_needed = 1;
     return wgs_needed < resident ? wgs_needed : resident;
 }

@@ -120,15 +120,15 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
 #define MZ_GATHER(dst, src, idx_expr) ((dst) = (uint32_t)__shfl((int)(src), (int)(idx_expr), 64))
 /* inclusive wave64 prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes
  * (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 to carry row totals (gfx9 DPP controls). */
-#define MZ_DPP(x, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xf, 0xf, false))
+#define MZ_DPP(x, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rmask), 0xf, true))
 __device__ __forceinline__ uint32_t mz_wave_incl_scan(uint32_t x, int lane) {
-    uint32_t t;
-    t = MZ_DPP(x, 0x111); x += ((lane & 15) >= 1) ? t : 0u;
-    t = MZ_DPP(x, 0x112); x += ((lane & 15) >= 2) ? t : 0u;
-    t = MZ_DPP(x, 0x114); x += ((lane & 15) >= 4) ? t : 0u;
-    t = MZ_DPP(x, 0x118); x += ((lane & 15) >= 8) ? t : 0u;
-    t = MZ_DPP(x, 0x142); x += ((lane & 31) >= 16) ? t : 0u;
-    t = MZ_DPP(x, 0x143); x += (lane >= 32) ? t : 0u;
+    (void)lane;
+    x += MZ_DPP(x, 0x111, 0xf); /* row_shr:1, lanes shifted in from outside the row read 0 */
+    x += MZ_DPP(x, 0x112, 0xf); /* row_shr:2 */
+    x += MZ_DPP(x, 0x114, 0xf); /* row_shr:4 */
+    x += MZ_DPP(x, 0x118, 0xf); /* row_shr:8 */
+    x += MZ_DPP(x, 0x142, 0xa); /* row_bcast:15 into rows 1 and 3 */
+    x += MZ_DPP(x, 0x143, 0xc); /* row_bcast:31 into rows 2 and 3 */
     return x;
 }
 #define MZ_INCL_SCAN(dst, src) ((dst) = mz_wave_incl_scan((src), lane))
