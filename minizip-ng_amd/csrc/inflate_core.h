@@ -61,6 +61,8 @@ typedef struct mz_inflate_lds {
     uint16_t rank_base[16];
     uint16_t lit_lim[16];  /* left-justified 15-bit upper bound of the codes of each length */
     int16_t lit_delta[16]; /* lit_offs[L] - lit_first[L] */
+    uint16_t dist_lim[16];
+    int16_t dist_delta[16];
     uint32_t hist[16];
     union {
         mz_inflate_hdr_scratch h;
@@ -130,76 +132,6 @@ MZ_DEV void mz_dist_base(uint32_t s, uint32_t *base, uint32_t *ext) {
         *base = 1 + ((2 + (s & 1)) << e);
         *ext = e;
     }
-}
-
-/* canonical search for codes longer than the fast table's root
- * (appnote.txt:2091-2106): v15 = next 15 stream bits, MSB-first. */
-MZ_DEV uint32_t mz_canon_slow(uint32_t lo, int root, const uint16_t *first, const uint16_t *count,
-                              const uint16_t *offs, const uint16_t *symtab, uint32_t *nbits) {
-    uint32_t v15 = mz_brev32(lo) >> 17;
-    for (int L = root + 1; L <= 15; L++) {
-        uint32_t c = v15 >> (15 - L);
-        uint32_t d = c - first[L];
-        if (d < count[L]) {
-            *nbits = (uint32_t)L;
-            return symtab[offs[L] + d];
-        }
-    }
-    *nbits = 0;
-    return 0;
-}
-
-/* A decoded candidate token.
- *   bits : total compressed bits (0 = no valid token starts here)
- *   olen : bytes it produces (1 literal, 3..258 match, 0 end-of-block)
- *   val  : literal byte | match distance | for bits==0: bits the verdict needed */
-MZ_DEV void mz_decode_token(uint64_t w, const mz_inflate_lds *t, uint32_t *bits, uint32_t *olen, uint32_t *val) {
-    uint32_t lo = (uint32_t)w;
-    uint32_t e = t->lit_fast[lo & ((1u << MZ_LROOT) - 1)];
-    uint32_t nb = e & 15u, sym = e >> 4;
-    if (nb == 0) {
-        sym = mz_canon_slow(lo, MZ_LROOT, t->lit_first, t->lit_count, t->lit_offs, t->lit_sym, &nb);
-        if (nb == 0) {
-            *bits = 0; *olen = 0; *val = 15;
-            return;
-        }
-    }
-    if (sym < 256) {
-        *bits = nb; *olen = 1; *val = sym;
-        return;
-    }
-    if (sym == 256) {
-        *bits = nb; *olen = 0; *val = 0;
-        return;
-    }
-    if (sym > 285) { /* 286, 287: invalid literal/length code */
-        *bits = 0; *olen = 0; *val = nb;
-        return;
-    }
-    uint32_t lbase, lext;
-    mz_len_base(sym - 257, &lbase, &lext);
-    uint32_t len = lbase + ((uint32_t)(w >> nb) & ((1u << lext) - 1));
-    nb += lext;
-    uint32_t dlo = (uint32_t)(w >> nb);
-    uint32_t d = t->dist_fast[dlo & ((1u << MZ_DROOT) - 1)];
-    uint32_t dn = d & 15u, dsym = d >> 4;
-    if (dn == 0) {
-        dsym = mz_canon_slow(dlo, MZ_DROOT, t->dist_first, t->dist_count, t->dist_offs, t->dist_sym, &dn);
-        if (dn == 0) {
-            *bits = 0; *olen = 0; *val = nb + 15;
-            return;
-        }
-    }
-    if (dsym > 29) { /* 30, 31: invalid distance code */
-        *bits = 0; *olen = 0; *val = nb + dn;
-        return;
-    }
-    uint32_t dbase, dext;
-    mz_dist_base(dsym, &dbase, &dext);
-    uint32_t dist = dbase + ((dlo >> dn) & ((1u << dext) - 1));
-    *bits = nb + dn + dext; /* <= 15+5+15+13 = 48 */
-    *olen = len;
-    *val = dist;
 }
 
 /* Build one Huffman decoding table from code lengths cl[0..n) with the whole
@@ -279,18 +211,36 @@ MZ_DEV void mz_decode_token(uint64_t w, const mz_inflate_lds *t, uint32_t *bits,
         (maxlen_out) = _max;                                                                                   \
     } while (0)
 
-/* per-length limits for the long-code (> MZ_LROOT bits) search: a 15-bit left-justified stream value v
- * carries a code of length L iff lim[L-1] <= v < lim[L]; the symbol is lit_sym[delta[L] + (v >> (15-L))]. */
-#define MZ_LIT_LIMITS(L_)                                                                                   \
+/* per-length limits for the long-code (> root bits) search: a 15-bit left-justified stream value v
+ * carries a code of length L iff lim[L-1] <= v < lim[L]; the symbol is symtab[delta[L] + (v >> (15-L))]. */
+#define MZ_CODE_LIMITS(lim_, delta_, first_, count_, offs_)                                                 \
     do {                                                                                                    \
         MZ_LANES {                                                                                          \
             if (lane >= 1 && lane < 16) {                                                                   \
-                (L_)->lit_lim[lane] = (uint16_t)(((uint32_t)(L_)->lit_first[lane] + (L_)->lit_count[lane]) << (15 - lane)); \
-                (L_)->lit_delta[lane] = (int16_t)((int32_t)(L_)->lit_offs[lane] - (int32_t)(L_)->lit_first[lane]); \
+                (lim_)[lane] = (uint16_t)(((uint32_t)(first_)[lane] + (count_)[lane]) << (15 - lane));      \
+                (delta_)[lane] = (int16_t)((int32_t)(offs_)[lane] - (int32_t)(first_)[lane]);               \
             }                                                                                               \
         }                                                                                                   \
         MZ_WAVE_SYNC();                                                                                     \
     } while (0)
+#define MZ_LIT_LIMITS(L_) MZ_CODE_LIMITS((L_)->lit_lim, (L_)->lit_delta, (L_)->lit_first, (L_)->lit_count, (L_)->lit_offs)
+#define MZ_DIST_LIMITS(L_) \
+    MZ_CODE_LIMITS((L_)->dist_lim, (L_)->dist_delta, (L_)->dist_first, (L_)->dist_count, (L_)->dist_offs)
+
+/* branch-free search for a code longer than `root` bits (see MZ_CODE_LIMITS): returns the symbol,
+ * *nbits = code length or 0 when no code matches (an unused code of an incomplete set) */
+MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const int16_t *delta, const uint16_t *symtab,
+                             uint32_t nsym, uint32_t *nbits) {
+    const uint32_t v15 = mz_brev32(lo) >> 17;
+    uint32_t len = (uint32_t)root + 1u;
+#pragma unroll
+    for (int k = root + 1; k < 15; k++) len += (v15 >= lim[k]) ? 1u : 0u;
+    const uint32_t ok = (v15 < lim[15]) ? 1u : 0u;
+    const uint32_t idx = (uint32_t)((int32_t)delta[len] + (int32_t)(v15 >> (15u - len)));
+    const uint32_t sy = symtab[(ok && idx < nsym) ? idx : 0u];
+    *nbits = ok ? len : 0u;
+    return sy;
+}
 
 /* uniform n-bit read at the block-header level */
 #define MZ_HDR_BITS(dst, n)                                                   \
@@ -403,6 +353,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_LIT_LIMITS(L);
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
                           L->dist_count, L->dist_offs);
+            MZ_DIST_LIMITS(L);
         } else {
             /* dynamic code, appnote.txt:2060-2106 */
             uint32_t h;
@@ -506,6 +457,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 status = MZHIP_DATA_ERROR; /* invalid distances set */
                 goto finish;
             }
+            MZ_DIST_LIMITS(L);
         }
 
         /* ---- compressed block body: speculative 64-offset decode ----
@@ -560,16 +512,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 MZ_BALLOT(slow, P(nbl) == 0);
                 if (slow) { /* some lane looks at a code longer than the fast table: branch-free limit search */
                     MZ_LANES {
-                        const uint32_t v15 = mz_brev32((uint32_t)P(win)) >> 17;
-                        uint32_t len = MZ_LROOT + 1;
-#pragma unroll
-                        for (int k = MZ_LROOT + 1; k < 15; k++) len += (v15 >= L->lit_lim[k]) ? 1u : 0u;
-                        const uint32_t ok = (v15 < L->lit_lim[15]) ? 1u : 0u;
-                        const uint32_t idx = (uint32_t)((int32_t)L->lit_delta[len] + (int32_t)(v15 >> (15u - len)));
-                        const uint32_t sy = L->lit_sym[ok ? (idx < 288u ? idx : 0u) : 0u];
+                        uint32_t nb;
+                        const uint32_t sy = mz_long_code((uint32_t)P(win), MZ_LROOT, L->lit_lim, L->lit_delta, L->lit_sym, 288u, &nb);
                         if (P(nbl) == 0) {
                             P(syml) = sy;
-                            P(nbl) = ok ? len : 0u;
+                            P(nbl) = nb;
                         }
                     }
                 }
@@ -594,10 +541,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 MZ_BALLOT(slow, P(syml) > 256u && P(dnl) == 0);
                 if (slow) {
                     MZ_LANES {
-                        if (P(syml) > 256u && P(dnl) == 0) {
-                            uint32_t dn;
-                            P(dsyml) = mz_canon_slow((uint32_t)(P(win) >> P(nb2l)), MZ_DROOT, L->dist_first, L->dist_count,
-                                                     L->dist_offs, L->dist_sym, &dn);
+                        uint32_t dn;
+                        const uint32_t sy = mz_long_code((uint32_t)(P(win) >> P(nb2l)), MZ_DROOT, L->dist_lim, L->dist_delta,
+                                                         L->dist_sym, 32u, &dn);
+                        if (P(dnl) == 0) {
+                            P(dsyml) = sy;
                             P(dnl) = dn;
                         }
                     }

@@ -56,7 +56,11 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
         MZ_WAVE_FETCH_ADD(e, a.counter);
         if (e >= a.n) break;
         mz_inflate_result r;
-        mz_inflate_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e], L, crc_tab, a.tabs, &r);
+        // entry descriptors are wave-uniform: pin them to SGPRs so addresses use the scalar base
+        const uint64_t io = a.in_off[e], oo = a.out_off[e];
+        const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
+        uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
+        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, &r);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
