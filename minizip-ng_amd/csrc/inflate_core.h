@@ -33,7 +33,9 @@
 #include "crc32_core.h"
 #include "wave.h"
 
+#ifndef MZ_LROOT
 #define MZ_LROOT 11 /* literal/length fast-table index bits */
+#endif
 #define MZ_DROOT 8  /* distance fast-table index bits        */
 #define MZ_CROOT 7  /* code-length-code table bits (== max)  */
 
@@ -571,30 +573,64 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     P(tk) = t;
                 }
 
-                /* phase 2: chain walk from offset 0 -- which lanes hold real tokens (scalar unit) */
+                /* phase 2: which candidates are real tokens?  Token i of this step starts at f^i(0), where
+                 * f(l) = l + bits(l).  Instead of hopping along that chain on the scalar unit, f is squared three
+                 * times with cross-lane gathers (f^2, f^4, f^8) and lane i (i < 16) composes f^i(0) from the binary
+                 * digits of i: seven ds_bpermute rounds, no scalar work, and the step's tokens come out COMPACTED
+                 * (lane i holds token i).  A value >= 64 is terminal: plain = bit offset where the next step
+                 * starts, |0x100 = end-of-block seen, |0x200 = invalid code at that offset.  At most 15 tokens are
+                 * retired per step; lane 15 only supplies the continuation offset. */
                 const uint32_t avail = total_bits - bitpos;
-                uint32_t pos = 0, eob = 0;
-                uint64_t sel = 0;
+                uint32_t pos, eob = 0, ntok;
                 int32_t chain_err = MZHIP_OK;
+                PV(uint32_t, cpos);
                 if (avail >= 64u + 48u) {
-                    /* single-exit hop loop: an invalid token or the end-of-block code pushes `cur` past 63 */
-                    uint32_t cur = 0, t = 0;
-                    do {
-                        pos = cur;
-                        t = MZ_READLANE(tk, cur);
-                        const uint32_t nb = t & 63u;
-                        sel |= 1ull << cur;
-                        cur += (nb != 0u) ? nb + (t & 64u) : 64u;
-                    } while (cur < 64u);
-                    if ((t & 63u) == 0u) {
-                        sel &= ~(1ull << pos); /* the walk stopped ON an invalid token: it is not selected */
-                        chain_err = MZHIP_DATA_ERROR;
-                    } else {
-                        pos += t & 63u;
-                        eob = (t >> 6) & 1u;
+                    PV(uint32_t, g1);
+                    PV(uint32_t, g2);
+                    PV(uint32_t, g4);
+                    PV(uint32_t, g8);
+                    PV(uint32_t, gt);
+                    MZ_LANES {
+                        const uint32_t t = P(tk), nb = t & 63u, nx = (uint32_t)lane + nb;
+                        P(g1) = (nb == 0u) ? (0x200u | (uint32_t)lane) : ((t & 64u) ? (0x100u | nx) : nx);
                     }
-                } else { /* within 14 bytes of the end of input: also police every token's extent */
-                    while (pos < 64u) {
+                    /* squaring f and composing f^i(0) are interleaved so that the two gathers of a round are
+                     * independent: 5 dependent rounds instead of 7 */
+                    PV(uint32_t, ct);
+                    MZ_LANES { P(cpos) = 0u; }
+                    MZ_GATHER(gt, g1, P(g1));
+                    MZ_GATHER(ct, g1, P(cpos));
+                    MZ_LANES {
+                        P(g2) = (P(g1) < 64u) ? P(gt) : P(g1);
+                        P(cpos) = ((uint32_t)lane & 1u) ? P(ct) : P(cpos);
+                    }
+                    MZ_GATHER(gt, g2, P(g2));
+                    MZ_GATHER(ct, g2, P(cpos));
+                    MZ_LANES {
+                        P(g4) = (P(g2) < 64u) ? P(gt) : P(g2);
+                        P(cpos) = (((uint32_t)lane & 2u) && P(cpos) < 64u) ? P(ct) : P(cpos);
+                    }
+                    MZ_GATHER(gt, g4, P(g4));
+                    MZ_GATHER(ct, g4, P(cpos));
+                    MZ_LANES {
+                        P(g8) = (P(g4) < 64u) ? P(gt) : P(g4);
+                        P(cpos) = (((uint32_t)lane & 4u) && P(cpos) < 64u) ? P(ct) : P(cpos);
+                    }
+                    MZ_GATHER(ct, g8, P(cpos));
+                    MZ_LANES { P(cpos) = (((uint32_t)lane & 8u) && P(cpos) < 64u) ? P(ct) : P(cpos); }
+                    uint64_t live;
+                    MZ_BALLOT(live, lane < 15 && P(cpos) < 64u);
+                    ntok = mz_popc64(live); /* tokens are lanes 0..ntok-1 (the chain never resumes once terminal) */
+                    const uint32_t term = MZ_READLANE(cpos, ntok);
+                    pos = term & 0xFFu;
+                    eob = (term >> 8) & 1u;
+                    if (term & 0x200u) chain_err = MZHIP_DATA_ERROR;
+                } else {
+                    /* within 14 bytes of the end of input: serial walk that also polices every token's extent */
+                    uint64_t sel = 0;
+                    pos = 0;
+                    ntok = 0;
+                    while (pos < 64u && ntok < 15u) {
                         const uint32_t t = MZ_READLANE(tk, pos);
                         const uint32_t nb = t & 63u;
                         if (nb == 0u) {
@@ -606,21 +642,34 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                             break;
                         }
                         sel |= 1ull << pos;
+                        ntok++;
                         pos += nb;
                         if (t & 64u) {
                             eob = 1;
                             break;
                         }
                     }
+                    MZ_LANES {
+                        if ((sel >> lane) & 1u) L->u.b.mslot[mz_popc64(sel & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                    }
+                    MZ_WAVE_SYNC();
+                    MZ_LANES { P(cpos) = ((uint32_t)lane < ntok) ? (uint32_t)L->u.b.mslot[lane & 15] : 0x400u; }
+                    MZ_WAVE_SYNC();
                 }
                 bitpos += pos;
 
-                /* phase 3: output offsets by a DPP prefix sum; literals scatter in one store */
+                /* phase 3: compacted tokens -> output offsets (prefix sum inside the first DPP row);
+                 * literals scatter in one store */
+                PV(uint32_t, tkc);
                 PV(uint32_t, olen);
                 PV(uint32_t, oend);
-                MZ_LANES { P(olen) = ((sel >> lane) & 1u) ? ((P(tk) >> 7) & 511u) : 0u; }
+                MZ_GATHER(tkc, tk, P(cpos));
+                MZ_LANES {
+                    if ((uint32_t)lane >= ntok) P(tkc) = 0u;
+                    P(olen) = (P(tkc) >> 7) & 511u;
+                }
                 MZ_INCL_SCAN(oend, olen);
-                const uint32_t total = MZ_READLANE(oend, 63);
+                const uint32_t total = MZ_READLANE(oend, 15);
                 if (total > out_cap - out_pos) {
                     status = MZHIP_OUT_FULL;
                     goto finish;
@@ -628,7 +677,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 uint64_t matm;
                 MZ_BALLOT(matm, P(olen) > 1u);
                 MZ_LANES {
-                    if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tk) >> 16);
+                    if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tkc) >> 16);
                 }
                 MZ_WAVE_SYNC();
 
@@ -651,7 +700,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                             const uint32_t g = done_m + ((uint32_t)lane >> 4);
                             P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 64u;
                         }
-                        MZ_GATHER(mtk, tk, P(msrc));
+                        MZ_GATHER(mtk, tkc, P(msrc));
                         MZ_GATHER(mend, oend, P(msrc));
                         uint64_t dep;
                         MZ_LANES {
@@ -676,7 +725,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     /* in-order cooperative path for what is left (64 bytes per instruction) */
                     while (done_m < nmatch) {
                         const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]);
-                        const uint32_t t = MZ_READLANE(tk, tl);
+                        const uint32_t t = MZ_READLANE(tkc, tl);
                         const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;
                         const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;
                         if (dist > dst) {
