@@ -7,22 +7,27 @@
  *
  * MI355X mapping (not a port of zlib's byte-serial state machine):
  *   - Huffman tables are built by the whole wave (histogram -> canonical first
- *     codes -> ranked symbols -> LDS lookup table), see mz_build_huff().
+ *     codes -> ranked symbols -> LDS lookup tables whose 32-bit entries are
+ *     ready-made tokens / operand descriptors), see MZ_BUILD_HUFF.
  *   - Symbol decode is SPECULATIVE AND PARALLEL: in every step lane l decodes
  *     the complete token (literal | length+distance | end-of-block) that would
- *     start at bit cursor+l, for all 64 bit offsets at once.  A short
- *     wave-uniform chain walk (v_readlane hops on the scalar unit) then picks
- *     the offsets that really are token starts.  One step therefore retires
- *     >= 64 bits of compressed input (about 6 tokens on text) for roughly the
- *     cost of one serial symbol decode.
- *   - Selected literals are scattered by their lanes in one store; matches
- *     (LZ77 back-references) are copied cooperatively, 64 bytes per
- *     instruction, overlapping (dist < len) runs included.
+ *     start at bit cursor+l, for all 64 bit offsets at once.
+ *   - Which candidates are real is decided without a serial walk: the successor
+ *     function f(l) = l + bits(l) is squared with cross-lane gathers and lane i
+ *     composes f^i(0); the step's tokens come out compacted in lanes 0..n-1.
+ *     One step retires >= 64 bits of compressed input (about 6 tokens on text).
+ *   - Compacted literals scatter in one store; matches (LZ77 back-references)
+ *     are copied four at a time, 16 lanes each, overlapping (dist < len) runs
+ *     and same-step dependencies falling back to an in-order cooperative copy.
  *   - The sliding window IS the output buffer: back-references read bytes this
- *     wave wrote earlier (L1/L2-resident; a wave's vector-memory operations
- *     execute in order), so no 32 KiB LDS window is needed and 32 waves/CU fit.
+ *     wave wrote earlier (a wave's vector-memory operations execute in order),
+ *     so no 32 KiB LDS window is needed; compressed input is staged through a
+ *     512-byte LDS ring with a register-held prefetch.
  *   - CRC-32 is folded from the freshly written output one 1 KiB tile at a
  *     time (crc32_core.h), so the output is never re-read from HBM.
+ *   - The kernel is VALU-issue-bound (measured), so the per-lane decode is kept
+ *     to 32-bit funnel shifts (v_alignbit), bit-field extracts and table entries
+ *     that need no arithmetic.
  *
  * Error classes mirror zlib's as the reference surfaces them
  * (mz_strm_zlib.c:159-189): malformed data -> -3, input exhausted -> -5.
@@ -34,38 +39,71 @@
 #include "wave.h"
 
 #ifndef MZ_LROOT
-#define MZ_LROOT 11 /* literal/length fast-table index bits */
+#define MZ_LROOT 9 /* literal/length fast-table index bits */
 #endif
-#define MZ_DROOT 8  /* distance fast-table index bits        */
-#define MZ_CROOT 7  /* code-length-code table bits (== max)  */
+#define MZ_DROOT 8 /* distance fast-table index bits        */
+#define MZ_CROOT 7 /* code-length-code table bits (== max)  */
+
+/* ---- table entry formats (32-bit) -------------------------------------------------------------
+ * token (what a candidate decodes to):
+ *     [5:0] total bits (0 = no valid token starts here)   [6] end-of-block
+ *     [15:7] bytes produced (1 literal, 3..258 match, 0 end-of-block)
+ *     [31:16] literal byte | match distance | (invalid) number of bits the verdict needed
+ * literal/length table entry = descriptor + code length in [5:0]; 0 = no code of <= root bits here:
+ *     literal      : 0x80 | byte << 16                    (already the finished token)
+ *     end-of-block : 0x40                                 (already the finished token)
+ *     length       : MZ_E_LEN | base << 7 | extra_bits << 16
+ *     286, 287     : MZ_E_BAD
+ * distance table entry = descriptor + code length in [3:0]; 0 = none:
+ *     distance     : extra_bits << 4 | base << 8
+ *     30, 31       : MZ_E_LEN (reused as the "invalid" mark)
+ * code-length-code entry: symbol << 4 | length. */
+#define MZ_E_LEN 0x80000000u
+#define MZ_E_BAD 0x40000000u
+
+MZ_DEV uint32_t mz_lit_ent(uint32_t s) {
+    if (s < 256u) return 0x80u | (s << 16);
+    if (s == 256u) return 0x40u;
+    if (s > 285u) return MZ_E_BAD;
+    s -= 257u; /* length base / extra bits, appnote.txt:2107-2120, computed */
+    if (s < 8u) return MZ_E_LEN | ((3u + s) << 7);
+    if (s == 28u) return MZ_E_LEN | (258u << 7);
+    const uint32_t ex = (s - 4u) >> 2;
+    return MZ_E_LEN | ((3u + ((4u + (s & 3u)) << ex)) << 7) | (ex << 16);
+}
+MZ_DEV uint32_t mz_dist_ent(uint32_t s) {
+    if (s > 29u) return MZ_E_LEN;
+    if (s < 4u) return (1u + s) << 8; /* distance base / extra bits, appnote.txt:2122-2133, computed */
+    const uint32_t ex = (s - 2u) >> 1;
+    return (ex << 4) | ((1u + ((2u + (s & 1u)) << ex)) << 8);
+}
+MZ_DEV uint32_t mz_clc_ent(uint32_t s) { return s << 4; }
 
 /* per-wave LDS scratch */
-typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed */
+typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed and tables are built */
     uint16_t clc_fast[1 << MZ_CROOT];
-    uint16_t clc_sym[20];
-    uint16_t clc_first[16], clc_count[16], clc_offs[16];
+    uint32_t clc_ent[20];
+    uint16_t first[16], count[16], offs[16]; /* canonical first code / population / rank offset per length */
+    uint16_t rank_base[16];
+    uint32_t hist[16];
     uint8_t cl[320];     /* code lengths of the current block (nlen + ndist <= 316; fixed: 288 + 32) */
     uint8_t clc_len[20]; /* lengths of the code-length code */
 } mz_inflate_hdr_scratch;
 
 typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
     uint32_t ring[128]; /* 512 B of compressed stream: aligned dword j of the entry at ring[j & 127] */
-    uint8_t mslot[64];  /* lane ids of this step's match tokens, compacted */
+    uint16_t mslot[64]; /* 4 * lane id of this step's match tokens, compacted */
 } mz_inflate_body_scratch;
 
 typedef struct mz_inflate_lds {
-    uint16_t lit_fast[1 << MZ_LROOT]; /* (symbol << 4) | code length, 0 = not a short code */
-    uint16_t dist_fast[1 << MZ_DROOT];
-    uint16_t lit_sym[288]; /* symbols sorted by (length, value): canonical order */
-    uint16_t dist_sym[32];
-    uint16_t lit_first[16], lit_count[16], lit_offs[16];
-    uint16_t dist_first[16], dist_count[16], dist_offs[16];
-    uint16_t rank_base[16];
+    uint32_t lit_fast[1 << MZ_LROOT];
+    uint32_t dist_fast[1 << MZ_DROOT];
+    uint32_t lit_ent[288]; /* descriptors in canonical (length, symbol) order, for codes longer than the root */
+    uint32_t dist_ent[32];
     uint16_t lit_lim[16];  /* left-justified 15-bit upper bound of the codes of each length */
-    int16_t lit_delta[16]; /* lit_offs[L] - lit_first[L] */
+    int16_t lit_delta[16]; /* rank offset - first code, per length */
     uint16_t dist_lim[16];
     int16_t dist_delta[16];
-    uint32_t hist[16];
     union {
         mz_inflate_hdr_scratch h;
         mz_inflate_body_scratch b;
@@ -79,9 +117,26 @@ typedef struct mz_inflate_result {
     uint32_t crc;
 } mz_inflate_result;
 
+/* 32 bits of (hi:lo) starting at bit (s & 31): v_alignbit_b32 */
+MZ_DEV uint32_t mz_funnel(uint32_t hi, uint32_t lo, uint32_t s) {
+#if defined(MZHIP_HOST_EMUL)
+    s &= 31u;
+    return s ? ((lo >> s) | (hi << (32u - s))) : lo;
+#else
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#endif
+}
+/* bits [off, off+width) of x, width 0 -> 0: v_bfe_u32 */
+MZ_DEV uint32_t mz_bfe(uint32_t x, uint32_t off, uint32_t width) {
+#if defined(MZHIP_HOST_EMUL)
+    return width ? ((x >> off) & (0xFFFFFFFFu >> (32u - width))) : 0u;
+#else
+    return __builtin_amdgcn_ubfe(x, off, width);
+#endif
+}
+
 /* 64 bits of the stream starting at bit `bitpos`, LSB first, zero-padded past
- * the end.  Aligned dword loads; the slow path assembles bytes near the end so
- * no byte outside [in, in+in_len) is ever touched. */
+ * the end (block headers only; the body reads the LDS ring). */
 MZ_DEV uint64_t mz_bits_at(const uint8_t *in, uint32_t in_len, uint32_t bitpos) {
     uint32_t byte = (uint32_t)(bitpos >> 3);
     uint32_t sh = (uint32_t)bitpos & 7u;
@@ -110,59 +165,57 @@ MZ_DEV uint64_t mz_bits_at(const uint8_t *in, uint32_t in_len, uint32_t bitpos) 
     return w;
 }
 
-/* length symbol 257..285 -> (base, extra bits): appnote.txt:2107-2120, computed */
-MZ_DEV void mz_len_base(uint32_t s /* sym-257 */, uint32_t *base, uint32_t *ext) {
-    if (s < 8) {
-        *base = 3 + s;
-        *ext = 0;
-    } else if (s == 28) {
-        *base = 258;
-        *ext = 0;
-    } else {
-        uint32_t e = (s - 4) >> 2;
-        *base = 3 + ((4 + (s & 3)) << e);
-        *ext = e;
-    }
-}
-/* distance symbol 0..29 -> (base, extra bits): appnote.txt:2122-2133, computed */
-MZ_DEV void mz_dist_base(uint32_t s, uint32_t *base, uint32_t *ext) {
-    if (s < 4) {
-        *base = 1 + s;
-        *ext = 0;
-    } else {
-        uint32_t e = (s - 2) >> 1;
-        *base = 1 + ((2 + (s & 1)) << e);
-        *ext = e;
-    }
+/* Branch-free search for a code longer than `root` bits.  With lim[L] = (first[L] + count[L]) << (15 - L)
+ * a 15-bit left-justified stream value v carries a code of length L iff lim[L-1] <= v < lim[L]; its
+ * descriptor is ent[delta[L] + (v >> (15 - L))].  Returns descriptor + length, or 0 when no code matches
+ * (an unused code of an incomplete set). */
+MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const int16_t *delta, const uint32_t *ent,
+                             uint32_t nent) {
+    const uint32_t v15 = mz_brev32(lo) >> 17;
+    uint32_t len = (uint32_t)root + 1u;
+#pragma unroll
+    for (int k = root + 1; k < 15; k++) len += (v15 >= lim[k]) ? 1u : 0u;
+    const uint32_t idx = (uint32_t)((int32_t)delta[len] + (int32_t)(v15 >> (15u - len)));
+    const uint32_t ok = (v15 < lim[15] && idx < nent) ? 1u : 0u;
+    const uint32_t e = ent[ok ? idx : 0u];
+    return ok ? e + len : 0u;
 }
 
-/* Build one Huffman decoding table from code lengths cl[0..n) with the whole
- * wave.  Returns (wave-uniform) the number of unused codes `left` (>0
- * incomplete, <0 over-subscribed) and the longest length in *maxlen. */
-#define MZ_BUILD_HUFF(left_out, maxlen_out, L_, cl_, n_, fast_, root_, symtab_, first_, count_, offs_)         \
+/* Build one Huffman decoding table from code lengths cl[0..n) with the whole wave: fast_[] gets
+ * ENT_(symbol) + length at every index whose low bits are the (bit-reversed) code, ent_[] gets ENT_(symbol)
+ * in canonical order.  Returns (wave-uniform) the number of unused codes `left` (>0 incomplete, <0
+ * over-subscribed) and the longest length.  lim_/delta_ (may be NULL) receive the long-code search limits. */
+#define MZ_BUILD_HUFF(left_out, maxlen_out, L_, cl_, n_, fast_, root_, ent_, ENT_, lim_, delta_)               \
     do {                                                                                                       \
+        mz_inflate_hdr_scratch *_H = &(L_)->u.h;                                                               \
+        uint16_t *_lim = (lim_);                                                                               \
+        int16_t *_dlt = (delta_);                                                                              \
         MZ_LANES {                                                                                             \
-            if (lane < 16) { (L_)->hist[lane] = 0; (L_)->rank_base[lane] = 0; }                                \
-            for (int _k = lane; _k < (1 << (root_)) / 2; _k += 64) ((uint32_t *)(fast_))[_k] = 0;              \
+            if (lane < 16) { _H->hist[lane] = 0; _H->rank_base[lane] = 0; }                                    \
+            for (int _k = lane; _k < (1 << (root_)); _k += 64) (fast_)[_k] = 0;                                \
         }                                                                                                      \
         MZ_WAVE_SYNC();                                                                                        \
         MZ_LANES {                                                                                             \
             for (int _s = lane; _s < (int)(n_); _s += 64) {                                                    \
                 uint32_t _l = (cl_)[_s];                                                                       \
-                if (_l) MZ_LDS_ATOMIC_INC(&(L_)->hist[_l]);                                                    \
+                if (_l) MZ_LDS_ATOMIC_INC(&_H->hist[_l]);                                                      \
             }                                                                                                  \
         }                                                                                                      \
         MZ_WAVE_SYNC();                                                                                        \
         int32_t _left = 1, _over = 0;                                                                          \
         uint32_t _code = 0, _off = 0, _max = 0;                                                                \
         for (int _l = 1; _l <= 15; _l++) {                                                                     \
-            uint32_t _c = MZ_UNIFORM((L_)->hist[_l]);                                                          \
+            uint32_t _c = MZ_UNIFORM(_H->hist[_l]);                                                            \
             _left = (_left << 1) - (int32_t)_c;                                                                \
             if (_left < 0) _over = 1;                                                                          \
-            MZ_LANES { /* uniform store: every lane writes the same value (no lane-0 branch) */              \
-                (first_)[_l] = (uint16_t)_code;                                                                \
-                (count_)[_l] = (uint16_t)_c;                                                                   \
-                (offs_)[_l] = (uint16_t)_off;                                                                  \
+            MZ_LANES { /* uniform stores: every lane writes the same value (no lane-0 branch) */              \
+                _H->first[_l] = (uint16_t)_code;                                                               \
+                _H->count[_l] = (uint16_t)_c;                                                                  \
+                _H->offs[_l] = (uint16_t)_off;                                                                 \
+                if (_lim) {                                                                                    \
+                    _lim[_l] = (uint16_t)((_code + _c) << (15 - _l));                                          \
+                    _dlt[_l] = (int16_t)((int32_t)_off - (int32_t)_code);                                      \
+                }                                                                                              \
             }                                                                                                  \
             _code = (_code + _c) << 1;                                                                         \
             _off += _c;                                                                                        \
@@ -185,10 +238,10 @@ MZ_DEV void mz_dist_base(uint32_t s, uint32_t *base, uint32_t *ext) {
                     uint32_t _lt = MZ_READLANE(_len, _t);                                                      \
                     uint64_t _m;                                                                               \
                     MZ_BALLOT(_m, P(_len) == _lt);                                                             \
-                    uint32_t _rb = MZ_UNIFORM((L_)->rank_base[_lt]);                                           \
+                    uint32_t _rb = MZ_UNIFORM(_H->rank_base[_lt]);                                             \
                     MZ_LANES {                                                                                 \
                         if (P(_len) == _lt) P(_rank) = _rb + mz_popc64(_m & ((1ull << lane) - 1));            \
-                        (L_)->rank_base[_lt] = (uint16_t)(_rb + mz_popc64(_m)); /* uniform store */          \
+                        _H->rank_base[_lt] = (uint16_t)(_rb + mz_popc64(_m)); /* uniform store */              \
                     }                                                                                          \
                     MZ_WAVE_SYNC();                                                                            \
                     _pending &= ~_m;                                                                           \
@@ -197,12 +250,12 @@ MZ_DEV void mz_dist_base(uint32_t s, uint32_t *base, uint32_t *ext) {
                     uint32_t _l = P(_len);                                                                     \
                     if (_l) {                                                                                  \
                         uint32_t _s = (uint32_t)(_base + lane);                                                \
-                        uint32_t _cd = (uint32_t)(first_)[_l] + P(_rank);                                      \
-                        (symtab_)[(offs_)[_l] + P(_rank)] = (uint16_t)_s;                                      \
+                        uint32_t _cd = (uint32_t)_H->first[_l] + P(_rank);                                     \
+                        uint32_t _e = ENT_(_s);                                                                \
+                        (ent_)[_H->offs[_l] + P(_rank)] = _e;                                                  \
                         if (_l <= (uint32_t)(root_)) {                                                         \
                             uint32_t _rv = mz_brev32(_cd) >> (32 - _l);                                        \
-                            uint16_t _e = (uint16_t)((_s << 4) | _l);                                          \
-                            for (uint32_t _k = _rv; _k < (1u << (root_)); _k += (1u << _l)) (fast_)[_k] = _e;  \
+                            for (uint32_t _k = _rv; _k < (1u << (root_)); _k += (1u << _l)) (fast_)[_k] = _e + _l; \
                         }                                                                                      \
                     }                                                                                          \
                 }                                                                                              \
@@ -212,37 +265,6 @@ MZ_DEV void mz_dist_base(uint32_t s, uint32_t *base, uint32_t *ext) {
         (left_out) = _over ? -1 : _left;                                                                       \
         (maxlen_out) = _max;                                                                                   \
     } while (0)
-
-/* per-length limits for the long-code (> root bits) search: a 15-bit left-justified stream value v
- * carries a code of length L iff lim[L-1] <= v < lim[L]; the symbol is symtab[delta[L] + (v >> (15-L))]. */
-#define MZ_CODE_LIMITS(lim_, delta_, first_, count_, offs_)                                                 \
-    do {                                                                                                    \
-        MZ_LANES {                                                                                          \
-            if (lane >= 1 && lane < 16) {                                                                   \
-                (lim_)[lane] = (uint16_t)(((uint32_t)(first_)[lane] + (count_)[lane]) << (15 - lane));      \
-                (delta_)[lane] = (int16_t)((int32_t)(offs_)[lane] - (int32_t)(first_)[lane]);               \
-            }                                                                                               \
-        }                                                                                                   \
-        MZ_WAVE_SYNC();                                                                                     \
-    } while (0)
-#define MZ_LIT_LIMITS(L_) MZ_CODE_LIMITS((L_)->lit_lim, (L_)->lit_delta, (L_)->lit_first, (L_)->lit_count, (L_)->lit_offs)
-#define MZ_DIST_LIMITS(L_) \
-    MZ_CODE_LIMITS((L_)->dist_lim, (L_)->dist_delta, (L_)->dist_first, (L_)->dist_count, (L_)->dist_offs)
-
-/* branch-free search for a code longer than `root` bits (see MZ_CODE_LIMITS): returns the symbol,
- * *nbits = code length or 0 when no code matches (an unused code of an incomplete set) */
-MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const int16_t *delta, const uint16_t *symtab,
-                             uint32_t nsym, uint32_t *nbits) {
-    const uint32_t v15 = mz_brev32(lo) >> 17;
-    uint32_t len = (uint32_t)root + 1u;
-#pragma unroll
-    for (int k = root + 1; k < 15; k++) len += (v15 >= lim[k]) ? 1u : 0u;
-    const uint32_t ok = (v15 < lim[15]) ? 1u : 0u;
-    const uint32_t idx = (uint32_t)((int32_t)delta[len] + (int32_t)(v15 >> (15u - len)));
-    const uint32_t sy = symtab[(ok && idx < nsym) ? idx : 0u];
-    *nbits = ok ? len : 0u;
-    return sy;
-}
 
 /* uniform n-bit read at the block-header level */
 #define MZ_HDR_BITS(dst, n)                                                   \
@@ -350,12 +372,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     L->u.h.cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
             }
             MZ_WAVE_SYNC();
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, 288, L->lit_fast, MZ_LROOT, L->lit_sym, L->lit_first, L->lit_count,
-                          L->lit_offs);
-            MZ_LIT_LIMITS(L);
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
-                          L->dist_count, L->dist_offs);
-            MZ_DIST_LIMITS(L);
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, 288, L->lit_fast, MZ_LROOT, L->lit_ent, mz_lit_ent, L->lit_lim,
+                          L->lit_delta);
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_ent, mz_dist_ent,
+                          L->dist_lim, L->dist_delta);
         } else {
             /* dynamic code, appnote.txt:2060-2106 */
             uint32_t h;
@@ -381,8 +401,8 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
             bitpos += 3u * ncode;
             MZ_WAVE_SYNC();
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.clc_len, 19, L->u.h.clc_fast, MZ_CROOT, L->u.h.clc_sym, L->u.h.clc_first, L->u.h.clc_count,
-                          L->u.h.clc_offs);
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.clc_len, 19, L->u.h.clc_fast, MZ_CROOT, L->u.h.clc_ent, mz_clc_ent,
+                          (uint16_t *)0, (int16_t *)0);
             if (left != 0) {
                 status = MZHIP_DATA_ERROR; /* invalid code lengths set */
                 goto finish;
@@ -446,20 +466,20 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 status = MZHIP_DATA_ERROR; /* invalid code -- missing end-of-block */
                 goto finish;
             }
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, nlen, L->lit_fast, MZ_LROOT, L->lit_sym, L->lit_first,
-                          L->lit_count, L->lit_offs);
+            /* incomplete sets are accepted only when the longest code is 1 bit (zlib 1.2.11 inftrees.c);
+             * the distance set may also be empty */
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, nlen, L->lit_fast, MZ_LROOT, L->lit_ent, mz_lit_ent, L->lit_lim,
+                          L->lit_delta);
             if (left < 0 || (left > 0 && maxlen != 1)) {
                 status = MZHIP_DATA_ERROR; /* invalid literal/lengths set */
                 goto finish;
             }
-            MZ_LIT_LIMITS(L);
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + nlen, ndist, L->dist_fast, MZ_DROOT, L->dist_sym, L->dist_first,
-                          L->dist_count, L->dist_offs);
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + nlen, ndist, L->dist_fast, MZ_DROOT, L->dist_ent, mz_dist_ent,
+                          L->dist_lim, L->dist_delta);
             if (left < 0 || (left > 0 && maxlen > 1)) {
                 status = MZHIP_DATA_ERROR; /* invalid distances set */
                 goto finish;
             }
-            MZ_DIST_LIMITS(L);
         }
 
         /* ---- compressed block body: speculative 64-offset decode ----
@@ -495,136 +515,110 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     MZ_WAVE_SYNC();
                 }
 
-                /* phase 1: every lane decodes the token that would start at bit cursor + lane */
-                PV(uint64_t, win);
-                PV(uint32_t, nbl);
-                PV(uint32_t, syml);
+                /* phase 1: every lane decodes the token that would start at bit cursor + lane.
+                 * w0/w1 = stream bits [0,32) / [32,64) from that offset (funnel shifts of ring dwords). */
+                PV(uint32_t, w0);
+                PV(uint32_t, w1);
+                PV(uint32_t, le); /* literal/length table entry */
                 MZ_LANES {
                     const uint32_t pl = pbit + (uint32_t)lane;
-                    const uint32_t j = pl >> 5, sh = pl & 31u;
+                    const uint32_t j = pl >> 5;
                     const uint32_t d0 = ring[j & 127u], d1 = ring[(j + 1u) & 127u], d2 = ring[(j + 2u) & 127u];
-                    uint64_t w = ((((uint64_t)d1) << 32) | d0) >> sh;
-                    w |= ((uint64_t)d2 << 1) << (63u - sh);
-                    const uint32_t e = L->lit_fast[(uint32_t)w & ((1u << MZ_LROOT) - 1)];
-                    P(win) = w;
-                    P(nbl) = e & 15u;
-                    P(syml) = e >> 4;
+                    P(w0) = mz_funnel(d1, d0, pl);
+                    P(w1) = mz_funnel(d2, d1, pl);
+                    P(le) = L->lit_fast[P(w0) & ((1u << MZ_LROOT) - 1)];
                 }
                 uint64_t slow;
-                MZ_BALLOT(slow, P(nbl) == 0);
-                if (slow) { /* some lane looks at a code longer than the fast table: branch-free limit search */
+                MZ_BALLOT(slow, P(le) == 0u);
+                if (slow) { /* some lane looks at a code longer than the fast table */
                     MZ_LANES {
-                        uint32_t nb;
-                        const uint32_t sy = mz_long_code((uint32_t)P(win), MZ_LROOT, L->lit_lim, L->lit_delta, L->lit_sym, 288u, &nb);
-                        if (P(nbl) == 0) {
-                            P(syml) = sy;
-                            P(nbl) = nb;
-                        }
+                        const uint32_t e = mz_long_code(P(w0), MZ_LROOT, L->lit_lim, L->lit_delta, L->lit_ent, 288u);
+                        if (P(le) == 0u) P(le) = e;
                     }
                 }
                 PV(uint32_t, lenl);
                 PV(uint32_t, nb2l);
-                PV(uint32_t, dnl);
-                PV(uint32_t, dsyml);
+                PV(uint32_t, dlo);
+                PV(uint32_t, de); /* distance table entry */
                 MZ_LANES {
-                    /* length base / extra bits, branch-free (appnote.txt:2107-2120) */
-                    const uint32_t s = (P(syml) - 257u) & 31u;
-                    const uint32_t ex = (s < 8u || s >= 28u) ? 0u : ((s - 4u) >> 2);
-                    uint32_t lbase = (s < 8u) ? (3u + s) : (3u + ((4u + (s & 3u)) << ex));
-                    lbase = (s == 28u) ? 258u : lbase;
-                    const uint32_t wl = (uint32_t)(P(win) >> P(nbl));
-                    P(lenl) = lbase + (wl & ((1u << ex) - 1u));
-                    const uint32_t nb2 = P(nbl) + ex;
-                    const uint32_t d = L->dist_fast[(uint32_t)(P(win) >> nb2) & ((1u << MZ_DROOT) - 1)];
+                    const uint32_t e = P(le);
+                    const uint32_t nb = e & 63u, ex = mz_bfe(e, 16, 4);
+                    P(lenl) = mz_bfe(e, 7, 9) + mz_bfe(mz_funnel(P(w1), P(w0), nb), 0, ex);
+                    const uint32_t nb2 = nb + ex; /* <= 20 */
+                    const uint32_t dl = mz_funnel(P(w1), P(w0), nb2);
                     P(nb2l) = nb2;
-                    P(dnl) = d & 15u;
-                    P(dsyml) = d >> 4;
+                    P(dlo) = dl;
+                    P(de) = L->dist_fast[dl & ((1u << MZ_DROOT) - 1)];
                 }
-                MZ_BALLOT(slow, P(syml) > 256u && P(dnl) == 0);
+                MZ_BALLOT(slow, (P(le) & MZ_E_LEN) && P(de) == 0u);
                 if (slow) {
                     MZ_LANES {
-                        uint32_t dn;
-                        const uint32_t sy = mz_long_code((uint32_t)(P(win) >> P(nb2l)), MZ_DROOT, L->dist_lim, L->dist_delta,
-                                                         L->dist_sym, 32u, &dn);
-                        if (P(dnl) == 0) {
-                            P(dsyml) = sy;
-                            P(dnl) = dn;
-                        }
+                        const uint32_t e = mz_long_code(P(dlo), MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
+                        if (P(de) == 0u) P(de) = e;
                     }
                 }
-                /* packed token: [5:0] bits (0 = invalid), [6] end-of-block, [15:7] bytes produced,
-                 * [31:16] literal byte | match distance | (invalid) bits the verdict needed */
                 PV(uint32_t, tk);
+                PV(uint32_t, g1); /* 4 * successor offset; >= 256: terminal (|0x400 end-of-block, |0x800 invalid) */
                 MZ_LANES {
-                    const uint32_t sym = P(syml), nb = P(nbl);
-                    const uint32_t ds = P(dsyml), dn = P(dnl);
-                    const uint32_t dex = (ds < 4u) ? 0u : ((ds - 2u) >> 1);
-                    const uint32_t dbase = (ds < 4u) ? (1u + ds) : (1u + ((2u + (ds & 1u)) << dex));
-                    const uint32_t dlo = (uint32_t)(P(win) >> P(nb2l));
-                    const uint32_t dist = dbase + ((dlo >> dn) & ((1u << dex) - 1u));
-                    const uint32_t nb2 = P(nb2l);
+                    const uint32_t e = P(le), d = P(de), nb2 = P(nb2l);
+                    const uint32_t dn = d & 15u, dex = mz_bfe(d, 4, 4);
+                    const uint32_t dist = mz_bfe(d, 8, 15) + mz_bfe(P(dlo), dn, dex);
                     const uint32_t t_match = (nb2 + dn + dex) | (P(lenl) << 7) | (dist << 16);
-                    const uint32_t t_badd = ((dn == 0u) ? (nb2 + 15u) : (nb2 + dn)) << 16; /* invalid distance code */
-                    const uint32_t t_len = (dn == 0u || ds > 29u) ? t_badd : t_match;
-                    const uint32_t t_hi = (sym > 285u) ? (nb << 16) /* 286, 287 */ : t_len;
-                    const uint32_t t_lo = (sym < 256u) ? (nb | (1u << 7) | (sym << 16)) : (nb | 64u);
-                    uint32_t t = (sym <= 256u) ? t_lo : t_hi;
-                    t = (nb == 0u) ? (15u << 16) /* invalid literal/length code: verdict needed 15 bits */ : t;
+                    const uint32_t t_badd = ((d == 0u) ? (nb2 + 15u) : (nb2 + dn)) << 16; /* invalid distance code */
+                    const uint32_t t_len = (d == 0u || (d & MZ_E_LEN)) ? t_badd : t_match;
+                    const uint32_t t_bad = (e == 0u) ? (15u << 16) : ((e & 63u) << 16); /* no code | 286, 287 */
+                    uint32_t t = (e & MZ_E_LEN) ? t_len : e;
+                    t = (e == 0u || (e & MZ_E_BAD)) ? t_bad : t;
                     P(tk) = t;
+                    const uint32_t nb = t & 63u;
+                    const uint32_t nx4 = 4u * ((uint32_t)lane + nb) + ((t & 64u) << 4);
+                    P(g1) = (nb == 0u) ? (0x800u | (4u * (uint32_t)lane)) : nx4;
                 }
 
                 /* phase 2: which candidates are real tokens?  Token i of this step starts at f^i(0), where
-                 * f(l) = l + bits(l).  Instead of hopping along that chain on the scalar unit, f is squared three
-                 * times with cross-lane gathers (f^2, f^4, f^8) and lane i (i < 16) composes f^i(0) from the binary
-                 * digits of i: seven ds_bpermute rounds, no scalar work, and the step's tokens come out COMPACTED
-                 * (lane i holds token i).  A value >= 64 is terminal: plain = bit offset where the next step
-                 * starts, |0x100 = end-of-block seen, |0x200 = invalid code at that offset.  At most 15 tokens are
-                 * retired per step; lane 15 only supplies the continuation offset. */
+                 * f(l) = l + bits(l).  f is squared three times with cross-lane gathers (f^2, f^4, f^8) and
+                 * lane i (i < 16) composes f^i(0) from the binary digits of i; squaring and composing are
+                 * interleaved, so it is five dependent ds_bpermute rounds, no scalar work, and the step's tokens
+                 * come out COMPACTED (lane i holds token i).  Offsets are kept multiplied by 4 (the gather's byte
+                 * address).  At most 15 tokens retire per step; lane 15 only supplies the continuation offset. */
                 const uint32_t avail = total_bits - bitpos;
                 uint32_t pos, eob = 0, ntok;
                 int32_t chain_err = MZHIP_OK;
                 PV(uint32_t, cpos);
                 if (avail >= 64u + 48u) {
-                    PV(uint32_t, g1);
                     PV(uint32_t, g2);
                     PV(uint32_t, g4);
                     PV(uint32_t, g8);
                     PV(uint32_t, gt);
-                    MZ_LANES {
-                        const uint32_t t = P(tk), nb = t & 63u, nx = (uint32_t)lane + nb;
-                        P(g1) = (nb == 0u) ? (0x200u | (uint32_t)lane) : ((t & 64u) ? (0x100u | nx) : nx);
-                    }
-                    /* squaring f and composing f^i(0) are interleaved so that the two gathers of a round are
-                     * independent: 5 dependent rounds instead of 7 */
                     PV(uint32_t, ct);
                     MZ_LANES { P(cpos) = 0u; }
-                    MZ_GATHER(gt, g1, P(g1));
-                    MZ_GATHER(ct, g1, P(cpos));
+                    MZ_GATHER4(gt, g1, P(g1));
+                    MZ_GATHER4(ct, g1, P(cpos));
                     MZ_LANES {
-                        P(g2) = (P(g1) < 64u) ? P(gt) : P(g1);
+                        P(g2) = (P(g1) < 256u) ? P(gt) : P(g1);
                         P(cpos) = ((uint32_t)lane & 1u) ? P(ct) : P(cpos);
                     }
-                    MZ_GATHER(gt, g2, P(g2));
-                    MZ_GATHER(ct, g2, P(cpos));
+                    MZ_GATHER4(gt, g2, P(g2));
+                    MZ_GATHER4(ct, g2, P(cpos));
                     MZ_LANES {
-                        P(g4) = (P(g2) < 64u) ? P(gt) : P(g2);
-                        P(cpos) = (((uint32_t)lane & 2u) && P(cpos) < 64u) ? P(ct) : P(cpos);
+                        P(g4) = (P(g2) < 256u) ? P(gt) : P(g2);
+                        P(cpos) = (((uint32_t)lane & 2u) && P(cpos) < 256u) ? P(ct) : P(cpos);
                     }
-                    MZ_GATHER(gt, g4, P(g4));
-                    MZ_GATHER(ct, g4, P(cpos));
+                    MZ_GATHER4(gt, g4, P(g4));
+                    MZ_GATHER4(ct, g4, P(cpos));
                     MZ_LANES {
-                        P(g8) = (P(g4) < 64u) ? P(gt) : P(g4);
-                        P(cpos) = (((uint32_t)lane & 4u) && P(cpos) < 64u) ? P(ct) : P(cpos);
+                        P(g8) = (P(g4) < 256u) ? P(gt) : P(g4);
+                        P(cpos) = (((uint32_t)lane & 4u) && P(cpos) < 256u) ? P(ct) : P(cpos);
                     }
-                    MZ_GATHER(ct, g8, P(cpos));
-                    MZ_LANES { P(cpos) = (((uint32_t)lane & 8u) && P(cpos) < 64u) ? P(ct) : P(cpos); }
+                    MZ_GATHER4(ct, g8, P(cpos));
+                    MZ_LANES { P(cpos) = (((uint32_t)lane & 8u) && P(cpos) < 256u) ? P(ct) : P(cpos); }
                     uint64_t live;
-                    MZ_BALLOT(live, lane < 15 && P(cpos) < 64u);
+                    MZ_BALLOT(live, lane < 15 && P(cpos) < 256u);
                     ntok = mz_popc64(live); /* tokens are lanes 0..ntok-1 (the chain never resumes once terminal) */
                     const uint32_t term = MZ_READLANE(cpos, ntok);
-                    pos = term & 0xFFu;
-                    eob = (term >> 8) & 1u;
-                    if (term & 0x200u) chain_err = MZHIP_DATA_ERROR;
+                    pos = (term >> 2) & 0xFFu;
+                    eob = (term >> 10) & 1u;
+                    if (term & 0x800u) chain_err = MZHIP_DATA_ERROR;
                 } else {
                     /* within 14 bytes of the end of input: serial walk that also polices every token's extent */
                     uint64_t sel = 0;
@@ -650,10 +644,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         }
                     }
                     MZ_LANES {
-                        if ((sel >> lane) & 1u) L->u.b.mslot[mz_popc64(sel & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                        if ((sel >> lane) & 1u) L->u.b.mslot[mz_popc64(sel & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);
                     }
                     MZ_WAVE_SYNC();
-                    MZ_LANES { P(cpos) = ((uint32_t)lane < ntok) ? (uint32_t)L->u.b.mslot[lane & 15] : 0x400u; }
+                    MZ_LANES { P(cpos) = ((uint32_t)lane < ntok) ? (uint32_t)L->u.b.mslot[lane & 15] : 0x1000u; }
                     MZ_WAVE_SYNC();
                 }
                 bitpos += pos;
@@ -663,10 +657,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 PV(uint32_t, tkc);
                 PV(uint32_t, olen);
                 PV(uint32_t, oend);
-                MZ_GATHER(tkc, tk, P(cpos));
+                MZ_GATHER4(tkc, tk, P(cpos));
                 MZ_LANES {
                     if ((uint32_t)lane >= ntok) P(tkc) = 0u;
-                    P(olen) = (P(tkc) >> 7) & 511u;
+                    P(olen) = mz_bfe(P(tkc), 7, 9);
                 }
                 MZ_INCL_SCAN(oend, olen);
                 const uint32_t total = MZ_READLANE(oend, 15);
@@ -689,7 +683,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     const uint32_t nmatch = mz_popc64(matm);
                     uint32_t done_m = 0;
                     MZ_LANES {
-                        if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+                        if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);
                     }
                     MZ_WAVE_SYNC();
                     while (done_m < nmatch) {
@@ -698,23 +692,23 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         PV(uint32_t, mend);
                         MZ_LANES {
                             const uint32_t g = done_m + ((uint32_t)lane >> 4);
-                            P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 64u;
+                            P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 256u;
                         }
-                        MZ_GATHER(mtk, tkc, P(msrc));
-                        MZ_GATHER(mend, oend, P(msrc));
+                        MZ_GATHER4(mtk, tkc, P(msrc));
+                        MZ_GATHER4(mend, oend, P(msrc));
                         uint64_t dep;
                         MZ_LANES {
-                            if (P(msrc) >= 64u) { P(mtk) = 0; P(mend) = 0; }
+                            if (P(msrc) >= 256u) { P(mtk) = 0; P(mend) = 0; }
                         }
                         /* independent iff the source ends at or before this step's first output byte
                          * (out_pos + mend - dist <= out_pos, which also rules out self-overlap) and the distance
                          * stays inside the entry; everything else takes the in-order path below */
                         MZ_BALLOT(dep, P(mend) > (P(mtk) >> 16) ||
-                                           (P(mtk) >> 16) > out_pos + P(mend) - ((P(mtk) >> 7) & 511u));
+                                           (P(mtk) >> 16) > out_pos + P(mend) - mz_bfe(P(mtk), 7, 9));
                         if (dep) { break; }
                         MZ_LANES {
-                            if (P(msrc) < 64u) {
-                                const uint32_t ln = (P(mtk) >> 7) & 511u, dist = P(mtk) >> 16;
+                            if (P(msrc) < 256u) {
+                                const uint32_t ln = mz_bfe(P(mtk), 7, 9), dist = P(mtk) >> 16;
                                 const uint32_t dst = out_pos + P(mend) - ln;
                                 for (uint32_t i = (uint32_t)lane & 15u; i < ln; i += 16u) out[dst + i] = out[dst - dist + i];
                             }
@@ -724,7 +718,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     }
                     /* in-order cooperative path for what is left (64 bytes per instruction) */
                     while (done_m < nmatch) {
-                        const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]);
+                        const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]) >> 2;
                         const uint32_t t = MZ_READLANE(tkc, tl);
                         const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;
                         const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;

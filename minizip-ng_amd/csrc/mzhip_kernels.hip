@@ -3,9 +3,9 @@
 // owns launch geometry, work distribution and the device context.
 //
 // Launch shape (MI355X: 256 CUs x 4 SIMDs, 160 KiB LDS/CU, 8 XCDs):
-//   - one wavefront per ZIP entry, 4 wavefronts per workgroup, ~6.2 KiB LDS per wave
-//     (Huffman tables + a 512 B input ring -- the LZ77 window is the output buffer itself), so 6
-//     workgroups = 24 waves fit per CU by LDS; registers (96 VGPRs) allow 5 waves per SIMD;
+//   - one wavefront per ZIP entry, 4 wavefronts per workgroup, ~5.2 KiB LDS per wave
+//     (Huffman tables + a 512 B input ring -- the LZ77 window is the output buffer itself), so 7
+//     workgroups = 28 waves fit per CU by LDS; registers (72 VGPRs) allow 7 waves per SIMD;
 //   - persistent waves: the grid is sized to the chip (CUs x resident workgroups) and every wave pulls
 //     its next entry index from one device-scope counter, so short and long entries balance and
 //     a 100k-entry batch is a single launch with no host involvement.
@@ -24,7 +24,7 @@
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
 #ifndef MZ_MIN_WAVES_PER_SIMD
-#define MZ_MIN_WAVES_PER_SIMD 6 /* register budget: 80 VGPRs -> 6 waves per SIMD, 24 per CU (matches the LDS budget) */
+#define MZ_MIN_WAVES_PER_SIMD 7 /* register budget: 72 VGPRs -> 7 waves per SIMD, 28 per CU (matches the LDS budget: 7 workgroups) */
 #endif
 
 struct InflateArgs {

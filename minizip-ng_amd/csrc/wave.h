@@ -59,6 +59,15 @@
         for (int lane = 0; lane < 64; ++lane)                        \
             dst[lane] = _gt[lane];                                   \
     } while (0)
+/* same with a byte index (4 * lane), the native form of ds_bpermute */
+#define MZ_GATHER4(dst, src, byteidx_expr)                           \
+    do {                                                             \
+        uint32_t _gt[64];                                            \
+        for (int lane = 0; lane < 64; ++lane)                        \
+            _gt[lane] = src[((uint32_t)(byteidx_expr) >> 2) & 63u];  \
+        for (int lane = 0; lane < 64; ++lane)                        \
+            dst[lane] = _gt[lane];                                   \
+    } while (0)
 /* inclusive prefix sum across the wave */
 #define MZ_INCL_SCAN(dst, src)                                       \
     do {                                                             \
@@ -118,6 +127,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
     } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
 #define MZ_GATHER(dst, src, idx_expr) ((dst) = (uint32_t)__shfl((int)(src), (int)(idx_expr), 64))
+#define MZ_GATHER4(dst, src, byteidx_expr) ((dst) = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byteidx_expr), (int)(src)))
 /* inclusive wave64 prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes
  * (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 to carry row totals (gfx9 DPP controls). */
 #define MZ_DPP(x, ctrl, rmask) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), (rmask), 0xf, true))
