@@ -91,12 +91,30 @@ MZHIP_API int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, c
                                    uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,
                                    int32_t *d_status, void *stream);
 
+/* K4: raw-DEFLATE encode (fixed-Huffman blocks) with fused CRC-32 of the input ------------- */
+
+/* Replaces, for n pieces at once, mz_stream_zlib_write/_close (mz_strm_zlib.c:203-264,280-305 -> zlib
+ * deflate(), raw, level 1) + mz_crypt_crc32_update (mz_zip.c:2064).  Piece i compresses
+ * d_in + d_in_off[i] .. + d_in_len[i] into d_out + d_out_off[i] (d_out_cap[i] >= len + len/8 + 64 always
+ * suffices).  d_final (may be NULL = all 1): 1 -> the piece is a complete raw-DEFLATE stream (a ZIP entry);
+ * 0 -> a non-final block closed by an empty stored block, so pieces of one stream concatenate on byte
+ * boundaries.  The bytes are valid DEFLATE (appnote.txt:2030-2166) but not zlib's bytes: compressor output
+ * is not a format property -- parity is "reference inflate(output) == input and CRC equal".
+ * d_crc = CRC-32 of the INPUT piece. */
+MZHIP_API int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                      void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                                      const uint8_t *d_final, uint32_t n, uint32_t *d_out_len, uint32_t *d_crc,
+                                      int32_t *d_status, void *stream);
+
 /* Host-buffer conveniences (H2D + kernel + D2H, synchronous); these are what the
  * vtbl shim uses for one-entry-at-a-time callers. */
 MZHIP_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
                                      uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
 MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                   uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+/* one segment of a stream: 64 KiB pieces, the last one final iff `final`; *crc = CRC-32 of `in` */
+MZHIP_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
+                                     uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
 MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size);
 
 /* Geometry the last launch used (for reports): workgroups, waves per workgroup, LDS bytes per workgroup. */

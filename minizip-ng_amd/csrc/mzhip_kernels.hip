@@ -18,6 +18,7 @@
 #include "../../include/mzhip.h"
 #include "inflate_core.h"
 #include "lzma_core.h"
+#include "deflate_core.h"
 
 #define MZ_WAVES_PER_WG 4
 #define MZ_CRC_TAB_BYTES 1024
@@ -136,6 +137,49 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
+        a.crc[e] = r.crc;
+        a.status[e] = r.status;
+    }
+}
+
+struct DeflateArgs {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    const uint32_t *in_len;
+    uint8_t *out;
+    const uint64_t *out_off;
+    const uint32_t *out_cap;
+    const uint8_t *final_flag; // may be null: every piece is a complete stream
+    uint32_t n;
+    uint32_t *out_len;
+    uint32_t *crc;
+    int32_t *status;
+    uint32_t *counter;
+    const mzhip_crc_tables *tabs;
+};
+
+#define MZ_DEF_LDS_STRIDE ((sizeof(mz_deflate_lds) + 15) & ~(size_t)15)
+
+// K4: one wave per piece, 4 waves per workgroup, 8.3 KiB LDS per wave (hash heads + bit staging).
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *crc_tab = (uint32_t *)smem;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    const int wave = threadIdx.x >> 6;
+    mz_deflate_lds *L = (mz_deflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_DEF_LDS_STRIDE);
+    for (;;) {
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
+        if (e >= a.n) break;
+        const uint64_t io = a.in_off[e], oo = a.out_off[e];
+        const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
+        uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
+        const uint32_t fin = a.final_flag ? MZ_UNIFORM((uint32_t)a.final_flag[e]) : 1u;
+        mz_deflate_result r;
+        mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin, L, crc_tab, a.tabs, &r);
+        a.out_len[e] = r.out_len;
         a.crc[e] = r.crc;
         a.status[e] = r.status;
     }
@@ -327,6 +371,37 @@ int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint3
     return 0;
 }
 
+int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                            const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_final, uint32_t n,
+                            uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    if (n == 0) return 0;
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    DeflateArgs a;
+    a.in = (const uint8_t *)d_in;
+    a.in_off = d_in_off;
+    a.in_len = d_in_len;
+    a.out = (uint8_t *)d_out;
+    a.out_off = d_out_off;
+    a.out_cap = d_out_cap;
+    a.final_flag = d_final;
+    a.n = n;
+    a.out_len = d_out_len;
+    a.crc = d_crc;
+    a.status = d_status;
+    a.counter = take_counter(c);
+    a.tabs = c->d_tabs;
+    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
+    const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE;
+    uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
+    uint32_t resident = (uint32_t)c->cu_count * 4u; /* 35 KiB LDS per workgroup -> 4 per CU */
+    hipLaunchKernelGGL(k_deflate_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- host-buffer conveniences (synchronous): staging through one scratch allocation per call
 
 namespace {
@@ -409,6 +484,68 @@ int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
     if (in_used) *in_used = m.in_used;
     if (crc) *crc = m.crc;
     return m.status;
+}
+
+// One stream segment: split into 64 KiB pieces (one wave each); every piece but the last ends with an empty
+// stored block so the pieces concatenate on byte boundaries; the last piece is final iff `final`.
+int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
+                           uint32_t *out_len, uint32_t *crc) {
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    const uint32_t piece = 64u << 10;
+    const uint32_t np = in_len ? (in_len + piece - 1) / piece : 1u;
+    const uint32_t pcap = piece + piece / 8 + 64; /* fixed-Huffman worst case is 9/8 of the input */
+    const size_t meta = (size_t)np * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 1);
+    const size_t meta_pad = (meta + 63) & ~(size_t)63;
+    const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
+    Scratch sc;
+    HIP_TRY(hipMalloc(&sc.p, meta_pad + in_pad + (size_t)np * pcap));
+    uint8_t *base = (uint8_t *)sc.p;
+    uint8_t *hm = (uint8_t *)calloc(1, meta_pad);
+    if (!hm) return -4;
+    uint64_t *h_in_off = (uint64_t *)hm, *h_out_off = h_in_off + np;
+    uint32_t *h_in_len = (uint32_t *)(h_out_off + np), *h_out_cap = h_in_len + np, *h_out_len = h_out_cap + np,
+             *h_crc = h_out_len + np;
+    int32_t *h_status = (int32_t *)(h_crc + np);
+    uint8_t *h_final = (uint8_t *)(h_status + np);
+    for (uint32_t i = 0; i < np; i++) {
+        h_in_off[i] = meta_pad + (uint64_t)i * piece;
+        const uint32_t left = in_len - (in_len ? i * piece : 0);
+        h_in_len[i] = left < piece ? left : piece;
+        h_out_off[i] = meta_pad + in_pad + (uint64_t)i * pcap;
+        h_out_cap[i] = pcap;
+        h_final[i] = (uint8_t)((i + 1 == np && final) ? 1 : 0);
+    }
+    hipError_t he = hipMemcpy(base, hm, meta, hipMemcpyHostToDevice);
+    if (he == hipSuccess && in_len) he = hipMemcpy(base + meta_pad, in, in_len, hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        free(hm);
+        return fail("hipMemcpy (deflate input)", he);
+    }
+    uint64_t *d_in_off = (uint64_t *)base, *d_out_off = d_in_off + np;
+    uint32_t *d_in_len = (uint32_t *)(d_out_off + np), *d_out_cap = d_in_len + np, *d_out_len = d_out_cap + np,
+             *d_crc = d_out_len + np;
+    int32_t *d_status = (int32_t *)(d_crc + np);
+    uint8_t *d_final = (uint8_t *)(d_status + np);
+    rc = mzhip_deflate_batch(base, d_in_off, d_in_len, base, d_out_off, d_out_cap, d_final, np, d_out_len, d_crc,
+                             d_status, nullptr);
+    if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -104;
+    if (rc == 0 && hipMemcpy(hm, base, meta, hipMemcpyDeviceToHost) != hipSuccess) rc = -104;
+    uint32_t total = 0, k = 0;
+    for (uint32_t i = 0; rc == 0 && i < np; i++) {
+        if (h_status[i] != 0) rc = h_status[i];
+        else if (h_out_len[i] > out_cap - total) rc = MZHIP_STATUS_OUT_FULL;
+        else if (hipMemcpy(out + total, base + h_out_off[i], h_out_len[i], hipMemcpyDeviceToHost) != hipSuccess) rc = -104;
+        else {
+            total += h_out_len[i];
+            k = (i == 0) ? h_crc[0] : mzhip_crc32_combine_host(k, h_crc[i], h_in_len[i]); /* checksums only */
+        }
+    }
+    free(hm);
+    if (out_len) *out_len = total;
+    if (crc) *crc = k;
+    return rc;
 }
 
 uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {

@@ -12,7 +12,8 @@
  *                      TOTAL_IN_MAX (:141-144), negative base reads returned
  *                      verbatim (:148-149), zlib-numbered error returned instead
  *                      of a byte count once an error is latched (:186-189)
- *   close    :280-305  MZ_CLOSE_ERROR if an error is latched
+ *   write    :243-264  returns size; TOTAL_IN += size; compressed bytes go to base in <=32767-byte writes
+ *   close    :280-305  WRITE: finish the stream and flush; MZ_CLOSE_ERROR if an error is latched
  *   props    :312-355  TOTAL_IN / TOTAL_IN_MAX / TOTAL_OUT / HEADER_SIZE(0) /
  *                      COMPRESS_WINDOW get; COMPRESS_LEVEL / TOTAL_IN_MAX /
  *                      COMPRESS_WINDOW set; everything else MZ_EXIST_ERROR
@@ -95,9 +96,12 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->dev_in_used = 0;
     z->next_attempt = 0;
     if (mode & MZH_OPEN_MODE_WRITE) {
-        /* K4 (device DEFLATE encode) is not wired into the stream yet; same answer as a
-         * reference build with MZ_ZIP_NO_COMPRESSION (mz_strm_zlib.c:80-82). */
-        return MZH_SUPPORT_ERROR;
+        if (z->window_bits != -15) /* zlib / gzip wrappers: SURVEY 8(f) rank 2 */
+            return MZH_SUPPORT_ERROR;
+        if (mzhip_device_count() <= 0) {
+            z->error = MZH_STREAM_ERROR;
+            return MZH_OPEN_ERROR;
+        }
     } else if (mode & MZH_OPEN_MODE_READ) {
         if (z->window_bits != -15) /* zlib / gzip wrappers: SURVEY 8(f) rank 2 */
             return MZH_SUPPORT_ERROR;
@@ -233,11 +237,75 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
     return n;
 }
 
+/* what mz_stream_write does before dispatching (mz_strm.c:101-110) */
+static int32_t base_write(mzhip_stream *base, const void *buf, int32_t size) {
+    if (size == 0)
+        return size;
+    if (!base || !base->vtbl || !base->vtbl->write)
+        return MZH_PARAM_ERROR;
+    if (!base->vtbl->is_open || base->vtbl->is_open(base) != MZH_OK)
+        return MZH_STREAM_ERROR;
+    return base->vtbl->write(base, buf, size);
+}
+
+/* Compress what has been collected (device K4) and push it to base in staging-sized writes
+ * (the reference flushes its 32767-byte buffer the same way, mz_strm_zlib.c:196-201,211-219). */
+static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
+    if (z->wlen == 0 && !final)
+        return MZH_OK;
+    uint32_t cap = (uint32_t)(z->wlen + z->wlen / 8 + 128 + (z->wlen / 65536 + 1) * 80);
+    uint8_t *out = (uint8_t *)malloc(cap);
+    if (!out)
+        return MZH_MEM_ERROR;
+    uint32_t out_len = 0, crc = 0;
+    int32_t st = mzhip_deflate_host(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, out, cap, &out_len, &crc);
+    if (st != 0) {
+        free(out);
+        z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */
+        return MZH_DATA_ERROR;       /* mz_strm_zlib.c:233-236 */
+    }
+    uint32_t pos = 0;
+    while (pos < out_len) {
+        int32_t n = (int32_t)(out_len - pos < MZH_STAGING_BYTES ? out_len - pos : MZH_STAGING_BYTES);
+        if (base_write(z->stream.base, out + pos, n) != n) {
+            free(out);
+            return MZH_WRITE_ERROR; /* mz_strm_zlib.c:198-199 */
+        }
+        pos += (uint32_t)n;
+    }
+    free(out);
+    z->total_out += out_len;
+    z->wlen = 0;
+    return MZH_OK;
+}
+
+#define MZH_WRITE_SEGMENT (8 << 20) /* bytes collected per device launch (128 pieces of 64 KiB) */
+
 int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
-    (void)stream;
-    (void)buf;
-    (void)size;
-    return MZH_SUPPORT_ERROR;
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    const uint8_t *p = (const uint8_t *)buf;
+    int32_t left = size;
+    while (left > 0) {
+        if (z->wcap == 0) {
+            z->wbuf = (uint8_t *)malloc(MZH_WRITE_SEGMENT);
+            if (!z->wbuf)
+                return MZH_MEM_ERROR;
+            z->wcap = MZH_WRITE_SEGMENT;
+        }
+        int64_t room = z->wcap - z->wlen;
+        int32_t n = (int32_t)(left < room ? left : room);
+        memcpy(z->wbuf + z->wlen, p, (size_t)n);
+        z->wlen += n;
+        p += n;
+        left -= n;
+        if (z->wlen == z->wcap) {
+            int32_t err = flush_segment(z, 0);
+            if (err != MZH_OK)
+                return err;
+        }
+    }
+    z->total_in += size; /* mz_strm_zlib.c:261 */
+    return size;
 }
 
 int64_t mz_stream_zlib_tell(void *stream) {
@@ -254,6 +322,8 @@ int32_t mz_stream_zlib_seek(void *stream, int64_t offset, int32_t origin) {
 
 int32_t mz_stream_zlib_close(void *stream) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
+    if (z->mode & MZH_OPEN_MODE_WRITE)
+        flush_segment(z, 1); /* deflate(Z_FINISH) + flush, return value ignored like mz_strm_zlib.c:287-288 */
     z->initialized = 0;
     free(z->in);
     free(z->out);

@@ -50,6 +50,7 @@
         (dst) = _xor_acc;                            \
     } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) (++*(ptr))
+#define MZ_LDS_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
 /* dst[lane] = src[idx(lane)] -- a cross-lane gather (ds_bpermute on the device) */
 #define MZ_GATHER(dst, src, idx_expr)                                \
     do {                                                             \
@@ -126,6 +127,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
         (dst) = MZ_UNIFORM(_xor_acc);                                   \
     } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
+#define MZ_LDS_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
 #define MZ_GATHER(dst, src, idx_expr) ((dst) = (uint32_t)__shfl((int)(src), (int)(idx_expr), 64))
 #define MZ_GATHER4(dst, src, byteidx_expr) ((dst) = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byteidx_expr), (int)(src)))
 /* inclusive wave64 prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes

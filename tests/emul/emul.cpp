@@ -63,3 +63,19 @@ extern "C" int32_t emul_lzma(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     return r.status;
 }
 extern "C" uint32_t emul_lzma_lds_bytes(void) { return (uint32_t)sizeof(mz_lzma_lds); }
+
+#include "deflate_core.h"
+
+extern "C" int32_t emul_deflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
+                                uint32_t *out_len, uint32_t *crc) {
+    ready();
+    mz_deflate_lds *L = (mz_deflate_lds *)malloc(sizeof(mz_deflate_lds));
+    memset(L, 0xA5, sizeof(*L));
+    mz_deflate_result r;
+    mz_deflate_piece(in, in_len, out, out_cap, final, L, g_tabs.byte_tab, &g_tabs, &r);
+    free(L);
+    *out_len = r.out_len;
+    *crc = r.crc;
+    return r.status;
+}
+extern "C" uint32_t emul_deflate_lds_bytes(void) { return (uint32_t)sizeof(mz_deflate_lds); }

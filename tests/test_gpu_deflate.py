@@ -1,0 +1,124 @@
+"""GPU parity tests for K4 (DEFLATE encode, fixed-Huffman blocks, fused CRC-32 of the input) through the C ABI
+(mzhip_deflate_batch / mzhip_deflate_host) and through the drop-in mz_stream_zlib WRITE path.  Compressor
+output is not a format property, so parity = the reference side (oracle restatement, zlib 1.2.11, the compiled
+reference's mz_stream_zlib READ) inflates the bytes back to the input and every CRC agrees."""
+import ctypes as C
+import os
+import tempfile
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROP = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from tests import gpu_util
+
+    gpu_util.mz.require_gpu()
+    L = gpu_util.mz.lib()
+    L.mzhip_deflate_batch.restype = C.c_int32
+    L.mzhip_deflate_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 4
+    return gpu_util
+
+
+def run_deflate(gpu, datas, final=None):
+    import torch
+
+    caps = [len(d) + len(d) // 8 + 64 for d in datas]
+    b = gpu.make_batch(datas, caps)
+    n = len(datas)
+    dev = b["d_in"].device
+    out_len, crc, status = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    fin = torch.tensor(final, dtype=torch.uint8, device=dev) if final is not None else None
+    rc = gpu.mz.lib().mzhip_deflate_batch(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(),
+                                          b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(),
+                                          fin.data_ptr() if fin is not None else None, n, out_len.data_ptr(),
+                                          crc.data_ptr(), status.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    h = b["d_out"].cpu().numpy()
+    ol = out_len.cpu().numpy()
+    return [gpu.entry_bytes(b, h, i, int(ol[i])) for i in range(n)], gpu.mz.u32(crc), status.cpu().numpy()
+
+
+def test_deflate_batch_roundtrip(gpu):
+    c = synth.corpus()
+    rnd = np.random.RandomState(5)
+    datas = [b"", b"a", b"abc", b"abcd", b"aaaa", b"A" * 1000, b"ab" * 500, c[:100], c[:65536], rnd.bytes(5000),
+             c[:200000], bytes(70000), b"x" * 63, b"x" * 64, b"x" * 65, c[:70000] + c[:70000]]
+    datas += synth.slices(300, 65536, 1234) + synth.slices(500, 8192, 1235)
+    zs, crc, status = run_deflate(gpu, datas)
+    assert (status == 0).all()
+    tot_in = tot_out = 0
+    for i, d in enumerate(datas):
+        assert zlib.decompress(zs[i], -15) == d, i
+        assert crc[i] == zlib.crc32(d), i
+        tot_in += len(d)
+        tot_out += len(zs[i])
+    assert tot_out < 0.55 * tot_in
+    for i in range(0, len(datas), 37):                       # the slow restatement on a sample
+        so, used, out = oracle.inflate_raw(zs[i], len(datas[i]) + 8)
+        assert (so, used, out) == (0, len(zs[i]), datas[i]) and oracle.crc32(out) == crc[i]
+    # and back through the device decoder (K4 -> K1+K2)
+    b = gpu.make_batch(zs, [len(d) + 8 for d in datas])
+    out_len, in_used, crc2, st2 = gpu.run_inflate(b)
+    assert (st2 == 0).all() and (crc2 == crc).all() and (out_len == np.array([len(d) for d in datas])).all()
+
+
+def test_deflate_nonfinal_pieces_concatenate(gpu):
+    c = synth.corpus()
+    parts = [c[:30000], c[30000:90000], b"", c[90000:100000]]
+    zs, crc, status = run_deflate(gpu, parts, final=[0, 0, 0, 1])
+    assert (status == 0).all()
+    assert zlib.decompress(b"".join(zs), -15) == b"".join(parts)
+
+
+def test_zlib_stream_write_dropin(gpu):
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.fail("drop-in / reference libraries missing")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    c = synth.corpus()
+    rnd = np.random.RandomState(9)
+    for d in (c[:877], b"", b"test data", c[:150000], rnd.bytes(70000), c * 20):   # c*20 = 9.2 MB: > one segment
+        z, info = hip.stream_encode(8, d, level=1, chunk=65535)
+        # same contract the reference's own round-trip test checks (test_stream_compress.cc:78-82)
+        assert info["open"] == 0 and info["close"] == 0 and info["error"] == 0
+        assert info["total_in"] == len(d) and info["total_out"] == len(z)
+        r = ref.stream_decode(8, z, len(d) + 64, chunk=16384)     # decoded by the REFERENCE (zlib 1.2.11)
+        assert r["out"] == d and r["error"] == 0 and r["total_in"] == len(z)
+        h = hip.stream_decode(8, z, len(d) + 64, chunk=16384)     # and by the HIP stream
+        assert h["out"] == d and h["rets"] == r["rets"]
+
+
+def test_archives_written_through_unmodified_mz_zip(gpu):
+    """mz_zip_writer (reference, unmodified) on top of the HIP zlib stream writes an archive that the
+    all-reference reader extracts with CRC verification (mz_zip.c:2116-2128)."""
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.fail("drop-in / reference libraries missing")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(4)
+    n, size = 120, 65536
+    lens = rnd.randint(0, size + 1, size=n).astype(np.int32)
+    lens[:3] = (0, 1, size)
+    offs = rnd.randint(0, len(c) - size, size=n).astype(np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "hip_written.zip")
+        hip.zip_write(path, c, offs, lens, method=8, level=1)
+        t = ref.zip_index(path)
+        assert len(t) == n and (t[:, 0] == 8).all() and (t[:, 4] == lens).all()
+        out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+        o = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        _, crc, ulen, st = ref.zip_read_all(path, t[:, 6].copy(), nthreads=2, out=o, out_off=out_off)
+        assert (st == 0).all() and (ulen == lens).all()
+        for i in range(n):
+            assert o[out_off[i]:out_off[i] + lens[i]].tobytes() == c[offs[i]:offs[i] + lens[i]].tobytes()
+            assert crc[i] == zlib.crc32(c[offs[i]:offs[i] + lens[i]].tobytes()) == t[i, 2]

@@ -29,6 +29,7 @@ def emu():
     L = C.CDLL(so)
     L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
     L.emul_lzma.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_deflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.emul_crc32.restype = C.c_uint32
     L.emul_crc32.argtypes = [_u8p, C.c_uint32]
     return L
@@ -128,3 +129,40 @@ def test_lzma_fixture(emu, fixtures):
             continue
         st, used, out, crc = _run(emu.emul_lzma, e["payload"], e["usize"] + 4, C.c_int64(e["usize"]))
         assert (st, used, len(out), crc) == (0, e["csize"], e["usize"], e["crc"])
+
+
+def _deflate(emu, d, final=1):
+    a = np.frombuffer(d, dtype=np.uint8).copy() if len(d) else np.zeros(1, np.uint8)
+    cap = len(d) + len(d) // 8 + 64
+    out = np.zeros(cap, np.uint8)
+    ol, crc = C.c_uint32(), C.c_uint32()
+    st = emu.emul_deflate(a.ctypes.data_as(_u8p), len(d), out.ctypes.data_as(_u8p), cap, final, C.byref(ol), C.byref(crc))
+    return st, out[:ol.value].tobytes(), crc.value
+
+
+def test_deflate_roundtrip(emu):
+    """K4 parity = valid DEFLATE that the reference side inflates back to the input (oracle + zlib), CRC equal."""
+    c = synth.corpus()
+    rnd = np.random.RandomState(5)
+    cases = [b"", b"a", b"abc", b"abcd", b"aaaa", b"A" * 1000, b"ab" * 500, c[:100], c[:65536], c[1234:1234 + 8192],
+             rnd.bytes(5000), c[:200000], bytes(70000), b"x" * 63, b"x" * 64, b"x" * 65, c[:70000] + c[:70000]]
+    for d in cases:
+        st, z, crc = _deflate(emu, d)
+        assert st == 0 and crc == zlib.crc32(d) == oracle.crc32(d), len(d)
+        assert zlib.decompress(z, -15) == d, len(d)
+        so, used, out = oracle.inflate_raw(z, len(d) + 8)
+        assert (so, used, out) == (0, len(z), d), len(d)
+        # and back through the decoder core
+        st2, used2, out2, crc2 = _run(emu.emul_inflate, z, len(d) + 8)
+        assert (st2, used2, out2, crc2) == (0, len(z), d, crc)
+    assert _deflate(emu, b"")[1] == b"\x03\x00"            # the canonical empty fixed block
+    assert len(_deflate(emu, c[:65536])[1]) < 0.5 * 65536   # it does compress text
+    # non-final pieces concatenate on byte boundaries into one valid stream
+    parts = [c[:30000], c[30000:90000], b"", c[90000:100000]]
+    zs = b"".join(_deflate(emu, p, 0)[1] for p in parts[:-1]) + _deflate(emu, parts[-1], 1)[1]
+    assert zlib.decompress(zs, -15) == b"".join(parts)
+    # out_cap too small
+    a = np.frombuffer(rnd.bytes(4000), dtype=np.uint8).copy()
+    out = np.zeros(100, np.uint8)
+    ol, crc = C.c_uint32(), C.c_uint32()
+    assert emu.emul_deflate(a.ctypes.data_as(_u8p), 4000, out.ctypes.data_as(_u8p), 100, 1, C.byref(ol), C.byref(crc)) == -200
