@@ -117,6 +117,15 @@ MZHIP_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_
                                      uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
 MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size);
 
+/* Archive index (host, C) --------------------------------------------------------------- */
+
+/* One pass over a memory image of a ZIP archive -> flat entry table, 8 x int64 per entry:
+ * method, flag, crc, compressed size, uncompressed size, local-header offset, central-directory
+ * position, payload offset (-1 if the local header is unusable).  Same facts the reference yields one
+ * entry at a time (mz_zip.c:947-1100, :202-479, :2402-2412); SURVEY 8(f) row 1.  Returns the entry count
+ * (which may exceed max_entries: call again with a larger table) or MZ_FORMAT_ERROR (-103). */
+MZHIP_API int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table, int64_t max_entries);
+
 /* Geometry the last launch used (for reports): workgroups, waves per workgroup, LDS bytes per workgroup. */
 MZHIP_API void mzhip_inflate_launch_geometry(uint32_t n, uint32_t *grid, uint32_t *waves_per_wg, uint32_t *lds_bytes);
 

@@ -1,0 +1,165 @@
+"""Archive-level batch path: index a ZIP, shard its entries, decode a whole shard in a few launches.
+
+Host side of the "thousands of members in one launch" path (SURVEY 8b "Batching"): the central directory is
+indexed once by the C indexer (mzhip_zip_index_mem), the archive bytes are placed in HBM as they are (the entry
+payloads are used in place -- no repacking), and every entry of the shard is decoded by mzhip_inflate_batch /
+mzhip_lzma_batch / mzhip_crc32_batch according to its method.  The per-entry CRC is compared with the
+central-directory CRC exactly where the reference compares it (mz_zip.c:2116-2128).
+
+Sharding: entries are independent, so ranks take contiguous slices of the entry table balanced by
+compressed+uncompressed bytes; the only collective is the gather of the per-entry {crc, out_len, status} words.
+"""
+import ctypes as C
+import importlib
+import mmap
+import os
+
+import numpy as np
+
+_mz = importlib.import_module("minizip-ng_amd")
+
+COL_METHOD, COL_FLAG, COL_CRC, COL_CSIZE, COL_USIZE, COL_LOCAL, COL_CDPOS, COL_PAYLOAD = range(8)
+MZ_CRC_ERROR = -105       # mz.h:34
+MZ_SUPPORT_ERROR = -109   # mz.h:38
+
+
+def index_bytes(buf):
+    """Entry table [n, 8] int64 (columns COL_*) of the archive held in `buf` (bytes / mmap / uint8 array)."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    L = _mz.lib()
+    L.mzhip_zip_index_mem.restype = C.c_int64
+    L.mzhip_zip_index_mem.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64]
+    n = L.mzhip_zip_index_mem(a.ctypes.data, a.size, None, 0)
+    if n < 0:
+        raise _mz.MzHipError("mzhip_zip_index_mem: %d" % n)
+    t = np.zeros((max(n, 1), 8), dtype=np.int64)
+    n2 = L.mzhip_zip_index_mem(a.ctypes.data, a.size, t.ctypes.data, n)
+    assert n2 == n
+    return t[:n]
+
+
+def index_file(path):
+    with open(path, "rb") as f:
+        if os.fstat(f.fileno()).st_size == 0:
+            raise _mz.MzHipError("empty file")
+        with mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as m:
+            return index_bytes(m)
+
+
+def shard_bounds(table, world):
+    """Contiguous slices [b[r], b[r+1]) of the entry table, balanced by compressed + uncompressed bytes."""
+    w = (table[:, COL_CSIZE] + table[:, COL_USIZE] + 64).astype(np.float64)
+    cum = np.concatenate(([0.0], np.cumsum(w)))
+    targets = cum[-1] * np.arange(1, world) / world
+    cuts = np.searchsorted(cum, targets, side="left")
+    return np.concatenate(([0], cuts, [len(table)])).astype(np.int64)
+
+
+def gather_results(results, world, group=None):
+    """results: int64 tensor [n_local, 3] = (crc, out_len, status) of this rank's slice, any device.
+    All-gathers the (ragged) slices; returns the full [n, 3] table on every rank.  The ONLY collective."""
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return results
+    n_local = torch.tensor([results.shape[0]], dtype=torch.int64, device=results.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    m = int(max(int(c.item()) for c in counts))
+    pad = torch.zeros((m, 3), dtype=torch.int64, device=results.device)
+    pad[: results.shape[0]] = results
+    parts = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[: int(c.item())] for p, c in zip(parts, counts)], dim=0)
+
+
+class DeviceArchive:
+    """A ZIP archive resident in HBM, decoded shard-wise by the batch kernels."""
+
+    def __init__(self, path, device="cuda:0"):
+        import torch
+
+        _mz.require_gpu()
+        self.path = path
+        self.device = torch.device(device)
+        self.table = index_file(path)
+        self.h_file = np.fromfile(path, dtype=np.uint8)
+        self.d_file = torch.from_numpy(self.h_file).to(self.device)
+
+    def decode(self, lo=0, hi=None, keep_output=True):
+        """Decode entries [lo, hi).  Returns dict(crc u32[n], out_len i64[n], status i32[n], ok bool[n],
+        out (uint8 CUDA tensor) , out_off i64[n]).  status: 0, MZ_* / zlib-numbered errors, MZ_CRC_ERROR when
+        the CRC differs from the central directory, MZ_SUPPORT_ERROR for methods other than 0 / 8 / 14."""
+        import torch
+
+        t = self.table[lo:hi]
+        n = len(t)
+        dev = self.device
+        usize = t[:, COL_USIZE]
+        out_off = np.zeros(n, dtype=np.int64)
+        if n:
+            np.cumsum(((usize + 15) // 16 * 16)[:-1], out=out_off[1:])
+        total = int(out_off[-1] + (usize[-1] + 15) // 16 * 16) if n else 0
+        d_out = torch.empty(max(total, 16), dtype=torch.uint8, device=dev)
+        crc = np.zeros(n, dtype=np.uint32)
+        out_len = np.zeros(n, dtype=np.int64)
+        status = np.full(n, MZ_SUPPORT_ERROR, dtype=np.int32)
+        if (t[:, COL_PAYLOAD] < 0).any():
+            raise _mz.MzHipError("entry without a usable local header")
+        L = _mz.lib()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+        def dev_i64(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
+
+        def dev_i32(a):
+            return torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(dev)
+
+        with torch.cuda.device(dev):
+            for method in (8, 14, 0):
+                sel = np.nonzero((t[:, COL_METHOD] == method) & ((t[:, COL_FLAG] & 1) == 0))[0]
+                if len(sel) == 0:
+                    continue
+                k = len(sel)
+                if (t[sel, COL_CSIZE] >= 2**31).any() or (usize[sel] >= 2**31).any():
+                    raise _mz.MzHipError("entries >= 2 GiB are outside the batch path")
+                d_in_off, d_in_len = dev_i64(t[sel, COL_PAYLOAD]), dev_i32(t[sel, COL_CSIZE])
+                d_out_off, d_cap = dev_i64(out_off[sel]), dev_i32(usize[sel])
+                r_len, r_used, r_crc, r_st = (torch.zeros(k, dtype=torch.int32, device=dev) for _ in range(4))
+                if method == 8:
+                    rc = L.mzhip_inflate_batch(self.d_file.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(),
+                                               d_out.data_ptr(), d_out_off.data_ptr(), d_cap.data_ptr(), k,
+                                               r_len.data_ptr(), r_used.data_ptr(), r_crc.data_ptr(), r_st.data_ptr(),
+                                               stream)
+                elif method == 14:
+                    L.mzhip_lzma_batch.restype = C.c_int32
+                    L.mzhip_lzma_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 5
+                    d_max = dev_i64(usize[sel])   # TOTAL_OUT_MAX = uncompressed size (mz_zip.c:1845)
+                    rc = L.mzhip_lzma_batch(self.d_file.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(),
+                                            d_out.data_ptr(), d_out_off.data_ptr(), d_cap.data_ptr(), d_max.data_ptr(),
+                                            k, r_len.data_ptr(), r_used.data_ptr(), r_crc.data_ptr(), r_st.data_ptr(),
+                                            stream)
+                else:   # STORE: the payload IS the data (mz_stream_raw, mz_zip.c:1769); CRC in place, then copy
+                    rc = L.mzhip_crc32_batch(self.d_file.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), k, None,
+                                             r_crc.data_ptr(), stream)
+                    r_len = d_in_len.clone()
+                    r_used = d_in_len.clone()
+                    if keep_output:
+                        for j, e in enumerate(sel):   # host-driven D2D copies: STORE is the CPU-plumbing config
+                            c0, cl = int(t[e, COL_PAYLOAD]), int(t[e, COL_CSIZE])
+                            d_out[out_off[e]:out_off[e] + cl] = self.d_file[c0:c0 + cl]
+                if rc != 0:
+                    raise _mz.MzHipError("batch launch failed: %d %s" % (rc, L.mzhip_last_error().decode()))
+                torch.cuda.synchronize()
+                crc[sel] = _mz.u32(r_crc)
+                out_len[sel] = r_len.cpu().numpy()
+                st = r_st.cpu().numpy().astype(np.int32)
+                used = r_used.cpu().numpy().astype(np.int64)
+                # mz_zip_entry_read_close: CRC is verified iff the whole entry was consumed (mz_zip.c:2116-2128)
+                bad_crc = (st == 0) & (used == t[sel, COL_CSIZE]) & (crc[sel] != t[sel, COL_CRC].astype(np.uint32))
+                st[bad_crc] = MZ_CRC_ERROR
+                status[sel] = st
+        ok = (status == 0) & (out_len == usize)
+        return dict(crc=crc, out_len=out_len, status=status, ok=ok, out=d_out if keep_output else None,
+                    out_off=out_off)

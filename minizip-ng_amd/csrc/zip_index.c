@@ -1,0 +1,107 @@
+/* zip_index.c -- bulk central-directory indexer (host side, C).
+ *
+ * The batch path needs, for every entry of an archive, {method, flag, crc, sizes, payload offset} as one
+ * flat table so that a whole archive becomes a single device launch.  The reference produces the same
+ * facts one entry at a time (mz_zip_read_cd mz_zip.c:947-1100, mz_zip_entry_read_header :202-479,
+ * mz_zip_goto_next_entry :2402-2412, local header skip :1874-1913) with ~25 small stream reads per record;
+ * this is the "next" row f1 of SURVEY 8(f), restated as one pass over a memory image of the archive.
+ * Format: doc/zip/appnote.txt sections 4.3.7 (local header), 4.3.12 (central header), 4.3.14-4.3.16
+ * (ZIP64 end records / locator / end record), 4.5.3 (ZIP64 extended information extra field).
+ * Row layout (8 x int64) equals oracle/mz_driver.c drv_zip_index, which walks the archive with the
+ * reference's own API -- tests/test_zip_index.py compares the two row for row.
+ */
+#include <string.h>
+
+#include "mzhip.h"
+
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint64_t rd64(const uint8_t *p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
+
+#define SIG_LOCAL 0x04034b50u   /* mz_zip.c:59 */
+#define SIG_CD 0x02014b50u      /* mz_zip.c:60 */
+#define SIG_EOCD 0x06054b50u    /* mz_zip.c:61 */
+#define SIG_EOCD64 0x06064b50u  /* mz_zip.c:62 */
+#define SIG_LOC64 0x07064b50u   /* mz_zip.c:63 */
+
+int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table, int64_t max_entries) {
+    if (!zip || zip_len < 22)
+        return -103; /* MZ_FORMAT_ERROR */
+    /* end of central directory: scan back at most 1 MiB + comment (MZ_ZIP_EOCD_MAX_BACK, mz_zip.c:78-80) */
+    uint64_t lo = zip_len > (1u << 20) + 22 ? zip_len - ((1u << 20) + 22) : 0;
+    int64_t eocd = -1;
+    for (uint64_t i = zip_len - 22 + 1; i-- > lo;) {
+        if (rd32(zip + i) == SIG_EOCD) {
+            eocd = (int64_t)i;
+            break;
+        }
+    }
+    if (eocd < 0)
+        return -103;
+    uint64_t n_entries = rd16(zip + eocd + 10);
+    uint64_t cd_size = rd32(zip + eocd + 12);
+    uint64_t cd_off = rd32(zip + eocd + 16);
+    if (n_entries == 0xFFFF || cd_off == 0xFFFFFFFFu || cd_size == 0xFFFFFFFFu) {
+        /* ZIP64: locator sits right before the EOCD (appnote 4.3.15) */
+        if (eocd < 20 || rd32(zip + eocd - 20) != SIG_LOC64)
+            return -103;
+        uint64_t e64 = rd64(zip + eocd - 20 + 8);
+        if (e64 + 56 > zip_len || rd32(zip + e64) != SIG_EOCD64)
+            return -103;
+        n_entries = rd64(zip + e64 + 32);
+        cd_size = rd64(zip + e64 + 40);
+        cd_off = rd64(zip + e64 + 48);
+    }
+    if (cd_off + cd_size > zip_len)
+        return -103;
+    uint64_t p = cd_off;
+    int64_t n = 0;
+    for (uint64_t k = 0; k < n_entries; k++) {
+        if (p + 46 > zip_len || rd32(zip + p) != SIG_CD)
+            return -103;
+        const uint8_t *h = zip + p;
+        uint64_t flag = rd16(h + 8), method = rd16(h + 10), crc = rd32(h + 16);
+        uint64_t csize = rd32(h + 20), usize = rd32(h + 24);
+        uint32_t fn = rd16(h + 28), ex = rd16(h + 30), cm = rd16(h + 32);
+        uint64_t disk = rd16(h + 34);
+        uint64_t loff = rd32(h + 42);
+        if (p + 46 + fn + ex + cm > zip_len)
+            return -103;
+        /* ZIP64 extended information: only the fields that overflowed, in this fixed order (appnote 4.5.3) */
+        const uint8_t *x = h + 46 + fn, *xe = x + ex;
+        while (x + 4 <= xe) {
+            uint32_t id = rd16(x), sz = rd16(x + 2);
+            const uint8_t *q = x + 4;
+            if (q + sz > xe)
+                break;
+            if (id == 0x0001) {
+                if (usize == 0xFFFFFFFFu && q + 8 <= x + 4 + sz) { usize = rd64(q); q += 8; }
+                if (csize == 0xFFFFFFFFu && q + 8 <= x + 4 + sz) { csize = rd64(q); q += 8; }
+                if (loff == 0xFFFFFFFFu && q + 8 <= x + 4 + sz) { loff = rd64(q); q += 8; }
+                if (disk == 0xFFFF && q + 4 <= x + 4 + sz) { disk = rd32(q); q += 4; }
+            }
+            x += 4 + sz;
+        }
+        int64_t payload = -1;
+        if (loff + 30 <= zip_len && rd32(zip + loff) == SIG_LOCAL) {
+            uint64_t lfn = rd16(zip + loff + 26), lex = rd16(zip + loff + 28);
+            payload = (int64_t)(loff + 30 + lfn + lex);
+            if ((uint64_t)payload + csize > zip_len)
+                payload = -1;
+        }
+        if (n < max_entries && table) {
+            int64_t *t = table + n * 8;
+            t[0] = (int64_t)method;
+            t[1] = (int64_t)flag;
+            t[2] = (int64_t)crc;
+            t[3] = (int64_t)csize;
+            t[4] = (int64_t)usize;
+            t[5] = (int64_t)loff;
+            t[6] = (int64_t)p; /* position of this record: what mz_zip_get_entry() returns (mz_zip.c:2368) */
+            t[7] = payload;
+        }
+        n++;
+        p += 46 + fn + ex + cm;
+    }
+    return n;
+}

@@ -1,0 +1,112 @@
+"""GPU tests of the archive-level batch path (DeviceArchive): BASELINE.json's configs at test scale.
+Archives are written by the REFERENCE writer (oracle/_ref), indexed by the C indexer, decoded in HBM by the
+batch kernels, and every CRC is compared with the central directory (mz_zip.c:2116-2128) and every byte with
+the reference reader's extraction."""
+import importlib
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not oracle.have_ref():
+        pytest.fail("oracle/_ref/libmzref.so missing")
+    return importlib.import_module("minizip-ng_amd.archive"), oracle.ref()
+
+
+def _check(archive, ref, path, table_lens):
+    da = archive.DeviceArchive(path)
+    r = da.decode()
+    assert r["ok"].all(), (r["status"][~r["ok"]][:5])
+    assert (r["crc"] == da.table[:, archive.COL_CRC].astype(np.uint32)).all()
+    assert (r["out_len"] == table_lens).all()
+    # bytes vs the reference reader
+    want = np.zeros(int(table_lens.sum()) + 1, dtype=np.uint8)
+    woff = np.concatenate(([0], np.cumsum(table_lens[:-1]))).astype(np.int64)
+    _, crc_r, ulen_r, st_r = ref.zip_read_all(path, da.table[:, archive.COL_CDPOS].copy(), nthreads=4, out=want,
+                                              out_off=woff)
+    assert (st_r == 0).all() and (crc_r == r["crc"]).all()
+    h = r["out"].cpu().numpy()
+    for i in range(0, len(table_lens), max(1, len(table_lens) // 200)):
+        a = h[r["out_off"][i]:r["out_off"][i] + table_lens[i]]
+        assert (a == want[woff[i]:woff[i] + table_lens[i]]).all(), i
+    return da, r
+
+
+def test_config0_store_1k(env):
+    """STORE (method 0) 1k-entry archive, sizes uniform in [0, 256 KiB] incl. 0 and 1 byte: CRC-only path."""
+    archive, ref = env
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(1)
+    n = 1000
+    lens = rnd.randint(0, 256 * 1024 + 1, size=n).astype(np.int32)
+    lens[:2] = (0, 1)
+    offs = rnd.randint(0, len(c) - 256 * 1024 - 1, size=n).astype(np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "store.zip")
+        ref.zip_write(path, c, offs, lens, method=0, level=0)
+        _check(archive, ref, path, lens.astype(np.int64))
+
+
+def test_config1_and_2_deflate(env):
+    """DEFLATE level-6 entries: 64 KiB (config 2 shape) and 8 KiB (config 3 shape) slices, plus ragged sizes."""
+    archive, ref = env
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(2)
+    with tempfile.TemporaryDirectory() as tmp:
+        for size, n in ((65536, 1200), (8192, 5000)):
+            lens = np.full(n, size, dtype=np.int32)
+            lens[::17] = rnd.randint(0, size, size=len(lens[::17]))
+            offs = rnd.randint(0, len(c) - size - 1, size=n).astype(np.int64)
+            path = os.path.join(tmp, "d%d.zip" % size)
+            ref.zip_write(path, c, offs, lens, method=8, level=6)
+            _check(archive, ref, path, lens.astype(np.int64))
+
+
+def test_config3_lzma_1mib(env):
+    """LZMA (method 14, EOS marker) 1 MiB entries written by the reference's mz_stream_lzma."""
+    archive, ref = env
+    rnd = np.random.RandomState(3)
+    c = synth.corpus()
+    words = c.split()
+    # a seeded word-shuffle expansion of the corpus so 1 MiB entries are not periodic
+    blob = b" ".join(words[i] for i in rnd.randint(0, len(words), size=1_400_000))
+    blob = np.frombuffer(blob[:6 << 20], dtype=np.uint8)
+    n = 6
+    lens = np.full(n, 1 << 20, dtype=np.int32)
+    offs = (np.arange(n) * (1 << 20)).astype(np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "lzma.zip")
+        ref.zip_write(path, blob, offs, lens, method=14, level=6)
+        da, r = _check(archive, ref, path, lens.astype(np.int64))
+        assert (da.table[:, archive.COL_FLAG] & 2).all()       # MZ_ZIP_FLAG_LZMA_EOS_MARKER (mz_zip.c:1984)
+
+
+def test_crc_mismatch_is_reported_like_mz_zip(env):
+    """A payload whose CD CRC is wrong decodes fine but must surface MZ_CRC_ERROR (mz_zip.c:2122-2126)."""
+    archive, ref = env
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "bad.zip")
+        lens = np.full(8, 30000, dtype=np.int32)
+        ref.zip_write(path, c, np.arange(8, dtype=np.int64) * 1000, lens, method=8, level=6)
+        raw = bytearray(open(path, "rb").read())
+        t = archive.index_bytes(bytes(raw))
+        cd = int(t[3, archive.COL_CDPOS])
+        raw[cd + 16] ^= 0xFF                                     # corrupt entry 3's CRC in the central directory
+        open(path, "wb").write(raw)
+        da = archive.DeviceArchive(path)
+        r = da.decode()
+        assert r["status"][3] == archive.MZ_CRC_ERROR and (np.delete(r["status"], 3) == 0).all()
+        _, _, _, st = ref.zip_read_all(path, da.table[:, archive.COL_CDPOS].copy(), nthreads=1)
+        assert st[3] == archive.MZ_CRC_ERROR and (np.delete(st, 3) == 0).all()

@@ -1,0 +1,73 @@
+"""CPU test of the N>1 path (world_size 2, gloo): contiguous sharding of the entry table + the one collective
+(all-gather of the per-entry {crc, out_len, status} words).  The per-entry work itself is done by the ORACLE
+here -- this is a test of the host-side distribution logic, which is device-independent; on the GPU box the
+same functions carry the results of mzhip_inflate_batch (bench.py --gpus N, DeviceArchive)."""
+import importlib
+import json
+import os
+import socket
+import sys
+import tempfile
+import zipfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, zpath, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+
+    archive = importlib.import_module("minizip-ng_amd.archive")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    table = archive.index_file(zpath)
+    b = archive.shard_bounds(table, world)
+    lo, hi = int(b[rank]), int(b[rank + 1])
+    raw = open(zpath, "rb").read()
+    res = np.zeros((hi - lo, 3), dtype=np.int64)
+    for i in range(lo, hi):
+        p, cs, us = (int(table[i, k]) for k in (archive.COL_PAYLOAD, archive.COL_CSIZE, archive.COL_USIZE))
+        st, used, out = oracle.inflate_raw(raw[p:p + cs], us + 8)
+        res[i - lo] = (oracle.crc32(out), len(out), st if used == cs else -5)
+    full = archive.gather_results(torch.from_numpy(res), world).numpy()
+    ok = bool((full[:, 0] == table[:, archive.COL_CRC]).all() and (full[:, 1] == table[:, archive.COL_USIZE]).all()
+              and (full[:, 2] == 0).all() and len(full) == len(table))
+    with open(os.path.join(outdir, "r%d.json" % rank), "w") as f:
+        json.dump(dict(ok=ok, lo=lo, hi=hi, n=len(full)), f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather():
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, ROOT)
+    from tests import synth
+
+    c = synth.corpus()
+    with tempfile.TemporaryDirectory() as tmp:
+        zpath = os.path.join(tmp, "a.zip")
+        with zipfile.ZipFile(zpath, "w", zipfile.ZIP_DEFLATED) as z:
+            for i in range(301):                       # ragged sizes, incl. empty entries
+                z.writestr("e/%04d" % i, c[i * 97:i * 97 + (i * 131) % 9000])
+        world = 2
+        mp.spawn(_worker, args=(world, _free_port(), zpath, tmp), nprocs=world, join=True)
+        rs = [json.load(open(os.path.join(tmp, "r%d.json" % r))) for r in range(world)]
+        assert all(r["ok"] and r["n"] == 301 for r in rs)
+        assert rs[0]["lo"] == 0 and rs[0]["hi"] == rs[1]["lo"] and rs[1]["hi"] == 301
+        assert 0 < rs[0]["hi"] < 301

@@ -1,0 +1,82 @@
+"""CPU tests: the C bulk central-directory indexer (mzhip_zip_index_mem) against the reference's own
+entry walk (oracle/_ref: mz_zip_goto_first/next_entry + mz_zip_entry_get_info + local-header skip)."""
+import importlib
+import os
+import tempfile
+import zipfile
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+
+archive = importlib.import_module("minizip-ng_amd.archive")
+needs_ref = pytest.mark.skipif(not (oracle.have_ref() or os.path.exists("/root/reference/mz_zip.c")),
+                               reason="oracle/_ref not built and /root/reference absent")
+
+
+@needs_ref
+def test_index_matches_reference_walk():
+    ref = oracle.ref()
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(8)
+    with tempfile.TemporaryDirectory() as tmp:
+        for method, level, n, size in ((8, 6, 300, 20000), (0, 0, 1000, 3000), (14, 6, 10, 40000), (8, 1, 1, 0)):
+            lens = rnd.randint(0, size + 1, size=n).astype(np.int32)
+            offs = rnd.randint(0, len(c) - size - 1, size=n).astype(np.int64)
+            path = os.path.join(tmp, "a%d_%d.zip" % (method, n))
+            ref.zip_write(path, c, offs, lens, method=method, level=level)
+            want = ref.zip_index(path)
+            got = archive.index_file(path)
+            assert got.shape == want.shape and (got == want).all(), (method, n)
+
+
+@needs_ref
+def test_index_zip64_many_entries():
+    """> 65 535 entries forces the ZIP64 end-of-central-directory records (mz_zip.c:1011-1059)."""
+    ref = oracle.ref()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "many.zip")
+        with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+            for i in range(70000):
+                z.writestr("e/%06d" % i, b"x" * (i % 7))
+        got = archive.index_file(path)
+        assert len(got) == 70000
+        want = ref.zip_index(path)
+        assert (got == want).all()
+
+
+def test_index_python_zipfile_and_errors():
+    c = synth.corpus()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "py.zip")
+        with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED) as z:
+            for i in range(50):
+                z.writestr("f%d.txt" % i, c[i * 1000:i * 1000 + 5000 + i])
+            z.comment = b"archive comment " * 10
+        t = archive.index_file(path)
+        raw = open(path, "rb").read()
+        with zipfile.ZipFile(path) as z:
+            for i, info in enumerate(z.infolist()):
+                assert t[i, archive.COL_CRC] == info.CRC and t[i, archive.COL_CSIZE] == info.compress_size
+                assert t[i, archive.COL_USIZE] == info.file_size and t[i, archive.COL_METHOD] == 8
+                p = int(t[i, archive.COL_PAYLOAD])
+                import zlib
+                assert zlib.decompress(raw[p:p + info.compress_size], -15) == c[i * 1000:i * 1000 + 5000 + i]
+        mz = importlib.import_module("minizip-ng_amd")
+        with pytest.raises(mz.MzHipError):
+            archive.index_bytes(b"not a zip file at all, just some bytes............")
+
+
+def test_shard_bounds_balanced():
+    t = np.zeros((1000, 8), dtype=np.int64)
+    rnd = np.random.RandomState(1)
+    t[:, archive.COL_CSIZE] = rnd.randint(0, 30000, 1000)
+    t[:, archive.COL_USIZE] = t[:, archive.COL_CSIZE] * 3
+    for world in (1, 2, 3, 8):
+        b = archive.shard_bounds(t, world)
+        assert b[0] == 0 and b[-1] == 1000 and (np.diff(b) >= 0).all() and len(b) == world + 1
+        w = (t[:, archive.COL_CSIZE] + t[:, archive.COL_USIZE]).astype(float)
+        loads = [w[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(loads) <= 1.15 * (sum(loads) / world) + 1
