@@ -1,0 +1,83 @@
+"""GPU probe (not a pytest): throughput of K3 (LZMA decode) and K4 (DEFLATE encode) at config-like shapes."""
+import ctypes as C
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from tests import gpu_util, synth  # noqa: E402
+from tests.test_oracle import _zip_lzma  # noqa: E402
+
+mz = gpu_util.mz
+L = mz.lib()
+L.mzhip_lzma_batch.restype = C.c_int32
+L.mzhip_lzma_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 5
+L.mzhip_deflate_batch.restype = C.c_int32
+L.mzhip_deflate_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 4
+dev = torch.device("cuda:0")
+which = sys.argv[1] if len(sys.argv) > 1 else "both"
+
+
+def timed(fn, reps=3):
+    best = None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    return best
+
+
+if which in ("lzma", "both"):
+    n_unique, n_total, size = 16, int(sys.argv[2]) if len(sys.argv) > 2 else 2560, 1 << 20
+    rnd = np.random.RandomState(3)
+    words = synth.corpus().split()
+    datas = []
+    for u in range(n_unique):
+        blob = b" ".join(words[i] for i in rnd.randint(0, len(words), size=240000))
+        datas.append(blob[:size])
+    pays = [_zip_lzma(d) for d in datas]
+    idx = np.arange(n_total) % n_unique
+    b = gpu_util.make_batch([pays[i] for i in idx], [size] * n_total)
+    out_len, in_used, crc, status = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(4))
+    mo = torch.full((n_total,), size, dtype=torch.int64, device=dev)
+
+    def run():
+        assert L.mzhip_lzma_batch(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(),
+                                  b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(),
+                                  mo.data_ptr(), n_total, out_len.data_ptr(), in_used.data_ptr(), crc.data_ptr(),
+                                  status.data_ptr(), None) == 0
+    ms = timed(run, 2)
+    want = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)[idx]
+    ok = bool((status.cpu().numpy() == 0).all() and (mz.u32(crc) == want).all())
+    ratio = sum(len(p) for p in pays) / (n_unique * size)
+    print("LZMA decode: %d x %d B, ratio %.3f: %.1f ms  %.2f GiB/s out  ok=%s" % (
+        n_total, size, ratio, ms, n_total * size / 2**30 / (ms / 1e3), ok), flush=True)
+
+if which in ("deflate", "both"):
+    n_unique, n_total, size = 512, 20000, 65536
+    datas = synth.slices(n_unique, size, 1234)
+    idx = np.arange(n_total) % n_unique
+    b = gpu_util.make_batch([datas[i] for i in idx], [size + size // 8 + 64] * n_total)
+    out_len, crc, status = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(3))
+
+    def run2():
+        assert L.mzhip_deflate_batch(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(),
+                                     b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None,
+                                     n_total, out_len.data_ptr(), crc.data_ptr(), status.data_ptr(), None) == 0
+    ms = timed(run2)
+    want = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)[idx]
+    ol = out_len.cpu().numpy()
+    h = b["d_out"].cpu().numpy()
+    ok = bool((status.cpu().numpy() == 0).all() and (mz.u32(crc) == want).all())
+    for i in range(0, n_total, 997):
+        ok = ok and zlib.decompress(gpu_util.entry_bytes(b, h, i, int(ol[i])), -15) == datas[idx[i]]
+    print("DEFLATE encode: %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.3f  ok=%s" % (
+        n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), ok), flush=True)
