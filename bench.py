@@ -75,11 +75,11 @@ def _compress_one(off_size):
     return co.compress(d) + co.flush(), zlib.crc32(d)
 
 
-def make_unique(n_unique, size, seed, gen_seconds):
+def make_unique(n_unique, size, seed, gen_seconds, world=1):
     c = corpus()
     rnd = random.Random(seed)
     offs = [(rnd.randrange(len(c) - size), size) for _ in range(n_unique)]
-    procs = max(1, min(os.cpu_count() or 1, 64))
+    procs = max(1, min((os.cpu_count() or 1) // max(world, 1), 64))  # ranks share the host cores
     t0 = time.time()
     out = []
     with mp.Pool(procs) as pool:
@@ -157,7 +157,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     size, n = args.entry_size, args.entries
-    c, offs, pays, crcs = make_unique(args.unique, size, 1234 + rank, args.gen_seconds)
+    c, offs, pays, crcs = make_unique(args.unique, size, 1234 + rank, args.gen_seconds, world)
     U = len(pays)
     # tile the unique slices over this rank's shard; every entry gets its own bytes in HBM
     rnd = np.random.RandomState(99 + rank)

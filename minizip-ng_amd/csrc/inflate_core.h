@@ -54,12 +54,16 @@
  *     end-of-block : 0x40                                 (already the finished token)
  *     length       : MZ_E_LEN | base << 7 | extra_bits << 16
  *     286, 287     : MZ_E_BAD
+ *     long code    : MZ_E_SUB | sub-table offset << 8 | sub-table index bits   (root table only; the
+ *                    sub-table entry, indexed by the next bits of the stream, is one of the above)
  * distance table entry = descriptor + code length in [3:0]; 0 = none:
  *     distance     : extra_bits << 4 | base << 8
  *     30, 31       : MZ_E_LEN (reused as the "invalid" mark)
  * code-length-code entry: symbol << 4 | length. */
 #define MZ_E_LEN 0x80000000u
 #define MZ_E_BAD 0x40000000u
+#define MZ_E_SUB 0x20000000u
+#define MZ_LIT_SUB_ENTRIES 344 /* zlib's enough.c bound for 286 symbols, 9-bit root, 15-bit codes: 852 - 512 = 340 */
 
 MZ_DEV uint32_t mz_lit_ent(uint32_t s) {
     if (s < 256u) return 0x80u | (s << 16);
@@ -98,12 +102,11 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
 typedef struct mz_inflate_lds {
     uint32_t lit_fast[1 << MZ_LROOT];
     uint32_t dist_fast[1 << MZ_DROOT];
-    uint32_t lit_ent[288]; /* descriptors in canonical (length, symbol) order, for codes longer than the root */
-    uint32_t dist_ent[32];
-    uint16_t lit_lim[16];  /* left-justified 15-bit upper bound of the codes of each length */
-    int16_t lit_delta[16]; /* rank offset - first code, per length */
-    uint16_t dist_lim[16];
-    int16_t dist_delta[16];
+    uint32_t lit_sub[MZ_LIT_SUB_ENTRIES]; /* second-level tables for literal/length codes longer than the root
+                                             (during the build: descriptors in canonical order) */
+    uint32_t dist_ent[32]; /* distance descriptors in canonical (length, symbol) order, for codes > root */
+    uint16_t dist_lim[16]; /* left-justified 15-bit upper bound of the distance codes of each length */
+    int16_t dist_delta[16]; /* rank offset - first code, per length */
     union {
         mz_inflate_hdr_scratch h;
         mz_inflate_body_scratch b;
@@ -266,6 +269,78 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
         (maxlen_out) = _max;                                                                                   \
     } while (0)
 
+/* Second-level tables for the literal/length codes longer than MZ_LROOT bits (after MZ_BUILD_HUFF, which left
+ * the descriptors in canonical order in lit_sub[] and first/count/offs in the header scratch).  Every root index
+ * that is the prefix of long codes gets a sub-table of 2^(longest code in the group - root) entries:
+ *   A  long symbols (<= 5 per lane, kept in registers) atomicMax their length into the root entry;
+ *   B  a prefix sum over the 512 root entries hands out sub-table offsets, root entry <- MZ_E_SUB | off | bits;
+ *   C  the sub-tables are filled (shorter codes of a group replicated). */
+#define MZ_BUILD_LIT_SUB(err_out, L_)                                                                          \
+    do {                                                                                                       \
+        mz_inflate_hdr_scratch *_H = &(L_)->u.h;                                                               \
+        const uint32_t _lo = MZ_UNIFORM(_H->offs[MZ_LROOT + 1]);                                               \
+        const uint32_t _hi = MZ_UNIFORM((uint32_t)_H->offs[15] + _H->count[15]);                               \
+        PV2(uint32_t, _e5, 5);                                                                                 \
+        PV2(uint32_t, _r5, 5); /* bit-reversed code | length << 16; 0 = none */                                \
+        MZ_LANES {                                                                                             \
+            for (int _j = 0; _j < 5; _j++) {                                                                   \
+                const uint32_t _i = _lo + (uint32_t)lane + 64u * (uint32_t)_j;                                 \
+                uint32_t _rv = 0, _e = 0;                                                                      \
+                if (_i < _hi) {                                                                                \
+                    uint32_t _l = MZ_LROOT + 1;                                                                \
+                    for (int _k = MZ_LROOT + 2; _k <= 15; _k++) _l += (_i >= _H->offs[_k]) ? 1u : 0u;          \
+                    const uint32_t _cd = (uint32_t)_H->first[_l] + (_i - _H->offs[_l]);                        \
+                    _rv = (mz_brev32(_cd) >> (32u - _l)) | (_l << 16);                                         \
+                    _e = (L_)->lit_sub[_i];                                                                    \
+                    MZ_LDS_ATOMIC_MAX(&(L_)->lit_fast[_rv & ((1u << MZ_LROOT) - 1)], _l);                      \
+                }                                                                                              \
+                P(_e5)[_j] = _e;                                                                               \
+                P(_r5)[_j] = _rv;                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        MZ_WAVE_SYNC();                                                                                        \
+        PV(uint32_t, _sz);                                                                                     \
+        PV(uint32_t, _szend);                                                                                  \
+        MZ_LANES {                                                                                             \
+            uint32_t _t = 0;                                                                                   \
+            for (int _j = 0; _j < (1 << MZ_LROOT) / 64; _j++) {                                                \
+                const uint32_t _v = (L_)->lit_fast[((1 << MZ_LROOT) / 64) * lane + _j];                        \
+                _t += (_v > MZ_LROOT && _v <= 15u) ? (1u << (_v - MZ_LROOT)) : 0u;                             \
+            }                                                                                                  \
+            P(_sz) = _t;                                                                                       \
+        }                                                                                                      \
+        MZ_INCL_SCAN(_szend, _sz);                                                                             \
+        const uint32_t _total = MZ_READLANE(_szend, 63);                                                       \
+        (err_out) = (_total > MZ_LIT_SUB_ENTRIES) ? 1 : 0;                                                     \
+        if (!(err_out)) {                                                                                      \
+            MZ_LANES {                                                                                         \
+                for (int _j = lane; _j < MZ_LIT_SUB_ENTRIES; _j += 64) (L_)->lit_sub[_j] = 0u;                 \
+                uint32_t _off = P(_szend) - P(_sz);                                                            \
+                for (int _j = 0; _j < (1 << MZ_LROOT) / 64; _j++) {                                            \
+                    const uint32_t _ix = ((1 << MZ_LROOT) / 64) * lane + _j;                                   \
+                    const uint32_t _v = (L_)->lit_fast[_ix];                                                   \
+                    if (_v > MZ_LROOT && _v <= 15u) {                                                          \
+                        (L_)->lit_fast[_ix] = MZ_E_SUB | (_off << 8) | (_v - MZ_LROOT);                        \
+                        _off += 1u << (_v - MZ_LROOT);                                                         \
+                    }                                                                                          \
+                }                                                                                              \
+            }                                                                                                  \
+            MZ_WAVE_SYNC();                                                                                    \
+            MZ_LANES {                                                                                         \
+                for (int _j = 0; _j < 5; _j++) {                                                               \
+                    const uint32_t _rv = P(_r5)[_j] & 0xFFFFu, _l = P(_r5)[_j] >> 16;                          \
+                    if (_l) {                                                                                  \
+                        const uint32_t _re = (L_)->lit_fast[_rv & ((1u << MZ_LROOT) - 1)];                     \
+                        const uint32_t _of = (_re >> 8) & 0x1FFu, _kb = _re & 7u;                              \
+                        for (uint32_t _t = _rv >> MZ_LROOT; _t < (1u << _kb); _t += 1u << (_l - MZ_LROOT))     \
+                            (L_)->lit_sub[_of + _t] = P(_e5)[_j] + _l;                                         \
+                    }                                                                                          \
+                }                                                                                              \
+            }                                                                                                  \
+        }                                                                                                      \
+        MZ_WAVE_SYNC();                                                                                        \
+    } while (0)
+
 /* uniform n-bit read at the block-header level */
 #define MZ_HDR_BITS(dst, n)                                                   \
     do {                                                                      \
@@ -372,8 +447,13 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     L->u.h.cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
             }
             MZ_WAVE_SYNC();
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, 288, L->lit_fast, MZ_LROOT, L->lit_ent, mz_lit_ent, L->lit_lim,
-                          L->lit_delta);
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, 288, L->lit_fast, MZ_LROOT, L->lit_sub, mz_lit_ent, (uint16_t *)0,
+                          (int16_t *)0);
+            {
+                int suberr;
+                MZ_BUILD_LIT_SUB(suberr, L);
+                (void)suberr; /* the fixed code has no literal/length code longer than 9 bits */
+            }
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_ent, mz_dist_ent,
                           L->dist_lim, L->dist_delta);
         } else {
@@ -468,11 +548,19 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
             /* incomplete sets are accepted only when the longest code is 1 bit (zlib 1.2.11 inftrees.c);
              * the distance set may also be empty */
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, nlen, L->lit_fast, MZ_LROOT, L->lit_ent, mz_lit_ent, L->lit_lim,
-                          L->lit_delta);
+            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, nlen, L->lit_fast, MZ_LROOT, L->lit_sub, mz_lit_ent, (uint16_t *)0,
+                          (int16_t *)0);
             if (left < 0 || (left > 0 && maxlen != 1)) {
                 status = MZHIP_DATA_ERROR; /* invalid literal/lengths set */
                 goto finish;
+            }
+            {
+                int suberr;
+                MZ_BUILD_LIT_SUB(suberr, L);
+                if (suberr) { /* cannot happen for a complete code (zlib enough.c bound) */
+                    status = MZHIP_DATA_ERROR;
+                    goto finish;
+                }
             }
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + nlen, ndist, L->dist_fast, MZ_DROOT, L->dist_ent, mz_dist_ent,
                           L->dist_lim, L->dist_delta);
@@ -528,14 +616,13 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     P(w1) = mz_funnel(d2, d1, pl);
                     P(le) = L->lit_fast[P(w0) & ((1u << MZ_LROOT) - 1)];
                 }
-                uint64_t slow;
-                MZ_BALLOT(slow, P(le) == 0u);
-                if (slow) { /* some lane looks at a code longer than the fast table */
-                    MZ_LANES {
-                        const uint32_t e = mz_long_code(P(w0), MZ_LROOT, L->lit_lim, L->lit_delta, L->lit_ent, 288u);
-                        if (P(le) == 0u) P(le) = e;
-                    }
+                MZ_LANES { /* codes longer than the root: one more lookup in the group's sub-table */
+                    const uint32_t e = P(le);
+                    const uint32_t sx = ((e >> 8) & 0x1FFu) + mz_bfe(P(w0), MZ_LROOT, e & 7u);
+                    const uint32_t e2 = L->lit_sub[(e & MZ_E_SUB) ? sx : 0u];
+                    P(le) = (e & MZ_E_SUB) ? e2 : e;
                 }
+                uint64_t slow;
                 PV(uint32_t, lenl);
                 PV(uint32_t, nb2l);
                 PV(uint32_t, dlo);

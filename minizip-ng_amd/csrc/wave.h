@@ -31,6 +31,7 @@
 #define MZ_LANE_DECL
 #define MZ_LANES for (int lane = 0; lane < 64; ++lane)
 #define PV(type, name) type name[64]
+#define PV2(type, name, n) type name[64][n] /* small per-lane array */
 #define P(name) name[lane]
 #define MZ_READLANE(name, idx) (name[(idx)])
 #define MZ_UNIFORM(x) (x)
@@ -51,6 +52,7 @@
     } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) (++*(ptr))
 #define MZ_LDS_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
+#define MZ_LDS_ATOMIC_MAX(ptr, v) (*(ptr) = (*(ptr) > (v)) ? *(ptr) : (v))
 /* dst[lane] = src[idx(lane)] -- a cross-lane gather (ds_bpermute on the device) */
 #define MZ_GATHER(dst, src, idx_expr)                                \
     do {                                                             \
@@ -94,6 +96,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
 #define MZ_LANE_DECL const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 #define MZ_LANES
 #define PV(type, name) type name
+#define PV2(type, name, n) type name[n]
 #define P(name) name
 #define MZ_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
 #define MZ_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
@@ -128,6 +131,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
     } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
 #define MZ_LDS_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
+#define MZ_LDS_ATOMIC_MAX(ptr, v) atomicMax((ptr), (v))
 #define MZ_GATHER(dst, src, idx_expr) ((dst) = (uint32_t)__shfl((int)(src), (int)(idx_expr), 64))
 #define MZ_GATHER4(dst, src, byteidx_expr) ((dst) = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byteidx_expr), (int)(src)))
 /* inclusive wave64 prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes
