@@ -126,6 +126,20 @@ MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t s
  * (which may exceed max_entries: call again with a larger table) or MZ_FORMAT_ERROR (-103). */
 MZHIP_API int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table, int64_t max_entries);
 
+/* Prime (SURVEY 8b "Batching") ------------------------------------------------------------- */
+
+/* Decode every DEFLATE entry of an archive (file or memory image) in one launch and keep the results in a
+ * host cache.  Afterwards the drop-in mz_stream_zlib READ path recognises a primed entry (base-stream position
+ * == payload offset, first payload bytes equal) and serves read() calls from the cache; the matching
+ * mz_crypt_crc32_update calls are answered from GPU-computed per-65 535-byte-segment CRCs, so the reference's
+ * untouched mz_zip_reader loop runs at memcpy speed while mz_zip.c:2116-2128 still verifies every entry against
+ * the central directory.  Entries that did not decode cleanly are not cached (they take the ordinary path and
+ * its exact error behaviour).  Returns the number of cached entries or a negative MZ_* code. */
+MZHIP_API int64_t mzhip_prime_file(const char *path);
+MZHIP_API int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len);
+MZHIP_API void mzhip_prime_clear(void);
+MZHIP_API void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
+
 /* Geometry the last launch used (for reports): workgroups, waves per workgroup, LDS bytes per workgroup. */
 MZHIP_API void mzhip_inflate_launch_geometry(uint32_t n, uint32_t *grid, uint32_t *waves_per_wg, uint32_t *lds_bytes);
 

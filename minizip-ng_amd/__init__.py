@@ -19,6 +19,7 @@ BATCH_SYMBOLS = [
     "mzhip_device_count", "mzhip_init", "mzhip_last_error", "mzhip_version", "mzhip_inflate_batch",
     "mzhip_crc32_batch", "mzhip_inflate_host", "mzhip_crc32_host", "mzhip_inflate_launch_geometry",
     "mzhip_lzma_batch", "mzhip_lzma_host", "mzhip_deflate_batch", "mzhip_deflate_host", "mzhip_zip_index_mem",
+    "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_clear", "mzhip_prime_stats",
 ]
 
 _u64p, _u32p, _i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)

@@ -5,13 +5,24 @@
  * chaining contract: crc(crc(0,A),B) == crc(0,A||B); size <= 0 returns `value`
  * unchanged, as every reference back-end does for an empty buffer.
  * The bytes are reduced on the device (k_crc32_batch, wave-parallel tile
- * folding); there is no table-driven CPU loop in this file.
+ * folding); there is no table-driven CPU loop in this file.  When the buffer is
+ * one that a primed stream just served (see mzhip_prime_*), the device already
+ * computed its CRC and only the GF(2) chaining arithmetic happens here.
  */
 #include "mz_strm_hip.h"
 #include "mzhip.h"
+#include "shim_common.h"
+
+__thread mzhip_served mzhip_last_served;
 
 uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int32_t size) {
     if (size <= 0 || !buf)
         return value;
+    if (mzhip_last_served.valid && mzhip_last_served.buf == (const void *)buf && mzhip_last_served.size == size) {
+        /* these exact bytes were just served from the prime cache; their CRC was computed on the device */
+        mzhip_last_served.valid = 0;
+        return mzhip_crc32_combine(value, mzhip_last_served.crc, (uint64_t)size);
+    }
+    mzhip_last_served.valid = 0;
     return mzhip_crc32_host(value, buf, (size_t)size);
 }

@@ -34,6 +34,7 @@
 
 #include "mz_strm_hip.h"
 #include "mzhip.h"
+#include "shim_common.h"
 
 typedef struct mzhip_zlib_s {
     mzhip_stream stream; /* must be first (mz_strm.h:69-72) */
@@ -55,6 +56,9 @@ typedef struct mzhip_zlib_s {
     int32_t dev_status;
     int64_t dev_in_used;
     int64_t next_attempt; /* try the device again once in_len reaches this */
+    int8_t tried_cache, out_borrowed; /* prime cache: looked up once; out points into the cache */
+    int64_t base_pos0;                /* base position at the first read = payload offset */
+    const uint32_t *seg_crc;          /* GPU CRCs of the 65 535-byte segments of a primed entry */
     /* write side */
     uint8_t *wbuf;
     int64_t wlen, wcap;
@@ -76,7 +80,9 @@ static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
 
 static void free_buffers(mzhip_zlib *z) {
     free(z->in);
-    free(z->out);
+    if (!z->out_borrowed)
+        free(z->out);
+    z->out_borrowed = 0;
     free(z->wbuf);
     z->in = z->out = z->wbuf = NULL;
     z->in_len = z->in_cap = z->out_len = z->out_cap = z->out_served = 0;
@@ -95,6 +101,9 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->dev_status = 0;
     z->dev_in_used = 0;
     z->next_attempt = 0;
+    z->tried_cache = 0;
+    z->base_pos0 = -1;
+    z->seg_crc = NULL;
     if (mode & MZH_OPEN_MODE_WRITE) {
         if (z->window_bits != -15) /* zlib / gzip wrappers: SURVEY 8(f) rank 2 */
             return MZH_SUPPORT_ERROR;
@@ -196,10 +205,33 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
     if (z->error != 0)
         return z->error; /* mz_strm_zlib.c:186-189 */
 
+    if (!z->tried_cache && z->in_len == 0) {
+        mzhip_stream *b = z->stream.base;
+        if (b && b->vtbl && b->vtbl->tell && b->vtbl->is_open && b->vtbl->is_open(b) == MZH_OK)
+            z->base_pos0 = b->vtbl->tell(b);
+    }
     while (!z->decoded) {
         int32_t rd = pull_chunk(z);
         if (rd < 0)
             return rd; /* mz_strm_zlib.c:148-149 */
+        if (!z->tried_cache) {
+            /* was this entry decoded by mzhip_prime_*()?  (payload offset + first payload bytes must agree) */
+            z->tried_cache = 1;
+            const uint8_t *data = NULL;
+            int64_t usize = 0, csize = 0;
+            uint32_t crc = 0;
+            if (z->base_pos0 >= 0 && mzhip_prime_lookup(z->base_pos0, z->in, (int32_t)(z->in_len < 16 ? z->in_len : 16),
+                                                         &data, &usize, &csize, &crc, &z->seg_crc) == 1 &&
+                (z->max_total_in <= 0 || z->max_total_in >= csize)) {
+                z->out = (uint8_t *)(uintptr_t)data;
+                z->out_borrowed = 1;
+                z->out_len = usize;
+                z->dev_in_used = csize;
+                z->dev_status = 0;
+                z->decoded = 1;
+                break;
+            }
+        }
         if (!z->base_eof && z->in_len < z->next_attempt)
             continue;
         int32_t r = attempt_decode(z);
@@ -222,6 +254,14 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
     int32_t n = (int32_t)(avail < size ? avail : size);
     if (n > 0) {
         memcpy(buf, z->out + z->out_served, (size_t)n);
+        if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
+            (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
+            /* a whole primed segment: remember its device-computed CRC for the mz_crypt_crc32_update that follows */
+            mzhip_last_served.buf = buf;
+            mzhip_last_served.size = n;
+            mzhip_last_served.crc = z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT];
+            mzhip_last_served.valid = 1;
+        }
         z->out_served += n;
         z->total_out += n;
     }
@@ -326,7 +366,9 @@ int32_t mz_stream_zlib_close(void *stream) {
         flush_segment(z, 1); /* deflate(Z_FINISH) + flush, return value ignored like mz_strm_zlib.c:287-288 */
     z->initialized = 0;
     free(z->in);
-    free(z->out);
+    if (!z->out_borrowed)
+        free(z->out);
+    z->out_borrowed = 0;
     free(z->wbuf);
     z->in = z->out = z->wbuf = NULL;
     z->in_cap = z->out_cap = z->wcap = 0;
@@ -399,7 +441,8 @@ void mz_stream_zlib_delete(void **stream) {
     z = (mzhip_zlib *)*stream;
     if (z) {
         free(z->in);
-        free(z->out);
+        if (!z->out_borrowed)
+            free(z->out);
         free(z->wbuf);
         free(z);
     }

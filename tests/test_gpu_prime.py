@@ -1,0 +1,73 @@
+"""GPU test of the prime path (SURVEY 8b "Batching"): one batch launch decodes the archive, after which the
+reference's UNMODIFIED one-entry-at-a-time loop (mz_zip_entry_read -> mz_stream_zlib_read -> mz_crypt_crc32_update,
+then the CRC verification of mz_zip_entry_read_close) is served from the cache -- same results, call for call."""
+import ctypes as C
+import importlib
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROP = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+
+
+def test_prime_serves_unmodified_reader_loop():
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    L = mz.lib()
+    L.mzhip_prime_file.restype = C.c_int64
+    L.mzhip_prime_file.argtypes = [C.c_char_p]
+    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(6)
+    n, size = 1500, 65536
+    lens = np.full(n, size, dtype=np.int32)
+    lens[::11] = rnd.randint(0, 200000, size=len(lens[::11]))      # ragged, some beyond one 65 535-byte segment
+    lens[:3] = (0, 1, 65535)
+    offs = rnd.randint(0, len(c) - 200000, size=n).astype(np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "p.zip")
+        ref.zip_write(path, c, offs, lens, method=8, level=6)
+        table = ref.zip_index(path)
+        cd = table[:, 6].copy()
+        out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+        o_ref = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        t_ref, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_ref, out_off=out_off)
+        assert (st_r == 0).all()
+
+        L.mzhip_prime_clear()
+        cached = L.mzhip_prime_file(path.encode())
+        assert cached == n - int((lens == 0).sum()) or cached == n      # empty entries have no stream to prime
+        t_hip, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_hip, out_off=out_off)
+        ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        assert (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all()
+        assert (o_hip == o_ref).all()
+        assert hits.value >= cached - 2 and miss.value == 0
+        print("reference 1 thread: %.3f s   primed drop-in 1 thread: %.3f s   (%.1fx)" % (t_ref, t_hip, t_ref / t_hip))
+        assert t_hip < t_ref                                            # memcpy-speed serving beats CPU inflate
+
+        # a corrupted payload is not cached as good: it takes the ordinary path and fails like the reference
+        raw = bytearray(open(path, "rb").read())
+        p5 = int(table[5, 7])
+        raw[p5 + 40] ^= 0x5A
+        bad = os.path.join(tmp, "bad.zip")
+        open(bad, "wb").write(raw)
+        L.mzhip_prime_file(bad.encode())
+        _, _, _, st_b = hip.zip_read_all(bad, cd, nthreads=1)
+        _, _, _, st_rb = ref.zip_read_all(bad, cd, nthreads=1)
+        assert st_b[5] != 0 and st_rb[5] != 0 and (np.delete(st_b, 5) == 0).all()
+        L.mzhip_prime_clear()
+        # after clear the ordinary per-entry device path still works
+        _, crc2, _, st2 = hip.zip_read_all(path, cd[:40], nthreads=1)      # own_crc: the driver's extra CRC calls hit the device
+        assert (st2 == 0).all() and (crc2 == crc_r[:40]).all()
