@@ -136,3 +136,41 @@ def test_crc32_batch_and_host(gpu):
     assert gpu.mz.crc32_host(big) == zlib.crc32(big)
     assert gpu.mz.crc32_host(big[:1000], 0xDEADBEEF) == zlib.crc32(big[:1000], 0xDEADBEEF)
     assert gpu.mz.crc32_host(b"123456789") == 0xCBF43926
+
+
+def test_differential_fuzz_batch(gpu):
+    """3000 randomly corrupted / truncated streams in one launch: status class, and bytes + consumed input +
+    CRC wherever the stream still decodes, against the oracle."""
+    import random
+
+    rnd = random.Random(777)
+    c = synth.corpus()
+    bases = [synth.deflate_raw(c[o:o + n], level=lv) for o, n, lv in ((100, 3000, 6), (5000, 20000, 9), (70000, 9000, 1))]
+    bases.append(synth.deflate_raw(c[:6000], strategy=zlib.Z_FIXED))
+    bases.append(synth.stored_blocks(c[:3000], block=1000))
+    pays = []
+    for it in range(3000):
+        z = bytearray(rnd.choice(bases))
+        kind = rnd.randrange(4)
+        if kind == 0:
+            z[rnd.randrange(len(z))] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            z[rnd.randrange(len(z))] = rnd.randrange(256)
+        elif kind == 2:
+            del z[rnd.randrange(1, len(z)):]
+        else:
+            z[rnd.randrange(min(len(z), 40))] = rnd.randrange(256)
+        pays.append(bytes(z))
+    cap = 120000
+    batch = gpu.make_batch(pays, [cap] * len(pays), align=1)
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    h_out = batch["d_out"].cpu().numpy()
+    n_ok = 0
+    for i, z in enumerate(pays):
+        so, uo, oo = oracle.inflate_raw(z, cap)
+        assert status[i] == so, (i, status[i], so)
+        if so == 0:
+            assert in_used[i] == uo and out_len[i] == len(oo) and crc[i] == oracle.crc32(oo), i
+            assert gpu.entry_bytes(batch, h_out, i, len(oo)) == oo, i
+            n_ok += 1
+    assert n_ok > 100

@@ -166,3 +166,39 @@ def test_deflate_roundtrip(emu):
     out = np.zeros(100, np.uint8)
     ol, crc = C.c_uint32(), C.c_uint32()
     assert emu.emul_deflate(a.ctypes.data_as(_u8p), 4000, out.ctypes.data_as(_u8p), 100, 1, C.byref(ol), C.byref(crc)) == -200
+
+
+def test_inflate_differential_fuzz(emu):
+    """Random single-byte / bit corruptions and truncations of valid streams: the device core (emulated) and the
+    oracle must agree on the status class, and on bytes / consumed input whenever the stream still decodes."""
+    import random
+
+    rnd = random.Random(2024)
+    c = synth.corpus()
+    bases = [synth.deflate_raw(c[o:o + n], level=lv) for o, n, lv in ((100, 3000, 6), (5000, 20000, 9), (70000, 9000, 1))]
+    bases.append(synth.deflate_raw(c[:6000], strategy=zlib.Z_FIXED))
+    bases.append(synth.stored_blocks(c[:3000], block=1000))
+    n_ok = n_err = 0
+    for it in range(400):
+        z = bytearray(rnd.choice(bases))
+        kind = rnd.randrange(4)
+        if kind == 0:
+            z[rnd.randrange(len(z))] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            z[rnd.randrange(len(z))] = rnd.randrange(256)
+        elif kind == 2:
+            del z[rnd.randrange(1, len(z)):]
+        else:
+            i = rnd.randrange(min(len(z), 40))          # hit the block header / code-length area
+            z[i] = rnd.randrange(256)
+        z = bytes(z)
+        cap = 120000
+        st, used, out, crc = _run(emu.emul_inflate, z, cap)
+        so, uo, oo = oracle.inflate_raw(z, cap)
+        assert st == so, (it, kind, st, so)
+        if so == 0:
+            assert (used, out) == (uo, oo) and crc == oracle.crc32(oo), it
+            n_ok += 1
+        else:
+            n_err += 1
+    assert n_ok > 20 and n_err > 100
