@@ -74,6 +74,11 @@ MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off
 MZHIP_API int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
                                     const uint32_t *d_init, uint32_t *d_crc, void *stream);
 
+/* K5: Adler-32 of n buffers -- the zlib-wrapper trailer (RFC 1950), needed when mz_stream_zlib is opened with a
+ * positive COMPRESS_WINDOW (mz_strm_zlib.c:80,104,348-350; minigzip.c:80 uses 15+16).  d_adler[i] = adler32(1, buf_i). */
+MZHIP_API int32_t mzhip_adler32_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
+                                      uint32_t *d_adler, void *stream);
+
 /* K3: raw-LZMA1 range decode with fused CRC-32 ---------------------------- */
 
 /* Replaces, for n method-14 entries at once, mz_stream_lzma_read (mz_strm_lzma.c:147-241 ->
@@ -115,6 +120,11 @@ MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *o
 /* one segment of a stream: 64 KiB pieces, the last one final iff `final`; *crc = CRC-32 of `in` */
 MZHIP_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
                                      uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
+/* the same two with the Adler-32 (of the decoded bytes / of `in`) the zlib wrapper needs; adler may be NULL */
+MZHIP_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
+                                      uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t *adler);
+MZHIP_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
+                                      uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler);
 MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size);
 
 /* Archive index (host, C) --------------------------------------------------------------- */

@@ -22,6 +22,7 @@
 #include "inflate_core.h"
 #include "lzma_core.h"
 #include "deflate_core.h"
+#include "adler32_core.h"
 
 #define MZ_WAVES_PER_WG 4
 #define MZ_CRC_TAB_BYTES 1024
@@ -103,6 +104,21 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_crc32_batch(CrcArgs a)
         MZ_CRC_FOLD_TILES(acc, done, buf, n, crc_tab, tabs->kx);
         MZ_CRC_FINISH_FROM(result, acc, tmp, done, buf, n, crc_tab, tabs, ~init);
         a.crc[e] = result; // uniform store
+    }
+}
+
+// Adler-32 of n buffers (zlib-wrapper trailer): one wave per buffer, persistent waves.
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_adler32_batch(CrcArgs a) {
+    MZ_LANE_DECL
+    for (;;) {
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
+        if (e >= a.n) break;
+        const uint8_t *buf = a.buf + a.off[e];
+        const uint32_t n = MZ_UNIFORM(a.len[e]);
+        uint32_t r;
+        MZ_ADLER32(r, buf, n);
+        a.crc[e] = r; // uniform store
     }
 }
 
@@ -343,6 +359,28 @@ int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *d_off, const uint32
     return 0;
 }
 
+int32_t mzhip_adler32_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
+                            uint32_t *d_adler, void *stream) {
+    if (n == 0) return 0;
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    CrcArgs a;
+    a.buf = (const uint8_t *)d_buf;
+    a.off = d_off;
+    a.len = d_len;
+    a.n = n;
+    a.init = nullptr;
+    a.crc = d_adler;
+    a.counter = take_counter(c);
+    a.tabs = c->d_tabs;
+    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_adler32_batch, dim3(grid_for(c, n)), dim3(MZ_WAVES_PER_WG * 64), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                          const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out, uint32_t n,
                          uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
@@ -416,8 +454,8 @@ struct Scratch {
 };
 } // namespace
 
-int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
-                           uint32_t *in_used, uint32_t *crc) {
+int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                            uint32_t *in_used, uint32_t *crc, uint32_t *adler) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -431,6 +469,7 @@ int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
         uint64_t in_off, out_off;
         uint32_t in_len, out_cap, out_len, in_used, crc;
         int32_t status;
+        uint32_t adler, pad;
     } m;
     memset(&m, 0, sizeof(m));
     m.in_off = 64;
@@ -444,12 +483,24 @@ int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
                              &dm->in_used, &dm->crc, &dm->status, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    if (adler) { /* zlib wrapper: Adler-32 of the decoded bytes, reduced on the device as well */
+        HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
+        rc = mzhip_adler32_batch(base, &dm->out_off, &dm->out_len, 1, &dm->adler, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+    }
     HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
     if (m.out_len && out) HIP_TRY(hipMemcpy(out, base + m.out_off, m.out_len, hipMemcpyDeviceToHost));
     if (out_len) *out_len = m.out_len;
     if (in_used) *in_used = m.in_used;
     if (crc) *crc = m.crc;
+    if (adler) *adler = m.adler;
     return m.status;
+}
+
+int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                           uint32_t *in_used, uint32_t *crc) {
+    return mzhip_inflate_host2(in, in_len, out, out_cap, out_len, in_used, crc, nullptr);
 }
 
 int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
@@ -491,15 +542,15 @@ int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
 
 // One stream segment: split into 64 KiB pieces (one wave each); every piece but the last ends with an empty
 // stored block so the pieces concatenate on byte boundaries; the last piece is final iff `final`.
-int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
-                           uint32_t *out_len, uint32_t *crc) {
+int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
+                            uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
     const uint32_t piece = 64u << 10;
     const uint32_t np = in_len ? (in_len + piece - 1) / piece : 1u;
     const uint32_t pcap = piece + piece / 8 + 64; /* fixed-Huffman worst case is 9/8 of the input */
-    const size_t meta = (size_t)np * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 1);
+    const size_t meta = (size_t)np * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 1);
     const size_t meta_pad = (meta + 63) & ~(size_t)63;
     const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
     Scratch sc;
@@ -511,7 +562,8 @@ int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, u
     uint32_t *h_in_len = (uint32_t *)(h_out_off + np), *h_out_cap = h_in_len + np, *h_out_len = h_out_cap + np,
              *h_crc = h_out_len + np;
     int32_t *h_status = (int32_t *)(h_crc + np);
-    uint8_t *h_final = (uint8_t *)(h_status + np);
+    uint32_t *h_adler = (uint32_t *)(h_status + np);
+    uint8_t *h_final = (uint8_t *)(h_adler + np);
     for (uint32_t i = 0; i < np; i++) {
         h_in_off[i] = meta_pad + (uint64_t)i * piece;
         const uint32_t left = in_len - (in_len ? i * piece : 0);
@@ -530,12 +582,16 @@ int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, u
     uint32_t *d_in_len = (uint32_t *)(d_out_off + np), *d_out_cap = d_in_len + np, *d_out_len = d_out_cap + np,
              *d_crc = d_out_len + np;
     int32_t *d_status = (int32_t *)(d_crc + np);
-    uint8_t *d_final = (uint8_t *)(d_status + np);
+    uint32_t *d_adler = (uint32_t *)(d_status + np);
+    uint8_t *d_final = (uint8_t *)(d_adler + np);
     rc = mzhip_deflate_batch(base, d_in_off, d_in_len, base, d_out_off, d_out_cap, d_final, np, d_out_len, d_crc,
                              d_status, nullptr);
     if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -104;
+    /* zlib wrapper: Adler-32 of the same pieces, one wave each, combined below from the checksums alone */
+    if (rc == 0 && adler) rc = mzhip_adler32_batch(base, d_in_off, d_in_len, np, d_adler, nullptr);
+    if (rc == 0 && adler && hipDeviceSynchronize() != hipSuccess) rc = -104;
     if (rc == 0 && hipMemcpy(hm, base, meta, hipMemcpyDeviceToHost) != hipSuccess) rc = -104;
-    uint32_t total = 0, k = 0;
+    uint32_t total = 0, k = 0, ad = 1;
     for (uint32_t i = 0; rc == 0 && i < np; i++) {
         if (h_status[i] != 0) rc = h_status[i];
         else if (h_out_len[i] > out_cap - total) rc = MZHIP_STATUS_OUT_FULL;
@@ -543,12 +599,23 @@ int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, u
         else {
             total += h_out_len[i];
             k = (i == 0) ? h_crc[0] : mzhip_crc32_combine_host(k, h_crc[i], h_in_len[i]); /* checksums only */
+            if (adler) ad = mzhip_adler32_combine_host(ad, h_adler[i], h_in_len[i]);
         }
     }
     free(hm);
     if (out_len) *out_len = total;
     if (crc) *crc = k;
+    if (adler) *adler = ad;
     return rc;
+}
+
+int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
+                           uint32_t *out_len, uint32_t *crc) {
+    return mzhip_deflate_host2(in, in_len, final, out, out_cap, out_len, crc, nullptr);
+}
+
+__attribute__((visibility("hidden"))) uint32_t mzhip_adler32_combine(uint32_t ad1, uint32_t ad2, uint64_t len2) {
+    return mzhip_adler32_combine_host(ad1, ad2, len2);
 }
 
 uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {

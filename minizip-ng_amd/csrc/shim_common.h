@@ -9,6 +9,9 @@ int32_t mzhip_prime_lookup(int64_t payload_off, const uint8_t *head, int32_t hea
 /* crc(A||B) from crc(A), crc(B), |B|: arithmetic on checksums, no data bytes involved */
 uint32_t mzhip_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 
+/* adler(A||B) from adler(A), adler(B), |B| */
+uint32_t mzhip_adler32_combine(uint32_t ad_a, uint32_t ad_b, uint64_t len_b);
+
 /* The last buffer a primed stream handed to its caller, with the GPU-computed CRC-32 of exactly those bytes:
  * lets mz_crypt_crc32_update (called by mz_zip_entry_read right after the read, mz_zip.c:2047-2049) answer
  * without a second trip to the device. */

@@ -28,6 +28,13 @@
  * exact number of compressed bytes the stream occupies (what mz_zip.c:2090,2116
  * need); it is only reported once every decoded byte has been served, so a
  * caller that stops early does not trip the CRC comparison at mz_zip.c:2116.
+ *
+ * COMPRESS_WINDOW (mz_strm_zlib.c:80,104): -15 = raw (what mz_zip.c uses), 15 = zlib wrapper (RFC 1950),
+ * 15+16 = gzip wrapper (RFC 1952; minigzip.c:80), 15+32 = detect on READ.  The wrappers are framing around
+ * the same device path: header fields are parsed/emitted here, the trailer is checked against / filled from
+ * the checksums the device computed (fused CRC-32, K5 Adler-32).  Error numbering follows zlib's inflate():
+ * a bad header or trailer is Z_DATA_ERROR (-3), a preset dictionary request is Z_NEED_DICT (2), input that
+ * ends inside the header or trailer is Z_BUF_ERROR (-5).  Other window sizes answer MZ_SUPPORT_ERROR.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -59,9 +66,16 @@ typedef struct mzhip_zlib_s {
     int8_t tried_cache, out_borrowed; /* prime cache: looked up once; out points into the cache */
     int64_t base_pos0;                /* base position at the first read = payload offset */
     const uint32_t *seg_crc;          /* GPU CRCs of the 65 535-byte segments of a primed entry */
+    int32_t wrap;      /* 0 raw, 1 zlib, 2 gzip (resolved from window_bits; 3 = detect, resolved by the header) */
+    int64_t hdr_len;   /* wrapper header bytes in front of the DEFLATE payload (0 = not parsed yet) */
+    int8_t payload_done; /* device verdict on the payload is in; only the trailer is outstanding */
+    uint32_t out_crc, out_adler;
     /* write side */
     uint8_t *wbuf;
     int64_t wlen, wcap;
+    uint32_t w_crc, w_adler;
+    int64_t w_total;   /* uncompressed bytes already handed to the device */
+    int8_t w_header_done;
 } mzhip_zlib;
 
 static mzhip_stream_vtbl mzhip_zlib_vtbl = {
@@ -104,16 +118,27 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->tried_cache = 0;
     z->base_pos0 = -1;
     z->seg_crc = NULL;
+    z->hdr_len = 0;
+    z->payload_done = 0;
+    z->w_crc = 0;
+    z->w_adler = 1;
+    z->w_total = 0;
+    z->w_header_done = 0;
+    switch (z->window_bits) {
+    case -15: z->wrap = 0; break;
+    case 15: z->wrap = 1; break;
+    case 15 + 16: z->wrap = 2; break;
+    case 15 + 32: z->wrap = 3; break; /* READ only: gzip or zlib, decided by the first two bytes */
+    default: return MZH_SUPPORT_ERROR;
+    }
     if (mode & MZH_OPEN_MODE_WRITE) {
-        if (z->window_bits != -15) /* zlib / gzip wrappers: SURVEY 8(f) rank 2 */
+        if (z->wrap == 3)
             return MZH_SUPPORT_ERROR;
         if (mzhip_device_count() <= 0) {
             z->error = MZH_STREAM_ERROR;
             return MZH_OPEN_ERROR;
         }
     } else if (mode & MZH_OPEN_MODE_READ) {
-        if (z->window_bits != -15) /* zlib / gzip wrappers: SURVEY 8(f) rank 2 */
-            return MZH_SUPPORT_ERROR;
         if (mzhip_device_count() <= 0) {
             z->error = MZH_STREAM_ERROR;
             return MZH_OPEN_ERROR; /* mz_strm_zlib.c:101-102 */
@@ -160,18 +185,115 @@ static int32_t pull_chunk(mzhip_zlib *z) {
     return rd;
 }
 
+static uint32_t le32(const uint8_t *p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+/* final verdict without (further) device work */
+static int32_t verdict(mzhip_zlib *z, int32_t status, int64_t in_used) {
+    z->dev_status = status;
+    z->dev_in_used = in_used;
+    z->decoded = 1;
+    return 0;
+}
+
+/* Wrapper header in front of the DEFLATE payload, field by field as zlib's inflate() HEAD..HCRC / DICTID
+ * states read it.  Returns 1 = header complete (z->hdr_len set), 0 = verdict reached (error), 2 = more input
+ * needed. */
+static int32_t parse_wrapper_header(mzhip_zlib *z) {
+    const uint8_t *p = z->in;
+    const int64_t n = z->in_len;
+#define NEED(k)                                                    \
+    do {                                                           \
+        if (n < (k)) {                                             \
+            if (!z->base_eof)                                      \
+                return 2;                                          \
+            verdict(z, MZHIP_STATUS_BUF_ERROR, n);                 \
+            return 0;                                              \
+        }                                                          \
+    } while (0)
+    NEED(2);
+    int32_t wrap = z->wrap;
+    if (wrap == 3)
+        wrap = (p[0] == 0x1F && p[1] == 0x8B) ? 2 : 1;
+    if (wrap == 2) {
+        if (p[0] != 0x1F || p[1] != 0x8B) {
+            verdict(z, MZHIP_STATUS_DATA_ERROR, 2); /* "incorrect header check" */
+            return 0;
+        }
+        NEED(4);
+        if (p[2] != 8 || (p[3] & 0xE0)) {
+            verdict(z, MZHIP_STATUS_DATA_ERROR, 4); /* "unknown compression method" / "unknown header flags set" */
+            return 0;
+        }
+        const int32_t flg = p[3];
+        int64_t pos = 10; /* MTIME(4) XFL OS */
+        NEED(pos);
+        if (flg & 0x04) { /* FEXTRA */
+            NEED(pos + 2);
+            pos += 2 + ((int64_t)p[pos] | ((int64_t)p[pos + 1] << 8));
+            NEED(pos);
+        }
+        for (int32_t bit = 0x08; bit <= 0x10; bit <<= 1) { /* FNAME, FCOMMENT: zero-terminated */
+            if (!(flg & bit))
+                continue;
+            for (;;) {
+                NEED(pos + 1);
+                if (p[pos++] == 0)
+                    break;
+            }
+        }
+        if (flg & 0x02) { /* FHCRC: low 16 bits of the CRC-32 of the header so far (checksum on the device) */
+            NEED(pos + 2);
+            const uint32_t want = (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8);
+            if ((mzhip_crc32_host(0, p, (size_t)pos) & 0xFFFFu) != want) {
+                verdict(z, MZHIP_STATUS_DATA_ERROR, pos + 2); /* "header crc mismatch" */
+                return 0;
+            }
+            pos += 2;
+        }
+        z->wrap = 2;
+        z->hdr_len = pos;
+        return 1;
+    }
+    /* zlib: CMF FLG, ((CMF << 8) | FLG) % 31 == 0, CM == 8, CINFO <= 7 */
+    if ((((uint32_t)p[0] << 8) | p[1]) % 31u != 0 || (p[0] & 0x0F) != 8 || (p[0] >> 4) > 7) {
+        verdict(z, MZHIP_STATUS_DATA_ERROR, 2);
+        return 0;
+    }
+    if (p[1] & 0x20) { /* FDICT: 4-byte dictionary id, then inflate() asks for the dictionary */
+        NEED(6);
+        verdict(z, 2 /* Z_NEED_DICT */, 6);
+        return 0;
+    }
+    z->wrap = 1;
+    z->hdr_len = 2;
+    return 1;
+#undef NEED
+}
+
 /* run the device over everything pulled so far; 0 = verdict reached, 1 = wants more input */
 static int32_t attempt_decode(mzhip_zlib *z) {
-    for (;;) {
+    if (z->wrap != 0 && z->hdr_len == 0) {
+        const int32_t h = parse_wrapper_header(z);
+        if (h == 0)
+            return 0;
+        if (h == 2) {
+            z->next_attempt = z->in_len + 1;
+            return 1;
+        }
+    }
+    while (!z->payload_done) {
         if (z->out_cap == 0) {
             z->out_cap = z->in_len * 4 + 65536;
             z->out = (uint8_t *)malloc((size_t)z->out_cap);
             if (!z->out)
                 return MZH_MEM_ERROR;
         }
-        uint32_t out_len = 0, in_used = 0, crc = 0;
-        int32_t st = mzhip_inflate_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &out_len, &in_used,
-                                        &crc);
+        uint32_t out_len = 0, in_used = 0;
+        int32_t st = mzhip_inflate_host2(z->in + z->hdr_len, (uint32_t)(z->in_len - z->hdr_len), z->out,
+                                         (uint32_t)z->out_cap, &out_len, &in_used, &z->out_crc,
+                                         z->wrap == 1 ? &z->out_adler : NULL);
         if (st == MZHIP_STATUS_OUT_FULL) {
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
@@ -185,19 +307,37 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             z->out_cap = ncap;
             continue;
         }
-        if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof)
+        if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof) {
+            z->next_attempt = z->in_len * 2;
             return 1; /* input ended early, but base may have more */
-        if (st != MZHIP_STATUS_OK && st != MZHIP_STATUS_BUF_ERROR && st != MZHIP_STATUS_DATA_ERROR) {
-            /* device/runtime failure: never substitute a CPU result */
-            z->dev_status = MZH_STREAM_ERROR;
-        } else {
-            z->dev_status = st;
         }
         z->out_len = out_len;
-        z->dev_in_used = in_used;
-        z->decoded = 1;
-        return 0;
+        if (st != MZHIP_STATUS_OK && st != MZHIP_STATUS_BUF_ERROR && st != MZHIP_STATUS_DATA_ERROR)
+            return verdict(z, MZH_STREAM_ERROR, z->hdr_len + in_used); /* device/runtime failure: no CPU substitute */
+        if (st != MZHIP_STATUS_OK || z->wrap == 0)
+            return verdict(z, st, z->hdr_len + in_used);
+        z->dev_in_used = z->hdr_len + in_used;
+        z->payload_done = 1;
     }
+    /* wrapper trailer: gzip = CRC-32 then ISIZE, little endian; zlib = Adler-32, big endian */
+    const int64_t tl = z->wrap == 2 ? 8 : 4;
+    if (z->in_len - z->dev_in_used < tl) {
+        if (!z->base_eof) {
+            z->next_attempt = z->dev_in_used + tl;
+            return 1;
+        }
+        return verdict(z, MZHIP_STATUS_BUF_ERROR, z->in_len);
+    }
+    const uint8_t *t = z->in + z->dev_in_used;
+    if (z->wrap == 2) {
+        if (le32(t) != z->out_crc) /* "incorrect data check": inflate() stops after the CRC field */
+            return verdict(z, MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 4);
+        if (le32(t + 4) != (uint32_t)z->out_len) /* "incorrect length check" */
+            return verdict(z, MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 8);
+        return verdict(z, MZHIP_STATUS_OK, z->dev_in_used + 8);
+    }
+    const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+    return verdict(z, want == z->out_adler ? MZHIP_STATUS_OK : MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 4);
 }
 
 int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
@@ -220,7 +360,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             const uint8_t *data = NULL;
             int64_t usize = 0, csize = 0;
             uint32_t crc = 0;
-            if (z->base_pos0 >= 0 && mzhip_prime_lookup(z->base_pos0, z->in, (int32_t)(z->in_len < 16 ? z->in_len : 16),
+            if (z->wrap == 0 && z->base_pos0 >= 0 && mzhip_prime_lookup(z->base_pos0, z->in, (int32_t)(z->in_len < 16 ? z->in_len : 16),
                                                          &data, &usize, &csize, &crc, &z->seg_crc) == 1 &&
                 (z->max_total_in <= 0 || z->max_total_in >= csize)) {
                 z->out = (uint8_t *)(uintptr_t)data;
@@ -239,8 +379,6 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             z->error = r;
             return r;
         }
-        if (r == 1)
-            z->next_attempt = z->in_len * 2;
     }
 
     int64_t avail = z->out_len - z->out_served;
@@ -290,32 +428,73 @@ static int32_t base_write(mzhip_stream *base, const void *buf, int32_t size) {
 
 /* Compress what has been collected (device K4) and push it to base in staging-sized writes
  * (the reference flushes its 32767-byte buffer the same way, mz_strm_zlib.c:196-201,211-219). */
+static int32_t push_to_base(mzhip_zlib *z, const uint8_t *out, uint32_t out_len) {
+    uint32_t pos = 0;
+    while (pos < out_len) {
+        int32_t n = (int32_t)(out_len - pos < MZH_STAGING_BYTES ? out_len - pos : MZH_STAGING_BYTES);
+        if (base_write(z->stream.base, out + pos, n) != n)
+            return MZH_WRITE_ERROR; /* mz_strm_zlib.c:198-199 */
+        pos += (uint32_t)n;
+    }
+    z->total_out += out_len;
+    return MZH_OK;
+}
+
 static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
     if (z->wlen == 0 && !final)
         return MZH_OK;
+    if (z->wrap != 0 && !z->w_header_done) {
+        /* the header deflate() emits when no gz_header was set: gzip = magic, CM 8, no flags, no mtime, XFL from
+         * the level (2 = best, 4 = fastest), OS 3; zlib = 0x78, level class in FLG bits 7:6, FCHECK */
+        uint8_t h[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 3};
+        uint32_t hl = 10;
+        if (z->wrap == 2) {
+            h[8] = (uint8_t)(z->level == 9 ? 2 : (z->level >= 0 && z->level < 2) ? 4 : 0);
+        } else {
+            const int32_t lv = z->level < 0 ? 6 : z->level;
+            uint32_t w = (0x78u << 8) | ((uint32_t)(lv < 2 ? 0 : lv < 6 ? 1 : lv == 6 ? 2 : 3) << 6);
+            w += 31u - w % 31u;
+            h[0] = (uint8_t)(w >> 8);
+            h[1] = (uint8_t)w;
+            hl = 2;
+        }
+        z->w_header_done = 1;
+        if (push_to_base(z, h, hl) != MZH_OK)
+            return MZH_WRITE_ERROR;
+    }
     uint32_t cap = (uint32_t)(z->wlen + z->wlen / 8 + 128 + (z->wlen / 65536 + 1) * 80);
     uint8_t *out = (uint8_t *)malloc(cap);
     if (!out)
         return MZH_MEM_ERROR;
-    uint32_t out_len = 0, crc = 0;
-    int32_t st = mzhip_deflate_host(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, out, cap, &out_len, &crc);
+    uint32_t out_len = 0, crc = 0, adler = 1;
+    int32_t st = mzhip_deflate_host2(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, out, cap, &out_len, &crc,
+                                     z->wrap == 1 ? &adler : NULL);
     if (st != 0) {
         free(out);
         z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */
         return MZH_DATA_ERROR;       /* mz_strm_zlib.c:233-236 */
     }
-    uint32_t pos = 0;
-    while (pos < out_len) {
-        int32_t n = (int32_t)(out_len - pos < MZH_STAGING_BYTES ? out_len - pos : MZH_STAGING_BYTES);
-        if (base_write(z->stream.base, out + pos, n) != n) {
-            free(out);
-            return MZH_WRITE_ERROR; /* mz_strm_zlib.c:198-199 */
-        }
-        pos += (uint32_t)n;
-    }
+    /* running wrapper checksums: arithmetic on the device-computed segment checksums only */
+    z->w_crc = z->w_total == 0 ? crc : mzhip_crc32_combine(z->w_crc, crc, (uint64_t)z->wlen);
+    if (z->wrap == 1)
+        z->w_adler = mzhip_adler32_combine(z->w_adler, adler, (uint64_t)z->wlen);
+    z->w_total += z->wlen;
+    int32_t err = push_to_base(z, out, out_len);
     free(out);
-    z->total_out += out_len;
+    if (err != MZH_OK)
+        return err;
     z->wlen = 0;
+    if (final && z->wrap == 2) {
+        const uint32_t isz = (uint32_t)z->w_total;
+        uint8_t t[8] = {(uint8_t)z->w_crc, (uint8_t)(z->w_crc >> 8), (uint8_t)(z->w_crc >> 16), (uint8_t)(z->w_crc >> 24),
+                        (uint8_t)isz,      (uint8_t)(isz >> 8),      (uint8_t)(isz >> 16),      (uint8_t)(isz >> 24)};
+        return push_to_base(z, t, 8);
+    }
+    if (final && z->wrap == 1) {
+        uint8_t t[4] = {(uint8_t)(z->w_adler >> 24), (uint8_t)(z->w_adler >> 16), (uint8_t)(z->w_adler >> 8),
+                        (uint8_t)z->w_adler};
+        return push_to_base(z, t, 4);
+    }
     return MZH_OK;
 }
 

@@ -50,6 +50,13 @@
             _xor_acc ^= name[lane];                  \
         (dst) = _xor_acc;                            \
     } while (0)
+#define MZ_WAVE_SUM(dst, name)                       \
+    do {                                             \
+        uint32_t _sum_acc = 0;                       \
+        for (int lane = 0; lane < 64; ++lane)        \
+            _sum_acc += name[lane];                  \
+        (dst) = _sum_acc;                            \
+    } while (0)
 #define MZ_LDS_ATOMIC_INC(ptr) (++*(ptr))
 #define MZ_LDS_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
 #define MZ_LDS_ATOMIC_MAX(ptr, v) (*(ptr) = (*(ptr) > (v)) ? *(ptr) : (v))
@@ -148,6 +155,7 @@ __device__ __forceinline__ uint32_t mz_wave_incl_scan(uint32_t x, int lane) {
     return x;
 }
 #define MZ_INCL_SCAN(dst, src) ((dst) = mz_wave_incl_scan((src), lane))
+#define MZ_WAVE_SUM(dst, name) ((dst) = (uint32_t)__builtin_amdgcn_readlane((int)mz_wave_incl_scan((name), lane), 63))
 MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__popcll(v); }
 MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 MZ_DEV uint32_t mz_brev32(uint32_t v) { return __brev(v); }

@@ -45,6 +45,18 @@ extern "C" uint32_t emul_crc32(const uint8_t *buf, uint32_t n) {
     return result;
 }
 
+#include "adler32_core.h"
+
+extern "C" uint32_t emul_adler32(const uint8_t *buf, uint32_t n) {
+    uint32_t result;
+    MZ_ADLER32(result, buf, n);
+    return result;
+}
+
+extern "C" uint32_t emul_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b) {
+    return mzhip_adler32_combine_host(a, b, len_b);
+}
+
 extern "C" uint32_t emul_lds_bytes(void) { return (uint32_t)sizeof(mz_inflate_lds); }
 
 #include "lzma_core.h"

@@ -1,0 +1,161 @@
+"""GPU parity tests for SURVEY 8(f) row 2: mz_stream_zlib opened with a positive COMPRESS_WINDOW -- the zlib
+(RFC 1950, Adler-32) and gzip (RFC 1952, CRC-32 + ISIZE) wrappers around the same DEFLATE payload, the way
+minigzip.c:80 uses the stream.  The drop-in build (reference stream layer + libmzhip.so) and the all-reference
+build are driven through the same C driver; read() sequences, TOTAL_IN/OUT, close()/error() codes and bytes must
+agree, for valid streams and for every header / trailer failure zlib's inflate() distinguishes."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROP = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+KEYS = ("rets", "out", "total_in", "total_out", "close", "error", "open")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    import importlib
+
+    importlib.import_module("minizip-ng_amd").require_gpu()
+    if not os.path.exists(DROP) or not oracle.have_ref():
+        pytest.skip("drop-in / reference builds missing (built where /root/reference exists)")
+    return oracle.MzDriver(DROP), oracle.ref()
+
+
+def _wrap(d, wbits, level=6):
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits)
+    return co.compress(d) + co.flush()
+
+
+def test_adler32_batch_abi():
+    import torch
+    from tests import gpu_util
+
+    gpu_util.mz.require_gpu()
+    L = gpu_util.mz.lib()
+    L.mzhip_adler32_batch.restype = C.c_int32
+    L.mzhip_adler32_batch.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 2
+    rnd = np.random.RandomState(6)
+    datas = [b"", b"a", b"\xff" * 70000, rnd.bytes(1023), rnd.bytes(1024), rnd.bytes(1025), synth.corpus()[:300000]]
+    datas += [rnd.bytes(int(n)) for n in rnd.randint(0, 5000, size=500)]
+    b = gpu_util.make_batch(datas, [1] * len(datas))
+    ad = torch.empty(len(datas), dtype=torch.int32, device=b["d_in"].device)
+    assert L.mzhip_adler32_batch(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(), len(datas),
+                                 ad.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert gpu_util.mz.u32(ad).tolist() == [zlib.adler32(d) for d in datas]
+
+
+def test_wrapped_read_parity(libs):
+    hip, ref = libs
+    c = synth.corpus()
+    for d in (c[:100000], b"", b"a", c[:300], b"\xff" * 200000, c[:400000]):
+        for wb_stream, wb_open in ((31, 31), (15, 15), (31, 47), (15, 47)):
+            z = _wrap(d, wb_stream)
+            for chunk, extra in ((65535, b""), (1000 if len(d) < 200000 else 30000, b"\x00" * 100), (65535, z)):
+                a = hip.stream_decode(8, z + extra, len(d) + 64, chunk=chunk, window_bits=wb_open)
+                b = ref.stream_decode(8, z + extra, len(d) + 64, chunk=chunk, window_bits=wb_open)
+                assert {k: a[k] for k in KEYS} == {k: b[k] for k in KEYS}, (len(d), wb_stream, wb_open, chunk)
+                assert a["out"] == d and a["total_in"] == len(z)
+
+
+def test_gzip_optional_header_fields(libs):
+    hip, ref = libs
+    d = synth.corpus()[:70000]
+    body = _wrap(d, -15)
+    tail = struct.pack("<II", zlib.crc32(d), len(d))
+    for flg in range(0, 32):
+        hdr = b"\x1f\x8b\x08" + bytes([flg]) + b"\x12\x34\x56\x78\x02\x03"
+        if flg & 4:
+            hdr += struct.pack("<H", 300) + bytes(range(256)) + b"x" * 44
+        if flg & 8:
+            hdr += b"file name.txt\x00"
+        if flg & 16:
+            hdr += b"a comment\x00"
+        for ok in (True, False):
+            h = hdr
+            if flg & 2:
+                h += struct.pack("<H", (zlib.crc32(hdr) & 0xFFFF) ^ (0 if ok else 0x100))
+            elif not ok:
+                continue
+            a = hip.stream_decode(8, h + body + tail, len(d) + 64, window_bits=31)
+            b = ref.stream_decode(8, h + body + tail, len(d) + 64, window_bits=31)
+            assert {k: a[k] for k in KEYS} == {k: b[k] for k in KEYS}, (flg, ok)
+            assert (a["error"] == 0) == ok
+
+
+def test_wrapper_error_parity(libs):
+    hip, ref = libs
+    d = synth.corpus()[:100000]
+    g, zl = _wrap(d, 31), _wrap(d, 15)
+
+    def flip(z, i, m=1):
+        b = bytearray(z)
+        b[i] ^= m
+        return bytes(b)
+
+    fd = 0x7800 | 0x20
+    fd += 31 - fd % 31
+    cases = [("gz as zlib", g, 15, {}), ("zlib as gz", zl, 31, {}), ("gz trunc hdr", g[:5], 31, {}),
+             ("gz trunc 1", g[:1], 31, {}), ("gz trunc trailer", g[:-3], 31, {}), ("gz trunc mid", g[:len(g) // 2], 31, {}),
+             ("zl trunc trailer", zl[:-1], 15, {}), ("zl trunc mid", zl[:len(zl) // 3], 15, {}),
+             ("gz bad crc", flip(g, -8), 31, {}), ("gz bad isize", flip(g, -1), 31, {}),
+             ("zl bad adler", flip(zl, -1), 15, {}), ("zl bad adler hi", flip(zl, -4, 0x80), 15, {}),
+             ("zl bad fcheck", flip(zl, 1), 15, {}), ("zl cm", flip(zl, 0, 1), 15, {}),
+             ("zl cinfo 8", b"\x88" + bytes([31 - (0x8800 % 31)]) + zl[2:], 15, {}),
+             ("zl fdict trunc", struct.pack(">H", fd) + b"\0\0", 15, {}),
+             ("gz reserved flag", b"\x1f\x8b\x08\x20" + g[4:], 31, {}), ("gz cm 7", b"\x1f\x8b\x07" + g[3:], 31, {}),
+             ("gz payload flip", flip(g, len(g) // 2, 0x10), 31, {}), ("zl payload flip", flip(zl, len(zl) // 2, 0x10), 15, {}),
+             ("empty gz", b"", 31, {}), ("empty zl", b"", 15, {}), ("empty auto", b"", 47, {}),
+             ("gz max_in", g, 31, dict(max_in=len(g) - 4)), ("zl max_in", zl, 15, dict(max_in=len(zl) - 2)),
+             ("auto garbage", b"\x00\x01\x02\x03" * 10, 47, {})]
+    for name, data, wb, kw in cases:
+        a = hip.stream_decode(8, data, len(d) + 70000, window_bits=wb, **kw)
+        b = ref.stream_decode(8, data, len(d) + 70000, window_bits=wb, **kw)
+        assert (a["rets"][-1], a["close"], a["error"], a["total_in"]) == \
+               (b["rets"][-1], b["close"], b["error"], b["total_in"]), (name, a["rets"], b["rets"], a["total_in"], b["total_in"])
+        assert b["error"] != 0, name
+        if "flip" not in name:      # framing failures: everything decoded before the failure is identical too
+            assert (a["rets"], a["total_out"]) == (b["rets"], b["total_out"]), name
+    # preset dictionary request: inflate() answers Z_NEED_DICT (2) on every call (mz_strm_zlib.c:177-180,186-189)
+    data = struct.pack(">H", fd) + b"\0\0\0\1" + zl[2:]
+    a = hip.stream_decode(8, data, 4096, window_bits=15)
+    b = ref.stream_decode(8, data, 4096, window_bits=15)
+    assert a["rets"][:4] == b["rets"][:4] == [2, 2, 2, 2] and (a["error"], a["total_in"]) == (b["error"], b["total_in"]) == (2, 6)
+
+
+def test_unsupported_windows_are_refused(libs):
+    hip, _ = libs
+    for wb in (9, -9, 24, 0x100):
+        assert hip.stream_decode(8, b"\x03\x00", 64, window_bits=wb)["open"] == -109      # MZ_SUPPORT_ERROR
+
+
+def test_wrapped_write_roundtrip(libs):
+    """gzip / zlib streams produced on the HIP deflate must be accepted by the reference reader, by zlib itself
+    and by Python's gzip framing, trailer checksums included; header bytes equal the ones zlib emits."""
+    hip, ref = libs
+    c = synth.corpus()
+    for d in (c[:100000], b"", b"a", c + c[:123457] + bytes(9 << 20), b"\xff" * 70001):
+        for wb in (31, 15):
+            for level in (1, 6, 9):
+                z, info = hip.stream_encode(8, d, level=level, window_bits=wb)
+                zr, info_r = ref.stream_encode(8, d, level=level, window_bits=wb)
+                assert (info["total_in"], info["close"], info["error"], info["open"]) == (len(d), 0, 0, 0)
+                assert info["total_out"] == len(z)
+                hl = 10 if wb == 31 else 2
+                assert z[:hl] == zr[:hl], (wb, level)
+                assert z[-(8 if wb == 31 else 4):] == zr[-(8 if wb == 31 else 4):]       # same checksums / ISIZE
+                assert zlib.decompress(z, wb) == d
+                b = ref.stream_decode(8, z, len(d) + 64, window_bits=wb)
+                assert (b["out"], b["error"], b["total_in"]) == (d, 0, len(z)), (len(d), wb, level)
+                if level == 6:
+                    a = hip.stream_decode(8, z, len(d) + 64, window_bits=wb)
+                    assert (a["out"], a["error"], a["total_in"]) == (d, 0, len(z))

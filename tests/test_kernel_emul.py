@@ -30,6 +30,10 @@ def emu():
     L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
     L.emul_lzma.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
     L.emul_deflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.emul_adler32.restype = C.c_uint32
+    L.emul_adler32.argtypes = [_u8p, C.c_uint32]
+    L.emul_adler32_combine.restype = C.c_uint32
+    L.emul_adler32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
     L.emul_crc32.restype = C.c_uint32
     L.emul_crc32.argtypes = [_u8p, C.c_uint32]
     return L
@@ -56,6 +60,18 @@ def test_crc_tiles_and_tail(emu):
         d = rnd.bytes(n)
         a = np.frombuffer(d, dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
         assert emu.emul_crc32(a.ctypes.data_as(_u8p), n) == zlib.crc32(d) == oracle.crc32(d), n
+
+
+def test_adler32_tiles_tail_and_combine(emu):
+    """K5 (zlib-wrapper trailer) against zlib.adler32: tile boundaries, 0xFF worst case for the modular sums,
+    and adler(A||B) from the two halves."""
+    rnd = np.random.RandomState(1)
+    for n in (0, 1, 15, 16, 17, 1023, 1024, 1025, 5000, 65535, 65536, 100001, 1 << 20):
+        for d in (rnd.bytes(n), b"\xff" * n):
+            a = np.frombuffer(d, dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+            assert emu.emul_adler32(a.ctypes.data_as(_u8p), n) == zlib.adler32(d), n
+            k = n // 3
+            assert emu.emul_adler32_combine(zlib.adler32(d[:k]), zlib.adler32(d[k:]), n - k) == zlib.adler32(d), n
 
 
 def test_inflate_edges(emu):
