@@ -81,6 +81,37 @@ def inflate_raw(data, out_cap):
     return int(st), int(iu.value), out[: ol.value].tobytes()
 
 
+def xz_decode(data, out_cap, max_out=-1):
+    """-> (status, in_used, out_bytes) for a method-95 payload (one .xz stream)"""
+    L = lib()
+    L.orc_xz_decode.restype = C.c_int32
+    L.orc_xz_decode.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int64, C.POINTER(C.c_size_t),
+                                C.POINTER(C.c_size_t)]
+    a = _as_u8(data)
+    out = np.zeros(max(out_cap, 1), dtype=np.uint8)
+    iu, ol = C.c_size_t(), C.c_size_t()
+    st = L.orc_xz_decode(_ptr(a), a.size, _ptr(out), out_cap, max_out, C.byref(iu), C.byref(ol))
+    return st, iu.value, out[:ol.value].tobytes()
+
+
+def crc64(data):
+    L = lib()
+    L.orc_crc64.restype = C.c_uint64
+    L.orc_crc64.argtypes = [_u8p, C.c_size_t]
+    a = _as_u8(data)
+    return L.orc_crc64(_ptr(a), a.size)
+
+
+def sha256(data):
+    L = lib()
+    L.orc_sha256.restype = None
+    L.orc_sha256.argtypes = [_u8p, C.c_size_t, _u8p]
+    a = _as_u8(data)
+    out = np.zeros(32, dtype=np.uint8)
+    L.orc_sha256(_ptr(a), a.size, _ptr(out))
+    return out.tobytes()
+
+
 def lzma_zip_decode(data, out_cap, max_out=-1):
     a = _as_u8(data)
     out = np.zeros(max(out_cap, 1), dtype=np.uint8)

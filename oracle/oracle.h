@@ -57,6 +57,14 @@ int32_t orc_inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
 int32_t orc_lzma_zip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, int64_t max_out,
                             size_t *in_used, size_t *out_len);
 
+/* .xz decode as mz_stream_lzma_read drives it for method 95 (mz_strm_lzma.c:127-128: lzma_stream_decoder,
+ * flags 0): one stream, LZMA2 filter only, checks none/CRC32/CRC64/SHA-256 verified.  in_used = bytes through
+ * the stream footer.  -109 = filter chain outside the backend's scope. */
+int32_t orc_xz_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, int64_t max_out, size_t *in_used,
+                      size_t *out_len);
+uint64_t orc_crc64(const uint8_t *p, size_t n);                 /* ECMA-182, the .xz check id 4 */
+void orc_sha256(const uint8_t *p, size_t n, uint8_t out[32]);  /* FIPS 180-4, the .xz check id 10 */
+
 #ifdef __cplusplus
 }
 #endif

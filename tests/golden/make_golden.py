@@ -6,7 +6,7 @@ Run in the build container (needs /root/reference and oracle/_ref):
     python tests/golden/make_golden.py
 
 For every entry of every archive under test/fuzz/unzip_fuzzer_seed_corpus/ whose method is
-STORE(0), DEFLATE(8) or LZMA(14) the script records the raw entry payload exactly as it sits
+STORE(0), DEFLATE(8), LZMA(14) or XZ(95) the script records the raw entry payload exactly as it sits
 in the archive, plus the (crc32, compressed size, uncompressed size, flag) the archive's
 central directory pins for it -- these are the golden (payload, bytes, CRC) triples that
 third-party tools wrote and that the reference verifies at mz_zip.c:2116-2128.  Each payload is
@@ -55,7 +55,7 @@ def main():
             print("skip", name, e)
             continue
         for info in zf.infolist():
-            if info.compress_type not in (0, 8, 14) or info.flag_bits & 1:
+            if info.compress_type not in (0, 8, 14, 95) or info.flag_bits & 1:
                 continue
             if info.file_size > (1 << 20):
                 continue
@@ -67,7 +67,7 @@ def main():
                 data = pl
             else:
                 kw = {}
-                if info.compress_type == 14 and info.flag_bits & 2:
+                if info.compress_type in (14, 95) and info.flag_bits & 2:
                     kw = dict(max_in=info.compress_size, max_out=info.file_size)  # mz_zip.c:1842-1847
                 r = ref.stream_decode(info.compress_type, pl, info.file_size + 64, **kw)
                 data = r["out"]

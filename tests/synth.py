@@ -85,3 +85,91 @@ def corruptions(z, seed=3):
     i = len(z) // 3
     out.append(("xor55_third", z[:i] + bytes([z[i] ^ 0x55]) + z[i + 1:]))
     return out
+
+
+# ---- .xz helpers (method 95) -------------------------------------------------------------------------------
+def _vli(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _read_vli(b, p):
+    v = s = 0
+    while True:
+        v |= (b[p] & 0x7F) << s
+        s += 7
+        p += 1
+        if not b[p - 1] & 0x80:
+            return v, p
+
+
+def xz_blocks(x):
+    """Split a single-stream .xz image into (check_id, [(block_bytes, unpadded_size, uncompressed_size)])."""
+    check = x[7]
+    csz = (0, 4, 4, 4, 8, 8, 8, 16, 16, 16, 32, 32, 32, 64, 64, 64)[check]
+    isize = (int.from_bytes(x[-8:-4], "little") + 1) * 4
+    ipos = len(x) - 12 - isize
+    n, p = _read_vli(x, ipos + 1)
+    recs = []
+    for _ in range(n):
+        unp, p = _read_vli(x, p)
+        usz, p = _read_vli(x, p)
+        recs.append((unp, usz))
+    pos, out = 12, []
+    for unp, usz in recs:
+        padded = (unp + 3) & ~3
+        out.append((x[pos:pos + padded], unp, usz))
+        pos += padded
+    assert pos == ipos and csz >= 0
+    return check, out
+
+
+def xz_join(streams):
+    """One .xz stream holding every block of the given single-stream images (same check id): a multi-block
+    stream like `xz -T` / --block-size writes."""
+    check, blocks = None, []
+    for x in streams:
+        c, b = xz_blocks(x)
+        assert check in (None, c)
+        check = c
+        blocks += b
+    flags = bytes([0, check])
+    out = b"\xfd7zXZ\x00" + flags + zlib.crc32(flags).to_bytes(4, "little")
+    for blk, _, _ in blocks:
+        out += blk
+    idx = b"\x00" + _vli(len(blocks)) + b"".join(_vli(u) + _vli(s) for _, u, s in blocks)
+    idx += b"\x00" * (-len(idx) % 4)
+    idx += zlib.crc32(idx).to_bytes(4, "little")
+    tail = (len(idx) // 4 - 1).to_bytes(4, "little") + flags
+    return out + idx + zlib.crc32(tail).to_bytes(4, "little") + tail + b"YZ"
+
+
+def xz_cases():
+    """(name, data, xz_stream) covering presets, every verified check id, lc/lp/pb variety, stored (uncompressed)
+    LZMA2 chunks, multi-chunk and multi-block streams."""
+    import lzma
+
+    c = corpus()
+    rnd = np.random.RandomState(11)
+    noise = rnd.bytes(70000)
+    cases = []
+    for name, d in (("text100k", c[:100000]), ("empty", b""), ("one", b"a"), ("noise", noise), ("zeros", bytes(300000)),
+                    ("text+noise", c[:50000] + noise + c[50000:90000])):
+        for chk in (lzma.CHECK_NONE, lzma.CHECK_CRC32, lzma.CHECK_CRC64, lzma.CHECK_SHA256):
+            cases.append(("%s/check%d" % (name, chk), d, lzma.compress(d, format=lzma.FORMAT_XZ, check=chk, preset=6)))
+        for preset in (0, 9):
+            cases.append(("%s/preset%d" % (name, preset), d, lzma.compress(d, format=lzma.FORMAT_XZ, preset=preset)))
+        for lc, lp, pb, ds in ((0, 2, 0, 4096), (4, 0, 4, 1 << 16), (0, 4, 2, 1 << 20), (1, 3, 1, 1 << 12)):
+            f = [{"id": lzma.FILTER_LZMA2, "lc": lc, "lp": lp, "pb": pb, "dict_size": ds}]
+            cases.append(("%s/lc%dlp%dpb%d" % (name, lc, lp, pb), d, lzma.compress(d, format=lzma.FORMAT_XZ, filters=f)))
+    big = c + c[:200000]          # > 2 MiB would need a bigger corpus; several 64 KiB-compressed chunks is what matters
+    cases.append(("multi-chunk", big, lzma.compress(big, format=lzma.FORMAT_XZ, preset=1)))
+    parts = [c[:70000], noise[:5000], b"", c[70000:200000]]
+    cases.append(("multi-block", b"".join(parts), xz_join([lzma.compress(p, format=lzma.FORMAT_XZ) for p in parts])))
+    cases.append(("multi-block-sha", b"".join(parts),
+                  xz_join([lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_SHA256) for p in parts])))
+    return cases
