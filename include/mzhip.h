@@ -41,6 +41,7 @@ extern "C" {
 #define MZHIP_STATUS_DATA_ERROR (-3)
 #define MZHIP_STATUS_BUF_ERROR (-5)
 #define MZHIP_STATUS_OUT_FULL (-200)
+#define MZHIP_STATUS_UNSUPPORTED (-109) /* MZ_SUPPORT_ERROR (mz.h:38): construct outside the backend's scope */
 
 /* Library / device ------------------------------------------------------ */
 
@@ -96,6 +97,27 @@ MZHIP_API int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, c
                                    uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,
                                    int32_t *d_status, void *stream);
 
+/* .xz decode (ZIP method 95) with fused CRC-32 ------------------------------------------ */
+
+/* Replaces, for n method-95 entries at once, mz_stream_lzma_read with lzma_stream_decoder(flags 0)
+ * (mz_strm_lzma.c:127-128,147-241) + mz_crypt_crc32_update (mz_zip.c:2049).  Entry i's input is one .xz stream
+ * (stream header, blocks of LZMA2 chunks, index, footer); block checks none / CRC32 / CRC64 / SHA-256 are verified
+ * on the device.  Same argument and status conventions as mzhip_lzma_batch; d_in_used = bytes through the stream
+ * footer.  -109: filter chain other than a single LZMA2 filter, or lc + lp = 4. */
+MZHIP_API int32_t mzhip_xz_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                                 const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out,
+                                 uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,
+                                 int32_t *d_status, void *stream);
+
+/* SHA-1 / SHA-224 / SHA-256 of n buffers ----------------------------- */
+
+/* What the reader's hash verification computes per entry on the CPU: mz_crypt_sha_begin/_update/_end over the
+ * decoded bytes (mz_zip_rw.c:409-451,465-466; mz_crypt.h:29-35).  algorithm = MZ_HASH_SHA1 (20), MZ_HASH_SHA224
+ * (22) or MZ_HASH_SHA256 (23) (mz.h:127-131).  d_digest receives n x 32 bytes: the digest in its standard byte
+ * order followed by zero bytes.  One lane per buffer. */
+MZHIP_API int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
+                                  uint32_t algorithm, void *d_digest, void *stream);
+
 /* K4: raw-DEFLATE encode (fixed-Huffman blocks) with fused CRC-32 of the input ------------- */
 
 /* Replaces, for n pieces at once, mz_stream_zlib_write/_close (mz_strm_zlib.c:203-264,280-305 -> zlib
@@ -117,6 +139,8 @@ MZHIP_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t
                                      uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
 MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                   uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+MZHIP_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                                uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
 /* one segment of a stream: 64 KiB pieces, the last one final iff `final`; *crc = CRC-32 of `in` */
 MZHIP_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
                                      uint32_t out_cap, uint32_t *out_len, uint32_t *crc);

@@ -1,0 +1,173 @@
+/* hash_core.h -- the block checks of the .xz container that CRC-32 does not cover, and the hashes of SURVEY 8(f)
+ * row 4: SHA-256 / SHA-224 / SHA-1 (FIPS 180-4) as per-LANE functions -- a digest chain is strictly serial inside
+ * one message, so the parallel axis is messages: in k_sha_batch every lane hashes its own ZIP entry
+ * (mz_zip_rw.c:465-466 feeds mz_crypt_sha_update with the decoded bytes of one entry at a time); in the .xz
+ * kernel all 64 lanes of the wave that decoded the block run the same chain redundantly.  CRC-64 (ECMA-182,
+ * .xz check id 4) is wave-parallel: 64 contiguous pieces, one table-driven register per lane, then a six-level
+ * combine tree of GF(2) multiplications by x^(8 * piece * 2^k).
+ */
+#ifndef MZHIP_HASH_CORE_H
+#define MZHIP_HASH_CORE_H
+
+#include "crc32_core.h"
+#include "wave.h"
+
+#if defined(MZHIP_HOST_EMUL)
+#define MZ_CONST_TABLE static const
+#else
+#define MZ_CONST_TABLE __device__ __constant__ static const
+#endif
+
+MZ_CONST_TABLE uint32_t mz_k256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+#define MZ_ROR32(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+
+/* message word i (big endian) of the padded message: data, 0x80, zeros, 64-bit bit count */
+MZ_DEV uint32_t mz_sha_word(const uint8_t *p, uint64_t n, uint64_t total_words, uint64_t i) {
+    const uint64_t o = 4 * i;
+    if (o + 4 <= n) return __builtin_bswap32(mz_load_u32(p + o));
+    if (i == total_words - 1) return (uint32_t)(n << 3);
+    if (i == total_words - 2) return (uint32_t)(n >> 29);
+    uint32_t w = 0;
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint64_t q = o + k;
+        const uint32_t b = q < n ? p[q] : (q == n ? 0x80u : 0u);
+        w |= b << (24 - 8 * k);
+    }
+    return w;
+}
+
+/* SHA-256 family: h[] holds the initial value on entry and the digest words on return */
+MZ_DEV void mz_sha256_run(const uint8_t *p, uint64_t n, uint32_t h[8]) {
+    const uint64_t blocks = (n + 9 + 63) / 64, total_words = blocks * 16;
+    for (uint64_t b = 0; b < blocks; b++) {
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = mz_sha_word(p, n, total_words, b * 16 + (uint64_t)i);
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+            if (i >= 16) {
+                const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const uint32_t s0 = MZ_ROR32(w15, 7) ^ MZ_ROR32(w15, 18) ^ (w15 >> 3);
+                const uint32_t s1 = MZ_ROR32(w2, 17) ^ MZ_ROR32(w2, 19) ^ (w2 >> 10);
+                w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            }
+            const uint32_t t1 = hh + (MZ_ROR32(e, 6) ^ MZ_ROR32(e, 11) ^ MZ_ROR32(e, 25)) + ((e & f) ^ (~e & g)) + mz_k256[i] +
+                                w[i & 15];
+            const uint32_t t2 = (MZ_ROR32(a, 2) ^ MZ_ROR32(a, 13) ^ MZ_ROR32(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+}
+
+MZ_DEV void mz_sha256_init(uint32_t h[8], int is224) {
+    if (is224) {
+        h[0] = 0xc1059ed8; h[1] = 0x367cd507; h[2] = 0x3070dd17; h[3] = 0xf70e5939;
+        h[4] = 0xffc00b31; h[5] = 0x68581511; h[6] = 0x64f98fa7; h[7] = 0xbefa4fa4;
+    } else {
+        h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+        h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+    }
+}
+
+MZ_DEV void mz_sha1_run(const uint8_t *p, uint64_t n, uint32_t h[5]) {
+    const uint64_t blocks = (n + 9 + 63) / 64, total_words = blocks * 16;
+    h[0] = 0x67452301; h[1] = 0xEFCDAB89; h[2] = 0x98BADCFE; h[3] = 0x10325476; h[4] = 0xC3D2E1F0;
+    for (uint64_t b = 0; b < blocks; b++) {
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = mz_sha_word(p, n, total_words, b * 16 + (uint64_t)i);
+        uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
+#pragma unroll
+        for (int i = 0; i < 80; i++) {
+            if (i >= 16) {
+                const uint32_t x = w[(i - 3) & 15] ^ w[(i - 8) & 15] ^ w[(i - 14) & 15] ^ w[i & 15];
+                w[i & 15] = MZ_ROR32(x, 31);
+            }
+            uint32_t f, k;
+            if (i < 20) { f = (bb & c) | (~bb & d); k = 0x5A827999; }
+            else if (i < 40) { f = bb ^ c ^ d; k = 0x6ED9EBA1; }
+            else if (i < 60) { f = (bb & c) | (bb & d) | (c & d); k = 0x8F1BBCDC; }
+            else { f = bb ^ c ^ d; k = 0xCA62C1D6; }
+            const uint32_t t = MZ_ROR32(a, 27) + f + e + k + w[i & 15];
+            e = d; d = c; c = MZ_ROR32(bb, 2); bb = a; a = t;
+        }
+        h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e;
+    }
+}
+
+/* ---- CRC-64 (ECMA-182 reflected, 0xC96C5795D7870F42), wave-parallel ---------------------------------------- */
+#define MZ_CRC64_POLY 0xC96C5795D7870F42ull
+
+static inline void mzhip_crc64_table_init(uint64_t *t) {
+    for (uint32_t i = 0; i < 256; i++) {
+        uint64_t r = i;
+        for (int k = 0; k < 8; k++) r = (r >> 1) ^ ((r & 1) ? MZ_CRC64_POLY : 0);
+        t[i] = r;
+    }
+}
+
+/* a * b mod P64 on reflected polynomials (bit 63 = x^0) */
+MZ_DEV uint64_t mz_gf2_mul64(uint64_t a, uint64_t b) {
+    uint64_t p = 0;
+    for (int i = 0; i < 64; i++) {
+        p ^= b & (0ull - (a >> 63));
+        a <<= 1;
+        b = (b >> 1) ^ (MZ_CRC64_POLY & (0ull - (b & 1)));
+    }
+    return p;
+}
+
+/* result (uniform) = CRC-64/XZ of buf[0..n); tab64 = 256-entry table (LDS) */
+#define MZ_CRC64(result, buf, n, tab64)                                                                  \
+    do {                                                                                                 \
+        const uint64_t _n = (n);                                                                         \
+        uint64_t _res = 0;                                                                               \
+        if (_n != 0) {                                                                                   \
+            const uint64_t _piece = (_n + 63) / 64;                                                      \
+            PV(uint32_t, _lo);                                                                           \
+            PV(uint32_t, _hi);                                                                           \
+            PV(uint32_t, _olo);                                                                          \
+            PV(uint32_t, _ohi);                                                                          \
+            /* pieces are aligned to the END of the buffer, so every lane is followed by (63 - lane) whole pieces */ \
+            MZ_LANES {                                                                                   \
+                const int64_t _s = (int64_t)_n - (int64_t)(64 - lane) * (int64_t)_piece;                 \
+                const int64_t _e = _s + (int64_t)_piece;                                                 \
+                uint64_t _r = (_s <= 0 && _e > 0) ? ~0ull : 0ull;                                        \
+                for (int64_t _i = _s < 0 ? 0 : _s; _i < _e; _i++)                                        \
+                    _r = (tab64)[(uint8_t)_r ^ (buf)[_i]] ^ (_r >> 8);                                   \
+                P(_lo) = (uint32_t)_r;                                                                   \
+                P(_hi) = (uint32_t)(_r >> 32);                                                           \
+            }                                                                                            \
+            /* X = x^(8 * piece): square-and-multiply on uniform values */                               \
+            uint64_t _x = 1ull << 63, _sq = 1ull << 55; /* x^0, x^8 */                                   \
+            for (uint64_t _b = _piece; _b; _b >>= 1) {                                                   \
+                if (_b & 1) _x = mz_gf2_mul64(_x, _sq);                                                  \
+                _sq = mz_gf2_mul64(_sq, _sq);                                                            \
+            }                                                                                            \
+            for (int _k = 1; _k < 64; _k <<= 1) {                                                        \
+                MZ_GATHER(_olo, _lo, lane + _k);                                                         \
+                MZ_GATHER(_ohi, _hi, lane + _k);                                                         \
+                MZ_LANES {                                                                               \
+                    const uint64_t _r = mz_gf2_mul64(((uint64_t)P(_hi) << 32) | P(_lo), _x) ^            \
+                                        (((uint64_t)P(_ohi) << 32) | P(_olo));                           \
+                    P(_lo) = (uint32_t)_r;                                                               \
+                    P(_hi) = (uint32_t)(_r >> 32);                                                       \
+                }                                                                                        \
+                _x = mz_gf2_mul64(_x, _x);                                                               \
+            }                                                                                            \
+            _res = ~(((uint64_t)MZ_READLANE(_hi, 0) << 32) | MZ_READLANE(_lo, 0));                       \
+        }                                                                                                \
+        (result) = _res;                                                                                 \
+    } while (0)
+
+#endif

@@ -63,14 +63,14 @@ typedef struct mz_lzma_result {
             uint32_t _o = in_base + 4u * (uint32_t)lane;                                \
             uint32_t _d = 0;                                                            \
             for (uint32_t _b = 0; _b < 4; _b++)                                         \
-                if (_o + _b < in_len) _d |= (uint32_t)in[_o + _b] << (8 * _b);          \
+                if (_o + _b < rc_len) _d |= (uint32_t)rc_in[_o + _b] << (8 * _b);          \
             P(win) = _d;                                                                \
         }                                                                               \
     } while (0)
 
 #define LZ_NEXT_BYTE(dst)                                                               \
     do {                                                                                \
-        if (in_pos >= in_len) {                                                         \
+        if (in_pos >= rc_len) {                                                         \
             eof = 1;                                                                    \
             (dst) = 0;                                                                  \
         } else {                                                                        \
@@ -157,6 +157,171 @@ typedef struct mz_lzma_result {
         }                                                                               \
     } while (0)
 
+/* The packet loop, shared by K3 (LZMA1 to the end marker: lzma2 = 0, dict_start = 0) and the .xz kernel
+ * (LZMA2 chunk with a known uncompressed size: lzma2 = 1, stops at opos == chunk_end).  Expects the coder,
+ * model and output locals of its caller by name; leaves through `goto finish` with `status` on any failure. */
+#define LZ_PACKET_LOOP()                                                                                              \
+    for (;;) {                                                                                                        \
+        if (eof) goto finish; /* truncated input */                                                                   \
+        if (lzma2 && opos == chunk_end) break; /* LZMA2: the chunk's uncompressed size has been produced */           \
+        const uint32_t ps = opos & pb_mask;                                                                           \
+        uint32_t bit;                                                                                                 \
+        LZ_BIT(bit, LZ_IS_MATCH + state * 16 + ps);                                                                   \
+        if (!bit) {                                                                                                   \
+            /* literal */                                                                                             \
+            const uint32_t lbase = LZ_LIT + 0x300u * (((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));            \
+            uint32_t sym = 1;                                                                                         \
+            if (state >= 7) {                                                                                         \
+                uint32_t mb = match_byte;                                                                             \
+                do {                                                                                                  \
+                    uint32_t mbit = (mb >> 7) & 1u;                                                                   \
+                    mb <<= 1;                                                                                         \
+                    uint32_t b;                                                                                       \
+                    LZ_BIT(b, lbase + ((1u + mbit) << 8) + sym);                                                      \
+                    sym = (sym << 1) | b;                                                                             \
+                    if (mbit != b) break;                                                                             \
+                } while (sym < 0x100);                                                                                \
+            }                                                                                                         \
+            while (sym < 0x100) {                                                                                     \
+                uint32_t b;                                                                                           \
+                LZ_BIT(b, lbase + sym);                                                                               \
+                sym = (sym << 1) | b;                                                                                 \
+            }                                                                                                         \
+            if (eof) goto finish;                                                                                     \
+            if (opos == out_cap) {                                                                                    \
+                status = MZHIP_OUT_FULL;                                                                              \
+                goto finish;                                                                                          \
+            }                                                                                                         \
+            MZ_LANES { out[opos] = (uint8_t)sym; } /* uniform store */                                                \
+            MZ_WAVE_SYNC();                                                                                           \
+            prev_byte = sym & 0xFFu;                                                                                  \
+            opos++;                                                                                                   \
+            state = state < 4 ? 0 : (state < 10 ? state - 3 : state - 6);                                             \
+            if ((opos & (MZ_CRC_TILE - 1)) == 0) MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);  \
+            continue;                                                                                                 \
+        }                                                                                                             \
+        uint32_t len;                                                                                                 \
+        LZ_BIT(bit, LZ_IS_REP + state);                                                                               \
+        if (bit) {                                                                                                    \
+            if (opos == dict_start) goto finish; /* rep with an empty dictionary */                                   \
+            LZ_BIT(bit, LZ_IS_REP_G0 + state);                                                                        \
+            if (!bit) {                                                                                               \
+                LZ_BIT(bit, LZ_IS_REP0_LONG + state * 16 + ps);                                                       \
+                if (!bit) {                                                                                           \
+                    /* short rep: one byte from rep0 */                                                               \
+                    if (eof) goto finish;                                                                             \
+                    if (rep0 >= opos - dict_start || rep0 >= dict) goto finish;                                       \
+                    if (opos == out_cap) {                                                                            \
+                        status = MZHIP_OUT_FULL;                                                                      \
+                        goto finish;                                                                                  \
+                    }                                                                                                 \
+                    uint32_t b = MZ_UNIFORM(out[opos - rep0 - 1]);                                                    \
+                    MZ_LANES { out[opos] = (uint8_t)b; } /* uniform store */                                          \
+                    MZ_WAVE_SYNC();                                                                                   \
+                    prev_byte = b;                                                                                    \
+                    opos++;                                                                                           \
+                    match_byte = MZ_UNIFORM(out[opos - rep0 - 1]);                                                    \
+                    state = state < 7 ? 9 : 11;                                                                       \
+                    if ((opos & (MZ_CRC_TILE - 1)) == 0)                                                              \
+                        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);                           \
+                    continue;                                                                                         \
+                }                                                                                                     \
+            } else {                                                                                                  \
+                uint32_t dist;                                                                                        \
+                LZ_BIT(bit, LZ_IS_REP_G1 + state);                                                                    \
+                if (!bit) {                                                                                           \
+                    dist = rep1;                                                                                      \
+                } else {                                                                                              \
+                    LZ_BIT(bit, LZ_IS_REP_G2 + state);                                                                \
+                    if (!bit) {                                                                                       \
+                        dist = rep2;                                                                                  \
+                    } else {                                                                                          \
+                        dist = rep3;                                                                                  \
+                        rep3 = rep2;                                                                                  \
+                    }                                                                                                 \
+                    rep2 = rep1;                                                                                      \
+                }                                                                                                     \
+                rep1 = rep0;                                                                                          \
+                rep0 = dist;                                                                                          \
+            }                                                                                                         \
+            LZ_LEN_DECODE(len, LZ_REP_LEN, ps);                                                                       \
+            state = state < 7 ? 8 : 11;                                                                               \
+        } else {                                                                                                      \
+            rep3 = rep2;                                                                                              \
+            rep2 = rep1;                                                                                              \
+            rep1 = rep0;                                                                                              \
+            LZ_LEN_DECODE(len, LZ_LEN, ps);                                                                           \
+            state = state < 7 ? 7 : 10;                                                                               \
+            uint32_t slot;                                                                                            \
+            LZ_BITTREE(slot, LZ_POS_SLOT + (len < 4 ? len : 3u) * 64, 6);                                             \
+            if (slot < 4) {                                                                                           \
+                rep0 = slot;                                                                                          \
+            } else {                                                                                                  \
+                const uint32_t nb = (slot >> 1) - 1;                                                                  \
+                rep0 = (2u | (slot & 1u)) << nb;                                                                      \
+                uint32_t low;                                                                                         \
+                if (slot < 14) {                                                                                      \
+                    LZ_BITTREE_REV(low, LZ_POS_DEC + rep0 - slot, nb);                                                \
+                    rep0 += low;                                                                                      \
+                } else {                                                                                              \
+                    uint32_t direct = 0;                                                                              \
+                    for (uint32_t i = 0; i < nb - 4; i++) {                                                           \
+                        LZ_NORM();                                                                                    \
+                        range >>= 1;                                                                                  \
+                        code -= range;                                                                                \
+                        uint32_t t = 0u - (code >> 31);                                                               \
+                        code += range & t;                                                                            \
+                        direct = (direct << 1) + (t + 1);                                                             \
+                    }                                                                                                 \
+                    rep0 += direct << 4;                                                                              \
+                    LZ_BITTREE_REV(low, LZ_ALIGN, 4);                                                                 \
+                    rep0 += low;                                                                                      \
+                }                                                                                                     \
+            }                                                                                                         \
+            if (rep0 == 0xFFFFFFFFu) {                                                                                \
+                /* end-of-stream marker */                                                                            \
+                if (eof) goto finish;                                                                                 \
+                if (lzma2) goto finish; /* not allowed when the size is known */                                      \
+                LZ_NORM();                                                                                            \
+                if (eof) goto finish;                                                                                 \
+                status = (code == 0) ? MZHIP_OK : MZHIP_DATA_ERROR;                                                   \
+                goto finish;                                                                                          \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (eof) goto finish;                                                                                         \
+        len += 2;                                                                                                     \
+        if (rep0 >= opos - dict_start || rep0 >= dict) goto finish; /* distance beyond the dictionary */              \
+        if (lzma2 && len > chunk_end - opos) goto finish; /* match runs past the chunk's uncompressed size */         \
+        {                                                                                                             \
+            uint32_t n = len;                                                                                         \
+            int full = 0;                                                                                             \
+            if (n > out_cap - opos) {                                                                                 \
+                n = out_cap - opos;                                                                                   \
+                full = 1;                                                                                             \
+            }                                                                                                         \
+            const uint32_t dist = rep0 + 1;                                                                           \
+            const uint8_t *src = out + (opos - dist);                                                                 \
+            if (dist >= n) {                                                                                          \
+                MZ_LANES {                                                                                            \
+                    for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = src[i];                         \
+                }                                                                                                     \
+            } else {                                                                                                  \
+                MZ_LANES {                                                                                            \
+                    for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = src[i % dist];                  \
+                }                                                                                                     \
+            }                                                                                                         \
+            MZ_WAVE_SYNC();                                                                                           \
+            opos += n;                                                                                                \
+            if (full) {                                                                                               \
+                status = MZHIP_OUT_FULL;                                                                              \
+                goto finish;                                                                                          \
+            }                                                                                                         \
+            prev_byte = MZ_UNIFORM(out[opos - 1]);                                                                    \
+            match_byte = MZ_UNIFORM(out[opos - dist]);                                                                \
+            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);                                       \
+        }                                                                                                             \
+    }
+
 /* Decode one ZIP-LZMA entry.  All arguments wave-uniform.  max_out < 0: no clamp. */
 MZ_DEV void mz_lzma_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                           mz_lzma_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
@@ -164,6 +329,8 @@ MZ_DEV void mz_lzma_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
     MZ_LANE_DECL
     uint16_t *pr = L->probs;
     int32_t status = MZHIP_DATA_ERROR;
+    const uint8_t *rc_in = in;
+    const uint32_t rc_len = in_len, lzma2 = 0, dict_start = 0, chunk_end = 0;
     uint32_t opos = 0;
     uint32_t in_pos = 9, in_base = 9, eof = 0;
     uint32_t range = 0xFFFFFFFFu, code = 0;
@@ -214,163 +381,7 @@ MZ_DEV void mz_lzma_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint
         uint32_t prev_byte = 0, match_byte = 0;
         const uint32_t pb_mask = (1u << pb) - 1, lp_mask = (1u << lp) - 1;
 
-        for (;;) {
-            if (eof) goto finish; /* truncated input */
-            const uint32_t ps = opos & pb_mask;
-            uint32_t bit;
-            LZ_BIT(bit, LZ_IS_MATCH + state * 16 + ps);
-            if (!bit) {
-                /* literal */
-                const uint32_t lbase = LZ_LIT + 0x300u * (((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));
-                uint32_t sym = 1;
-                if (state >= 7) {
-                    uint32_t mb = match_byte;
-                    do {
-                        uint32_t mbit = (mb >> 7) & 1u;
-                        mb <<= 1;
-                        uint32_t b;
-                        LZ_BIT(b, lbase + ((1u + mbit) << 8) + sym);
-                        sym = (sym << 1) | b;
-                        if (mbit != b) break;
-                    } while (sym < 0x100);
-                }
-                while (sym < 0x100) {
-                    uint32_t b;
-                    LZ_BIT(b, lbase + sym);
-                    sym = (sym << 1) | b;
-                }
-                if (eof) goto finish;
-                if (opos == out_cap) {
-                    status = MZHIP_OUT_FULL;
-                    goto finish;
-                }
-                MZ_LANES { out[opos] = (uint8_t)sym; } /* uniform store */
-                MZ_WAVE_SYNC();
-                prev_byte = sym & 0xFFu;
-                opos++;
-                state = state < 4 ? 0 : (state < 10 ? state - 3 : state - 6);
-                if ((opos & (MZ_CRC_TILE - 1)) == 0) MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
-                continue;
-            }
-            uint32_t len;
-            LZ_BIT(bit, LZ_IS_REP + state);
-            if (bit) {
-                if (opos == 0) goto finish; /* rep with an empty dictionary */
-                LZ_BIT(bit, LZ_IS_REP_G0 + state);
-                if (!bit) {
-                    LZ_BIT(bit, LZ_IS_REP0_LONG + state * 16 + ps);
-                    if (!bit) {
-                        /* short rep: one byte from rep0 */
-                        if (eof) goto finish;
-                        if (rep0 >= opos || rep0 >= dict) goto finish;
-                        if (opos == out_cap) {
-                            status = MZHIP_OUT_FULL;
-                            goto finish;
-                        }
-                        uint32_t b = MZ_UNIFORM(out[opos - rep0 - 1]);
-                        MZ_LANES { out[opos] = (uint8_t)b; } /* uniform store */
-                        MZ_WAVE_SYNC();
-                        prev_byte = b;
-                        opos++;
-                        match_byte = MZ_UNIFORM(out[opos - rep0 - 1]);
-                        state = state < 7 ? 9 : 11;
-                        if ((opos & (MZ_CRC_TILE - 1)) == 0)
-                            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
-                        continue;
-                    }
-                } else {
-                    uint32_t dist;
-                    LZ_BIT(bit, LZ_IS_REP_G1 + state);
-                    if (!bit) {
-                        dist = rep1;
-                    } else {
-                        LZ_BIT(bit, LZ_IS_REP_G2 + state);
-                        if (!bit) {
-                            dist = rep2;
-                        } else {
-                            dist = rep3;
-                            rep3 = rep2;
-                        }
-                        rep2 = rep1;
-                    }
-                    rep1 = rep0;
-                    rep0 = dist;
-                }
-                LZ_LEN_DECODE(len, LZ_REP_LEN, ps);
-                state = state < 7 ? 8 : 11;
-            } else {
-                rep3 = rep2;
-                rep2 = rep1;
-                rep1 = rep0;
-                LZ_LEN_DECODE(len, LZ_LEN, ps);
-                state = state < 7 ? 7 : 10;
-                uint32_t slot;
-                LZ_BITTREE(slot, LZ_POS_SLOT + (len < 4 ? len : 3u) * 64, 6);
-                if (slot < 4) {
-                    rep0 = slot;
-                } else {
-                    const uint32_t nb = (slot >> 1) - 1;
-                    rep0 = (2u | (slot & 1u)) << nb;
-                    uint32_t low;
-                    if (slot < 14) {
-                        LZ_BITTREE_REV(low, LZ_POS_DEC + rep0 - slot, nb);
-                        rep0 += low;
-                    } else {
-                        uint32_t direct = 0;
-                        for (uint32_t i = 0; i < nb - 4; i++) {
-                            LZ_NORM();
-                            range >>= 1;
-                            code -= range;
-                            uint32_t t = 0u - (code >> 31);
-                            code += range & t;
-                            direct = (direct << 1) + (t + 1);
-                        }
-                        rep0 += direct << 4;
-                        LZ_BITTREE_REV(low, LZ_ALIGN, 4);
-                        rep0 += low;
-                    }
-                }
-                if (rep0 == 0xFFFFFFFFu) {
-                    /* end-of-stream marker */
-                    if (eof) goto finish;
-                    LZ_NORM();
-                    if (eof) goto finish;
-                    status = (code == 0) ? MZHIP_OK : MZHIP_DATA_ERROR;
-                    goto finish;
-                }
-            }
-            if (eof) goto finish;
-            len += 2;
-            if (rep0 >= opos || rep0 >= dict) goto finish; /* distance beyond the dictionary */
-            {
-                uint32_t n = len;
-                int full = 0;
-                if (n > out_cap - opos) {
-                    n = out_cap - opos;
-                    full = 1;
-                }
-                const uint32_t dist = rep0 + 1;
-                const uint8_t *src = out + (opos - dist);
-                if (dist >= n) {
-                    MZ_LANES {
-                        for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = src[i];
-                    }
-                } else {
-                    MZ_LANES {
-                        for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = src[i % dist];
-                    }
-                }
-                MZ_WAVE_SYNC();
-                opos += n;
-                if (full) {
-                    status = MZHIP_OUT_FULL;
-                    goto finish;
-                }
-                prev_byte = MZ_UNIFORM(out[opos - 1]);
-                match_byte = MZ_UNIFORM(out[opos - dist]);
-                MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
-            }
-        }
+        LZ_PACKET_LOOP();
     }
 
 finish:

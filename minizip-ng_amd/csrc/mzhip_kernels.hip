@@ -23,6 +23,7 @@
 #include "lzma_core.h"
 #include "deflate_core.h"
 #include "adler32_core.h"
+#include "xz_core.h"
 
 #define MZ_WAVES_PER_WG 4
 #define MZ_CRC_TAB_BYTES 1024
@@ -137,6 +138,7 @@ struct LzmaArgs {
     int32_t *status;
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
+    const uint64_t *tab64; // CRC-64 byte table (.xz kernel only)
 };
 
 // K3: one wave per workgroup, the wave's whole probability model (15.6 KiB) in LDS -> 10 waves per CU.
@@ -159,6 +161,59 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
         a.crc[e] = r.crc;
         a.status[e] = r.status;
     }
+}
+
+// .xz (method 95): one wave per workgroup like K3; LDS = probability model + CRC-64 table (17.6 KiB) -> 8 per CU.
+__global__ __launch_bounds__(64) void k_xz_batch(LzmaArgs a) {
+    __shared__ __attribute__((aligned(16))) mz_xz_lds lds;
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        crc_tab[i] = a.tabs->byte_tab[i];
+        lds.crc64_tab[i] = a.tab64[i];
+    }
+    __syncthreads();
+    MZ_LANE_DECL
+    for (;;) {
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
+        if (e >= a.n) break;
+        mz_lzma_result r;
+        mz_xz_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
+                    a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs, &r);
+        a.out_len[e] = r.out_len; // wave-uniform results: stored by all lanes
+        a.in_used[e] = r.in_used;
+        a.crc[e] = r.crc;
+        a.status[e] = r.status;
+    }
+}
+
+struct ShaArgs {
+    const uint8_t *buf;
+    const uint64_t *off;
+    const uint32_t *len;
+    uint32_t n;
+    uint32_t algorithm; // MZ_HASH_SHA1 20, MZ_HASH_SHA224 22, MZ_HASH_SHA256 23 (mz.h:127-131)
+    uint8_t *digest;    // n x 32 bytes, big-endian words, unused tail bytes zero
+};
+
+// SHA-1 / SHA-224 / SHA-256 of n buffers: a digest chain is serial, so ONE LANE hashes one buffer (64 per wave).
+__global__ __launch_bounds__(256) void k_sha_batch(ShaArgs a) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n) return;
+    const uint8_t *p = a.buf + a.off[e];
+    const uint64_t n = a.len[e];
+    uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t words;
+    if (a.algorithm == 20) {
+        mz_sha1_run(p, n, h);
+        words = 5;
+    } else {
+        mz_sha256_init(h, a.algorithm == 22);
+        mz_sha256_run(p, n, h);
+        words = a.algorithm == 22 ? 7 : 8;
+    }
+    uint32_t *d = (uint32_t *)(a.digest + (size_t)e * 32);
+    for (uint32_t i = 0; i < 8; i++) d[i] = i < words ? __builtin_bswap32(h[i]) : 0u;
 }
 
 struct DeflateArgs {
@@ -211,6 +266,7 @@ namespace {
 struct DeviceCtx {
     bool ready = false;
     mzhip_crc_tables *d_tabs = nullptr;
+    uint64_t *d_tab64 = nullptr;
     uint32_t *d_counters = nullptr;
     uint32_t next_counter = 0;
     int cu_count = 0;
@@ -247,6 +303,10 @@ int32_t ctx_for_current(DeviceCtx **out) {
         mzhip_crc_tables_init(&h);
         HIP_TRY(hipMalloc((void **)&c.d_tabs, sizeof(h)));
         HIP_TRY(hipMemcpy(c.d_tabs, &h, sizeof(h), hipMemcpyHostToDevice));
+        uint64_t t64[256];
+        mzhip_crc64_table_init(t64);
+        HIP_TRY(hipMalloc((void **)&c.d_tab64, sizeof(t64)));
+        HIP_TRY(hipMemcpy(c.d_tab64, t64, sizeof(t64), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&c.d_counters, MZ_NUM_COUNTERS * sizeof(uint32_t)));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -381,9 +441,9 @@ int32_t mzhip_adler32_batch(const void *d_buf, const uint64_t *d_off, const uint
     return 0;
 }
 
-int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
-                         const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out, uint32_t n,
-                         uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
+static int32_t lzma_family_batch(int xz, const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                                 const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out, uint32_t n,
+                                 uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
     if (n == 0) return 0;
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
@@ -404,10 +464,48 @@ int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint3
     a.status = d_status;
     a.counter = take_counter(c);
     a.tabs = c->d_tabs;
+    a.tab64 = c->d_tab64;
     HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
-    uint32_t resident = (uint32_t)c->cu_count * 10u; /* 16 KiB LDS per wave -> 10 single-wave workgroups per CU */
+    /* 16 KiB LDS per wave -> 10 single-wave workgroups per CU (K3); 17.6 KiB -> 8 (.xz) */
+    uint32_t resident = (uint32_t)c->cu_count * (xz ? 8u : 10u);
     uint32_t grid = n < resident ? n : resident;
-    hipLaunchKernelGGL(k_lzma_batch, dim3(grid), dim3(64), 0, s, a);
+    if (xz)
+        hipLaunchKernelGGL(k_xz_batch, dim3(grid), dim3(64), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_lzma_batch, dim3(grid), dim3(64), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                         const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out, uint32_t n,
+                         uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    return lzma_family_batch(0, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_max_out, n, d_out_len, d_in_used,
+                             d_crc, d_status, stream);
+}
+
+int32_t mzhip_xz_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                       const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out, uint32_t n,
+                       uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    return lzma_family_batch(1, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_max_out, n, d_out_len, d_in_used,
+                             d_crc, d_status, stream);
+}
+
+int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n, uint32_t algorithm,
+                        void *d_digest, void *stream) {
+    if (algorithm != 20 && algorithm != 22 && algorithm != 23) return MZHIP_STATUS_UNSUPPORTED;
+    if (n == 0) return 0;
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    ShaArgs a;
+    a.buf = (const uint8_t *)d_buf;
+    a.off = d_off;
+    a.len = d_len;
+    a.n = n;
+    a.algorithm = algorithm;
+    a.digest = (uint8_t *)d_digest;
+    hipLaunchKernelGGL(k_sha_batch, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -503,8 +601,8 @@ int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
     return mzhip_inflate_host2(in, in_len, out, out_cap, out_len, in_used, crc, nullptr);
 }
 
-int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
-                        uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+static int32_t lzma_family_host(int xz, const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                                uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -528,8 +626,8 @@ int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
     HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
     if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
     Meta *dm = (Meta *)base;
-    rc = mzhip_lzma_batch(base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, &dm->max_out, 1,
-                          &dm->out_len, &dm->in_used, &dm->crc, &dm->status, nullptr);
+    rc = lzma_family_batch(xz, base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, &dm->max_out, 1,
+                           &dm->out_len, &dm->in_used, &dm->crc, &dm->status, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
@@ -538,6 +636,16 @@ int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
     if (in_used) *in_used = m.in_used;
     if (crc) *crc = m.crc;
     return m.status;
+}
+
+int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                        uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    return lzma_family_host(0, in, in_len, out, out_cap, max_out, out_len, in_used, crc);
+}
+
+int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                      uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    return lzma_family_host(1, in, in_len, out, out_cap, max_out, out_len, in_used, crc);
 }
 
 // One stream segment: split into 64 KiB pieces (one wave each); every piece but the last ends with an empty

@@ -3,9 +3,10 @@
  * Drop-in for the reference's mz_strm_lzma.c (13 exported symbols,
  * mz_strm_lzma.h:20-35).  READ of method 14 (raw LZMA1 behind the ZIP-LZMA
  * header) is decoded by the device range decoder (K3, lzma_core.h) through
- * mzhip_lzma_host(); method 95 (XZ/LZMA2) and WRITE answer MZ_SUPPORT_ERROR,
- * which is what a reference build without that codec answers
- * (mz_strm_lzma.c:71-75,111-115).
+ * mzhip_lzma_host(); READ of method 95 (one .xz stream of LZMA2 blocks, what
+ * lzma_stream_decoder handles at mz_strm_lzma.c:127-128) by the .xz kernel
+ * (xz_core.h) through mzhip_xz_host().  WRITE answers MZ_SUPPORT_ERROR, which
+ * is what a reference build without compression answers (mz_strm_lzma.c:71-75).
  *
  * Contract mirrored from the reference (file:line = mz_strm_lzma.c):
  *   create :429-438  method LZMA, preset default, max_total_out -1
@@ -88,8 +89,8 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     if (mode & MZH_OPEN_MODE_WRITE)
         return MZH_SUPPORT_ERROR;
     if (mode & MZH_OPEN_MODE_READ) {
-        if (z->method != MZH_COMPRESS_METHOD_LZMA)
-            return MZH_SUPPORT_ERROR;
+        if (z->method != MZH_COMPRESS_METHOD_LZMA && z->method != MZH_COMPRESS_METHOD_XZ)
+            return MZH_OPEN_ERROR; /* neither decoder initialised: lzma->error stays non-OK, mz_strm_lzma.c:131-132 */
         if (mzhip_device_count() <= 0) {
             z->error = 1;
             return MZH_OPEN_ERROR;
@@ -98,14 +99,15 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
          * device input, which starts at the ZIP-LZMA header (mz_strm_lzma.c:118-124) */
         if (grow_in(z, 65536) != MZH_OK)
             return MZH_OPEN_ERROR;
-        for (int i = 0; i < LZMA_MAGIC_SIZE; i++) {
+        for (int i = 0; z->method == MZH_COMPRESS_METHOD_LZMA && i < LZMA_MAGIC_SIZE; i++) {
             uint8_t b = 0;
             if (base_read(z->stream.base, &b, 1) == 1)
                 z->in[z->in_len++] = b;
             else
                 z->in[z->in_len++] = 0; /* the reference ignores short reads here too */
         }
-        z->total_in += LZMA_MAGIC_SIZE;
+        if (z->method == MZH_COMPRESS_METHOD_LZMA)
+            z->total_in += LZMA_MAGIC_SIZE;
     }
     z->initialized = 1;
     z->mode = mode;
@@ -148,8 +150,8 @@ static int32_t attempt_decode(mzhip_lzma *z) {
                 return MZH_MEM_ERROR;
         }
         uint32_t out_len = 0, in_used = 0, crc = 0;
-        int32_t st = mzhip_lzma_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, z->max_total_out,
-                                     &out_len, &in_used, &crc);
+        int32_t st = (z->method == MZH_COMPRESS_METHOD_XZ ? mzhip_xz_host : mzhip_lzma_host)(
+            z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, z->max_total_out, &out_len, &in_used, &crc);
         if (st == MZHIP_STATUS_OUT_FULL) {
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
@@ -210,7 +212,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         int64_t est = z->out_len ? (z->dev_in_used * z->out_served) / z->out_len : 0;
         if (est >= z->dev_in_used)
             est = z->dev_in_used - 1;
-        if (est < LZMA_MAGIC_SIZE)
+        if (est < LZMA_MAGIC_SIZE && z->method == MZH_COMPRESS_METHOD_LZMA)
             est = LZMA_MAGIC_SIZE;
         z->total_in = est;
     }

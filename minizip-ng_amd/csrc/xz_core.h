@@ -1,0 +1,366 @@
+/* xz_core.h -- .xz decode (ZIP method 95) of ONE entry by ONE wavefront, CRC-32 of the output fused.
+ *
+ * Replaces what the reference does for a method-95 entry through mz_stream_lzma_read (mz_strm_lzma.c:127-128,
+ * 147-241 -> liblzma lzma_stream_decoder(flags 0) / lzma_code): one stream -- stream header, blocks (header,
+ * LZMA2 chunks, padding, check), index, stream footer ("The .xz File Format" 1.0.4) -- no concatenation, no
+ * stream padding.  The LZMA2 layer re-initialises the range coder for every chunk and carries the dictionary
+ * (the output buffer itself), the probability model (LDS) and the state / rep registers across chunks; the
+ * packet loop is the one K3 uses (lzma_core.h, LZ_PACKET_LOOP with lzma2 = 1).  Checks verified on the device:
+ * none, CRC32, CRC64 (wave-parallel, hash_core.h), SHA-256 (the wave runs the chain redundantly); other check
+ * ids are skipped unverified like lzma_stream_decoder does without LZMA_TELL_UNSUPPORTED_CHECK.
+ * Framing is parsed by wave-uniform code (it is a few dozen bytes per block).  Filter chains other than a
+ * single LZMA2 filter, and lc + lp = 4 (model larger than the LDS slice), answer MZHIP_UNSUPPORTED.
+ * Every framing / check / LZMA2 failure is MZHIP_DATA_ERROR (mz_stream_lzma_read maps all liblzma errors to
+ * MZ_DATA_ERROR, mz_strm_lzma.c:236-237); input that ends early is MZHIP_BUF_ERROR.
+ */
+#ifndef MZHIP_XZ_CORE_H
+#define MZHIP_XZ_CORE_H
+
+#include "hash_core.h"
+#include "lzma_core.h"
+
+typedef struct mz_xz_lds {
+    mz_lzma_lds lz;
+    uint64_t crc64_tab[256];
+} mz_xz_lds;
+
+/* CRC-32 of a short byte range with the wave-parallel folding of crc32_core.h */
+#define XZ_CRC32_RANGE(result, buf, n)                                                   \
+    do {                                                                                 \
+        PV(uint32_t, _xa);                                                               \
+        PV(uint32_t, _xt);                                                               \
+        uint32_t _xd = 0;                                                                \
+        MZ_LANES { P(_xa) = (lane == 0) ? 0xFFFFFFFFu : 0u; }                            \
+        MZ_CRC_FOLD_TILES(_xa, _xd, buf, n, crc_tab, tabs->kx);                          \
+        MZ_CRC_FINISH(result, _xa, _xt, _xd, buf, n, crc_tab, tabs);                     \
+    } while (0)
+
+#define XZ_BYTE(p) MZ_UNIFORM(in[(p)])
+#define XZ_LE32(p) (XZ_BYTE(p) | (XZ_BYTE((p) + 1) << 8) | (XZ_BYTE((p) + 2) << 16) | (XZ_BYTE((p) + 3) << 24))
+/* bytes [pos, pos + k) must exist */
+#define XZ_NEED(k)                                                                       \
+    do {                                                                                 \
+        if ((uint64_t)in_len - pos < (uint64_t)(k)) {                                    \
+            pos = in_len;                                                                \
+            status = MZHIP_BUF_ERROR;                                                    \
+            goto finish;                                                                 \
+        }                                                                                \
+    } while (0)
+/* variable-length integer at `p`, limited to `lim` (exclusive); short = what running off `lim` means */
+#define XZ_VLI(dst, p, lim, short_status)                                                \
+    do {                                                                                 \
+        uint64_t _v = 0;                                                                 \
+        uint32_t _i = 0;                                                                 \
+        for (;;) {                                                                       \
+            if (_i == 9) goto finish;                                                    \
+            if ((p) >= (lim)) {                                                          \
+                status = (short_status);                                                 \
+                if ((short_status) == MZHIP_BUF_ERROR) pos = in_len;                     \
+                goto finish;                                                             \
+            }                                                                            \
+            const uint32_t _b = XZ_BYTE(p);                                              \
+            (p)++;                                                                       \
+            if (_b == 0 && _i != 0) goto finish;                                         \
+            _v |= (uint64_t)(_b & 0x7Fu) << (7 * _i);                                    \
+            _i++;                                                                        \
+            if (!(_b & 0x80u)) break;                                                    \
+        }                                                                                \
+        (dst) = _v;                                                                      \
+    } while (0)
+
+MZ_DEV uint64_t mz_xz_mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h * 0xFF51AFD7ED558CCDull;
+}
+
+/* Decode one method-95 entry.  All arguments wave-uniform.  max_out < 0: no clamp. */
+MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                        mz_xz_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs, mz_lzma_result *res) {
+    MZ_LANE_DECL
+    uint16_t *pr = L->lz.probs;
+    const uint64_t *tab64 = L->crc64_tab;
+    int32_t status = MZHIP_DATA_ERROR;
+    uint32_t pos = 0;  /* container cursor */
+    uint32_t opos = 0; /* output cursor = dictionary position */
+    /* range coder over the current chunk */
+    const uint8_t *rc_in = in;
+    uint32_t rc_len = 0, in_pos = 0, in_base = 0, eof = 0, range = 0xFFFFFFFFu, code = 0;
+    const uint32_t lzma2 = 1;
+    uint32_t chunk_end = 0, dict_start = 0, rc_short = 0;
+    uint64_t dict = 4096;
+    uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0, prev_byte = 0, match_byte = 0;
+    uint32_t lc = 0, pb_mask = 0, lp_mask = 0;
+    PV(uint32_t, win);
+    PV(uint32_t, crc_acc);
+    PV(uint32_t, crc_tmp);
+    uint32_t crc_done = 0;
+    MZ_LANES {
+        P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u;
+        P(win) = 0;
+    }
+
+    /* stream header (2.1.1): magic, flags {0x00, check id}, CRC32(flags) */
+    XZ_NEED(12);
+    if (XZ_BYTE(0) != 0xFD || XZ_BYTE(1) != '7' || XZ_BYTE(2) != 'z' || XZ_BYTE(3) != 'X' || XZ_BYTE(4) != 'Z' ||
+        XZ_BYTE(5) != 0 || XZ_BYTE(6) != 0 || (XZ_BYTE(7) & 0xF0u))
+        goto finish;
+    {
+        uint32_t k;
+        XZ_CRC32_RANGE(k, in + 6, 2u);
+        if (k != XZ_LE32(8)) goto finish;
+    }
+    {
+        const uint32_t check = XZ_BYTE(7);
+        const uint32_t check_size = check == 0 ? 0u : check < 4 ? 4u : check < 7 ? 8u : check < 10 ? 16u : check < 13 ? 32u : 64u;
+        uint64_t nblocks = 0, blocks_digest = 0;
+        pos = 12;
+
+        for (;;) {
+            XZ_NEED(1);
+            if (XZ_BYTE(pos) == 0) break; /* index indicator */
+            /* ---- block header (3.1) ---- */
+            const uint32_t hpos = pos, hsize = (XZ_BYTE(pos) + 1u) * 4u;
+            XZ_NEED(hsize);
+            {
+                uint32_t k;
+                XZ_CRC32_RANGE(k, in + hpos, hsize - 4u);
+                if (k != XZ_LE32(hpos + hsize - 4u)) goto finish;
+            }
+            const uint32_t bflags = XZ_BYTE(hpos + 1u);
+            if (bflags & 0x3Cu) goto finish; /* reserved bits */
+            uint32_t p = hpos + 2u;
+            const uint32_t hend = hpos + hsize - 4u;
+            uint64_t want_csize = ~0ull, want_usize = ~0ull;
+            if (bflags & 0x40u) {
+                XZ_VLI(want_csize, p, hend, MZHIP_DATA_ERROR);
+                if (want_csize == 0) goto finish;
+            }
+            if (bflags & 0x80u) XZ_VLI(want_usize, p, hend, MZHIP_DATA_ERROR);
+            {
+                uint64_t id, psize;
+                XZ_VLI(id, p, hend, MZHIP_DATA_ERROR);
+                XZ_VLI(psize, p, hend, MZHIP_DATA_ERROR);
+                if (psize > hend - p) goto finish;
+                if (id != 0x21 || (bflags & 3u) != 0) {
+                    status = MZHIP_UNSUPPORTED; /* delta / BCJ chains */
+                    goto finish;
+                }
+                if (psize != 1) goto finish;
+                const uint32_t db = XZ_BYTE(p);
+                p++;
+                if (db > 40) goto finish;
+                dict = db == 40 ? 0xFFFFFFFFull : (uint64_t)(2u | (db & 1u)) << (db / 2u + 11u);
+                if (dict < 4096) dict = 4096;
+                dict = (dict + 15) & ~(uint64_t)15;
+            }
+            for (; p < hend; p++)
+                if (XZ_BYTE(p) != 0) goto finish; /* header padding */
+            pos = hpos + hsize;
+
+            /* ---- LZMA2 chunks ---- */
+            const uint32_t data_pos = pos, block_out = opos;
+            uint32_t need_props = 1, need_dict_reset = 1;
+            for (;;) {
+                XZ_NEED(1);
+                const uint32_t ctl = XZ_BYTE(pos);
+                pos++;
+                if (ctl == 0) break;
+                if (ctl >= 0xE0 || ctl == 1) {
+                    need_props = 1;
+                    need_dict_reset = 0;
+                    dict_start = opos;
+                } else if (need_dict_reset) {
+                    goto finish;
+                }
+                if (ctl >= 0x80) {
+                    XZ_NEED(4);
+                    const uint32_t usize = ((ctl & 0x1Fu) << 16) + (XZ_BYTE(pos) << 8) + XZ_BYTE(pos + 1) + 1u;
+                    const uint32_t csize = (XZ_BYTE(pos + 2) << 8) + XZ_BYTE(pos + 3) + 1u;
+                    pos += 4;
+                    uint32_t reset_model = ctl >= 0xA0;
+                    if (ctl >= 0xC0) {
+                        XZ_NEED(1);
+                        uint32_t d = XZ_BYTE(pos);
+                        pos++;
+                        if (d > (4 * 5 + 4) * 9 + 8) goto finish;
+                        const uint32_t nlc = d % 9;
+                        d /= 9;
+                        const uint32_t nlp = d % 5, npb = d / 5;
+                        if (nlc + nlp > 4) goto finish;
+                        if (nlc + nlp > MZ_LZMA_MAX_LCLP) {
+                            status = MZHIP_UNSUPPORTED; /* model does not fit the LDS slice */
+                            goto finish;
+                        }
+                        lc = nlc;
+                        lp_mask = (1u << nlp) - 1;
+                        pb_mask = (1u << npb) - 1;
+                        need_props = 0;
+                    } else if (need_props) {
+                        goto finish;
+                    }
+                    if (reset_model) {
+                        MZ_LANES {
+                            for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64)
+                                ((uint32_t *)pr)[i] = 0x04000400u;
+                        }
+                        MZ_WAVE_SYNC();
+                        state = 0;
+                        rep0 = rep1 = rep2 = rep3 = 0;
+                    }
+                    /* the chunk's compressed bytes are one self-contained range-coder run */
+                    const uint32_t short_in = (in_len - pos) < csize;
+                    rc_in = in + pos;
+                    rc_len = short_in ? in_len - pos : csize;
+                    in_pos = 0;
+                    in_base = 0;
+                    eof = 0;
+                    range = 0xFFFFFFFFu;
+                    code = 0;
+                    if (rc_len > 0 && MZ_UNIFORM(rc_in[0]) != 0) goto finish; /* liblzma: first coder byte must be 0 */
+                    LZ_REFILL();
+                    for (int i = 0; i < 5; i++) {
+                        uint32_t b;
+                        LZ_NEXT_BYTE(b);
+                        code = (code << 8) | b;
+                    }
+                    chunk_end = opos + usize; /* running into out_cap first is MZHIP_OUT_FULL from the loop itself */
+                    if (opos > dict_start) prev_byte = MZ_UNIFORM(out[opos - 1]);
+                    else prev_byte = 0;
+                    if (state >= 7 && rep0 < opos - dict_start) match_byte = MZ_UNIFORM(out[opos - rep0 - 1]);
+                    rc_short = short_in;
+                    if (eof) goto finish;
+                    LZ_PACKET_LOOP();
+                    LZ_NORM(); /* liblzma normalises once more before it requires the coder to hold 0 */
+                    if (eof) goto finish;
+                    if (code != 0 || in_pos != csize) goto finish;
+                    pos += csize;
+                } else {
+                    if (ctl > 2) goto finish;
+                    XZ_NEED(2);
+                    uint32_t n = (XZ_BYTE(pos) << 8) + XZ_BYTE(pos + 1) + 1u;
+                    pos += 2;
+                    uint32_t short_in = 0, full = 0;
+                    if (n > in_len - pos) {
+                        n = in_len - pos;
+                        short_in = 1;
+                    }
+                    if (n > out_cap - opos) {
+                        n = out_cap - opos;
+                        full = 1;
+                        short_in = 0;
+                    }
+                    MZ_LANES {
+                        for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = in[pos + i];
+                    }
+                    MZ_WAVE_SYNC();
+                    opos += n;
+                    pos += n;
+                    MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
+                    if (full) {
+                        status = MZHIP_OUT_FULL;
+                        goto finish;
+                    }
+                    if (short_in) {
+                        status = MZHIP_BUF_ERROR;
+                        goto finish;
+                    }
+                }
+            }
+            /* ---- sizes, block padding, check (3.3, 3.4) ---- */
+            const uint32_t csize_blk = pos - data_pos, usize_blk = opos - block_out;
+            if ((want_csize != ~0ull && want_csize != csize_blk) || (want_usize != ~0ull && want_usize != usize_blk))
+                goto finish;
+            while ((pos - data_pos) & 3u) {
+                XZ_NEED(1);
+                if (XZ_BYTE(pos) != 0) goto finish;
+                pos++;
+            }
+            XZ_NEED(check_size);
+            if (check == 1) {
+                uint32_t k;
+                XZ_CRC32_RANGE(k, out + block_out, usize_blk);
+                if (k != XZ_LE32(pos)) goto finish;
+            } else if (check == 4) {
+                uint64_t k;
+                MZ_CRC64(k, out + block_out, (uint64_t)usize_blk, tab64);
+                if ((uint32_t)k != XZ_LE32(pos) || (uint32_t)(k >> 32) != XZ_LE32(pos + 4)) goto finish;
+            } else if (check == 10) {
+                uint32_t h[8], bad = 0;
+                mz_sha256_init(h, 0);
+                mz_sha256_run(out + block_out, (uint64_t)usize_blk, h);
+                for (uint32_t i = 0; i < 8; i++) {
+                    const uint32_t w = (XZ_BYTE(pos + 4 * i) << 24) | (XZ_BYTE(pos + 4 * i + 1) << 16) |
+                                       (XZ_BYTE(pos + 4 * i + 2) << 8) | XZ_BYTE(pos + 4 * i + 3);
+                    bad |= w ^ MZ_UNIFORM(h[i]);
+                }
+                if (bad) goto finish;
+            }
+            pos += check_size;
+            nblocks++;
+            blocks_digest = mz_xz_mix(mz_xz_mix(blocks_digest, (uint64_t)hsize + csize_blk + check_size), usize_blk);
+        }
+
+        /* ---- index (4) and stream footer (2.1.2) ---- */
+        {
+            const uint32_t ipos = pos;
+            uint32_t p = ipos + 1u;
+            uint64_t count, rec_digest = 0;
+            XZ_VLI(count, p, in_len, MZHIP_BUF_ERROR);
+            if (count != nblocks) goto finish;
+            for (uint64_t i = 0; i < count; i++) {
+                uint64_t unpadded, usz;
+                XZ_VLI(unpadded, p, in_len, MZHIP_BUF_ERROR);
+                XZ_VLI(usz, p, in_len, MZHIP_BUF_ERROR);
+                rec_digest = mz_xz_mix(mz_xz_mix(rec_digest, unpadded), usz);
+            }
+            if (rec_digest != blocks_digest) goto finish;
+            pos = p;
+            while ((pos - ipos) & 3u) {
+                XZ_NEED(1);
+                if (XZ_BYTE(pos) != 0) goto finish;
+                pos++;
+            }
+            XZ_NEED(4);
+            {
+                uint32_t k;
+                XZ_CRC32_RANGE(k, in + ipos, pos - ipos);
+                if (k != XZ_LE32(pos)) goto finish;
+            }
+            pos += 4;
+            const uint32_t isize = pos - ipos;
+            XZ_NEED(12);
+            const uint32_t f = pos;
+            pos += 12;
+            uint32_t k;
+            XZ_CRC32_RANGE(k, in + f + 4, 6u);
+            if (XZ_BYTE(f + 10) != 'Y' || XZ_BYTE(f + 11) != 'Z' || k != XZ_LE32(f) || XZ_BYTE(f + 8) != 0 ||
+                XZ_BYTE(f + 9) != check || ((uint64_t)XZ_LE32(f + 4) + 1u) * 4u != isize)
+                goto finish;
+            status = MZHIP_OK;
+        }
+    }
+
+finish:
+    {
+        uint32_t olen = opos;
+        if (max_out >= 0 && (int64_t)olen > max_out) olen = (uint32_t)max_out; /* mz_strm_lzma.c:214-215 */
+        if (status == MZHIP_DATA_ERROR && eof && rc_short) {
+            /* the coder ran off a chunk that the input does not hold completely: input ended early */
+            status = MZHIP_BUF_ERROR;
+            pos = in_len;
+        }
+        res->status = status;
+        res->out_len = olen;
+        res->in_used = pos > in_len ? in_len : pos;
+        uint32_t crc;
+        if (crc_done > olen) {
+            crc_done = 0;
+            MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
+        }
+        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, olen, crc_tab, tabs->kx);
+        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, out, olen, crc_tab, tabs);
+        res->crc = crc;
+    }
+}
+
+#endif

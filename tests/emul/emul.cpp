@@ -57,6 +57,50 @@ extern "C" uint32_t emul_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b)
     return mzhip_adler32_combine_host(a, b, len_b);
 }
 
+#include "hash_core.h"
+
+extern "C" uint64_t emul_crc64(const uint8_t *buf, uint64_t n) {
+    static uint64_t tab[256];
+    if (!tab[1]) mzhip_crc64_table_init(tab);
+    uint64_t r;
+    MZ_CRC64(r, buf, n, tab);
+    return r;
+}
+
+extern "C" void emul_sha(const uint8_t *buf, uint64_t n, int alg, uint8_t *digest) {
+    uint32_t h[8];
+    int words = 8;
+    if (alg == 20) {
+        mz_sha1_run(buf, n, h);
+        words = 5;
+    } else {
+        mz_sha256_init(h, alg == 22);
+        mz_sha256_run(buf, n, h);
+        words = alg == 22 ? 7 : 8;
+    }
+    for (int i = 0; i < words; i++)
+        for (int k = 0; k < 4; k++) digest[4 * i + k] = (uint8_t)(h[i] >> (24 - 8 * k));
+}
+
+#include "xz_core.h"
+
+extern "C" int32_t emul_xz(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                           uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    ready();
+    mz_xz_lds *L = (mz_xz_lds *)malloc(sizeof(mz_xz_lds));
+    memset(L, 0xA5, sizeof(*L));
+    mzhip_crc64_table_init(L->crc64_tab);
+    mz_lzma_result r;
+    mz_xz_entry(in, in_len, out, out_cap, max_out, L, g_tabs.byte_tab, &g_tabs, &r);
+    free(L);
+    *out_len = r.out_len;
+    *in_used = r.in_used;
+    *crc = r.crc;
+    return r.status;
+}
+
+extern "C" uint32_t emul_xz_lds_bytes(void) { return (uint32_t)sizeof(mz_xz_lds); }
+
 extern "C" uint32_t emul_lds_bytes(void) { return (uint32_t)sizeof(mz_inflate_lds); }
 
 #include "lzma_core.h"

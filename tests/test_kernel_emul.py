@@ -29,11 +29,16 @@ def emu():
     L = C.CDLL(so)
     L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
     L.emul_lzma.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_xz.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
     L.emul_deflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.emul_adler32.restype = C.c_uint32
     L.emul_adler32.argtypes = [_u8p, C.c_uint32]
     L.emul_adler32_combine.restype = C.c_uint32
     L.emul_adler32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+    L.emul_crc64.restype = C.c_uint64
+    L.emul_crc64.argtypes = [_u8p, C.c_uint64]
+    L.emul_sha.restype = None
+    L.emul_sha.argtypes = [_u8p, C.c_uint64, C.c_int, _u8p]
     L.emul_crc32.restype = C.c_uint32
     L.emul_crc32.argtypes = [_u8p, C.c_uint32]
     return L
@@ -72,6 +77,32 @@ def test_adler32_tiles_tail_and_combine(emu):
             assert emu.emul_adler32(a.ctypes.data_as(_u8p), n) == zlib.adler32(d), n
             k = n // 3
             assert emu.emul_adler32_combine(zlib.adler32(d[:k]), zlib.adler32(d[k:]), n - k) == zlib.adler32(d), n
+
+
+def test_crc64_and_sha_vs_hashlib(emu):
+    """The .xz block checks (CRC-64, SHA-256) and the row-4 hashes (SHA-1/224/256): piece alignment, padding
+    boundaries (55/56/63/64 bytes), and the reference's own KAT string (test/test_crypt.cc:26,50-116)."""
+    import hashlib
+
+    rnd = np.random.RandomState(4)
+    kat = b"the quick and lazy fox did his thang"
+    for n in (0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 1000, 4097, 100001):
+        d = rnd.bytes(n)
+        a = np.frombuffer(d, dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+        assert emu.emul_crc64(a.ctypes.data_as(_u8p), n) == oracle.crc64(d), n
+        for alg, fn in ((20, hashlib.sha1), (22, hashlib.sha224), (23, hashlib.sha256)):
+            out = np.zeros(32, np.uint8)
+            emu.emul_sha(a.ctypes.data_as(_u8p), n, alg, out.ctypes.data_as(_u8p))
+            assert out.tobytes()[:fn().digest_size] == fn(d).digest(), (n, alg)
+    a = np.frombuffer(b"123456789", dtype=np.uint8).copy()
+    assert emu.emul_crc64(a.ctypes.data_as(_u8p), 9) == 0x995DC9BBDF1939FA
+    a = np.frombuffer(kat, dtype=np.uint8).copy()
+    for alg, want in ((20, "3efb8392b6cd8e14bd76bd08081521dc73df418c"),
+                      (22, "9e444f5f0b6582a923bd48696155f4a2f0d914e044cb64b8729a6600"),
+                      (23, "7a31ea0848525f7ebfeec9ee532bcc5d6d26772427e097b86cf440a56546541c")):
+        out = np.zeros(32, np.uint8)
+        emu.emul_sha(a.ctypes.data_as(_u8p), len(kat), alg, out.ctypes.data_as(_u8p))
+        assert out.tobytes()[:len(want) // 2].hex() == want, alg
 
 
 def test_inflate_edges(emu):
@@ -145,6 +176,58 @@ def test_lzma_fixture(emu, fixtures):
             continue
         st, used, out, crc = _run(emu.emul_lzma, e["payload"], e["usize"] + 4, C.c_int64(e["usize"]))
         assert (st, used, len(out), crc) == (0, e["csize"], e["usize"], e["crc"])
+
+
+def test_xz_cases_and_fuzz(emu, fixtures):
+    """The .xz kernel (container + LZMA2 + checks) in emulation vs the oracle: every generated case, the xz.zip
+    fixture, the TOTAL_OUT_MAX clamp, out_cap, and 1500 corrupted / truncated streams (same accept / reject
+    decision; on accept the same bytes, consumed input and CRC)."""
+    import random
+
+    assert emu.emul_xz_lds_bytes() + 1024 <= 19 * 1024        # 8 single-wave workgroups per 160 KiB CU
+    cases = synth.xz_cases()
+    n_unsupported = 0
+    for name, d, x in cases:
+        st, used, out, crc = _run(emu.emul_xz, x + b"tail", len(d) + 64, C.c_int64(-1))
+        if st == -109:                                           # lc + lp = 4: model does not fit the LDS slice
+            assert ("lp4" in name or "lc4" in name or "lc1lp3" in name) and len(d) > 1, name
+            n_unsupported += 1
+            continue
+        assert (st, used, out, crc) == (0, len(x), d, zlib.crc32(d)), (name, st, used, len(x))
+    assert 4 <= n_unsupported <= 12
+    for e in fixtures:
+        if e["method"] == 95:
+            st, used, out, crc = _run(emu.emul_xz, e["payload"], e["usize"] + 4, C.c_int64(e["usize"]))
+            assert (st, used, len(out), crc) == (0, e["csize"], e["usize"], e["crc"])
+    name, d, x = cases[0]
+    st, used, out, crc = _run(emu.emul_xz, x, len(d) + 64, C.c_int64(3000))
+    assert st == 0 and out == d[:3000] and crc == zlib.crc32(d[:3000])
+    st, used, out, crc = _run(emu.emul_xz, x, len(d) - 1, C.c_int64(-1))
+    assert st == -200
+    rnd = random.Random(9)
+    bases = [x for n, d, x in cases if 0 < len(d) <= 100000 and "lp4" not in n and "lc4" not in n and "lc1lp3" not in n]
+    for it in range(1500):
+        x = bytearray(rnd.choice(bases))
+        k = rnd.randrange(5)
+        if k == 0:
+            x[rnd.randrange(len(x))] ^= 1 << rnd.randrange(8)
+        elif k == 1:
+            x[rnd.randrange(len(x))] = rnd.randrange(256)
+        elif k == 2:
+            del x[rnd.randrange(1, len(x)):]
+        elif k == 3:
+            x[rnd.randrange(min(len(x), 40))] = rnd.randrange(256)
+        else:
+            x[-rnd.randrange(1, 40)] = rnd.randrange(256)
+        x = bytes(x)
+        st, used, out, crc = _run(emu.emul_xz, x, 200000, C.c_int64(-1))
+        so, uo, oo = oracle.xz_decode(x, 200000)
+        if so == 0:
+            assert (st, used, out, crc) == (0, uo, oo, zlib.crc32(oo)), (it, k)
+        elif so == -109:
+            assert st in (-109, -3), (it, k, st)
+        else:
+            assert st == so or (st, so) in ((-109, -3),), (it, k, st, so)
 
 
 def _deflate(emu, d, final=1):
