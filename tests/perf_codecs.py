@@ -1,4 +1,5 @@
-"""GPU probe (not a pytest): throughput of K3 (LZMA decode) and K4 (DEFLATE encode) at config-like shapes."""
+"""GPU probe (not a pytest): throughput of K3 (LZMA decode), the .xz kernel, K4 (DEFLATE encode) and the SHA batch
+kernel at config-like shapes.  Usage: python tests/perf_codecs.py [lzma|xz|deflate|sha|both|all]"""
 import ctypes as C
 import sys
 import time
@@ -35,7 +36,7 @@ def timed(fn, reps=3):
     return best
 
 
-if which in ("lzma", "both"):
+if which in ("lzma", "both", "all"):
     n_unique, n_total, size = 16, int(sys.argv[2]) if len(sys.argv) > 2 else 2560, 1 << 20
     rnd = np.random.RandomState(3)
     words = synth.corpus().split()
@@ -61,7 +62,7 @@ if which in ("lzma", "both"):
     print("LZMA decode: %d x %d B, ratio %.3f: %.1f ms  %.2f GiB/s out  ok=%s" % (
         n_total, size, ratio, ms, n_total * size / 2**30 / (ms / 1e3), ok), flush=True)
 
-if which in ("deflate", "both"):
+if which in ("deflate", "both", "all"):
     n_unique, n_total, size = 512, 20000, 65536
     datas = synth.slices(n_unique, size, 1234)
     idx = np.arange(n_total) % n_unique
@@ -81,3 +82,49 @@ if which in ("deflate", "both"):
         ok = ok and zlib.decompress(gpu_util.entry_bytes(b, h, i, int(ol[i])), -15) == datas[idx[i]]
     print("DEFLATE encode: %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.3f  ok=%s" % (
         n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), ok), flush=True)
+
+if which in ("xz", "all"):
+    import lzma as pylzma
+
+    L.mzhip_xz_batch.restype = C.c_int32
+    L.mzhip_xz_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 5
+    n_unique, n_total, size = 16, 2048, 1 << 20
+    rnd = np.random.RandomState(3)
+    words = synth.corpus().split()
+    datas = [b" ".join(words[i] for i in rnd.randint(0, len(words), size=240000))[:size] for _ in range(n_unique)]
+    pays = [pylzma.compress(d, format=pylzma.FORMAT_XZ, preset=6) for d in datas]      # CRC64 check, like the reference writer
+    idx = np.arange(n_total) % n_unique
+    b = gpu_util.make_batch([pays[i] for i in idx], [size] * n_total)
+    out_len, in_used, crc, status = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(4))
+
+    def run3():
+        assert L.mzhip_xz_batch(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(),
+                                b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None, n_total,
+                                out_len.data_ptr(), in_used.data_ptr(), crc.data_ptr(), status.data_ptr(), None) == 0
+    ms = timed(run3, 2)
+    want = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)[idx]
+    ok = bool((status.cpu().numpy() == 0).all() and (mz.u32(crc) == want).all())
+    print(".xz decode (CRC64 verified): %d x %d B, ratio %.3f: %.1f ms  %.2f GiB/s out  ok=%s" % (
+        n_total, size, sum(len(p) for p in pays) / (n_unique * size), ms, n_total * size / 2**30 / (ms / 1e3), ok), flush=True)
+
+if which in ("sha", "all"):
+    import hashlib
+
+    L.mzhip_sha_batch.restype = C.c_int32
+    L.mzhip_sha_batch.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 2
+    n_unique, n_total, size = 512, 65536, 65536
+    datas = synth.slices(n_unique, size, 1234)
+    idx = np.arange(n_total) % n_unique
+    blob = torch.from_numpy(np.frombuffer(b"".join(datas), dtype=np.uint8).copy()).to(dev)
+    off = torch.from_numpy((idx.astype(np.int64) * size)).to(dev)
+    ln = torch.full((n_total,), size, dtype=torch.int32, device=dev)
+    dg = torch.zeros(n_total * 32, dtype=torch.uint8, device=dev)
+    for alg, fn in ((23, hashlib.sha256), (20, hashlib.sha1)):
+        def run4():
+            assert L.mzhip_sha_batch(blob.data_ptr(), off.data_ptr(), ln.data_ptr(), n_total, alg, dg.data_ptr(), None) == 0
+        ms = timed(run4)
+        h = dg.cpu().numpy().reshape(n_total, 32)
+        sz = fn().digest_size
+        ok = all(h[i, :sz].tobytes() == fn(datas[idx[i]]).digest() for i in range(0, n_total, 257))
+        print("SHA (alg %d) batch: %d x %d B: %.1f ms  %.2f GiB/s  ok=%s" % (alg, n_total, size, ms,
+                                                                            n_total * size / 2**30 / (ms / 1e3), ok), flush=True)
