@@ -1,23 +1,27 @@
-/* deflate_core.h -- raw-DEFLATE ENCODE of ONE piece by ONE wavefront, fixed-Huffman blocks, CRC-32 of
- * the input fused in (kernel K4 of SURVEY 2.1).
+/* deflate_core.h -- raw-DEFLATE ENCODE of ONE piece by ONE wavefront: LZ77 tokens chosen 64 positions at a
+ * time, then per 64 KiB block the cheapest of dynamic-Huffman / fixed-Huffman / stored coding, CRC-32 of the
+ * input fused in (kernel K4 of SURVEY 2.1).
  *
  * Replaces what the reference does per entry through mz_stream_zlib_write / _close
- * (mz_strm_zlib.c:203-264,280-305 -> zlib deflate(), raw, level 1) followed by
- * mz_crypt_crc32_update (mz_zip.c:2064).  Format: doc/zip/appnote.txt:2030-2166, fixed code :2050-2059.
- * The compressed bytes are NOT zlib's (compressor output is not a format property; zlib 1.2.11 and
- * zlib-ng already differ): parity for this kernel is "the reference's inflate of these bytes returns the
- * input, and the CRC matches" (hard parts).
+ * (mz_strm_zlib.c:203-264,280-305 -> zlib deflate(), raw) followed by mz_crypt_crc32_update (mz_zip.c:2064).
+ * Format: doc/zip/appnote.txt:2030-2166 (block types :2041-2063, dynamic header :2064-2106, fixed code
+ * :2050-2059).  The compressed bytes are NOT zlib's (compressor output is not a format property; zlib 1.2.11 and
+ * zlib-ng already differ): parity for this kernel is "the reference's inflate of these bytes returns the input,
+ * and the CRC matches" (hard parts).
  *
- * MI355X mapping: 64 input positions per step, one per lane.
+ * MI355X mapping, pass 1 (tokens), 64 input positions per step, one per lane:
  *   - match finding: each lane hashes its 4 bytes, looks the hash up in a per-wave LDS table of recent
- *     positions (read-then-update, one table access per lane per step) and measures the match in place
- *     with dword compares (minimum match 4, maximum 258, window 32 KiB);
+ *     positions (read-then-update) and measures the match in place with dword compares (min 4, max 258, 32 KiB);
  *   - greedy token selection is the same successor-chain problem as in the decoder (f(l) = l + len(l) or
- *     l + 1): f is squared five times with cross-lane gathers and lane r composes f^r(start), so the
- *     step's tokens land compacted in lanes 0..n-1 with no serial walk;
- *   - each token's fixed-Huffman bits (<= 31) are computed arithmetically (length / distance symbols by
- *     leading-zero count), bit offsets come from a DPP prefix sum, and lanes OR their bits into a small
- *     LDS staging area that is flushed to HBM as whole bytes.
+ *     l + 1): f is squared five times with cross-lane gathers and lane r composes f^r(start), so the step's
+ *     tokens land compacted in lanes 0..n-1 with no serial walk;
+ *   - tokens go to a per-wave scratch in HBM (<= 65 536 per block) and into LDS symbol histograms (atomics).
+ * Between the passes the wave builds the block's codes: rank sort of the used symbols (each lane counts the keys
+ * below its own), two-queue Huffman merge (wave-uniform), depths by walking to the root (per lane), halve-and-retry
+ * when a code would exceed 15 (7) bits, canonical codes by counting equal-length predecessors, the code-length
+ * sequence run-length coded as in appnote.txt:2070-2090, and the three block costs.
+ * Pass 2: 64 tokens per step, <= 48 bits each from the LDS code table, bit offsets from a DPP prefix sum, bits
+ * OR-ed into an LDS staging area that is flushed to HBM as whole bytes.
  */
 #ifndef MZHIP_DEFLATE_CORE_H
 #define MZHIP_DEFLATE_CORE_H
@@ -28,10 +32,31 @@
 #define MZ_DEF_HBITS 12
 #define MZ_DEF_MINMATCH 4u
 #define MZ_DEF_MAXMATCH 258u
+#define MZ_DEF_BLOCK 65536u /* input positions per DEFLATE block = token scratch entries per wave */
+#define MZ_DEF_NLIT 286u
+#define MZ_DEF_NDIST 30u
+#define MZ_DEF_NCL 19u
+#define MZ_DEF_DIST0 MZ_DEF_NLIT                 /* offsets into freq[] / code[] */
+#define MZ_DEF_CL0 (MZ_DEF_NLIT + MZ_DEF_NDIST)
+#define MZ_DEF_NSYM (MZ_DEF_NLIT + MZ_DEF_NDIST + MZ_DEF_NCL)
 
 typedef struct mz_deflate_lds {
-    uint16_t head[1 << MZ_DEF_HBITS]; /* low 16 bits of the most recent position with this hash */
-    uint32_t stage[72];               /* this step's bits, OR-ed in by the lanes (<= 64 x 31 bits + carry) */
+    union {
+        uint16_t head[1 << MZ_DEF_HBITS]; /* pass 1: low 16 bits of the most recent position with this hash */
+        struct {                          /* between the passes: code construction */
+            uint32_t wt[2 * MZ_DEF_NLIT];     /* node weights: sorted leaves, then internal nodes */
+            uint32_t sf[MZ_DEF_NLIT];         /* frequencies as scaled for the current attempt */
+            uint16_t parent[2 * MZ_DEF_NLIT];
+            uint16_t sym[MZ_DEF_NLIT];        /* sorted position -> symbol */
+            uint8_t cl_seq[MZ_DEF_NLIT + MZ_DEF_NDIST + 4]; /* header: code-length alphabet symbols ... */
+            uint8_t cl_ext[MZ_DEF_NLIT + MZ_DEF_NDIST + 4]; /* ... and their extra-bit values */
+        } hb;
+    } u;
+    uint32_t stage[104];          /* pass 2: this step's bits (<= 8 + 64 x 48) */
+    uint32_t freq[MZ_DEF_NSYM + 1]; /* histograms: literal/length, distance, code-length alphabet */
+    uint32_t code[MZ_DEF_NSYM + 1]; /* bit-reversed code | length << 16 */
+    uint32_t first[16];           /* canonical first code per length; bl_count while it is being made */
+    uint8_t lens[MZ_DEF_NSYM + 1];
 } mz_deflate_lds;
 
 typedef struct mz_deflate_result {
@@ -48,137 +73,282 @@ MZ_DEV uint32_t mz_clz32(uint32_t v) {
 #endif
 }
 
-/* fixed-Huffman code of a literal/length symbol, already bit-reversed for LSB-first packing
- * (appnote.txt:2050-2059); *nbits = its length */
-MZ_DEV uint32_t mz_fixed_litlen(uint32_t sym, uint32_t *nbits) {
-    uint32_t code, n;
-    if (sym < 144u) {
-        code = 0x30u + sym;
-        n = 8;
-    } else if (sym < 256u) {
-        code = 0x190u + (sym - 144u);
-        n = 9;
-    } else if (sym < 280u) {
-        code = sym - 256u;
-        n = 7;
-    } else {
-        code = 0xC0u + (sym - 280u);
-        n = 8;
-    }
-    *nbits = n;
-    return mz_brev32(code) >> (32u - n);
-}
-
-/* all bits of one token: literal, or length + distance with their extra bits (appnote.txt:2107-2133) */
-MZ_DEV uint32_t mz_token_bits(uint32_t mlen, uint32_t val, uint32_t *nbits) {
-    uint32_t n;
-    if (mlen == 0u) return mz_fixed_litlen(val, nbits);
-    /* length symbol */
-    uint32_t lsym, lex = 0, lxv = 0;
+/* length 3..258 -> symbol 257..285, number and value of extra bits (appnote.txt:2107-2120) */
+MZ_DEV uint32_t mz_len_sym(uint32_t mlen, uint32_t *ex, uint32_t *xv) {
     const uint32_t l = mlen - 3u;
-    if (mlen == 258u) {
-        lsym = 285u;
-    } else if (l < 8u) {
-        lsym = 257u + l;
-    } else {
-        const uint32_t k = 31u - mz_clz32(l);
-        lex = k - 2u;
-        lsym = 257u + 4u * lex + 4u + ((l >> lex) & 3u);
-        lxv = l & ((1u << lex) - 1u);
-    }
-    uint32_t bits = mz_fixed_litlen(lsym, &n);
-    bits |= lxv << n;
-    n += lex;
-    /* distance symbol: 5-bit fixed code */
-    const uint32_t d = val - 1u;
-    uint32_t dsym, dex = 0, dxv = 0;
-    if (d < 4u) {
-        dsym = d;
-    } else {
-        const uint32_t k = 31u - mz_clz32(d);
-        dex = k - 1u;
-        dsym = 2u * k + ((d >> (k - 1u)) & 1u);
-        dxv = d & ((1u << dex) - 1u);
-    }
-    bits |= (mz_brev32(dsym) >> 27) << n;
-    n += 5u;
-    bits |= dxv << n;
-    n += dex;
-    *nbits = n; /* <= 8 + 5 + 5 + 13 = 31 */
-    return bits;
+    *ex = 0;
+    *xv = 0;
+    if (mlen == 258u) return 285u;
+    if (l < 8u) return 257u + l;
+    const uint32_t k = 31u - mz_clz32(l);
+    *ex = k - 2u;
+    *xv = l & ((1u << (k - 2u)) - 1u);
+    return 257u + 4u * (k - 2u) + 4u + ((l >> (k - 2u)) & 3u);
 }
 
-/* Encode in[0..in_len) as one raw-DEFLATE piece.  final != 0: a complete stream (BFINAL block, padded to a
- * byte).  final == 0: a non-final block followed by an empty stored block, so that pieces of one stream can
- * be concatenated on byte boundaries.  All arguments wave-uniform. */
+/* distance 1..32768 -> symbol 0..29 (appnote.txt:2121-2133) */
+MZ_DEV uint32_t mz_dist_sym(uint32_t dist, uint32_t *ex, uint32_t *xv) {
+    const uint32_t d = dist - 1u;
+    *ex = 0;
+    *xv = 0;
+    if (d < 4u) return d;
+    const uint32_t k = 31u - mz_clz32(d);
+    *ex = k - 1u;
+    *xv = d & ((1u << (k - 1u)) - 1u);
+    return 2u * k + ((d >> (k - 1u)) & 1u);
+}
+
+/* position i of the code-length code lengths in the header: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+ * (appnote.txt:2083-2084), five bits per entry */
+MZ_DEV uint32_t mz_cl_order(uint32_t i) {
+    const uint64_t lo = 0x22CAA324E804A30ull, hi = 0x3C2E1346Cull;
+    return (uint32_t)((i < 12u ? lo >> (5u * i) : hi >> (5u * (i - 12u))) & 31u);
+}
+
+MZ_DEV uint32_t mz_fixed_litlen_bits(uint32_t sym) { return sym < 144u ? 8u : sym < 256u ? 9u : sym < 280u ? 7u : 8u; }
+
+/* Code lengths (<= maxbits) and canonical codes for the n-symbol alphabet at freq[base..]: results in
+ * L->lens[base + s] and L->code[base + s] = reversed code | len << 16.  Uses L->u.hb (the hash table is dead). */
+MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t maxbits) {
+    MZ_LANE_DECL
+    uint32_t *sf = L->u.hb.sf, *wt = L->u.hb.wt;
+    uint16_t *parent = L->u.hb.parent, *sym = L->u.hb.sym;
+    uint8_t *lens = L->lens + base;
+    PV(uint32_t, cnt);
+    MZ_LANES {
+        uint32_t c = 0;
+        for (uint32_t s = (uint32_t)lane; s < n; s += 64u) {
+            const uint32_t f = L->freq[base + s];
+            sf[s] = f;
+            lens[s] = 0;
+            c += f != 0u;
+        }
+        P(cnt) = c;
+    }
+    MZ_WAVE_SYNC();
+    uint32_t used;
+    MZ_WAVE_SUM(used, cnt);
+    if (used < 2u) {
+        /* a code needs two leaves; an unused symbol is given weight 1 (as zlib's build_tree does) */
+        const uint32_t f0 = MZ_UNIFORM(sf[0]);
+        MZ_LANES {
+            if (used == 0u || f0 == 0u) sf[0] = 1u;
+            if (used == 0u || f0 != 0u) sf[1] = 1u;
+        }
+        MZ_WAVE_SYNC();
+        used = 2u;
+    }
+    const uint32_t m = used, root = 2u * m - 2u;
+    for (;;) {
+        /* rank sort by (frequency, symbol): every lane counts the keys below its own */
+        MZ_LANES {
+            for (uint32_t s = (uint32_t)lane; s < n; s += 64u) {
+                const uint32_t f = sf[s];
+                if (f) {
+                    const uint32_t key = (f << 9) | s;
+                    uint32_t r = 0;
+                    for (uint32_t t = 0; t < n; t++) {
+                        const uint32_t ft = sf[t];
+                        r += (ft != 0u && ((ft << 9) | t) < key) ? 1u : 0u;
+                    }
+                    wt[r] = f;
+                    sym[r] = (uint16_t)s;
+                }
+            }
+        }
+        MZ_WAVE_SYNC();
+        /* two-queue merge, wave-uniform: leaves wt[0..m), internal nodes wt[m..2m-1) in creation order */
+        {
+            uint32_t i = 0, j = m;
+            uint32_t wi = MZ_UNIFORM(wt[0]), wj = 0xFFFFFFFFu;
+            for (uint32_t k = m; k <= root; k++) {
+                uint32_t a, b, wa, wb;
+                if (i < m && (j >= k || wi <= wj)) {
+                    a = i++;
+                    wa = wi;
+                    wi = i < m ? MZ_UNIFORM(wt[i]) : 0xFFFFFFFFu;
+                } else {
+                    a = j++;
+                    wa = wj;
+                    wj = j < k ? MZ_UNIFORM(wt[j]) : 0xFFFFFFFFu;
+                }
+                if (i < m && (j >= k || wi <= wj)) {
+                    b = i++;
+                    wb = wi;
+                    wi = i < m ? MZ_UNIFORM(wt[i]) : 0xFFFFFFFFu;
+                } else {
+                    b = j++;
+                    wb = wj;
+                    wj = j < k ? MZ_UNIFORM(wt[j]) : 0xFFFFFFFFu;
+                }
+                MZ_LANES {
+                    wt[k] = wa + wb;
+                    parent[a] = (uint16_t)k;
+                    parent[b] = (uint16_t)k;
+                }
+                MZ_WAVE_SYNC();
+                if (j == k) wj = wa + wb; /* the internal queue was empty: the new node is its head */
+            }
+        }
+        /* depth of every leaf = its code length */
+        PV(uint32_t, deep);
+        MZ_LANES {
+            uint32_t md = 0;
+            for (uint32_t r = (uint32_t)lane; r < m; r += 64u) {
+                uint32_t d = 0, k = r;
+                while (k != root) {
+                    k = parent[k];
+                    d++;
+                }
+                lens[sym[r]] = (uint8_t)d;
+                md = d > md ? d : md;
+            }
+            P(deep) = md;
+        }
+        MZ_WAVE_SYNC();
+        uint64_t over;
+        MZ_BALLOT(over, P(deep) > maxbits);
+        if (!over) break;
+        MZ_LANES {
+            for (uint32_t s = (uint32_t)lane; s < n; s += 64u) {
+                const uint32_t f = sf[s];
+                if (f) sf[s] = (f + 1u) >> 1;
+            }
+        }
+        MZ_WAVE_SYNC();
+    }
+    /* canonical codes (appnote.txt:2091-2106): count per length, first code per length, then rank inside the length */
+    MZ_LANES {
+        if (lane < 16) L->first[lane] = 0u;
+    }
+    MZ_WAVE_SYNC();
+    MZ_LANES {
+        for (uint32_t s = (uint32_t)lane; s < n; s += 64u)
+            if (lens[s]) MZ_LDS_ATOMIC_INC(&L->first[lens[s]]);
+    }
+    MZ_WAVE_SYNC();
+    {
+        uint32_t c = 0, prev = 0;
+        for (uint32_t b = 1; b <= 15u; b++) {
+            const uint32_t nb = MZ_UNIFORM(L->first[b]);
+            c = (c + prev) << 1;
+            prev = nb;
+            MZ_LANES { L->first[b] = c; }
+        }
+        MZ_WAVE_SYNC();
+    }
+    MZ_LANES {
+        for (uint32_t s = (uint32_t)lane; s < n; s += 64u) {
+            const uint32_t l = lens[s];
+            uint32_t v = 0;
+            if (l) {
+                uint32_t idx = 0;
+                for (uint32_t t = 0; t < s; t++) idx += (lens[t] == l) ? 1u : 0u;
+                v = (mz_brev32(L->first[l] + idx) >> (32u - l)) | (l << 16);
+            }
+            L->code[base + s] = v;
+        }
+    }
+    MZ_WAVE_SYNC();
+}
+
+/* append n (<= 32) bits to the output; keeps fewer than 8 bits pending */
+#define MZ_PUTBITS(v, n)                                                   \
+    do {                                                                   \
+        acc |= (uint64_t)(v) << nacc;                                      \
+        nacc += (n);                                                       \
+        while (nacc >= 8u) {                                               \
+            if (obyte == out_cap) {                                        \
+                status = MZHIP_OUT_FULL;                                   \
+                goto finish;                                               \
+            }                                                              \
+            MZ_LANES { out[obyte] = (uint8_t)acc; } /* uniform store */    \
+            obyte++;                                                       \
+            acc >>= 8;                                                     \
+            nacc -= 8u;                                                    \
+        }                                                                  \
+    } while (0)
+
+/* Encode in[0..in_len) as one raw-DEFLATE piece.  final != 0: a complete stream (last block BFINAL, padded to a
+ * byte).  final == 0: non-final blocks followed by an empty stored block, so that pieces of one stream can be
+ * concatenated on byte boundaries.  tok = this wave's token scratch (MZ_DEF_BLOCK words).  All arguments
+ * wave-uniform. */
 MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
-                             mz_deflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
+                             uint32_t *tok, mz_deflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
                              mz_deflate_result *res) {
     MZ_LANE_DECL
     int32_t status = MZHIP_OK;
-    uint32_t obyte = 0;                            /* whole bytes already written to out */
-    uint32_t carry = final ? 3u : 2u, cbits = 3u;  /* pending bits: BFINAL, BTYPE = 01 (fixed) */
-    uint32_t skip = 0;                             /* positions at the next step's start covered by a match */
+    uint32_t obyte = 0; /* whole bytes already written to out */
+    uint64_t acc = 0;   /* pending bits, fewer than 8 between operations */
+    uint32_t nacc = 0;
     PV(uint32_t, crc_acc);
     PV(uint32_t, crc_tmp);
     uint32_t crc_done = 0;
-    MZ_LANES {
-        P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u;
-        for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->head)[i] = 0u;
-    }
-    MZ_WAVE_SYNC();
+    MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
 
-    for (uint32_t p = 0; p < in_len; p += 64u) {
-        const uint32_t nv = (in_len - p < 64u) ? (in_len - p) : 64u; /* valid positions in this step */
-        /* ---- match candidates ---- */
-        PV(uint32_t, hh);
-        PV(uint32_t, cand);
+    for (uint32_t blk = 0; blk < in_len || blk == 0u; blk += MZ_DEF_BLOCK) {
+        const uint32_t blk_end = (in_len - blk < MZ_DEF_BLOCK) ? in_len : blk + MZ_DEF_BLOCK;
+        const uint32_t bfinal = (final && blk_end == in_len) ? 1u : 0u;
+        /* ================= pass 1: tokens and histograms ================= */
         MZ_LANES {
-            const uint32_t pos = p + (uint32_t)lane;
-            const uint32_t have4 = (pos + 4u <= in_len) ? 1u : 0u;
-            const uint32_t v = have4 ? mz_load_u32(in + pos) : 0u;
-            const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
-            P(hh) = have4 ? h : 0xFFFFFFFFu;
-            P(cand) = have4 ? (uint32_t)L->head[h] : 0u;
+            for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->u.head)[i] = 0u;
+            for (uint32_t i = (uint32_t)lane; i <= MZ_DEF_NSYM; i += 64u) L->freq[i] = 0u;
         }
         MZ_WAVE_SYNC();
-        MZ_LANES {
-            if (P(hh) != 0xFFFFFFFFu) L->head[P(hh)] = (uint16_t)(p + (uint32_t)lane);
-        }
-        MZ_WAVE_SYNC();
-        PV(uint32_t, pk); /* [8:0] match length (0 = literal), [24:9] distance | literal byte */
-        PV(uint32_t, g1); /* 4 * successor lane; bit 12 set: terminal */
-        MZ_LANES {
-            const uint32_t pos = p + (uint32_t)lane;
-            uint32_t mlen = 0, dist = 0;
-            if ((uint32_t)lane < nv) {
-                const uint32_t d = (pos - P(cand)) & 0xFFFFu;
-                if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos) {
-                    const uint8_t *a = in + pos, *b = in + (pos - d);
-                    const uint32_t maxl = (in_len - pos < MZ_DEF_MAXMATCH) ? (in_len - pos) : MZ_DEF_MAXMATCH;
-                    uint32_t l = 0;
-                    while (l + 4u <= maxl && mz_load_u32(a + l) == mz_load_u32(b + l)) l += 4u;
-                    while (l < maxl && a[l] == b[l]) l++;
-                    if (l >= MZ_DEF_MINMATCH) {
-                        mlen = l;
-                        dist = d;
+        uint32_t ntokens = 0, skip = 0;
+        PV(uint32_t, xbits); /* extra bits of this lane's tokens */
+        MZ_LANES { P(xbits) = 0; }
+        for (uint32_t p = blk; p < blk_end; p += 64u) {
+            const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u; /* valid positions in this step */
+            PV(uint32_t, hh);
+            PV(uint32_t, cand);
+            MZ_LANES {
+                const uint32_t pos = p + (uint32_t)lane;
+                const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
+                const uint32_t v = have4 ? mz_load_u32(in + pos) : 0u;
+                const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
+                P(hh) = have4 ? h : 0xFFFFFFFFu;
+                P(cand) = have4 ? (uint32_t)L->u.head[h] : 0u;
+            }
+            MZ_WAVE_SYNC();
+            MZ_LANES {
+                if (P(hh) != 0xFFFFFFFFu) L->u.head[P(hh)] = (uint16_t)(p + (uint32_t)lane);
+            }
+            MZ_WAVE_SYNC();
+            PV(uint32_t, pk); /* [8:0] match length (0 = literal), [24:9] distance | literal byte */
+            PV(uint32_t, g1); /* 4 * successor lane; bit 12 set: terminal */
+            MZ_LANES {
+                const uint32_t pos = p + (uint32_t)lane;
+                uint32_t mlen = 0, dist = 0;
+                if ((uint32_t)lane < nv) {
+                    const uint32_t d = (pos - P(cand)) & 0xFFFFu;
+                    /* the head table is cleared per block, so a candidate never precedes the block */
+                    if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - blk) {
+                        const uint8_t *a = in + pos, *b = in + (pos - d);
+                        const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
+                        uint32_t l = 0;
+                        while (l + 4u <= maxl && mz_load_u32(a + l) == mz_load_u32(b + l)) l += 4u;
+                        while (l < maxl && a[l] == b[l]) l++;
+                        if (l >= MZ_DEF_MINMATCH) {
+                            mlen = l;
+                            dist = d;
+                        }
                     }
                 }
+                P(pk) = mlen | ((mlen ? dist : (uint32_t)in[pos < blk_end ? pos : blk]) << 9);
+                const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
+                P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);
             }
-            P(pk) = mlen | ((mlen ? dist : (uint32_t)in[pos < in_len ? pos : 0u]) << 9);
-            const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
-            P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);
-        }
-        /* ---- greedy selection: lane r <- r-th element of the chain start, f(start), f(f(start)), ... ---- */
-        PV(uint32_t, g2);
-        PV(uint32_t, g4);
-        PV(uint32_t, g8);
-        PV(uint32_t, g16);
-        PV(uint32_t, g32);
-        PV(uint32_t, gt);
-        PV(uint32_t, ct);
-        PV(uint32_t, cpos);
-        MZ_LANES { P(cpos) = (skip >= nv) ? (0x1000u | (4u * skip)) : (4u * skip); }
+            /* greedy selection: lane r <- r-th element of the chain start, f(start), f(f(start)), ... */
+            PV(uint32_t, g2);
+            PV(uint32_t, g4);
+            PV(uint32_t, g8);
+            PV(uint32_t, g16);
+            PV(uint32_t, g32);
+            PV(uint32_t, gt);
+            PV(uint32_t, ct);
+            PV(uint32_t, cpos);
+            MZ_LANES { P(cpos) = (skip >= nv) ? (0x1000u | (4u * skip)) : (4u * skip); }
 #define MZ_DEF_ROUND(gin, gout, bit)                                                         \
     MZ_GATHER4(gt, gin, P(gin));                                                             \
     MZ_GATHER4(ct, gin, P(cpos));                                                            \
@@ -186,91 +356,267 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
         P(gout) = (P(gin) & 0x1000u) ? P(gin) : P(gt);                                       \
         P(cpos) = (((uint32_t)lane & (bit)) && !(P(cpos) & 0x1000u)) ? P(ct) : P(cpos);      \
     }
-        MZ_DEF_ROUND(g1, g2, 1u)
-        MZ_DEF_ROUND(g2, g4, 2u)
-        MZ_DEF_ROUND(g4, g8, 4u)
-        MZ_DEF_ROUND(g8, g16, 8u)
-        MZ_DEF_ROUND(g16, g32, 16u)
-        MZ_GATHER4(ct, g32, P(cpos));
-        MZ_LANES { P(cpos) = (((uint32_t)lane & 32u) && !(P(cpos) & 0x1000u)) ? P(ct) : P(cpos); }
+            MZ_DEF_ROUND(g1, g2, 1u)
+            MZ_DEF_ROUND(g2, g4, 2u)
+            MZ_DEF_ROUND(g4, g8, 4u)
+            MZ_DEF_ROUND(g8, g16, 8u)
+            MZ_DEF_ROUND(g16, g32, 16u)
+            MZ_GATHER4(ct, g32, P(cpos));
+            MZ_LANES { P(cpos) = (((uint32_t)lane & 32u) && !(P(cpos) & 0x1000u)) ? P(ct) : P(cpos); }
 #undef MZ_DEF_ROUND
-        uint64_t live;
-        MZ_BALLOT(live, !(P(cpos) & 0x1000u));
-        const uint32_t ntok = mz_popc64(live); /* tokens sit in lanes 0..ntok-1 */
-        /* ---- emit ---- */
-        PV(uint32_t, tpk);
-        PV(uint32_t, tbits);
-        PV(uint32_t, tn);
-        PV(uint32_t, tend);
-        MZ_GATHER4(tpk, pk, P(cpos));
-        MZ_LANES {
-            uint32_t n = 0, b = 0;
-            if ((uint32_t)lane < ntok) b = mz_token_bits(P(tpk) & 511u, P(tpk) >> 9, &n);
-            P(tbits) = b;
-            P(tn) = n;
-        }
-        MZ_INCL_SCAN(tend, tn);
-        const uint32_t total = MZ_READLANE(tend, 63);
-        if (ntok) { /* where the chain left this step: position of the last token + its length */
-            const uint32_t lastpos = MZ_READLANE(cpos, ntok - 1u) >> 2;
-            const uint32_t lastpk = MZ_READLANE(tpk, ntok - 1u);
-            const uint32_t nx = lastpos + ((lastpk & 511u) ? (lastpk & 511u) : 1u);
-            skip = nx > 64u ? nx - 64u : 0u;
-        } else {
-            skip = skip > 64u ? skip - 64u : 0u;
-        }
-        MZ_LANES {
-            for (uint32_t i = (uint32_t)lane; i < 72u; i += 64u) L->stage[i] = (i == 0u) ? carry : 0u;
-        }
-        MZ_WAVE_SYNC();
-        MZ_LANES {
-            if (P(tn)) {
-                const uint32_t off = cbits + P(tend) - P(tn);
-                const uint32_t w = off >> 5, sh = off & 31u;
-                MZ_LDS_ATOMIC_OR(&L->stage[w], P(tbits) << sh);
-                if (sh + P(tn) > 32u) MZ_LDS_ATOMIC_OR(&L->stage[w + 1u], P(tbits) >> (32u - sh));
-            }
-        }
-        MZ_WAVE_SYNC();
-        {
-            const uint32_t nbit = cbits + total, nbytes = nbit >> 3;
-            if (nbytes > out_cap - obyte) {
-                status = MZHIP_OUT_FULL;
-                goto finish;
+            uint64_t live;
+            MZ_BALLOT(live, !(P(cpos) & 0x1000u));
+            const uint32_t ntok = mz_popc64(live); /* tokens sit in lanes 0..ntok-1 */
+            PV(uint32_t, tpk);
+            MZ_GATHER4(tpk, pk, P(cpos));
+            if (ntok) { /* where the chain left this step: position of the last token + its length */
+                const uint32_t lastpos = MZ_READLANE(cpos, ntok - 1u) >> 2;
+                const uint32_t lastpk = MZ_READLANE(tpk, ntok - 1u);
+                const uint32_t nx = lastpos + ((lastpk & 511u) ? (lastpk & 511u) : 1u);
+                skip = nx > 64u ? nx - 64u : 0u;
+            } else {
+                skip = skip > 64u ? skip - 64u : 0u;
             }
             MZ_LANES {
-                for (uint32_t i = (uint32_t)lane; i < nbytes; i += 64u)
-                    out[obyte + i] = (uint8_t)(L->stage[i >> 2] >> (8u * (i & 3u)));
+                if ((uint32_t)lane < ntok) {
+                    const uint32_t t = P(tpk), mlen = t & 511u;
+                    tok[ntokens + (uint32_t)lane] = t;
+                    if (mlen == 0u) {
+                        MZ_LDS_ATOMIC_INC(&L->freq[t >> 9]);
+                    } else {
+                        uint32_t ex, xv, dx;
+                        MZ_LDS_ATOMIC_INC(&L->freq[mz_len_sym(mlen, &ex, &xv)]);
+                        MZ_LDS_ATOMIC_INC(&L->freq[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &dx, &xv)]);
+                        P(xbits) += ex + dx;
+                    }
+                }
             }
-            carry = (nbit & 7u) ? ((MZ_UNIFORM(L->stage[nbytes >> 2]) >> (8u * (nbytes & 3u))) & ((1u << (nbit & 7u)) - 1u)) : 0u;
-            cbits = nbit & 7u;
-            obyte += nbytes;
+            ntokens += ntok;
+            MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, (p + nv), crc_tab, tabs->kx);
         }
+        MZ_LANES { L->freq[256] = 1u; } /* end of block */
         MZ_WAVE_SYNC();
-        MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, (p + nv), crc_tab, tabs->kx);
+        uint32_t extra_total;
+        MZ_WAVE_SUM(extra_total, xbits);
+
+        /* ================= codes and the three block costs ================= */
+        mz_huff_build(L, 0u, MZ_DEF_NLIT, 15u);
+        mz_huff_build(L, MZ_DEF_DIST0, MZ_DEF_NDIST, 15u);
+        uint32_t nlit = MZ_DEF_NLIT, ndist = MZ_DEF_NDIST;
+        while (nlit > 257u && MZ_UNIFORM(L->lens[nlit - 1u]) == 0u) nlit--;
+        while (ndist > 1u && MZ_UNIFORM(L->lens[MZ_DEF_DIST0 + ndist - 1u]) == 0u) ndist--;
+        /* code-length sequence with run-length symbols 16 / 17 / 18 (appnote.txt:2070-2090), wave-uniform */
+        uint32_t nseq = 0;
+        {
+            const uint32_t total = nlit + ndist;
+#define MZ_DEF_LEN_AT(i) MZ_UNIFORM(L->lens[(i) < nlit ? (i) : MZ_DEF_DIST0 + (i) - nlit])
+#define MZ_DEF_SEQ(s, x)                                                                   \
+    do {                                                                                   \
+        const uint32_t _f = MZ_UNIFORM(L->freq[MZ_DEF_CL0 + (s)]) + 1u;                    \
+        MZ_LANES {                                                                         \
+            L->u.hb.cl_seq[nseq] = (uint8_t)(s);                                           \
+            L->u.hb.cl_ext[nseq] = (uint8_t)(x);                                           \
+            L->freq[MZ_DEF_CL0 + (s)] = _f;                                                \
+        }                                                                                  \
+        MZ_WAVE_SYNC();                                                                    \
+        nseq++;                                                                            \
+    } while (0)
+            uint32_t i = 0;
+            while (i < total) {
+                const uint32_t v = MZ_DEF_LEN_AT(i);
+                uint32_t run = 1;
+                while (i + run < total && MZ_DEF_LEN_AT(i + run) == v) run++;
+                i += run;
+                if (v == 0u) {
+                    while (run >= 11u) {
+                        const uint32_t r = run > 138u ? 138u : run;
+                        MZ_DEF_SEQ(18u, r - 11u);
+                        run -= r;
+                    }
+                    if (run >= 3u) {
+                        MZ_DEF_SEQ(17u, run - 3u);
+                        run = 0;
+                    }
+                } else {
+                    MZ_DEF_SEQ(v, 0u);
+                    run--;
+                    while (run >= 3u) {
+                        const uint32_t r = run > 6u ? 6u : run;
+                        MZ_DEF_SEQ(16u, r - 3u);
+                        run -= r;
+                    }
+                }
+                while (run) {
+                    MZ_DEF_SEQ(v, 0u);
+                    run--;
+                }
+            }
+#undef MZ_DEF_SEQ
+#undef MZ_DEF_LEN_AT
+        }
+        /* cl_seq / cl_ext are not among the u.hb members mz_huff_build works in, so they survive this call */
+        mz_huff_build(L, MZ_DEF_CL0, MZ_DEF_NCL, 7u);
+        uint32_t hclen = 19u;
+        PV(uint32_t, cost_d);
+        PV(uint32_t, cost_f);
+        MZ_LANES {
+            uint32_t cd = 0, cf = 0;
+            for (uint32_t s = (uint32_t)lane; s < MZ_DEF_NLIT + MZ_DEF_NDIST; s += 64u) {
+                const uint32_t f = L->freq[s];
+                cd += f * L->lens[s];
+                cf += f * (s < MZ_DEF_NLIT ? mz_fixed_litlen_bits(s) : 5u);
+            }
+            for (uint32_t s = (uint32_t)lane; s < MZ_DEF_NCL; s += 64u)
+                cd += L->freq[MZ_DEF_CL0 + s] * (L->lens[MZ_DEF_CL0 + s] + (s == 16u ? 2u : s == 17u ? 3u : s == 18u ? 7u : 0u));
+            P(cost_d) = cd;
+            P(cost_f) = cf;
+        }
+        uint32_t dyn_bits, fix_bits;
+        MZ_WAVE_SUM(dyn_bits, cost_d);
+        MZ_WAVE_SUM(fix_bits, cost_f);
+        {
+            /* HCLEN: code-length code lengths are sent in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 */
+            while (hclen > 4u && MZ_UNIFORM(L->lens[MZ_DEF_CL0 + mz_cl_order(hclen - 1u)]) == 0u) hclen--;
+            dyn_bits += 3u + 5u + 5u + 4u + 3u * hclen + extra_total;
+            fix_bits += 3u + extra_total;
+            const uint32_t blk_len = blk_end - blk;
+            const uint32_t stored_bits = 8u * blk_len + 40u * ((blk_len + 65534u) / 65535u) + 7u;
+            if (blk_len != 0u && stored_bits < dyn_bits && stored_bits < fix_bits) {
+                /* ---- stored blocks: header, pad to a byte, LEN, NLEN, raw bytes (appnote.txt:2045-2049) ---- */
+                for (uint32_t s0 = blk; s0 < blk_end; s0 += 65535u) {
+                    const uint32_t n = (blk_end - s0 < 65535u) ? (blk_end - s0) : 65535u;
+                    MZ_PUTBITS((bfinal && s0 + n == blk_end) ? 1u : 0u, 3u);
+                    if (nacc) MZ_PUTBITS(0u, 8u - nacc);
+                    MZ_PUTBITS(n | ((n ^ 0xFFFFu) << 16), 32u);
+                    if (n > out_cap - obyte) {
+                        status = MZHIP_OUT_FULL;
+                        goto finish;
+                    }
+                    MZ_LANES {
+                        for (uint32_t i = (uint32_t)lane; i < n; i += 64u) out[obyte + i] = in[s0 + i];
+                    }
+                    MZ_WAVE_SYNC();
+                    obyte += n;
+                }
+                continue;
+            }
+            if (dyn_bits < fix_bits) {
+                /* ---- dynamic block header (appnote.txt:2064-2090) ---- */
+                MZ_PUTBITS(bfinal | (2u << 1), 3u);
+                MZ_PUTBITS(nlit - 257u, 5u);
+                MZ_PUTBITS(ndist - 1u, 5u);
+                MZ_PUTBITS(hclen - 4u, 4u);
+                for (uint32_t i = 0; i < hclen; i++) MZ_PUTBITS(MZ_UNIFORM(L->lens[MZ_DEF_CL0 + mz_cl_order(i)]), 3u);
+                for (uint32_t i = 0; i < nseq; i++) {
+                    const uint32_t s = MZ_UNIFORM(L->u.hb.cl_seq[i]), c = MZ_UNIFORM(L->code[MZ_DEF_CL0 + s]);
+                    MZ_PUTBITS(c & 0xFFFFu, c >> 16);
+                    if (s >= 16u) MZ_PUTBITS(MZ_UNIFORM(L->u.hb.cl_ext[i]), s == 16u ? 2u : s == 17u ? 3u : 7u);
+                }
+            } else {
+                /* ---- fixed block: same pass 2 with the fixed code in the table (appnote.txt:2050-2059) ---- */
+                MZ_PUTBITS(bfinal | (1u << 1), 3u);
+                MZ_LANES {
+                    for (uint32_t s = (uint32_t)lane; s < MZ_DEF_NLIT + MZ_DEF_NDIST; s += 64u) {
+                        uint32_t c, n;
+                        if (s >= MZ_DEF_NLIT) {
+                            c = s - MZ_DEF_NLIT;
+                            n = 5;
+                        } else if (s < 144u) {
+                            c = 0x30u + s;
+                            n = 8;
+                        } else if (s < 256u) {
+                            c = 0x190u + (s - 144u);
+                            n = 9;
+                        } else if (s < 280u) {
+                            c = s - 256u;
+                            n = 7;
+                        } else {
+                            c = 0xC0u + (s - 280u);
+                            n = 8;
+                        }
+                        L->code[s] = (mz_brev32(c) >> (32u - n)) | (n << 16);
+                    }
+                }
+                MZ_WAVE_SYNC();
+            }
+        }
+        /* ================= pass 2: the tokens' bits ================= */
+        for (uint32_t t0 = 0; t0 < ntokens; t0 += 64u) {
+            const uint32_t nt = (ntokens - t0 < 64u) ? (ntokens - t0) : 64u;
+            PV(uint32_t, blo);
+            PV(uint32_t, bhi);
+            PV(uint32_t, tn);
+            PV(uint32_t, tend);
+            MZ_LANES {
+                uint64_t b = 0;
+                uint32_t n = 0;
+                if ((uint32_t)lane < nt) {
+                    const uint32_t t = tok[t0 + (uint32_t)lane], mlen = t & 511u;
+                    if (mlen == 0u) {
+                        const uint32_t c = L->code[t >> 9];
+                        b = c & 0xFFFFu;
+                        n = c >> 16;
+                    } else {
+                        uint32_t ex, xv;
+                        const uint32_t c = L->code[mz_len_sym(mlen, &ex, &xv)];
+                        b = (c & 0xFFFFu) | ((uint64_t)xv << (c >> 16));
+                        n = (c >> 16) + ex;
+                        const uint32_t cd = L->code[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &ex, &xv)];
+                        b |= (uint64_t)((cd & 0xFFFFu) | (xv << (cd >> 16))) << n;
+                        n += (cd >> 16) + ex; /* <= 15 + 5 + 15 + 13 = 48 */
+                    }
+                }
+                P(blo) = (uint32_t)b;
+                P(bhi) = (uint32_t)(b >> 32);
+                P(tn) = n;
+            }
+            MZ_INCL_SCAN(tend, tn);
+            const uint32_t total = MZ_READLANE(tend, 63);
+            MZ_LANES {
+                for (uint32_t i = (uint32_t)lane; i < 104u; i += 64u) L->stage[i] = (i == 0u) ? (uint32_t)acc : 0u;
+            }
+            MZ_WAVE_SYNC();
+            MZ_LANES {
+                if (P(tn)) {
+                    const uint32_t off = nacc + P(tend) - P(tn);
+                    const uint32_t w = off >> 5, sh = off & 31u;
+                    const uint64_t b = ((uint64_t)P(bhi) << 32) | P(blo);
+                    const uint64_t v0 = b << sh;
+                    MZ_LDS_ATOMIC_OR(&L->stage[w], (uint32_t)v0);
+                    if (sh + P(tn) > 32u) MZ_LDS_ATOMIC_OR(&L->stage[w + 1u], (uint32_t)(v0 >> 32));
+                    if (sh + P(tn) > 64u) MZ_LDS_ATOMIC_OR(&L->stage[w + 2u], (uint32_t)(b >> (64u - sh)));
+                }
+            }
+            MZ_WAVE_SYNC();
+            {
+                const uint32_t nbit = nacc + total, nbytes = nbit >> 3;
+                if (nbytes > out_cap - obyte) {
+                    status = MZHIP_OUT_FULL;
+                    goto finish;
+                }
+                MZ_LANES {
+                    for (uint32_t i = (uint32_t)lane; i < nbytes; i += 64u)
+                        out[obyte + i] = (uint8_t)(L->stage[i >> 2] >> (8u * (i & 3u)));
+                }
+                acc = (nbit & 7u) ? ((MZ_UNIFORM(L->stage[nbytes >> 2]) >> (8u * (nbytes & 3u))) & ((1u << (nbit & 7u)) - 1u)) : 0u;
+                nacc = nbit & 7u;
+                obyte += nbytes;
+            }
+            MZ_WAVE_SYNC();
+        }
+        {
+            const uint32_t c = MZ_UNIFORM(L->code[256]); /* end of block */
+            MZ_PUTBITS(c & 0xFFFFu, c >> 16);
+        }
     }
 
-    /* end-of-block (7 zero bits), then either pad the final block or append an empty stored block */
-    {
-        uint64_t tail = carry; /* EOB adds 7 zero bits */
-        uint32_t nbit = cbits + 7u;
-        if (!final) {
-            /* BFINAL = 0, BTYPE = 00, pad to a byte, LEN = 0x0000, NLEN = 0xFFFF (appnote.txt:2045-2049) */
-            nbit += 3u;
-            nbit = (nbit + 7u) & ~7u;
-            tail |= (uint64_t)0xFFFF0000u << nbit;
-            nbit += 32u;
-        }
-        const uint32_t nbytes = (nbit + 7u) >> 3; /* <= 2 (+5) bytes */
-        if (nbytes > out_cap - obyte) {
-            status = MZHIP_OUT_FULL;
-            goto finish;
-        }
-        MZ_LANES {
-            if ((uint32_t)lane < nbytes) out[obyte + (uint32_t)lane] = (uint8_t)(tail >> (8u * (uint32_t)lane));
-        }
-        MZ_WAVE_SYNC();
-        obyte += nbytes;
+    /* pad the final block to a byte, or append an empty stored block so that pieces concatenate on bytes */
+    if (final) {
+        if (nacc) MZ_PUTBITS(0u, 8u - nacc);
+    } else {
+        MZ_PUTBITS(0u, 3u); /* BFINAL = 0, BTYPE = 00 */
+        if (nacc) MZ_PUTBITS(0u, 8u - nacc);
+        MZ_PUTBITS(0xFFFF0000u, 32u); /* LEN = 0x0000, NLEN = 0xFFFF (appnote.txt:2045-2049) */
     }
 
 finish:

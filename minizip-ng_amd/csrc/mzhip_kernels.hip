@@ -230,11 +230,13 @@ struct DeflateArgs {
     int32_t *status;
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
+    uint32_t *tok; // token scratch: MZ_DEF_BLOCK words per resident wave
 };
 
 #define MZ_DEF_LDS_STRIDE ((sizeof(mz_deflate_lds) + 15) & ~(size_t)15)
 
-// K4: one wave per piece, 4 waves per workgroup, 8.3 KiB LDS per wave (hash heads + bit staging).
+// K4: one wave per piece, 4 waves per workgroup, 11.8 KiB LDS per wave (hash heads / code construction, histograms,
+// code table, bit staging) and 256 KiB of token scratch in HBM per resident wave.
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *crc_tab = (uint32_t *)smem;
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateA
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
         const uint32_t fin = a.final_flag ? MZ_UNIFORM((uint32_t)a.final_flag[e]) : 1u;
         mz_deflate_result r;
-        mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin, L, crc_tab, a.tabs, &r);
+        mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
+                         a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs, &r);
         a.out_len[e] = r.out_len;
         a.crc[e] = r.crc;
         a.status[e] = r.status;
@@ -267,6 +270,7 @@ struct DeviceCtx {
     bool ready = false;
     mzhip_crc_tables *d_tabs = nullptr;
     uint64_t *d_tab64 = nullptr;
+    uint32_t *d_tok = nullptr; // K4 token scratch, allocated on first use
     uint32_t *d_counters = nullptr;
     uint32_t next_counter = 0;
     int cu_count = 0;
@@ -535,7 +539,13 @@ int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE;
     uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
-    uint32_t resident = (uint32_t)c->cu_count * 4u; /* 35 KiB LDS per workgroup -> 4 per CU */
+    uint32_t resident = (uint32_t)c->cu_count * 3u; /* 48 KiB LDS per workgroup -> 3 per CU */
+    if (!c->d_tok) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!c->d_tok)
+            HIP_TRY(hipMalloc((void **)&c->d_tok, (size_t)resident * MZ_WAVES_PER_WG * MZ_DEF_BLOCK * sizeof(uint32_t)));
+    }
+    a.tok = c->d_tok;
     hipLaunchKernelGGL(k_deflate_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
     HIP_TRY(hipGetLastError());
     return 0;

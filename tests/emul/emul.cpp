@@ -128,7 +128,9 @@ extern "C" int32_t emul_deflate(const uint8_t *in, uint32_t in_len, uint8_t *out
     mz_deflate_lds *L = (mz_deflate_lds *)malloc(sizeof(mz_deflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_deflate_result r;
-    mz_deflate_piece(in, in_len, out, out_cap, final, L, g_tabs.byte_tab, &g_tabs, &r);
+    uint32_t *tok = (uint32_t *)malloc(MZ_DEF_BLOCK * sizeof(uint32_t));
+    mz_deflate_piece(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, &r);
+    free(tok);
     free(L);
     *out_len = r.out_len;
     *crc = r.crc;
