@@ -12,7 +12,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libmzhip.so")
+LIB_PATH = os.environ.get("MZHIP_LIB") or os.path.join(_HERE, "_build", "libmzhip.so")  # env: tuning builds only
 
 # symbols include/mzhip.h and include/mz_strm_hip.h declare (checked by tests/test_abi.py)
 BATCH_SYMBOLS = [

@@ -112,7 +112,7 @@ MZ_DEV uint32_t mz_crc_dword(uint32_t r, uint32_t d, const uint32_t *tab) {
         MZ_LANES {                                                                         \
             const uint8_t *_p = (buf) + (done) + 16u * (uint32_t)lane;                     \
             uint32_t _r = P(acc);                                                          \
-            if ((done) != 0) _r = mz_gf2_mul(_r, (kx)[0]); /* advance over 1008 bytes */   \
+            if ((done) != 0) _r = mz_gf2_mul_kx(_r, (kx));  /* advance over 1008 bytes */    \
             _r = mz_crc_dword(_r, mz_load_u32(_p), (tab));                                 \
             _r = mz_crc_dword(_r, mz_load_u32(_p + 4), (tab));                             \
             _r = mz_crc_dword(_r, mz_load_u32(_p + 8), (tab));                             \

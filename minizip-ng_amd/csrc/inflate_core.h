@@ -34,6 +34,12 @@
  */
 #ifndef MZHIP_INFLATE_CORE_H
 #define MZHIP_INFLATE_CORE_H
+#if defined(MZ_STATS)
+extern unsigned long long mz_stats[16];
+#define MZ_STAT(i, v) (mz_stats[i] += (v))
+#else
+#define MZ_STAT(i, v) ((void)0)
+#endif
 
 #include "crc32_core.h"
 #include "wave.h"
@@ -43,6 +49,9 @@
 #endif
 #define MZ_DROOT 8 /* distance fast-table index bits        */
 #define MZ_CROOT 7 /* code-length-code table bits (== max)  */
+#ifndef MZ_MLANES_LOG2
+#define MZ_MLANES_LOG2 3 /* lanes that copy one match together in the flush: 2^3 = 8, so 8 matches per round */
+#endif
 
 /* ---- table entry formats (32-bit) -------------------------------------------------------------
  * token (what a candidate decodes to):
@@ -591,6 +600,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 MZ_WAVE_SYNC();
             }
 
+            PV(uint32_t, tq); /* token queue: lane i = i-th pending token of this flush interval */
+            uint32_t qn = 0;
+            MZ_LANES { P(tq) = 0u; }
+
             for (;;) {
                 const uint32_t pbit = bitpos + pbase;
                 if ((pbit >> 11) + 1u >= ring_hi) {
@@ -739,18 +752,34 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
                 bitpos += pos;
 
-                /* phase 3: compacted tokens -> output offsets (prefix sum inside the first DPP row);
-                 * literals scatter in one store */
-                PV(uint32_t, tkc);
+                /* phase 3: the step's compacted tokens join a queue of up to 64 tokens held one per lane
+                 * (lane i = i-th pending token); output work below runs once per ~50 tokens instead of once per
+                 * step, with every lane busy. */
+                {
+                    PV(uint32_t, tkc);
+                    PV(uint32_t, tsh);
+                    MZ_GATHER4(tkc, tk, P(cpos));
+                    MZ_GATHER4(tsh, tkc, (4u * ((uint32_t)lane - qn)) & 255u);
+                    MZ_LANES {
+                        if ((uint32_t)lane >= qn && (uint32_t)lane < qn + ntok) P(tq) = P(tsh);
+                    }
+                    qn += ntok;
+                }
+                if (qn + 15u <= 64u && !eob && chain_err == MZHIP_OK) continue;
+
+                /* phase 4 (flush): queued tokens -> output offsets by a wave prefix sum; literals scatter in
+                 * one store */
                 PV(uint32_t, olen);
                 PV(uint32_t, oend);
-                MZ_GATHER4(tkc, tk, P(cpos));
                 MZ_LANES {
-                    if ((uint32_t)lane >= ntok) P(tkc) = 0u;
-                    P(olen) = mz_bfe(P(tkc), 7, 9);
+                    if ((uint32_t)lane >= qn) P(tq) = 0u;
+                    P(olen) = mz_bfe(P(tq), 7, 9);
                 }
+                MZ_STAT(4, qn);
+                MZ_STAT(6, 1);
+                qn = 0;
                 MZ_INCL_SCAN(oend, olen);
-                const uint32_t total = MZ_READLANE(oend, 15);
+                const uint32_t total = MZ_READLANE(oend, 63);
                 if (total > out_cap - out_pos) {
                     status = MZHIP_OUT_FULL;
                     goto finish;
@@ -758,14 +787,15 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 uint64_t matm;
                 MZ_BALLOT(matm, P(olen) > 1u);
                 MZ_LANES {
-                    if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tkc) >> 16);
+                    if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tq) >> 16);
                 }
                 MZ_WAVE_SYNC();
 
-                /* phase 4: LZ77 back-references.  Four matches at a time, 16 lanes each: one gather of the
-                 * match descriptors, one load, one store, while every source lies before this step's output.
-                 * Anything that reads bytes produced in this same step (or overlaps itself) takes the
-                 * in-order cooperative path below. */
+                /* LZ77 back-references, in stream order.  Eight matches at a time, 8 lanes each (one gather of
+                 * the match descriptors, one load, one store) as long as every source of the group ends at or
+                 * before the group's first destination byte -- everything earlier is complete: all literals of
+                 * the queue, every earlier match.  The first match of a group that reads inside the group (or
+                 * overlaps itself, or reaches before the entry) goes through the in-order cooperative path. */
                 if (matm) {
                     const uint32_t nmatch = mz_popc64(matm);
                     uint32_t done_m = 0;
@@ -773,58 +803,64 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);
                     }
                     MZ_WAVE_SYNC();
+                    MZ_STAT(0, 1); MZ_STAT(1, nmatch); MZ_STAT(5, mz_popc64(matm) ? 0 : 0);
                     while (done_m < nmatch) {
+                        MZ_STAT(2, 1);
                         PV(uint32_t, msrc);
                         PV(uint32_t, mtk);
                         PV(uint32_t, mend);
                         MZ_LANES {
-                            const uint32_t g = done_m + ((uint32_t)lane >> 4);
+                            const uint32_t g = done_m + ((uint32_t)lane >> MZ_MLANES_LOG2);
                             P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 256u;
                         }
-                        MZ_GATHER4(mtk, tkc, P(msrc));
+                        MZ_GATHER4(mtk, tq, P(msrc));
                         MZ_GATHER4(mend, oend, P(msrc));
-                        uint64_t dep;
                         MZ_LANES {
                             if (P(msrc) >= 256u) { P(mtk) = 0; P(mend) = 0; }
                         }
-                        /* independent iff the source ends at or before this step's first output byte
-                         * (out_pos + mend - dist <= out_pos, which also rules out self-overlap) and the distance
-                         * stays inside the entry; everything else takes the in-order path below */
-                        MZ_BALLOT(dep, P(mend) > (P(mtk) >> 16) ||
+                        /* group start = destination offset of its first match (lanes 0..15 hold it) */
+                        const uint32_t gs = MZ_READLANE(mend, 0) - mz_bfe(MZ_READLANE(mtk, 0), 7, 9);
+                        uint64_t dep;
+                        MZ_BALLOT(dep, P(mend) > (P(mtk) >> 16) + gs ||
                                            (P(mtk) >> 16) > out_pos + P(mend) - mz_bfe(P(mtk), 7, 9));
-                        if (dep) { break; }
-                        MZ_LANES {
-                            if (P(msrc) < 256u) {
-                                const uint32_t ln = mz_bfe(P(mtk), 7, 9), dist = P(mtk) >> 16;
-                                const uint32_t dst = out_pos + P(mend) - ln;
-                                for (uint32_t i = (uint32_t)lane & 15u; i < ln; i += 16u) out[dst + i] = out[dst - dist + i];
-                            }
-                        }
-                        MZ_WAVE_SYNC();
-                        done_m += 4u;
-                    }
-                    /* in-order cooperative path for what is left (64 bytes per instruction) */
-                    while (done_m < nmatch) {
-                        const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]) >> 2;
-                        const uint32_t t = MZ_READLANE(tkc, tl);
-                        const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;
-                        const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;
-                        if (dist > dst) {
-                            status = MZHIP_DATA_ERROR; /* invalid distance too far back */
-                            goto finish;
-                        }
-                        const uint8_t *src = out + (dst - dist);
-                        if (dist >= ln) {
+                        /* matches of the group before the first dependent one */
+                        const uint32_t nind = dep ? (mz_ctz64(dep) >> MZ_MLANES_LOG2) : (64u >> MZ_MLANES_LOG2);
+                        if (nind) {
                             MZ_LANES {
-                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i];
+                                if (P(msrc) < 256u && ((uint32_t)lane >> MZ_MLANES_LOG2) < nind) {
+                                    const uint32_t ln = mz_bfe(P(mtk), 7, 9), dist = P(mtk) >> 16;
+                                    const uint32_t dst = out_pos + P(mend) - ln;
+                                    for (uint32_t i = (uint32_t)lane & ((1u << MZ_MLANES_LOG2) - 1u); i < ln; i += 1u << MZ_MLANES_LOG2)
+                                        out[dst + i] = out[dst - dist + i];
+                                }
                             }
-                        } else { /* overlapping run: byte i repeats with period dist */
-                            MZ_LANES {
-                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i % dist];
-                            }
+                            MZ_WAVE_SYNC();
+                            done_m += nind;
                         }
-                        MZ_WAVE_SYNC();
-                        done_m++;
+                        if (dep && done_m < nmatch) {
+                            MZ_STAT(3, 1);
+                            /* in-order cooperative copy of the dependent match (64 bytes per instruction) */
+                            const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]) >> 2;
+                            const uint32_t t = MZ_READLANE(tq, tl);
+                            const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;
+                            const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;
+                            if (dist > dst) {
+                                status = MZHIP_DATA_ERROR; /* invalid distance too far back */
+                                goto finish;
+                            }
+                            const uint8_t *src = out + (dst - dist);
+                            if (dist >= ln) {
+                                MZ_LANES {
+                                    for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i];
+                                }
+                            } else { /* overlapping run: byte i repeats with period dist */
+                                MZ_LANES {
+                                    for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i % dist];
+                                }
+                            }
+                            MZ_WAVE_SYNC();
+                            done_m++;
+                        }
                     }
                 }
                 out_pos += total;
