@@ -104,7 +104,8 @@ typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed a
 } mz_inflate_hdr_scratch;
 
 typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
-    uint32_t ring[128]; /* 512 B of compressed stream: aligned dword j of the entry at ring[j & 127] */
+    uint32_t ring[130]; /* 512 B of compressed stream: aligned dword j of the entry at ring[j & 127]; entries 128, 129
+                           mirror 0, 1 so that a window read is one address plus constant offsets */
     uint16_t mslot[64]; /* 4 * lane id of this step's match tokens, compacted */
 } mz_inflate_body_scratch;
 
@@ -591,9 +592,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             {
                 const uint32_t blk = (bitpos + pbase) >> 11; /* 2048 bits per block */
                 MZ_LANES {
-                    ring[((blk & 1u) << 6) + (uint32_t)lane] = mz_load_stream_dword(in_al, in_mis, in_len, blk * 64u + (uint32_t)lane);
-                    ring[(((blk + 1u) & 1u) << 6) + (uint32_t)lane] =
-                        mz_load_stream_dword(in_al, in_mis, in_len, (blk + 1u) * 64u + (uint32_t)lane);
+                    const uint32_t da = mz_load_stream_dword(in_al, in_mis, in_len, blk * 64u + (uint32_t)lane);
+                    const uint32_t db = mz_load_stream_dword(in_al, in_mis, in_len, (blk + 1u) * 64u + (uint32_t)lane);
+                    ring[((blk & 1u) << 6) + (uint32_t)lane] = da;
+                    ring[(((blk + 1u) & 1u) << 6) + (uint32_t)lane] = db;
+                    if (lane < 2) ring[128 + lane] = (blk & 1u) ? db : da; /* mirror of ring[0], ring[1] */
                     P(wpre) = mz_load_stream_dword(in_al, in_mis, in_len, (blk + 2u) * 64u + (uint32_t)lane);
                 }
                 ring_hi = blk + 2u;
@@ -610,6 +613,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     /* the cursor entered the newest block: retire the oldest, start the next fetch */
                     MZ_LANES {
                         ring[((ring_hi & 1u) << 6) + (uint32_t)lane] = P(wpre);
+                        if (lane < 2 && !(ring_hi & 1u)) ring[128 + lane] = P(wpre); /* mirror of ring[0], ring[1] */
                         P(wpre) = mz_load_stream_dword(in_al, in_mis, in_len, (ring_hi + 1u) * 64u + (uint32_t)lane);
                     }
                     ring_hi++;
@@ -624,7 +628,8 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 MZ_LANES {
                     const uint32_t pl = pbit + (uint32_t)lane;
                     const uint32_t j = pl >> 5;
-                    const uint32_t d0 = ring[j & 127u], d1 = ring[(j + 1u) & 127u], d2 = ring[(j + 2u) & 127u];
+                    const uint32_t jr = j & 127u;
+                    const uint32_t d0 = ring[jr], d1 = ring[jr + 1u], d2 = ring[jr + 2u];
                     P(w0) = mz_funnel(d1, d0, pl);
                     P(w1) = mz_funnel(d2, d1, pl);
                     P(le) = L->lit_fast[P(w0) & ((1u << MZ_LROOT) - 1)];
@@ -659,17 +664,28 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
                 PV(uint32_t, tk);
                 PV(uint32_t, g1); /* 4 * successor offset; >= 256: terminal (|0x400 end-of-block, |0x800 invalid) */
+                uint64_t anybad; /* a candidate hit an unused code, 286 / 287, or distance code 30 / 31 */
+                MZ_BALLOT(anybad, P(le) == 0u || (P(le) & MZ_E_BAD) || ((P(le) & MZ_E_LEN) && (P(de) == 0u || (P(de) & MZ_E_LEN))));
                 MZ_LANES {
                     const uint32_t e = P(le), d = P(de), nb2 = P(nb2l);
                     const uint32_t dn = d & 15u, dex = mz_bfe(d, 4, 4);
                     const uint32_t dist = mz_bfe(d, 8, 15) + mz_bfe(P(dlo), dn, dex);
                     const uint32_t t_match = (nb2 + dn + dex) | (P(lenl) << 7) | (dist << 16);
-                    const uint32_t t_badd = ((d == 0u) ? (nb2 + 15u) : (nb2 + dn)) << 16; /* invalid distance code */
-                    const uint32_t t_len = (d == 0u || (d & MZ_E_LEN)) ? t_badd : t_match;
-                    const uint32_t t_bad = (e == 0u) ? (15u << 16) : ((e & 63u) << 16); /* no code | 286, 287 */
-                    uint32_t t = (e & MZ_E_LEN) ? t_len : e;
-                    t = (e == 0u || (e & MZ_E_BAD)) ? t_bad : t;
-                    P(tk) = t;
+                    P(tk) = (e & MZ_E_LEN) ? t_match : e;
+                }
+                if (anybad) { /* complete codes (every dynamic block zlib writes) never come here */
+                    MZ_LANES {
+                        const uint32_t e = P(le), d = P(de), nb2 = P(nb2l);
+                        const uint32_t t_badd = ((d == 0u) ? (nb2 + 15u) : (nb2 + (d & 15u))) << 16; /* invalid distance code */
+                        const uint32_t t_bad = (e == 0u) ? (15u << 16) : ((e & 63u) << 16);       /* no code | 286, 287 */
+                        uint32_t t = P(tk);
+                        t = ((e & MZ_E_LEN) && (d == 0u || (d & MZ_E_LEN))) ? t_badd : t;
+                        t = (e == 0u || (e & MZ_E_BAD)) ? t_bad : t;
+                        P(tk) = t;
+                    }
+                }
+                MZ_LANES {
+                    const uint32_t t = P(tk);
                     const uint32_t nb = t & 63u;
                     const uint32_t nx4 = 4u * ((uint32_t)lane + nb) + ((t & 64u) << 4);
                     P(g1) = (nb == 0u) ? (0x800u | (4u * (uint32_t)lane)) : nx4;
@@ -803,7 +819,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);
                     }
                     MZ_WAVE_SYNC();
-                    MZ_STAT(0, 1); MZ_STAT(1, nmatch); MZ_STAT(5, mz_popc64(matm) ? 0 : 0);
+                    MZ_STAT(0, 1); MZ_STAT(1, nmatch);
                     while (done_m < nmatch) {
                         MZ_STAT(2, 1);
                         PV(uint32_t, msrc);
