@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collect the per-round profile evidence on the GPU box (run through gpurun from the repo root):
+#   profiles/collect.sh <tag>      -> gpurun_out/<tag>/{bench.log,kernel_stats.csv,pmc_fetch_size.csv,pmc_write_size.csv}
+# Three separate runs of the same bench command: plain, rocprofv3 --kernel-trace --stats, and one --pmc pass per
+# counter (never combined with other trace domains).  Copy what should be judged into profiles/<round>/.
+set -u
+tag=${1:-run}
+what=${2:-all}   # all | bench | stats | FETCH_SIZE | WRITE_SIZE
+T=${MZ_COLLECT_TIMEOUT:-300}  # a pass that outlives this is killed (rocprofv3 has hung here once)
+root=$PWD
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+cmd="python $root/bench.py --steps 3 --warmup 1"
+if [ $what = all ] || [ $what = bench ]; then ( cd "$root" && timeout $T $cmd > "$out/bench.log" 2> "$out/bench.err" ); tail -1 "$out/bench.log"; fi
+cd /tmp
+if [ $what = all ] || [ $what = stats ]; then
+  timeout -k 10 $T rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- $cmd > "$out/stats.log" 2>&1
+  find "$out/stats" -name '*kernel_stats.csv' -exec cp {} "$out/kernel_stats.csv" \;
+fi
+for c in FETCH_SIZE WRITE_SIZE; do
+  if [ $what != all ] && [ $what != $c ]; then continue; fi
+  lc=$(echo $c | tr 'A-Z' 'a-z')
+  timeout -k 10 $T rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$lc" -o pmc --output-format csv -- $cmd > "$out/pmc_$lc.log" 2>&1
+  find "$out/pmc_$lc" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|k_inflate_batch" "$1" > "$2"' _ {} "$out/pmc_$lc.csv" \;
+done
+ls -la "$out"
+head -3 "$out/kernel_stats.csv"
