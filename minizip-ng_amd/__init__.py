@@ -17,9 +17,10 @@ LIB_PATH = os.environ.get("MZHIP_LIB") or os.path.join(_HERE, "_build", "libmzhi
 # symbols include/mzhip.h and include/mz_strm_hip.h declare (checked by tests/test_abi.py)
 BATCH_SYMBOLS = [
     "mzhip_device_count", "mzhip_init", "mzhip_last_error", "mzhip_version", "mzhip_inflate_batch",
-    "mzhip_crc32_batch", "mzhip_inflate_host", "mzhip_crc32_host", "mzhip_inflate_launch_geometry",
-    "mzhip_lzma_batch", "mzhip_lzma_host", "mzhip_deflate_batch", "mzhip_deflate_host", "mzhip_zip_index_mem",
-    "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_clear", "mzhip_prime_stats",
+    "mzhip_crc32_batch", "mzhip_adler32_batch", "mzhip_lzma_batch", "mzhip_xz_batch", "mzhip_deflate_batch",
+    "mzhip_sha_batch", "mzhip_inflate_host", "mzhip_inflate_host2", "mzhip_lzma_host", "mzhip_xz_host",
+    "mzhip_deflate_host", "mzhip_deflate_host2", "mzhip_crc32_host", "mzhip_inflate_launch_geometry",
+    "mzhip_zip_index_mem", "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_clear", "mzhip_prime_stats",
 ]
 
 _u64p, _u32p, _i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
