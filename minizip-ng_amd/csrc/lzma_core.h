@@ -79,7 +79,7 @@ typedef struct mz_lzma_result {
                 LZ_REFILL();                                                            \
             }                                                                           \
             uint32_t _rel = in_pos - in_base;                                           \
-            uint32_t _dw = MZ_READLANE(win, _rel >> 2);                                 \
+            uint32_t _dw = LZ_WIN_DW(_rel >> 2);                                        \
             (dst) = (_dw >> (8u * (_rel & 3u))) & 0xFFu;                                \
             in_pos++;                                                                   \
         }                                                                               \
@@ -100,7 +100,7 @@ typedef struct mz_lzma_result {
     do {                                                                                \
         LZ_NORM();                                                                      \
         uint32_t _pi = (idx);                                                           \
-        uint32_t _p = MZ_UNIFORM(pr[_pi]);                                              \
+        uint32_t _p = LZ_U(pr[_pi]);                                                    \
         uint32_t _bound = (range >> 11) * _p;                                           \
         if (code < _bound) {                                                            \
             range = _bound;                                                             \
@@ -215,12 +215,12 @@ typedef struct mz_lzma_result {
                         status = MZHIP_OUT_FULL;                                                                      \
                         goto finish;                                                                                  \
                     }                                                                                                 \
-                    uint32_t b = MZ_UNIFORM(out[opos - rep0 - 1]);                                                    \
+                    uint32_t b = LZ_U(out[opos - rep0 - 1]);                                                          \
                     MZ_LANES { out[opos] = (uint8_t)b; } /* uniform store */                                          \
                     MZ_WAVE_SYNC();                                                                                   \
                     prev_byte = b;                                                                                    \
                     opos++;                                                                                           \
-                    match_byte = MZ_UNIFORM(out[opos - rep0 - 1]);                                                    \
+                    match_byte = LZ_U(out[opos - rep0 - 1]);                                                          \
                     state = state < 7 ? 9 : 11;                                                                       \
                     if ((opos & (MZ_CRC_TILE - 1)) == 0)                                                              \
                         MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);                           \
@@ -316,93 +316,40 @@ typedef struct mz_lzma_result {
                 status = MZHIP_OUT_FULL;                                                                              \
                 goto finish;                                                                                          \
             }                                                                                                         \
-            prev_byte = MZ_UNIFORM(out[opos - 1]);                                                                    \
-            match_byte = MZ_UNIFORM(out[opos - dist]);                                                                \
+            prev_byte = LZ_U(out[opos - 1]);                                                                          \
+            match_byte = LZ_U(out[opos - dist]);                                                                      \
             MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);                                       \
         }                                                                                                             \
     }
 
-/* Decode one ZIP-LZMA entry.  All arguments wave-uniform.  max_out < 0: no clamp. */
-MZ_DEV void mz_lzma_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
-                          mz_lzma_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                          mz_lzma_result *res) {
-    MZ_LANE_DECL
-    uint16_t *pr = L->probs;
-    int32_t status = MZHIP_DATA_ERROR;
-    const uint8_t *rc_in = in;
-    const uint32_t rc_len = in_len, lzma2 = 0, dict_start = 0, chunk_end = 0;
-    uint32_t opos = 0;
-    uint32_t in_pos = 9, in_base = 9, eof = 0;
-    uint32_t range = 0xFFFFFFFFu, code = 0;
-    PV(uint32_t, win);
-    PV(uint32_t, crc_acc);
-    PV(uint32_t, crc_tmp);
-    uint32_t crc_done = 0;
-    MZ_LANES {
-        P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u;
-        P(win) = 0;
-    }
+/* Two builds of the same decoder, differing only in where the wave-uniform coder state lives:
+ *   mz_lzma_entry    LZ_U = readfirstlane: range / code / probabilities in SGPRs, the decision arithmetic issues on
+ *                    the CU's scalar port;
+ *   mz_lzma_entry_v  LZ_U = identity: the same values stay in VGPRs (all lanes equal), the arithmetic issues on the
+ *                    vector ports of the four SIMDs, only the uniform branches remain scalar.
+ * Measured for one full round of 2304 resident 1 MiB entries: scalar 480 ms, vector see DESIGN.md K3.  The kernel
+ * runs MZ_LZMA_VPORT_OF_8 of every 8 workgroups on the vector build.  The host emulation builds the first only. */
+#define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
+#define LZ_ENTRY_NAME mz_lzma_entry
+#include "lzma_entry.inc"
+#undef LZ_U
+#undef LZ_WIN_DW
+#undef LZ_ENTRY_NAME
 
-    if (in_len < 9) {
-        in_pos = in_len;
-        goto finish;
-    }
-    {
-        uint32_t d = MZ_UNIFORM(in[4]);
-        if (d >= 9 * 5 * 5) goto finish; /* LZMA_FORMAT_ERROR -> MZ_DATA_ERROR (mz_strm_lzma.c:236) */
-        const uint32_t lc = d % 9;
-        d /= 9;
-        const uint32_t lp = d % 5, pb = d / 5;
-        if (lc + lp > MZ_LZMA_MAX_LCLP) {
-            status = MZHIP_UNSUPPORTED;
-            goto finish;
-        }
-        uint64_t dict = MZ_UNIFORM((uint32_t)in[5] | ((uint32_t)in[6] << 8) | ((uint32_t)in[7] << 16) |
-                                   ((uint32_t)in[8] << 24));
-        if (dict < 4096) dict = 4096;
-        dict = (dict + 15) & ~(uint64_t)15;
+#if !defined(MZHIP_HOST_EMUL)
+#define LZ_U(x) (x)
+#define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
+#define LZ_ENTRY_NAME mz_lzma_entry_v
+#include "lzma_entry.inc"
+#undef LZ_U
+#undef LZ_WIN_DW
+#undef LZ_ENTRY_NAME
+#endif
 
-        MZ_LANES {
-            for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64)
-                ((uint32_t *)pr)[i] = 0x04000400u; /* every model starts at 1024/2048 */
-        }
-        MZ_WAVE_SYNC();
-
-        if (in_len > 9 && MZ_UNIFORM(in[9]) != 0) goto finish; /* liblzma: first coder byte must be 0 */
-        LZ_REFILL();
-        for (int i = 0; i < 5; i++) {
-            uint32_t b;
-            LZ_NEXT_BYTE(b);
-            code = (code << 8) | b;
-        }
-        if (eof) goto finish;
-
-        uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0;
-        uint32_t prev_byte = 0, match_byte = 0;
-        const uint32_t pb_mask = (1u << pb) - 1, lp_mask = (1u << lp) - 1;
-
-        LZ_PACKET_LOOP();
-    }
-
-finish:
-    {
-        uint32_t olen = opos;
-        if (max_out >= 0 && (int64_t)olen > max_out) olen = (uint32_t)max_out; /* mz_strm_lzma.c:214-215 */
-        if (status == MZHIP_DATA_ERROR && eof) status = MZHIP_BUF_ERROR;       /* input ended early */
-        res->status = status;
-        res->out_len = olen;
-        res->in_used = in_pos > in_len ? in_len : in_pos;
-        uint32_t crc;
-        /* the CRC covers the clamped length; tiles folded so far never exceed opos */
-        if (crc_done > olen) {
-            /* clamp fell inside folded tiles: restart the fold (rare: only when max_out < produced) */
-            crc_done = 0;
-            MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
-        }
-        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, olen, crc_tab, tabs->kx);
-        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, out, olen, crc_tab, tabs);
-        res->crc = crc;
-    }
-}
+/* for code that expands the coder macros outside the two entry builds (xz_core.h): the scalar-port forms (the
+ * vector-port forms measured 2x slower inside the larger .xz function) */
+#define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
 
 #endif

@@ -37,7 +37,7 @@ def timed(fn, reps=3):
 
 
 if which in ("lzma", "both", "all"):
-    n_unique, n_total, size = 16, int(sys.argv[2]) if len(sys.argv) > 2 else 2560, 1 << 20
+    n_unique, n_total, size = 16, int(sys.argv[2]) if len(sys.argv) > 2 else 4608, 1 << 20  # 2 x 2304 resident waves
     rnd = np.random.RandomState(3)
     words = synth.corpus().split()
     datas = []
