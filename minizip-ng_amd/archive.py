@@ -3,8 +3,10 @@
 Host side of the "thousands of members in one launch" path (SURVEY 8b "Batching"): the central directory is
 indexed once by the C indexer (mzhip_zip_index_mem), the archive bytes are placed in HBM as they are (the entry
 payloads are used in place -- no repacking), and every entry of the shard is decoded by mzhip_inflate_batch /
-mzhip_lzma_batch / mzhip_crc32_batch according to its method.  The per-entry CRC is compared with the
-central-directory CRC exactly where the reference compares it (mz_zip.c:2116-2128).
+mzhip_lzma_batch / mzhip_xz_batch / mzhip_crc32_batch according to its method.  The per-entry CRC is compared with
+the central-directory CRC exactly where the reference compares it (mz_zip.c:2116-2128); with verify_hash the first
+Hash extrafield (0x1a51, doc/mz_extrafield.md) of each entry is checked against a device-computed SHA digest the way
+mz_zip_reader_entry_open / _close do it on the CPU in a crypto build (mz_zip_rw.c:409-451,465-466).
 
 Sharding: entries are independent, so ranks take contiguous slices of the entry table balanced by
 compressed+uncompressed bytes; the only collective is the gather of the per-entry {crc, out_len, status} words.
@@ -21,6 +23,32 @@ _mz = importlib.import_module("minizip-ng_amd")
 COL_METHOD, COL_FLAG, COL_CRC, COL_CSIZE, COL_USIZE, COL_LOCAL, COL_CDPOS, COL_PAYLOAD = range(8)
 MZ_CRC_ERROR = -105       # mz.h:34
 MZ_SUPPORT_ERROR = -109   # mz.h:38
+MZ_ZIP_EXTENSION_HASH = 0x1A51   # mz.h:113
+MZ_HASH_SHA1, MZ_HASH_SHA256 = 20, 23   # mz.h:127,131
+
+
+def hash_fields(buf, table):
+    """First Hash extrafield of every entry's central-directory record (mz_zip_reader_entry_get_first_hash,
+    mz_zip_rw.c:560-600): -> (algorithm u16[n] (0 = none), digest_size u16[n], digest u8[n, 64])."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    n = len(table)
+    alg = np.zeros(n, dtype=np.uint16)
+    dsz = np.zeros(n, dtype=np.uint16)
+    dig = np.zeros((n, 64), dtype=np.uint8)
+    for i in range(n):
+        p = int(table[i, COL_CDPOS])
+        fn, ex = int(a[p + 28]) | int(a[p + 29]) << 8, int(a[p + 30]) | int(a[p + 31]) << 8
+        q, end = p + 46 + fn, p + 46 + fn + ex
+        while q + 4 <= end:
+            fid, fsz = int(a[q]) | int(a[q + 1]) << 8, int(a[q + 2]) | int(a[q + 3]) << 8
+            if fid == MZ_ZIP_EXTENSION_HASH and fsz >= 4 and q + 4 + fsz <= end:
+                alg[i] = int(a[q + 4]) | int(a[q + 5]) << 8
+                k = min(int(a[q + 6]) | int(a[q + 7]) << 8, fsz - 4, 64)
+                dsz[i] = k
+                dig[i, :k] = a[q + 8:q + 8 + k]
+                break
+            q += 4 + fsz
+    return alg, dsz, dig
 
 
 def index_bytes(buf):
@@ -87,10 +115,12 @@ class DeviceArchive:
         self.h_file = np.fromfile(path, dtype=np.uint8)
         self.d_file = torch.from_numpy(self.h_file).to(self.device)
 
-    def decode(self, lo=0, hi=None, keep_output=True):
+    def decode(self, lo=0, hi=None, keep_output=True, verify_hash=False):
         """Decode entries [lo, hi).  Returns dict(crc u32[n], out_len i64[n], status i32[n], ok bool[n],
         out (uint8 CUDA tensor) , out_off i64[n]).  status: 0, MZ_* / zlib-numbered errors, MZ_CRC_ERROR when
-        the CRC differs from the central directory, MZ_SUPPORT_ERROR for methods other than 0 / 8 / 14."""
+        the CRC differs from the central directory, MZ_SUPPORT_ERROR for methods other than 0 / 8 / 14 / 95.
+        verify_hash: entries carrying a Hash extrafield are also checked against a device-computed SHA-1 / SHA-256
+        (mismatch -> MZ_CRC_ERROR, other algorithms -> MZ_SUPPORT_ERROR, as mz_zip_reader_entry_open / _close)."""
         import torch
 
         t = self.table[lo:hi]
@@ -117,7 +147,7 @@ class DeviceArchive:
             return torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(dev)
 
         with torch.cuda.device(dev):
-            for method in (8, 14, 0):
+            for method in (8, 14, 95, 0):
                 sel = np.nonzero((t[:, COL_METHOD] == method) & ((t[:, COL_FLAG] & 1) == 0))[0]
                 if len(sel) == 0:
                     continue
@@ -132,14 +162,15 @@ class DeviceArchive:
                                                d_out.data_ptr(), d_out_off.data_ptr(), d_cap.data_ptr(), k,
                                                r_len.data_ptr(), r_used.data_ptr(), r_crc.data_ptr(), r_st.data_ptr(),
                                                stream)
-                elif method == 14:
-                    L.mzhip_lzma_batch.restype = C.c_int32
-                    L.mzhip_lzma_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 5
-                    d_max = dev_i64(usize[sel])   # TOTAL_OUT_MAX = uncompressed size (mz_zip.c:1845)
-                    rc = L.mzhip_lzma_batch(self.d_file.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(),
-                                            d_out.data_ptr(), d_out_off.data_ptr(), d_cap.data_ptr(), d_max.data_ptr(),
-                                            k, r_len.data_ptr(), r_used.data_ptr(), r_crc.data_ptr(), r_st.data_ptr(),
-                                            stream)
+                elif method in (14, 95):
+                    fn = L.mzhip_lzma_batch if method == 14 else L.mzhip_xz_batch
+                    fn.restype = C.c_int32
+                    fn.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 5
+                    # TOTAL_OUT_MAX = uncompressed size when the EOS flag is set (mz_zip.c:1833-1846), else none
+                    d_max = dev_i64(np.where(t[sel, COL_FLAG] & 2, usize[sel], -1))
+                    rc = fn(self.d_file.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(),
+                            d_out.data_ptr(), d_out_off.data_ptr(), d_cap.data_ptr(), d_max.data_ptr(),
+                            k, r_len.data_ptr(), r_used.data_ptr(), r_crc.data_ptr(), r_st.data_ptr(), stream)
                 else:   # STORE: the payload IS the data (mz_stream_raw, mz_zip.c:1769); CRC in place, then copy
                     rc = L.mzhip_crc32_batch(self.d_file.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), k, None,
                                              r_crc.data_ptr(), stream)
@@ -160,6 +191,30 @@ class DeviceArchive:
                 bad_crc = (st == 0) & (used == t[sel, COL_CSIZE]) & (crc[sel] != t[sel, COL_CRC].astype(np.uint32))
                 st[bad_crc] = MZ_CRC_ERROR
                 status[sel] = st
+        if verify_hash and n:
+            alg, dsz, dig = hash_fields(self.h_file, t)
+            status[(alg != 0) & (alg != MZ_HASH_SHA1) & (alg != MZ_HASH_SHA256) & (status == 0)] = MZ_SUPPORT_ERROR
+            L.mzhip_sha_batch.restype = C.c_int32
+            L.mzhip_sha_batch.argtypes = [C.c_void_p] * 3 + [C.c_uint32, C.c_uint32] + [C.c_void_p] * 2
+            with torch.cuda.device(dev):
+                for a_id in (MZ_HASH_SHA1, MZ_HASH_SHA256):
+                    sel = np.nonzero((alg == a_id) & (status == 0))[0]
+                    if len(sel) == 0:
+                        continue
+                    if not keep_output and (t[sel, COL_METHOD] == 0).any():
+                        raise _mz.MzHipError("verify_hash of STORE entries needs keep_output")
+                    d_dig = torch.zeros(len(sel) * 32, dtype=torch.uint8, device=dev)
+                    d_o, d_l = dev_i64(out_off[sel]), dev_i32(out_len[sel])   # keep both alive across the launch
+                    rc = L.mzhip_sha_batch(d_out.data_ptr(), d_o.data_ptr(), d_l.data_ptr(), len(sel), a_id,
+                                           d_dig.data_ptr(), stream)
+                    if rc != 0:
+                        raise _mz.MzHipError("mzhip_sha_batch failed: %d" % rc)
+                    torch.cuda.synchronize()
+                    got = d_dig.cpu().numpy().reshape(len(sel), 32)
+                    for j, e in enumerate(sel):   # memcmp over the extrafield's digest size (mz_zip_rw.c:446-447)
+                        k = min(int(dsz[e]), 32)
+                        if not (got[j, :k] == dig[e, :k]).all():
+                            status[e] = MZ_CRC_ERROR
         ok = (status == 0) & (out_len == usize)
         return dict(crc=crc, out_len=out_len, status=status, ok=ok, out=d_out if keep_output else None,
                     out_off=out_off)

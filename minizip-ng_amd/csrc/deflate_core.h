@@ -316,6 +316,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
             MZ_WAVE_SYNC();
             PV(uint32_t, pk); /* [8:0] match length (0 = literal), [24:9] distance | literal byte */
+            PV(uint32_t, lit);
             PV(uint32_t, g1); /* 4 * successor lane; bit 12 set: terminal */
             MZ_LANES {
                 const uint32_t pos = p + (uint32_t)lane;
@@ -335,7 +336,17 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         }
                     }
                 }
-                P(pk) = mlen | ((mlen ? dist : (uint32_t)in[pos < blk_end ? pos : blk]) << 9);
+                P(pk) = mlen | ((mlen ? dist : 0u) << 9);
+                P(lit) = (uint32_t)in[pos < blk_end ? pos : blk];
+            }
+            /* lazy evaluation (what zlib does from level 4 up): a match yields to a longer one starting at the
+             * next position -- this position then goes out as a literal */
+            PV(uint32_t, pkn);
+            MZ_GATHER4(pkn, pk, 4u * ((uint32_t)lane + 1u));
+            MZ_LANES {
+                uint32_t mlen = P(pk) & 511u;
+                if (mlen && (uint32_t)lane + 1u < nv && (P(pkn) & 511u) > mlen) mlen = 0u;
+                P(pk) = mlen ? P(pk) : (P(lit) << 9);
                 const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
                 P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);
             }

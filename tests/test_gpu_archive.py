@@ -110,3 +110,61 @@ def test_crc_mismatch_is_reported_like_mz_zip(env):
         assert r["status"][3] == archive.MZ_CRC_ERROR and (np.delete(r["status"], 3) == 0).all()
         _, _, _, st = ref.zip_read_all(path, da.table[:, archive.COL_CDPOS].copy(), nthreads=1)
         assert st[3] == archive.MZ_CRC_ERROR and (np.delete(st, 3) == 0).all()
+
+
+def test_xz_archive_method_95(env):
+    """XZ (method 95) entries written by the reference's mz_stream_lzma (liblzma stream encoder, CRC64 check)."""
+    archive, ref = env
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(17)
+    n, size = 24, 80000
+    lens = rnd.randint(0, size + 1, size=n).astype(np.int32)
+    lens[:3] = (0, 1, size)
+    offs = rnd.randint(0, len(c) - size, size=n).astype(np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "xz.zip")
+        ref.zip_write(path, c, offs, lens, method=95, level=6)
+        da, r = _check(archive, ref, path, lens.astype(np.int64))
+        assert (da.table[:, archive.COL_METHOD] == 95).all()
+
+
+def test_hash_extrafield_verification(env):
+    """the reader-side digest check of a crypto build (mz_zip_rw.c:409-451: first Hash
+    extrafield 0x1a51, SHA-1 / SHA-256 over the decoded bytes, mismatch -> MZ_CRC_ERROR, other algorithms ->
+    MZ_SUPPORT_ERROR) on device-computed digests.  The archive is written with Python's zipfile, which copies
+    ZipInfo.extra into the central directory; hashlib supplies the digests."""
+    import hashlib
+    import struct
+    import zipfile
+
+    archive, _ = env
+    c = synth.corpus()
+
+    def hx(alg, digest):
+        return struct.pack("<HHHH", 0x1A51, 4 + len(digest), alg, len(digest)) + digest
+
+    datas = [c[i * 5000:i * 5000 + 30000 + 777 * i] for i in range(8)] + [b""]
+    extras = [hx(23, hashlib.sha256(datas[0]).digest()),                       # good SHA-256, deflate
+              hx(20, hashlib.sha1(datas[1]).digest()),                         # good SHA-1, deflate
+              hx(23, hashlib.sha256(datas[2] + b"x").digest()),                # wrong digest -> MZ_CRC_ERROR
+              hx(10, hashlib.md5(datas[3]).digest()),                          # MD5 -> MZ_SUPPORT_ERROR
+              b"",                                                             # no hash field
+              struct.pack("<HHI", 0x7875, 4, 0) + hx(23, hashlib.sha256(datas[5]).digest()),   # after another field
+              hx(23, hashlib.sha256(datas[6]).digest()) + hx(20, b"\0" * 20),  # only the FIRST hash field counts
+              hx(20, hashlib.sha1(datas[7]).digest()),                         # good SHA-1, stored
+              hx(23, hashlib.sha256(b"").digest())]                            # empty entry
+    methods = [8, 8, 8, 8, 8, 8, 8, 0, 0]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "h.zip")
+        with zipfile.ZipFile(path, "w") as z:
+            for i, (d, ex, m) in enumerate(zip(datas, extras, methods)):
+                zi = zipfile.ZipInfo("e/%02d" % i)
+                zi.compress_type = m
+                zi.extra = ex
+                z.writestr(zi, d)
+        da = archive.DeviceArchive(path)
+        alg, dsz, dig = archive.hash_fields(da.h_file, da.table)
+        assert alg.tolist() == [23, 20, 23, 10, 0, 23, 23, 20, 23] and dsz.tolist() == [32, 20, 32, 16, 0, 32, 32, 20, 32]
+        r = da.decode(verify_hash=True)
+        assert r["status"].tolist() == [0, 0, archive.MZ_CRC_ERROR, archive.MZ_SUPPORT_ERROR, 0, 0, 0, 0, 0]
+        assert da.decode()["status"].tolist() == [0] * 9           # without the check every entry is fine

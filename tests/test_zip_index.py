@@ -80,3 +80,29 @@ def test_shard_bounds_balanced():
         w = (t[:, archive.COL_CSIZE] + t[:, archive.COL_USIZE]).astype(float)
         loads = [w[b[r]:b[r + 1]].sum() for r in range(world)]
         assert max(loads) <= 1.15 * (sum(loads) / world) + 1
+
+
+def test_hash_extrafield_parse():
+    """Hash extrafield (0x1a51, doc/mz_extrafield.md) of each central-directory record: first one wins, other
+    fields are skipped, entries without one report algorithm 0 (mz_zip_reader_entry_get_first_hash)."""
+    import hashlib
+    import io
+    import struct
+    import zipfile
+
+    archive = importlib.import_module("minizip-ng_amd.archive")
+    d = b"hello hash"
+    hx = struct.pack("<HHHH", 0x1A51, 36, 23, 32) + hashlib.sha256(d).digest()
+    buf = io.BytesIO()
+    with zipfile.ZipFile(buf, "w") as z:
+        for name, ex in (("a", hx), ("b", b""), ("c", struct.pack("<HHI", 0x7875, 4, 0) + hx),
+                         ("d", struct.pack("<HHHH", 0x1A51, 24, 20, 20) + hashlib.sha1(d).digest() + hx)):
+            zi = zipfile.ZipInfo(name)
+            zi.extra = ex
+            z.writestr(zi, d)
+    raw = buf.getvalue()
+    t = archive.index_bytes(raw)
+    alg, dsz, dig = archive.hash_fields(raw, t)
+    assert alg.tolist() == [23, 0, 23, 20] and dsz.tolist() == [32, 0, 32, 20]
+    assert dig[0, :32].tobytes() == hashlib.sha256(d).digest() == dig[2, :32].tobytes()
+    assert dig[3, :20].tobytes() == hashlib.sha1(d).digest()
