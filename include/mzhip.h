@@ -133,6 +133,21 @@ MZHIP_API int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off
                                       const uint8_t *d_final, uint32_t n, uint32_t *d_out_len, uint32_t *d_crc,
                                       int32_t *d_status, void *stream);
 
+/* LZMA1 encode (ZIP method 14 payloads, LZMA2 chunk payloads) ---------------------------- */
+
+/* Replaces, for n streams at once, mz_stream_lzma_write/_close (mz_strm_lzma.c:244-332 -> liblzma
+ * lzma_alone_encoder) + mz_crypt_crc32_update (mz_zip.c:2064).  Two kernels: the LZ77 parse (one wave per 64 KiB
+ * block of any stream) and the adaptive range coder (one wave per stream -- it is strictly serial).  d_mode (may be
+ * NULL = all 0): 0 -> a complete ZIP method-14 payload (4-byte magic, lc3/lp0/pb2 + 64 KiB dictionary, data, end
+ * marker: what mz_zip.c expects with MZ_ZIP_FLAG_LZMA_EOS_MARKER); 1 -> the raw payload of one LZMA2 chunk.
+ * max_in_len = upper bound of d_in_len[] (sizes the token scratch: 4 bytes per input position, stream-ordered
+ * allocation).  d_out_cap[i] >= len + len/8 + 1024 always suffices.  The bytes are valid LZMA but not liblzma's:
+ * parity is "the reference's mz_stream_lzma_read returns the input".  d_crc = CRC-32 of the INPUT. */
+MZHIP_API int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                          uint32_t max_in_len, void *d_out, const uint64_t *d_out_off,
+                                          const uint32_t *d_out_cap, const uint8_t *d_mode, uint32_t n,
+                                          uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream);
+
 /* Host-buffer conveniences (H2D + kernel + D2H, synchronous); these are what the
  * vtbl shim uses for one-entry-at-a-time callers. */
 MZHIP_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
@@ -141,6 +156,12 @@ MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *o
                                   uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                 uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+/* a whole entry: ZIP method-14 payload / one .xz stream (single block of independent 48 KiB LZMA2 chunks, CRC32
+ * check); *crc = CRC-32 of `in` */
+MZHIP_API int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
+                                         uint32_t *out_len, uint32_t *crc);
+MZHIP_API int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
+                                       uint32_t *out_len, uint32_t *crc);
 /* one segment of a stream: 64 KiB pieces, the last one final iff `final`; *crc = CRC-32 of `in` */
 MZHIP_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
                                      uint32_t out_cap, uint32_t *out_len, uint32_t *crc);

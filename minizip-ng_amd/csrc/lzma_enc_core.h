@@ -1,0 +1,443 @@
+/* lzma_enc_core.h -- LZMA1 ENCODE (ZIP method 14 entries and the LZMA2 chunks of method 95), two kernels.
+ *
+ * Replaces what the reference does through mz_stream_lzma_write / _close (mz_strm_lzma.c:244-332 -> liblzma
+ * lzma_alone_encoder / lzma_stream_encoder, preset 6).  The bytes are not liblzma's (compressor output is not a
+ * format property): parity is "liblzma -- the reference's mz_stream_lzma_read -- decodes them back to the input".
+ * Format: the LZMA specification (same model as lzma_core.h: 11-bit adaptive probabilities, 12 states, rep0-3, two
+ * length coders, 6-bit distance slots, aligned bits) and doc/zip/appnote.txt:2232-2275 for the ZIP framing.
+ *
+ * Split along what is parallel and what is not:
+ *   mz_lz_tokenize   one wave per 64 KiB block, 64 positions per step: the LZ77 parse of deflate_core.h (hash head
+ *                    table in LDS, in-place match measurement, lazy rule, greedy selection by pointer doubling);
+ *                    tokens (literal | length 4..258 + distance <= 32 KiB, inside the block) go to HBM;
+ *   mz_lzma_rc_encode one wave per stream: the adaptive range coder is strictly serial, so the token sequence is
+ *                    coded by wave-uniform code with the probability model in LDS; 64 tokens at a time are
+ *                    prepared in parallel (positions by prefix sum, the literal context byte and the match byte
+ *                    fetched from the input by the lanes) so that the serial loop never waits for HBM; output
+ *                    bytes are collected in a 256-byte VGPR window and stored coalesced.
+ * Properties written: lc 3, lp 0, pb 2, dictionary 64 KiB (every distance is below 32 KiB).
+ */
+#ifndef MZHIP_LZMA_ENC_CORE_H
+#define MZHIP_LZMA_ENC_CORE_H
+
+#include "deflate_core.h"
+#include "lzma_core.h"
+
+#define MZ_LZE_LC 3u
+#define MZ_LZE_PB 2u
+#define MZ_LZE_PROPS 0x5Du /* (pb * 5 + lp) * 9 + lc */
+#define MZ_LZE_DICT 0x10000u
+
+typedef struct mz_lz_tok_lds {
+    uint16_t head[1 << MZ_DEF_HBITS];
+} mz_lz_tok_lds;
+
+/* LZ77 parse of in[blk, blk_end) (blk_end - blk <= MZ_DEF_BLOCK); matches stay inside the block.  Returns the
+ * number of tokens written to tok[]: [8:0] match length (0 = literal), [24:9] distance | literal byte. */
+MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end, uint32_t *tok, mz_lz_tok_lds *L) {
+    MZ_LANE_DECL
+    MZ_LANES {
+        for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->head)[i] = 0u;
+    }
+    MZ_WAVE_SYNC();
+    uint32_t ntokens = 0, skip = 0;
+    for (uint32_t p = blk; p < blk_end; p += 64u) {
+        const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u;
+        PV(uint32_t, hh);
+        PV(uint32_t, cand);
+        MZ_LANES {
+            const uint32_t pos = p + (uint32_t)lane;
+            const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
+            const uint32_t v = have4 ? mz_load_u32(in + pos) : 0u;
+            const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
+            P(hh) = have4 ? h : 0xFFFFFFFFu;
+            P(cand) = have4 ? (uint32_t)L->head[h] : 0u;
+        }
+        MZ_WAVE_SYNC();
+        MZ_LANES {
+            if (P(hh) != 0xFFFFFFFFu) L->head[P(hh)] = (uint16_t)(p + (uint32_t)lane);
+        }
+        MZ_WAVE_SYNC();
+        PV(uint32_t, pk);
+        PV(uint32_t, lit);
+        PV(uint32_t, g1);
+        MZ_LANES {
+            const uint32_t pos = p + (uint32_t)lane;
+            uint32_t mlen = 0, dist = 0;
+            if ((uint32_t)lane < nv) {
+                const uint32_t d = (pos - P(cand)) & 0xFFFFu;
+                if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - blk) {
+                    const uint8_t *a = in + pos, *b = in + (pos - d);
+                    const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
+                    uint32_t l = 0;
+                    while (l + 4u <= maxl && mz_load_u32(a + l) == mz_load_u32(b + l)) l += 4u;
+                    while (l < maxl && a[l] == b[l]) l++;
+                    if (l >= MZ_DEF_MINMATCH) {
+                        mlen = l;
+                        dist = d;
+                    }
+                }
+            }
+            P(pk) = mlen | ((mlen ? dist : 0u) << 9);
+            P(lit) = (uint32_t)in[pos < blk_end ? pos : blk];
+        }
+        PV(uint32_t, pkn);
+        MZ_GATHER4(pkn, pk, 4u * ((uint32_t)lane + 1u));
+        MZ_LANES {
+            uint32_t mlen = P(pk) & 511u;
+            if (mlen && (uint32_t)lane + 1u < nv && (P(pkn) & 511u) > mlen) mlen = 0u; /* lazy rule */
+            P(pk) = mlen ? P(pk) : (P(lit) << 9);
+            const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
+            P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);
+        }
+        PV(uint32_t, g2);
+        PV(uint32_t, g4);
+        PV(uint32_t, g8);
+        PV(uint32_t, g16);
+        PV(uint32_t, g32);
+        PV(uint32_t, gt);
+        PV(uint32_t, ct);
+        PV(uint32_t, cpos);
+        MZ_LANES { P(cpos) = (skip >= nv) ? (0x1000u | (4u * skip)) : (4u * skip); }
+#define MZ_LZT_ROUND(gin, gout, bit)                                                         \
+    MZ_GATHER4(gt, gin, P(gin));                                                             \
+    MZ_GATHER4(ct, gin, P(cpos));                                                            \
+    MZ_LANES {                                                                               \
+        P(gout) = (P(gin) & 0x1000u) ? P(gin) : P(gt);                                       \
+        P(cpos) = (((uint32_t)lane & (bit)) && !(P(cpos) & 0x1000u)) ? P(ct) : P(cpos);      \
+    }
+        MZ_LZT_ROUND(g1, g2, 1u)
+        MZ_LZT_ROUND(g2, g4, 2u)
+        MZ_LZT_ROUND(g4, g8, 4u)
+        MZ_LZT_ROUND(g8, g16, 8u)
+        MZ_LZT_ROUND(g16, g32, 16u)
+        MZ_GATHER4(ct, g32, P(cpos));
+        MZ_LANES { P(cpos) = (((uint32_t)lane & 32u) && !(P(cpos) & 0x1000u)) ? P(ct) : P(cpos); }
+#undef MZ_LZT_ROUND
+        uint64_t live;
+        MZ_BALLOT(live, !(P(cpos) & 0x1000u));
+        const uint32_t ntok = mz_popc64(live);
+        PV(uint32_t, tpk);
+        MZ_GATHER4(tpk, pk, P(cpos));
+        if (ntok) {
+            const uint32_t lastpos = MZ_READLANE(cpos, ntok - 1u) >> 2;
+            const uint32_t lastpk = MZ_READLANE(tpk, ntok - 1u);
+            const uint32_t nx = lastpos + ((lastpk & 511u) ? (lastpk & 511u) : 1u);
+            skip = nx > 64u ? nx - 64u : 0u;
+        } else {
+            skip = skip > 64u ? skip - 64u : 0u;
+        }
+        MZ_LANES {
+            if ((uint32_t)lane < ntok) tok[ntokens + (uint32_t)lane] = P(tpk);
+        }
+        ntokens += ntok;
+    }
+    MZ_WAVE_SYNC();
+    return ntokens;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Range ENCODER, wave-uniform.  low is 33 bits wide; a byte leaves only when no later carry can change it. */
+#define LZE_OUT_BYTE(b)                                                                  \
+    do {                                                                                 \
+        ow |= (uint32_t)(b) << (8u * (on & 3u));                                         \
+        on++;                                                                            \
+        if ((on & 3u) == 0u) {                                                           \
+            MZ_WRITELANE(owin, ((on - 1u) >> 2) & 63u, ow);                              \
+            ow = 0;                                                                      \
+            if ((on & 255u) == 0u) LZE_FLUSH_WIN(256u);                                  \
+        }                                                                                \
+    } while (0)
+/* store the first nb (<= 256) bytes of the window */
+#define LZE_FLUSH_WIN(nb)                                                                \
+    do {                                                                                 \
+        const uint32_t _base = (on - 1u) & ~255u;                                        \
+        if (_base + (nb) > out_cap) {                                                    \
+            status = MZHIP_OUT_FULL;                                                     \
+            goto finish;                                                                 \
+        }                                                                                \
+        MZ_LANES {                                                                       \
+            for (uint32_t _k = 0; _k < 4u; _k++)                                         \
+                if (4u * (uint32_t)lane + _k < (nb)) out[_base + 4u * (uint32_t)lane + _k] = (uint8_t)(P(owin) >> (8u * _k)); \
+        }                                                                                \
+    } while (0)
+#define LZE_SHIFT_LOW()                                                                  \
+    do {                                                                                 \
+        if ((uint32_t)low < 0xFF000000u || (uint32_t)(low >> 32) != 0u) {                \
+            const uint32_t _carry = (uint32_t)(low >> 32);                               \
+            do {                                                                         \
+                LZE_OUT_BYTE((cache + _carry) & 0xFFu);                                  \
+                cache = 0xFFu;                                                           \
+            } while (--cache_size != 0u);                                                \
+            cache = ((uint32_t)low >> 24) & 0xFFu;                                       \
+        }                                                                                \
+        cache_size++;                                                                    \
+        low = (uint64_t)((uint32_t)low & 0x00FFFFFFu) << 8;                              \
+    } while (0)
+#define LZE_BIT(idx, bitv)                                                               \
+    do {                                                                                 \
+        const uint32_t _pi = (idx);                                                      \
+        uint32_t _p = MZ_UNIFORM(pr[_pi]);                                               \
+        const uint32_t _bound = (range >> 11) * _p;                                      \
+        if (!(bitv)) {                                                                   \
+            range = _bound;                                                              \
+            _p += (2048u - _p) >> 5;                                                     \
+        } else {                                                                         \
+            low += _bound;                                                               \
+            range -= _bound;                                                             \
+            _p -= _p >> 5;                                                               \
+        }                                                                                \
+        MZ_LANES { pr[_pi] = (uint16_t)_p; } /* uniform store */                         \
+        MZ_WAVE_SYNC();                                                                  \
+        while (range < (1u << 24)) {                                                     \
+            range <<= 8;                                                                 \
+            LZE_SHIFT_LOW();                                                             \
+        }                                                                                \
+    } while (0)
+#define LZE_DIRECT(val, nbits)                                                           \
+    do {                                                                                 \
+        for (int _i = (int)(nbits) - 1; _i >= 0; _i--) {                                 \
+            range >>= 1;                                                                 \
+            if (((val) >> _i) & 1u) low += range;                                        \
+            while (range < (1u << 24)) {                                                 \
+                range <<= 8;                                                             \
+                LZE_SHIFT_LOW();                                                         \
+            }                                                                            \
+        }                                                                                \
+    } while (0)
+#define LZE_BITTREE(base, nbits, sym)                                                    \
+    do {                                                                                 \
+        uint32_t _m = 1;                                                                 \
+        for (int _i = (int)(nbits) - 1; _i >= 0; _i--) {                                 \
+            const uint32_t _b = ((sym) >> _i) & 1u;                                      \
+            LZE_BIT((base) + _m, _b);                                                    \
+            _m = (_m << 1) | _b;                                                         \
+        }                                                                                \
+    } while (0)
+#define LZE_BITTREE_REV(base, nbits, sym)                                                \
+    do {                                                                                 \
+        uint32_t _m = 1;                                                                 \
+        for (int _i = 0; _i < (int)(nbits); _i++) {                                      \
+            const uint32_t _b = ((sym) >> _i) & 1u;                                      \
+            LZE_BIT((base) + _m, _b);                                                    \
+            _m = (_m << 1) | _b;                                                         \
+        }                                                                                \
+    } while (0)
+#define LZE_LEN(lbase, l, ps)                                                            \
+    do {                                                                                 \
+        if ((l) < 8u) {                                                                  \
+            LZE_BIT((lbase), 0u);                                                        \
+            LZE_BITTREE((lbase) + 2 + (ps) * 8, 3, (l));                                 \
+        } else if ((l) < 16u) {                                                          \
+            LZE_BIT((lbase), 1u);                                                        \
+            LZE_BIT((lbase) + 1, 0u);                                                    \
+            LZE_BITTREE((lbase) + 2 + 128 + (ps) * 8, 3, (l) - 8u);                      \
+        } else {                                                                         \
+            LZE_BIT((lbase), 1u);                                                        \
+            LZE_BIT((lbase) + 1, 1u);                                                    \
+            LZE_BITTREE((lbase) + 2 + 256, 8, (l) - 16u);                                \
+        }                                                                                \
+    } while (0)
+/* a new (non-rep) match: length then distance (0-based d) */
+#define LZE_MATCH_DIST(d, lenm2)                                                         \
+    do {                                                                                 \
+        uint32_t _slot, _nb = 0;                                                         \
+        if ((d) < 4u) {                                                                  \
+            _slot = (d);                                                                 \
+        } else {                                                                         \
+            _nb = 31u - mz_clz32(d);                                                     \
+            _slot = 2u * _nb + (((d) >> (_nb - 1u)) & 1u);                               \
+        }                                                                                \
+        LZE_BITTREE(LZ_POS_SLOT + ((lenm2) < 4u ? (lenm2) : 3u) * 64, 6, _slot);         \
+        if (_slot >= 4u) {                                                               \
+            const uint32_t _fb = (_slot >> 1) - 1u;                                      \
+            const uint32_t _base = (2u | (_slot & 1u)) << _fb;                           \
+            const uint32_t _rem = (d) - _base;                                           \
+            if (_slot < 14u) {                                                           \
+                LZE_BITTREE_REV(LZ_POS_DEC + _base - _slot, _fb, _rem);                  \
+            } else {                                                                     \
+                LZE_DIRECT(_rem >> 4, _fb - 4u);                                         \
+                LZE_BITTREE_REV(LZ_ALIGN, 4, _rem & 15u);                                \
+            }                                                                            \
+        }                                                                                \
+    } while (0)
+
+typedef struct mz_lzma_enc_result {
+    int32_t status;
+    uint32_t out_len;
+    uint32_t crc; /* CRC-32 of the input (what mz_zip_entry_write accumulates, mz_zip.c:2064) */
+} mz_lzma_enc_result;
+
+/* Range-code the token blocks of ONE stream.  in[0..in_len) = the stream's input; its tokens sit in blocks of
+ * MZ_DEF_BLOCK positions: block b at tok + b * MZ_DEF_BLOCK, ntok[b] of them.  mode 0: a ZIP method-14 payload
+ * (4-byte magic, 5 property bytes, range-coded data, end marker); mode 1: the payload of one LZMA2 chunk (raw
+ * range-coded data, no end marker).  All arguments wave-uniform. */
+MZ_DEV void mz_lzma_rc_encode(const uint8_t *in, uint32_t in_len, const uint32_t *tok, const uint32_t *ntok, uint32_t mode,
+                              uint8_t *out, uint32_t out_cap, mz_lzma_lds *L, const uint32_t *crc_tab,
+                              const mzhip_crc_tables *tabs, mz_lzma_enc_result *res) {
+    MZ_LANE_DECL
+    uint16_t *pr = L->probs;
+    int32_t status = MZHIP_OK;
+    uint64_t low = 0;
+    uint32_t range = 0xFFFFFFFFu, cache = 0, cache_size = 1;
+    uint32_t on = 0, ow = 0; /* bytes produced, dword being assembled */
+    PV(uint32_t, owin);
+    uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0, pos = 0;
+    PV(uint32_t, crc_acc);
+    PV(uint32_t, crc_tmp);
+    uint32_t crc_done = 0;
+    MZ_LANES {
+        P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u;
+        P(owin) = 0u;
+        for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64) ((uint32_t *)pr)[i] = 0x04000400u;
+    }
+    MZ_WAVE_SYNC();
+    if (mode == 0u) {
+        /* version 9.20, property size 5 (what liblzma-based writers put there; the reader ignores the version,
+         * mz_strm_lzma.c:118-121), then lc/lp/pb and the dictionary size (appnote.txt:2232-2275) */
+        LZE_OUT_BYTE(9u);
+        LZE_OUT_BYTE(20u);
+        LZE_OUT_BYTE(5u);
+        LZE_OUT_BYTE(0u);
+        LZE_OUT_BYTE(MZ_LZE_PROPS);
+        LZE_OUT_BYTE(MZ_LZE_DICT & 0xFFu);
+        LZE_OUT_BYTE((MZ_LZE_DICT >> 8) & 0xFFu);
+        LZE_OUT_BYTE((MZ_LZE_DICT >> 16) & 0xFFu);
+        LZE_OUT_BYTE((MZ_LZE_DICT >> 24) & 0xFFu);
+    }
+    {
+        const uint32_t nblocks = (in_len + MZ_DEF_BLOCK - 1u) / MZ_DEF_BLOCK;
+        for (uint32_t b = 0; b < nblocks; b++) {
+            const uint32_t *bt = tok + (size_t)b * MZ_DEF_BLOCK;
+            const uint32_t nt_blk = MZ_UNIFORM(ntok[b]);
+            for (uint32_t t0 = 0; t0 < nt_blk; t0 += 64u) {
+                const uint32_t nt = (nt_blk - t0 < 64u) ? (nt_blk - t0) : 64u;
+                /* 64 tokens prepared in parallel: start position, previous byte, byte at the previous token's
+                 * distance (the match byte if this token is a literal right after a match) */
+                PV(uint32_t, tk);
+                PV(uint32_t, tlen);
+                PV(uint32_t, tend);
+                PV(uint32_t, tprev);
+                PV(uint32_t, tctx);
+                MZ_LANES {
+                    const uint32_t t = ((uint32_t)lane < nt) ? bt[t0 + (uint32_t)lane] : 0u;
+                    P(tk) = t;
+                    P(tlen) = ((uint32_t)lane < nt) ? ((t & 511u) ? (t & 511u) : 1u) : 0u;
+                }
+                MZ_INCL_SCAN(tend, tlen);
+                MZ_GATHER4(tprev, tk, 4u * ((uint32_t)lane - 1u));
+                MZ_LANES {
+                    const uint32_t p = pos + P(tend) - P(tlen);
+                    uint32_t pb = 0, mb = 0;
+                    if ((uint32_t)lane < nt) {
+                        if (p) pb = in[p - 1u];
+                        /* distance of the token before this one; lane 0 takes the coder's rep0 */
+                        const uint32_t pd = ((uint32_t)lane == 0u) ? rep0 + 1u : ((P(tprev) & 511u) ? (P(tprev) >> 9) : 0u);
+                        if (pd && pd <= p) mb = in[p - pd];
+                    }
+                    P(tctx) = pb | (mb << 8);
+                }
+                for (uint32_t i = 0; i < nt; i++) {
+                    const uint32_t t = MZ_READLANE(tk, i), ctx = MZ_READLANE(tctx, i);
+                    const uint32_t mlen = t & 511u, ps = pos & ((1u << MZ_LZE_PB) - 1u);
+                    if (mlen == 0u) {
+                        const uint32_t sym = (t >> 9) & 0xFFu;
+                        LZE_BIT(LZ_IS_MATCH + state * 16 + ps, 0u);
+                        const uint32_t lbase = LZ_LIT + 0x300u * ((ctx & 0xFFu) >> (8u - MZ_LZE_LC));
+                        uint32_t m = 1;
+                        int k = 7;
+                        if (state >= 7u) {
+                            uint32_t mbyte = (ctx >> 8) & 0xFFu;
+                            for (; k >= 0; k--) {
+                                const uint32_t mbit = (mbyte >> 7) & 1u, bb = (sym >> k) & 1u;
+                                mbyte <<= 1;
+                                LZE_BIT(lbase + ((1u + mbit) << 8) + m, bb);
+                                m = (m << 1) | bb;
+                                if (mbit != bb) {
+                                    k--;
+                                    break;
+                                }
+                            }
+                        }
+                        for (; k >= 0; k--) {
+                            const uint32_t bb = (sym >> k) & 1u;
+                            LZE_BIT(lbase + m, bb);
+                            m = (m << 1) | bb;
+                        }
+                        state = state < 4u ? 0u : (state < 10u ? state - 3u : state - 6u);
+                        pos += 1u;
+                    } else {
+                        const uint32_t d = (t >> 9) - 1u; /* 0-based distance */
+                        LZE_BIT(LZ_IS_MATCH + state * 16 + ps, 1u);
+                        if (d == rep0 || d == rep1 || d == rep2 || d == rep3) {
+                            LZE_BIT(LZ_IS_REP + state, 1u);
+                            if (d == rep0) {
+                                LZE_BIT(LZ_IS_REP_G0 + state, 0u);
+                                LZE_BIT(LZ_IS_REP0_LONG + state * 16 + ps, 1u);
+                            } else {
+                                LZE_BIT(LZ_IS_REP_G0 + state, 1u);
+                                if (d == rep1) {
+                                    LZE_BIT(LZ_IS_REP_G1 + state, 0u);
+                                } else {
+                                    LZE_BIT(LZ_IS_REP_G1 + state, 1u);
+                                    if (d == rep2) {
+                                        LZE_BIT(LZ_IS_REP_G2 + state, 0u);
+                                    } else {
+                                        LZE_BIT(LZ_IS_REP_G2 + state, 1u);
+                                        rep3 = rep2;
+                                    }
+                                    rep2 = rep1;
+                                }
+                                rep1 = rep0;
+                                rep0 = d;
+                            }
+                            LZE_LEN(LZ_REP_LEN, mlen - 2u, ps);
+                            state = state < 7u ? 8u : 11u;
+                        } else {
+                            LZE_BIT(LZ_IS_REP + state, 0u);
+                            LZE_LEN(LZ_LEN, mlen - 2u, ps);
+                            LZE_MATCH_DIST(d, mlen - 2u);
+                            rep3 = rep2;
+                            rep2 = rep1;
+                            rep1 = rep0;
+                            rep0 = d;
+                            state = state < 7u ? 7u : 10u;
+                        }
+                        pos += mlen;
+                    }
+                }
+                MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, pos, crc_tab, tabs->kx);
+            }
+        }
+    }
+    if (mode == 0u) {
+        /* end marker: a match of the minimum length at distance 0xFFFFFFFF (appnote.txt:2262-2275, flag bit 1) */
+        const uint32_t ps = pos & ((1u << MZ_LZE_PB) - 1u);
+        LZE_BIT(LZ_IS_MATCH + state * 16 + ps, 1u);
+        LZE_BIT(LZ_IS_REP + state, 0u);
+        LZE_LEN(LZ_LEN, 0u, ps);
+        LZE_MATCH_DIST(0xFFFFFFFFu, 0u);
+    }
+    for (int i = 0; i < 5; i++) LZE_SHIFT_LOW();
+    /* what is left in the window */
+    if (on & 3u) MZ_WRITELANE(owin, (on >> 2) & 63u, ow);
+    if (on & 255u) {
+        const uint32_t nb = on & 255u;
+        on += 256u - nb; /* LZE_FLUSH_WIN addresses the window that ends at `on` */
+        LZE_FLUSH_WIN(nb);
+        on -= 256u - nb;
+    }
+    MZ_WAVE_SYNC();
+
+finish:
+    res->status = status;
+    res->out_len = on;
+    {
+        uint32_t crc;
+        MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, in_len, crc_tab, tabs->kx);
+        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, in, in_len, crc_tab, tabs);
+        res->crc = crc;
+    }
+}
+
+#endif

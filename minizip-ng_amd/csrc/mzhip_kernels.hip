@@ -24,6 +24,7 @@
 #include "deflate_core.h"
 #include "adler32_core.h"
 #include "xz_core.h"
+#include "lzma_enc_core.h"
 
 #define MZ_WAVES_PER_WG 4
 #define MZ_CRC_TAB_BYTES 1024
@@ -266,6 +267,71 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateA
         mz_deflate_result r;
         mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
                          a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs, &r);
+        a.out_len[e] = r.out_len;
+        a.crc[e] = r.crc;
+        a.status[e] = r.status;
+    }
+}
+
+struct LzmaEncArgs {
+    const uint8_t *in;
+    const uint64_t *in_off;
+    const uint32_t *in_len;
+    uint8_t *out;
+    const uint64_t *out_off;
+    const uint32_t *out_cap;
+    const uint8_t *mode; // may be null (all 0): 0 = ZIP method-14 payload, 1 = raw LZMA2 chunk payload
+    uint32_t n;
+    uint32_t maxb; // 64 KiB blocks reserved per entry in tok / ntok
+    uint32_t *tok;
+    uint32_t *ntok;
+    uint32_t *out_len;
+    uint32_t *crc;
+    int32_t *status;
+    uint32_t *counter;
+    const mzhip_crc_tables *tabs;
+};
+
+// LZMA encode, pass 1: the LZ77 parse, one wave per 64 KiB block of any entry (work item = entry * maxb + block).
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(LzmaEncArgs a) {
+    __shared__ __attribute__((aligned(16))) mz_lz_tok_lds lds[MZ_WAVES_PER_WG];
+    MZ_LANE_DECL
+    mz_lz_tok_lds *L = &lds[threadIdx.x >> 6];
+    const uint32_t items = a.n * a.maxb;
+    for (;;) {
+        uint32_t w;
+        MZ_WAVE_FETCH_ADD(w, a.counter);
+        if (w >= items) break;
+        const uint32_t e = w / a.maxb, b = w - e * a.maxb;
+        const uint32_t len = MZ_UNIFORM(a.in_len[e]);
+        const uint32_t lo = b * MZ_DEF_BLOCK;
+        uint32_t nt = 0;
+        if (lo < len) {
+            const uint64_t io = a.in_off[e];
+            const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
+            nt = mz_lz_tokenize(in, lo, (len - lo < MZ_DEF_BLOCK) ? len : lo + MZ_DEF_BLOCK, a.tok + (size_t)w * MZ_DEF_BLOCK, L);
+        }
+        a.ntok[w] = nt; // uniform store
+    }
+}
+
+// LZMA encode, pass 2: the adaptive range coder, one wave per stream (model in LDS like K3).
+__global__ __launch_bounds__(64) void k_lzma_rc_encode_batch(LzmaEncArgs a) {
+    __shared__ __attribute__((aligned(16))) mz_lzma_lds lds;
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    for (;;) {
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter + 1);
+        if (e >= a.n) break;
+        const uint64_t io = a.in_off[e], oo = a.out_off[e];
+        const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
+        uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
+        mz_lzma_enc_result r;
+        mz_lzma_rc_encode(in, MZ_UNIFORM(a.in_len[e]), a.tok + (size_t)e * a.maxb * MZ_DEF_BLOCK, a.ntok + (size_t)e * a.maxb,
+                          a.mode ? MZ_UNIFORM((uint32_t)a.mode[e]) : 0u, out, MZ_UNIFORM(a.out_cap[e]), &lds, crc_tab, a.tabs, &r);
         a.out_len[e] = r.out_len;
         a.crc[e] = r.crc;
         a.status[e] = r.status;
@@ -561,6 +627,50 @@ int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     return 0;
 }
 
+int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, uint32_t max_in_len,
+                                void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_mode,
+                                uint32_t n, uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    if (n == 0) return 0;
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    LzmaEncArgs a;
+    a.in = (const uint8_t *)d_in;
+    a.in_off = d_in_off;
+    a.in_len = d_in_len;
+    a.out = (uint8_t *)d_out;
+    a.out_off = d_out_off;
+    a.out_cap = d_out_cap;
+    a.mode = d_mode;
+    a.n = n;
+    a.maxb = max_in_len ? (max_in_len + MZ_DEF_BLOCK - 1) / MZ_DEF_BLOCK : 1u;
+    a.out_len = d_out_len;
+    a.crc = d_crc;
+    a.status = d_status;
+    a.tabs = c->d_tabs;
+    /* token scratch: 4 bytes per input position of the largest entry, for every entry; stream-ordered */
+    const size_t items = (size_t)n * a.maxb;
+    void *scratch = nullptr;
+    HIP_TRY(hipMallocAsync(&scratch, items * MZ_DEF_BLOCK * sizeof(uint32_t) + items * sizeof(uint32_t) + 64, s));
+    a.tok = (uint32_t *)scratch;
+    a.ntok = a.tok + items * MZ_DEF_BLOCK;
+    a.counter = a.ntok + items; /* two work counters behind the token counts */
+    HIP_TRY(hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), s));
+    {
+        uint32_t wgs = (uint32_t)((items + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG);
+        uint32_t resident = (uint32_t)c->cu_count * 4u; /* 33 KiB LDS per workgroup */
+        hipLaunchKernelGGL(k_lz_tokenize_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), 0, s, a);
+    }
+    {
+        uint32_t resident = (uint32_t)c->cu_count * 9u; /* 17 KiB LDS per single-wave workgroup */
+        hipLaunchKernelGGL(k_lzma_rc_encode_batch, dim3(n < resident ? n : resident), dim3(64), 0, s, a);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(scratch, s));
+    return 0;
+}
+
 // ---- host-buffer conveniences (synchronous): staging through one scratch allocation per call
 
 namespace {
@@ -666,6 +776,153 @@ int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
 int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                       uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
     return lzma_family_host(1, in, in_len, out, out_cap, max_out, out_len, in_used, crc);
+}
+
+// One ZIP method-14 payload from a host buffer.
+int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                               uint32_t *crc) {
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
+    const uint32_t cap = in_len + in_len / 8 + 1024;
+    Scratch sc;
+    HIP_TRY(hipMalloc(&sc.p, 64 + in_pad + cap));
+    uint8_t *base = (uint8_t *)sc.p;
+    struct Meta {
+        uint64_t in_off, out_off;
+        uint32_t in_len, out_cap, out_len, crc;
+        int32_t status;
+    } m;
+    memset(&m, 0, sizeof(m));
+    m.in_off = 64;
+    m.out_off = 64 + in_pad;
+    m.in_len = in_len;
+    m.out_cap = cap;
+    HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
+    if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
+    Meta *dm = (Meta *)base;
+    rc = mzhip_lzma_encode_batch(base, &dm->in_off, &dm->in_len, in_len, base, &dm->out_off, &dm->out_cap, nullptr, 1,
+                                 &dm->out_len, &dm->crc, &dm->status, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
+    if (m.status == 0 && m.out_len > out_cap) m.status = MZHIP_STATUS_OUT_FULL;
+    if (m.status == 0 && m.out_len) HIP_TRY(hipMemcpy(out, base + m.out_off, m.out_len, hipMemcpyDeviceToHost));
+    if (out_len) *out_len = m.out_len;
+    if (crc) *crc = m.crc;
+    return m.status;
+}
+
+// One .xz stream (single block, CRC32 check) from a host buffer: the input is cut into 48 KiB LZMA2 chunks that
+// reset dictionary, state and properties, so every chunk is an independent stream and all of them are coded in one
+// batch; framing bytes (a few per chunk) are laid out here, their CRC-32s come from the device as well.
+int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                             uint32_t *crc) {
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    const uint32_t piece = 48u << 10;
+    const uint32_t np = (in_len + piece - 1) / piece;
+    const uint32_t pcap = piece + piece / 8 + 1024;
+    const size_t meta = (size_t)np * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 1) + 64;
+    const size_t meta_pad = (meta + 63) & ~(size_t)63;
+    const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
+    Scratch sc;
+    HIP_TRY(hipMalloc(&sc.p, meta_pad + in_pad + (size_t)np * pcap + 64));
+    uint8_t *base = (uint8_t *)sc.p;
+    std::vector<uint8_t> hm(meta_pad, 0);
+    uint64_t *h_in_off = (uint64_t *)hm.data(), *h_out_off = h_in_off + np;
+    uint32_t *h_in_len = (uint32_t *)(h_out_off + np), *h_out_cap = h_in_len + np, *h_out_len = h_out_cap + np,
+             *h_crc = h_out_len + np;
+    int32_t *h_status = (int32_t *)(h_crc + np);
+    uint8_t *h_mode = (uint8_t *)(h_status + np);
+    for (uint32_t i = 0; i < np; i++) {
+        h_in_off[i] = meta_pad + (uint64_t)i * piece;
+        h_in_len[i] = (in_len - i * piece < piece) ? in_len - i * piece : piece;
+        h_out_off[i] = meta_pad + in_pad + (uint64_t)i * pcap;
+        h_out_cap[i] = pcap;
+        h_mode[i] = 1;
+    }
+    uint32_t total_crc = 0;
+    if (np) {
+        HIP_TRY(hipMemcpy(base, hm.data(), meta, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(base + meta_pad, in, in_len, hipMemcpyHostToDevice));
+        uint64_t *d_in_off = (uint64_t *)base, *d_out_off = d_in_off + np;
+        uint32_t *d_in_len = (uint32_t *)(d_out_off + np), *d_out_cap = d_in_len + np, *d_out_len = d_out_cap + np,
+                 *d_crc = d_out_len + np;
+        int32_t *d_status = (int32_t *)(d_crc + np);
+        uint8_t *d_mode = (uint8_t *)(d_status + np);
+        rc = mzhip_lzma_encode_batch(base, d_in_off, d_in_len, piece, base, d_out_off, d_out_cap, d_mode, np, d_out_len,
+                                     d_crc, d_status, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(hm.data(), base, meta, hipMemcpyDeviceToHost));
+    }
+    // ---- container (The .xz File Format 1.0.4): stream header, one block, index, footer
+    uint32_t pos = 0;
+    auto put = [&](const void *p, uint32_t n) -> bool {
+        if (n > out_cap - pos) return false;
+        memcpy(out + pos, p, n);
+        pos += n;
+        return true;
+    };
+    auto le32 = [](uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); };
+    auto vli = [](uint8_t *p, uint64_t v) -> uint32_t {
+        uint32_t k = 0;
+        while (v >= 0x80) { p[k++] = (uint8_t)(v | 0x80); v >>= 7; }
+        p[k++] = (uint8_t)v;
+        return k;
+    };
+    uint8_t hdr[12] = {0xFD, '7', 'z', 'X', 'Z', 0x00, 0x00, 0x01 /* check: CRC32 */, 0, 0, 0, 0};
+    le32(hdr + 8, mzhip_crc32_host(0, hdr + 6, 2));
+    uint8_t bh[12] = {0x02 /* (2 + 1) * 4 bytes */, 0x00 /* one filter, no sizes */, 0x21 /* LZMA2 */, 0x01, 0x08 /* 64 KiB */, 0, 0, 0, 0, 0, 0, 0};
+    le32(bh + 8, mzhip_crc32_host(0, bh, 8));
+    if (!put(hdr, 12) || !put(bh, 12)) return MZHIP_STATUS_OUT_FULL;
+    const uint32_t data_start = pos;
+    for (uint32_t i = 0; i < np; i++) {
+        if (h_status[i] != 0) return h_status[i];
+        const uint32_t us = h_in_len[i], cs = h_out_len[i];
+        total_crc = (i == 0) ? h_crc[0] : mzhip_crc32_combine_host(total_crc, h_crc[i], us);
+        if (cs >= us || cs > 65536u) { /* stored chunk: control 0x01 (dictionary reset), size - 1 big endian, the bytes */
+            uint8_t ch[3] = {0x01, (uint8_t)((us - 1) >> 8), (uint8_t)(us - 1)};
+            if (!put(ch, 3) || !put(in + (size_t)i * piece, us)) return MZHIP_STATUS_OUT_FULL;
+        } else { /* LZMA chunk resetting dictionary, state and properties: 0xE0 | size bits, sizes - 1, props */
+            uint8_t ch[6] = {(uint8_t)(0xE0 | ((us - 1) >> 16)), (uint8_t)((us - 1) >> 8), (uint8_t)(us - 1),
+                             (uint8_t)((cs - 1) >> 8), (uint8_t)(cs - 1), MZ_LZE_PROPS};
+            if (!put(ch, 6) || cs > out_cap - pos) return MZHIP_STATUS_OUT_FULL;
+            HIP_TRY(hipMemcpy(out + pos, base + h_out_off[i], cs, hipMemcpyDeviceToHost));
+            pos += cs;
+        }
+    }
+    const uint8_t zero4[4] = {0, 0, 0, 0};
+    if (!put(zero4, 1)) return MZHIP_STATUS_OUT_FULL; /* end of the LZMA2 data */
+    const uint32_t csize_blk = pos - data_start;
+    if (!put(zero4, (4u - (csize_blk & 3u)) & 3u)) return MZHIP_STATUS_OUT_FULL;
+    uint8_t chk[4];
+    le32(chk, total_crc);
+    if (!put(chk, 4)) return MZHIP_STATUS_OUT_FULL;
+    uint8_t idx[32];
+    uint32_t k = 0;
+    idx[k++] = 0x00;
+    idx[k++] = 0x01;
+    k += vli(idx + k, 12ull + csize_blk + 4ull);
+    k += vli(idx + k, in_len);
+    while (k & 3u) idx[k++] = 0;
+    le32(idx + k, mzhip_crc32_host(0, idx, k));
+    k += 4;
+    if (!put(idx, k)) return MZHIP_STATUS_OUT_FULL;
+    uint8_t ft[12];
+    le32(ft + 4, k / 4 - 1);
+    ft[8] = 0x00;
+    ft[9] = 0x01;
+    le32(ft, mzhip_crc32_host(0, ft + 4, 6));
+    ft[10] = 'Y';
+    ft[11] = 'Z';
+    if (!put(ft, 12)) return MZHIP_STATUS_OUT_FULL;
+    if (out_len) *out_len = pos;
+    if (crc) *crc = total_crc;
+    return 0;
 }
 
 // One stream segment: split into 64 KiB pieces (one wave each); every piece but the last ends with an empty

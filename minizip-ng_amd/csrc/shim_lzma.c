@@ -5,8 +5,11 @@
  * header) is decoded by the device range decoder (K3, lzma_core.h) through
  * mzhip_lzma_host(); READ of method 95 (one .xz stream of LZMA2 blocks, what
  * lzma_stream_decoder handles at mz_strm_lzma.c:127-128) by the .xz kernel
- * (xz_core.h) through mzhip_xz_host().  WRITE answers MZ_SUPPORT_ERROR, which
- * is what a reference build without compression answers (mz_strm_lzma.c:71-75).
+ * (xz_core.h) through mzhip_xz_host().  WRITE collects the entry and codes it at
+ * close() on the device (lzma_enc_core.h): method 14 as one LZMA1 stream with the
+ * ZIP-LZMA header and the end marker (mz_strm_lzma.c:94-104, mz_zip.c:1984), method
+ * 95 as one .xz stream of independent LZMA2 chunks.  The bytes are valid but not
+ * liblzma's; the reference's reader decodes them back (tests/test_gpu_lzma_enc.py).
  *
  * Contract mirrored from the reference (file:line = mz_strm_lzma.c):
  *   create :429-438  method LZMA, preset default, max_total_out -1
@@ -44,6 +47,9 @@ typedef struct mzhip_lzma_s {
     int32_t dev_status;
     int64_t dev_in_used;
     int64_t next_attempt;
+    /* write side: the whole entry is collected, coded at close() */
+    uint8_t *wbuf;
+    int64_t wlen, wcap;
 } mzhip_lzma;
 
 static mzhip_stream_vtbl mzhip_lzma_vtbl = {
@@ -86,9 +92,17 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->dev_status = 0;
     z->dev_in_used = 0;
     z->next_attempt = 0;
-    if (mode & MZH_OPEN_MODE_WRITE)
-        return MZH_SUPPORT_ERROR;
-    if (mode & MZH_OPEN_MODE_READ) {
+    free(z->wbuf);
+    z->wbuf = NULL;
+    z->wlen = z->wcap = 0;
+    if (mode & MZH_OPEN_MODE_WRITE) {
+        if (z->method != MZH_COMPRESS_METHOD_LZMA && z->method != MZH_COMPRESS_METHOD_XZ)
+            return MZH_OPEN_ERROR;
+        if (mzhip_device_count() <= 0) {
+            z->error = 1;
+            return MZH_OPEN_ERROR;
+        }
+    } else if (mode & MZH_OPEN_MODE_READ) {
         if (z->method != MZH_COMPRESS_METHOD_LZMA && z->method != MZH_COMPRESS_METHOD_XZ)
             return MZH_OPEN_ERROR; /* neither decoder initialised: lzma->error stays non-OK, mz_strm_lzma.c:131-132 */
         if (mzhip_device_count() <= 0) {
@@ -219,11 +233,65 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
     return n;
 }
 
+#define MZH_LZMA_WRITE_LIMIT ((int64_t)1 << 30) /* one stream = one launch: the entry is held in host memory */
+
 int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
-    (void)stream;
-    (void)buf;
-    (void)size;
-    return MZH_SUPPORT_ERROR;
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    if (size <= 0)
+        return size;
+    if (z->wlen + size > MZH_LZMA_WRITE_LIMIT)
+        return MZH_MEM_ERROR;
+    if (z->wlen + size > z->wcap) {
+        int64_t ncap = z->wcap ? z->wcap * 2 : (1 << 20);
+        while (ncap < z->wlen + size)
+            ncap *= 2;
+        uint8_t *p = (uint8_t *)realloc(z->wbuf, (size_t)ncap);
+        if (!p)
+            return MZH_MEM_ERROR;
+        z->wbuf = p;
+        z->wcap = ncap;
+    }
+    memcpy(z->wbuf + z->wlen, buf, (size_t)size);
+    z->wlen += size;
+    z->total_in += size; /* mz_strm_lzma.c:322 */
+    return size;
+}
+
+static int32_t base_write(mzhip_stream *base, const void *buf, int32_t size) {
+    if (size == 0)
+        return size;
+    if (!base || !base->vtbl || !base->vtbl->write)
+        return MZH_PARAM_ERROR;
+    if (!base->vtbl->is_open || base->vtbl->is_open(base) != MZH_OK)
+        return MZH_STREAM_ERROR;
+    return base->vtbl->write(base, buf, size);
+}
+
+/* code everything collected and hand it to base in staging-sized writes (mz_strm_lzma.c:244-248) */
+static int32_t finish_write(mzhip_lzma *z) {
+    uint32_t cap = (uint32_t)(z->wlen + z->wlen / 8 + 4096 + (z->wlen / 49152 + 1) * 8);
+    uint8_t *out = (uint8_t *)malloc(cap);
+    if (!out)
+        return MZH_MEM_ERROR;
+    uint32_t out_len = 0, crc = 0;
+    int32_t st = (z->method == MZH_COMPRESS_METHOD_XZ ? mzhip_xz_encode_host : mzhip_lzma_encode_host)(
+        z->wbuf ? z->wbuf : (const uint8_t *)"", (uint32_t)z->wlen, out, cap, &out_len, &crc);
+    if (st != 0) {
+        free(out);
+        return MZH_DATA_ERROR; /* device failure: never substitute a CPU result */
+    }
+    uint32_t pos = 0;
+    while (pos < out_len) {
+        int32_t n = (int32_t)(out_len - pos < MZH_STAGING_BYTES ? out_len - pos : MZH_STAGING_BYTES);
+        if (base_write(z->stream.base, out + pos, n) != n) {
+            free(out);
+            return MZH_WRITE_ERROR;
+        }
+        pos += (uint32_t)n;
+    }
+    free(out);
+    z->total_out += out_len;
+    return MZH_OK;
 }
 
 int64_t mz_stream_lzma_tell(void *stream) {
@@ -240,6 +308,11 @@ int32_t mz_stream_lzma_seek(void *stream, int64_t offset, int32_t origin) {
 
 int32_t mz_stream_lzma_close(void *stream) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
+    if ((z->mode & MZH_OPEN_MODE_WRITE) && z->initialized == 1 && finish_write(z) != MZH_OK)
+        z->error = 11; /* LZMA_PROG_ERROR: reported as MZ_CLOSE_ERROR below */
+    free(z->wbuf);
+    z->wbuf = NULL;
+    z->wlen = z->wcap = 0;
     z->initialized = 0;
     free(z->in);
     free(z->out);
@@ -321,6 +394,7 @@ void mz_stream_lzma_delete(void **stream) {
     if (z) {
         free(z->in);
         free(z->out);
+        free(z->wbuf);
         free(z);
     }
     *stream = NULL;

@@ -34,6 +34,7 @@
 #define PV2(type, name, n) type name[64][n] /* small per-lane array */
 #define P(name) name[lane]
 #define MZ_READLANE(name, idx) (name[(idx)])
+#define MZ_WRITELANE(name, idx, val) (name[(idx)] = (val)) /* one wave-uniform value into lane idx */
 #define MZ_UNIFORM(x) (x)
 #define MZ_WAVE_SYNC() ((void)0)
 #define MZ_BALLOT(dst, cond)                         \
@@ -106,6 +107,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
 #define PV2(type, name, n) type name[n]
 #define P(name) name
 #define MZ_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
+#define MZ_WRITELANE(name, idx, val) ((name) = ((uint32_t)lane == (uint32_t)(idx)) ? (uint32_t)(val) : (name)) /* a select, not a branch */
 #define MZ_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 /* orders this wave's memory operations for the compiler; the hardware already
  * executes one wave's LDS (and vector-memory) instructions in issue order. */

@@ -1,5 +1,5 @@
 """GPU probe (not a pytest): throughput of K3 (LZMA decode), the .xz kernel, K4 (DEFLATE encode) and the SHA batch
-kernel at config-like shapes.  Usage: python tests/perf_codecs.py [lzma|xz|deflate|sha|both|all]"""
+kernel at config-like shapes.  Usage: python tests/perf_codecs.py [lzma|xz|deflate|sha|lzmaenc|both|all]"""
 import ctypes as C
 import sys
 import time
@@ -128,3 +128,34 @@ if which in ("sha", "all"):
         ok = all(h[i, :sz].tobytes() == fn(datas[idx[i]]).digest() for i in range(0, n_total, 257))
         print("SHA (alg %d) batch: %d x %d B: %.1f ms  %.2f GiB/s  ok=%s" % (alg, n_total, size, ms,
                                                                             n_total * size / 2**30 / (ms / 1e3), ok), flush=True)
+
+if which in ("lzmaenc", "all"):
+    import lzma as pylzma
+
+    L.mzhip_lzma_encode_batch.restype = C.c_int32
+    L.mzhip_lzma_encode_batch.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 4
+    for n_unique, n_total, size, tag in ((512, 18432, 65536, "64 KiB entries"), (16, 2304, 1 << 20, "1 MiB entries")):
+        if size == 65536:
+            datas = synth.slices(n_unique, size, 1234)
+        else:
+            rnd = np.random.RandomState(3)
+            words = synth.corpus().split()
+            datas = [b" ".join(words[i] for i in rnd.randint(0, len(words), size=240000))[:size] for _ in range(n_unique)]
+        idx = np.arange(n_total) % n_unique
+        b = gpu_util.make_batch([datas[i] for i in idx], [size + size // 8 + 1024] * n_total)
+        out_len, crc, status = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(3))
+
+        def run5():
+            assert L.mzhip_lzma_encode_batch(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(), size,
+                                             b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None,
+                                             n_total, out_len.data_ptr(), crc.data_ptr(), status.data_ptr(), None) == 0
+        ms = timed(run5, 2)
+        want = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)[idx]
+        ol = out_len.cpu().numpy()
+        h = b["d_out"].cpu().numpy()
+        ok = bool((status.cpu().numpy() == 0).all() and (mz.u32(crc) == want).all())
+        for i in range(0, n_total, 1777):
+            z = gpu_util.entry_bytes(b, h, i, int(ol[i]))
+            ok = ok and pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == datas[idx[i]]
+        print("LZMA encode (%s): %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.3f  ok=%s" % (
+            tag, n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), ok), flush=True)

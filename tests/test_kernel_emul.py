@@ -30,6 +30,7 @@ def emu():
     L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
     L.emul_lzma.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
     L.emul_xz.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_lzma_encode.argtypes = [_u8p, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.emul_deflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.emul_adler32.restype = C.c_uint32
     L.emul_adler32.argtypes = [_u8p, C.c_uint32]
@@ -265,6 +266,64 @@ def test_deflate_roundtrip(emu):
     out = np.zeros(100, np.uint8)
     ol, crc = C.c_uint32(), C.c_uint32()
     assert emu.emul_deflate(a.ctypes.data_as(_u8p), 4000, out.ctypes.data_as(_u8p), 100, 1, C.byref(ol), C.byref(crc)) == -200
+
+
+def _lzma_encode(emu, d, mode=0):
+    a = np.frombuffer(d, dtype=np.uint8).copy() if len(d) else np.zeros(1, np.uint8)
+    cap = len(d) + len(d) // 8 + 1024
+    out = np.zeros(cap, np.uint8)
+    ol, crc = C.c_uint32(), C.c_uint32()
+    st = emu.emul_lzma_encode(a.ctypes.data_as(_u8p), len(d), mode, out.ctypes.data_as(_u8p), cap, C.byref(ol), C.byref(crc))
+    return st, out[:ol.value].tobytes(), crc.value
+
+
+def test_lzma_encode_roundtrip(emu):
+    """LZMA encode parity = valid streams that the reference side decodes back to the input: ZIP method-14 payloads
+    through the oracle restatement, liblzma (Python's lzma) and -- where built -- the compiled reference; LZMA2 chunk
+    payloads wrapped into an .xz stream exactly like mzhip_xz_encode_host lays it out."""
+    import lzma as pylzma
+
+    c = synth.corpus()
+    rnd = np.random.RandomState(3)
+    cases = [b"", b"a", b"ab", b"a" * 20, c[:100], c[:5000], c[:65536], c[:200000], rnd.bytes(3000), bytes(100000),
+             c[:70000] + rnd.bytes(500) + c[:70000], b"abcabcabc" * 1000, c[:65535], c[:65537]]
+    for d in cases:
+        st, z, crc = _lzma_encode(emu, d)
+        assert st == 0 and crc == zlib.crc32(d), len(d)
+        assert z[:9] == bytes([9, 20, 5, 0, 0x5D, 0, 0, 1, 0])
+        so, used, out = oracle.lzma_zip_decode(z, len(d) + 64, -1)
+        assert (so, used, out) == (0, len(z), d), len(d)
+        assert pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == d
+        if oracle.have_ref():
+            r = oracle.ref().stream_decode(14, z, len(d) + 64, max_in=len(z), max_out=len(d))
+            assert r["out"] == d and r["total_in"] == len(z) and r["close"] == 0, len(d)
+        st2, used2, out2, crc2 = _run(emu.emul_lzma, z, len(d) + 64, C.c_int64(-1))      # and back through K3's core
+        assert (st2, used2, out2, crc2) == (0, len(z), d, crc)
+    assert len(_lzma_encode(emu, c[:65536])[1]) < 0.4 * 65536
+    # LZMA2 chunk payloads -> one .xz stream (single block, CRC32 check, every chunk resets dict + state + props)
+    for d in (c[:150000], rnd.bytes(60000) + c[:1000], b"x"):
+        body = b""
+        for o in range(0, len(d), 49152):
+            piece = d[o:o + 49152]
+            st, z, crc = _lzma_encode(emu, piece, 1)
+            assert st == 0 and crc == zlib.crc32(piece)
+            us, cs = len(piece), len(z)
+            if cs >= us:
+                body += bytes([1, (us - 1) >> 8, (us - 1) & 255]) + piece
+            else:
+                body += bytes([0xE0 | ((us - 1) >> 16), ((us - 1) >> 8) & 255, (us - 1) & 255, (cs - 1) >> 8, (cs - 1) & 255, 0x5D]) + z
+        body += b"\x00"
+        flags = b"\x00\x01"
+        bh = bytes([2, 0, 0x21, 1, 8, 0, 0, 0])
+        x = b"\xfd7zXZ\x00" + flags + zlib.crc32(flags).to_bytes(4, "little") + bh + zlib.crc32(bh).to_bytes(4, "little")
+        x += body + b"\x00" * (-len(body) % 4) + zlib.crc32(d).to_bytes(4, "little")
+        idx = b"\x00\x01" + synth._vli(12 + len(body) + 4) + synth._vli(len(d))
+        idx += b"\x00" * (-len(idx) % 4)
+        idx += zlib.crc32(idx).to_bytes(4, "little")
+        tail = (len(idx) // 4 - 1).to_bytes(4, "little") + flags
+        x += idx + zlib.crc32(tail).to_bytes(4, "little") + tail + b"YZ"
+        assert pylzma.decompress(x) == d
+        assert oracle.xz_decode(x, len(d) + 64) == (0, len(x), d)
 
 
 def test_inflate_differential_fuzz(emu):
