@@ -136,6 +136,16 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
     return ntokens;
 }
 
+/* Like K3, the coder arithmetic can issue on the scalar port (LZE_U = readfirstlane) or stay in VGPRs and issue on
+ * the vector ports (identity); see DESIGN.md K3 / K6 for the measurement that picks the default. */
+#ifndef LZE_U
+#if defined(MZHIP_HOST_EMUL) || defined(MZ_LZE_SCALAR_PORT)
+#define LZE_U(x) MZ_UNIFORM(x)
+#else
+#define LZE_U(x) (x)
+#endif
+#endif
+
 /* ---------------------------------------------------------------------------------------------------------
  * Range ENCODER, wave-uniform.  low is 33 bits wide; a byte leaves only when no later carry can change it. */
 #define LZE_OUT_BYTE(b)                                                                  \
@@ -177,7 +187,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
 #define LZE_BIT(idx, bitv)                                                               \
     do {                                                                                 \
         const uint32_t _pi = (idx);                                                      \
-        uint32_t _p = MZ_UNIFORM(pr[_pi]);                                               \
+        uint32_t _p = LZE_U(pr[_pi]);                                                    \
         const uint32_t _bound = (range >> 11) * _p;                                      \
         if (!(bitv)) {                                                                   \
             range = _bound;                                                              \
