@@ -347,9 +347,13 @@ typedef struct mz_lzma_result {
 #undef LZ_ENTRY_NAME
 #endif
 
-/* for code that expands the coder macros outside the two entry builds (xz_core.h): the scalar-port forms (the
- * vector-port forms measured 2x slower inside the larger .xz function) */
+/* for code that expands the coder macros outside the two entry builds (xz_core.h): vector-port forms on the device */
+#if defined(MZHIP_HOST_EMUL)
 #define LZ_U(x) MZ_UNIFORM(x)
 #define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
+#else
+#define LZ_U(x) (x)
+#define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
+#endif
 
 #endif

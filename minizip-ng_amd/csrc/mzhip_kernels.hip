@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
 }
 
 // .xz (method 95): one wave per workgroup like K3; LDS = probability model + CRC-64 table (17.6 KiB) -> 8 per CU.
-__global__ __launch_bounds__(64) void k_xz_batch(LzmaArgs a) {
+__global__ __launch_bounds__(64, 2) void k_xz_batch(LzmaArgs a) {
     __shared__ __attribute__((aligned(16))) mz_xz_lds lds;
     __shared__ uint32_t crc_tab[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
