@@ -183,8 +183,9 @@ MZHIP_API int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int6
 
 /* Prime (SURVEY 8b "Batching") ------------------------------------------------------------- */
 
-/* Decode every DEFLATE entry of an archive (file or memory image) in one launch and keep the results in a
- * host cache.  Afterwards the drop-in mz_stream_zlib READ path recognises a primed entry (base-stream position
+/* Decode every DEFLATE / LZMA / XZ entry (methods 8, 14, 95) of an archive (file or memory image) in one launch
+ * per codec and keep the results in a host cache.  Afterwards the drop-in mz_stream_zlib / mz_stream_lzma READ
+ * path recognises a primed entry (base-stream position
  * == payload offset, first payload bytes equal) and serves read() calls from the cache; the matching
  * mz_crypt_crc32_update calls are answered from GPU-computed per-65 535-byte-segment CRCs, so the reference's
  * untouched mz_zip_reader loop runs at memcpy speed while mz_zip.c:2116-2128 still verifies every entry against

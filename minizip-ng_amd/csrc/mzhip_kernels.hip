@@ -1064,6 +1064,7 @@ struct PrimedEntry {
     uint32_t crc;
     int32_t status;
     int64_t seg0; // index of this entry's first segment CRC
+    int32_t method;
     uint8_t head[16];
 };
 struct PrimeCache {
@@ -1096,12 +1097,15 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     std::vector<PrimedEntry> ents;
     std::vector<uint64_t> in_off, out_off;
     std::vector<uint32_t> in_len, out_cap;
+    std::vector<int64_t> max_out;
     uint64_t total_out = 0;
     for (int64_t i = 0; i < n; i++) {
         const int64_t *t = &table[(size_t)i * 8];
-        if (t[0] != 8 || (t[1] & 1) || t[7] < 0 || t[3] >= (1ll << 28) || t[4] >= (1ll << 31)) continue;
+        if ((t[0] != 8 && t[0] != 14 && t[0] != 95) || (t[1] & 1) || t[7] < 0 || t[3] >= (1ll << 28) || t[4] >= (1ll << 31))
+            continue;
         PrimedEntry e;
         memset(&e, 0, sizeof(e));
+        e.method = (int32_t)t[0];
         e.payload_off = t[7];
         e.csize = t[3];
         e.usize = t[4];
@@ -1112,10 +1116,36 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
         in_len.push_back((uint32_t)t[3]);
         out_off.push_back(total_out);
         out_cap.push_back((uint32_t)t[4]);
+        /* TOTAL_OUT_MAX as mz_zip.c:1833-1846 sets it: the uncompressed size when the EOS flag is set */
+        max_out.push_back((t[0] != 8 && (t[1] & 2)) ? t[4] : -1);
         total_out += ((uint64_t)t[4] + 15) & ~15ull;
     }
     const uint32_t k = (uint32_t)ents.size();
     if (k == 0) return 0;
+    {
+        /* group the launch arrays by method (8, 14, 95): one batch launch per codec */
+        std::vector<uint32_t> order(k);
+        for (uint32_t i = 0; i < k; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ents[a].method < ents[b].method; });
+        std::vector<PrimedEntry> e2(k);
+        std::vector<uint64_t> io(k), oo(k);
+        std::vector<uint32_t> il(k), oc(k);
+        std::vector<int64_t> mo(k);
+        for (uint32_t i = 0; i < k; i++) {
+            e2[i] = ents[order[i]];
+            io[i] = in_off[order[i]];
+            oo[i] = out_off[order[i]];
+            il[i] = in_len[order[i]];
+            oc[i] = out_cap[order[i]];
+            mo[i] = max_out[order[i]];
+        }
+        ents.swap(e2);
+        in_off.swap(io);
+        out_off.swap(oo);
+        in_len.swap(il);
+        out_cap.swap(oc);
+        max_out.swap(mo);
+    }
     // segments for the chunked CRC updates
     std::vector<uint64_t> seg_off;
     std::vector<uint32_t> seg_len;
@@ -1127,7 +1157,7 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
         }
     }
     const uint32_t ns = (uint32_t)seg_off.size();
-    const size_t meta = (size_t)k * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4) + (size_t)ns * (8 + 4 + 4) + 256;
+    const size_t meta = (size_t)k * (8 + 8 + 8 + 4 + 4 + 4 + 4 + 4 + 4) + (size_t)ns * (8 + 4 + 4) + 256;
     Scratch d_zip, d_out, d_meta;
     HIP_TRY(hipMalloc(&d_zip.p, zip_len + 16));
     HIP_TRY(hipMalloc(&d_out.p, total_out + 16));
@@ -1135,7 +1165,8 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     HIP_TRY(hipMemcpy(d_zip.p, zip, zip_len, hipMemcpyHostToDevice));
     uint8_t *m = (uint8_t *)d_meta.p;
     uint64_t *d_in_off = (uint64_t *)m, *d_out_off = d_in_off + k, *d_seg_off = d_out_off + k;
-    uint32_t *d_in_len = (uint32_t *)(d_seg_off + ns), *d_out_cap = d_in_len + k, *d_out_len = d_out_cap + k,
+    int64_t *d_max_out = (int64_t *)(d_seg_off + ns);
+    uint32_t *d_in_len = (uint32_t *)(d_max_out + k), *d_out_cap = d_in_len + k, *d_out_len = d_out_cap + k,
              *d_in_used = d_out_len + k, *d_crc = d_in_used + k;
     int32_t *d_status = (int32_t *)(d_crc + k);
     uint32_t *d_seg_len = (uint32_t *)(d_status + k), *d_seg_crc = d_seg_len + ns;
@@ -1143,13 +1174,25 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     HIP_TRY(hipMemcpy(d_out_off, out_off.data(), k * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_in_len, in_len.data(), k * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_out_cap, out_cap.data(), k * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_max_out, max_out.data(), k * 8, hipMemcpyHostToDevice));
     if (ns) {
         HIP_TRY(hipMemcpy(d_seg_off, seg_off.data(), ns * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_seg_len, seg_len.data(), ns * 4, hipMemcpyHostToDevice));
     }
-    rc = mzhip_inflate_batch(d_zip.p, d_in_off, d_in_len, d_out.p, d_out_off, d_out_cap, k, d_out_len, d_in_used,
-                             d_crc, d_status, nullptr);
-    if (rc) return rc;
+    for (uint32_t g0 = 0; g0 < k;) {
+        uint32_t g1 = g0;
+        while (g1 < k && ents[g1].method == ents[g0].method) g1++;
+        const uint32_t gn = g1 - g0;
+        if (ents[g0].method == 8)
+            rc = mzhip_inflate_batch(d_zip.p, d_in_off + g0, d_in_len + g0, d_out.p, d_out_off + g0, d_out_cap + g0, gn,
+                                     d_out_len + g0, d_in_used + g0, d_crc + g0, d_status + g0, nullptr);
+        else
+            rc = lzma_family_batch(ents[g0].method == 95, d_zip.p, d_in_off + g0, d_in_len + g0, d_out.p, d_out_off + g0,
+                                   d_out_cap + g0, d_max_out + g0, gn, d_out_len + g0, d_in_used + g0, d_crc + g0,
+                                   d_status + g0, nullptr);
+        if (rc) return rc;
+        g0 = g1;
+    }
     if (ns) {
         rc = mzhip_crc32_batch(d_out.p, d_seg_off, d_seg_len, ns, nullptr, d_seg_crc, nullptr);
         if (rc) return rc;
@@ -1212,7 +1255,7 @@ void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses) {
 
 // Used by shim_zlib.c: is the entry whose payload starts at `payload_off` (first bytes `head`) primed?
 // On a hit returns 1 and the cached output / sizes / CRCs (pointers stay valid until the next prime/clear).
-__attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup(int64_t payload_off, const uint8_t *head,
+__attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup2(int32_t method, int64_t payload_off, const uint8_t *head,
                                                                   int32_t head_len, const uint8_t **data,
                                                                   int64_t *usize, int64_t *csize, uint32_t *crc,
                                                                   const uint32_t **seg_crc) {
@@ -1229,7 +1272,7 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup(int64_t payload
     }
     const PrimedEntry &e = g_prime.entries[lo];
     const int32_t cmp = (int32_t)(e.csize < 16 ? e.csize : 16);
-    if (head_len < cmp || memcmp(head, e.head, (size_t)cmp) != 0) {
+    if (e.method != method || head_len < cmp || memcmp(head, e.head, (size_t)cmp) != 0) {
         g_prime.misses++;
         return 0;
     }
@@ -1240,6 +1283,12 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup(int64_t payload
     *crc = e.crc;
     *seg_crc = g_prime.seg_crc.data() + e.seg0;
     return 1;
+}
+
+__attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup(int64_t payload_off, const uint8_t *head, int32_t head_len,
+                                                                 const uint8_t **data, int64_t *usize, int64_t *csize,
+                                                                 uint32_t *crc, const uint32_t **seg_crc) {
+    return mzhip_prime_lookup2(8, payload_off, head, head_len, data, usize, csize, crc, seg_crc);
 }
 
 // checksums only: crc(A||B) from crc(A), crc(B), |B| (shared with shim_crc32.c)

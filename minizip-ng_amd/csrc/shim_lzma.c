@@ -22,11 +22,13 @@
  *                    lzma_ret values LZMA_DATA_ERROR / LZMA_BUF_ERROR)
  *   props  :380-428  adds COMPRESS_METHOD, TOTAL_OUT_MAX (>= -1), HEADER_SIZE=4
  */
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "mz_strm_hip.h"
 #include "mzhip.h"
+#include "shim_common.h"
 
 #define LZMA_MAGIC_SIZE 4 /* mz_strm_lzma.c:19 */
 
@@ -47,6 +49,9 @@ typedef struct mzhip_lzma_s {
     int32_t dev_status;
     int64_t dev_in_used;
     int64_t next_attempt;
+    int8_t tried_cache, out_borrowed; /* prime cache: looked up once; out points into the cache */
+    int64_t base_pos0;                /* base position at open = payload offset */
+    const uint32_t *seg_crc;          /* GPU CRCs of the 65 535-byte segments of a primed entry */
     /* write side: the whole entry is collected, coded at close() */
     uint8_t *wbuf;
     int64_t wlen, wcap;
@@ -85,7 +90,12 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->total_in = z->total_out = 0;
     z->error = 0;
     free(z->in);
-    free(z->out);
+    if (!z->out_borrowed)
+        free(z->out);
+    z->out_borrowed = 0;
+    z->tried_cache = 0;
+    z->seg_crc = NULL;
+    z->base_pos0 = -1;
     z->in = z->out = NULL;
     z->in_len = z->in_cap = z->out_len = z->out_cap = z->out_served = 0;
     z->base_eof = z->decoded = 0;
@@ -108,6 +118,11 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
         if (mzhip_device_count() <= 0) {
             z->error = 1;
             return MZH_OPEN_ERROR;
+        }
+        {
+            mzhip_stream *b = z->stream.base;
+            if (b && b->vtbl && b->vtbl->tell && b->vtbl->is_open && b->vtbl->is_open(b) == MZH_OK)
+                z->base_pos0 = b->vtbl->tell(b); /* the payload offset, for the prime cache */
         }
         /* the 4 magic bytes are consumed at open and kept as the front of the
          * device input, which starts at the ZIP-LZMA header (mz_strm_lzma.c:118-124) */
@@ -197,6 +212,25 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         int32_t rd = pull_chunk(z);
         if (rd < 0)
             return rd;
+        if (!z->tried_cache) {
+            /* was this entry decoded by mzhip_prime_*()?  (payload offset + first payload bytes must agree) */
+            z->tried_cache = 1;
+            const uint8_t *data = NULL;
+            int64_t usize = 0, csize = 0;
+            uint32_t crc = 0;
+            if (z->base_pos0 >= 0 &&
+                mzhip_prime_lookup2(z->method, z->base_pos0, z->in, (int32_t)(z->in_len < 16 ? z->in_len : 16), &data, &usize,
+                                    &csize, &crc, &z->seg_crc) == 1 &&
+                (z->max_total_in <= 0 || z->max_total_in >= csize) && (z->max_total_out < 0 || z->max_total_out >= usize)) {
+                z->out = (uint8_t *)(uintptr_t)data;
+                z->out_borrowed = 1;
+                z->out_len = usize;
+                z->dev_in_used = csize;
+                z->dev_status = 0;
+                z->decoded = 1;
+                break;
+            }
+        }
         if (!z->base_eof && z->in_len < z->next_attempt)
             continue;
         int32_t r = attempt_decode(z);
@@ -217,6 +251,14 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
     int32_t n = (int32_t)(avail < size ? avail : size);
     if (n > 0) {
         memcpy(buf, z->out + z->out_served, (size_t)n);
+        if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
+            (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
+            /* a whole primed segment: its device-computed CRC answers the mz_crypt_crc32_update that follows */
+            mzhip_last_served.buf = buf;
+            mzhip_last_served.size = n;
+            mzhip_last_served.crc = z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT];
+            mzhip_last_served.valid = 1;
+        }
         z->out_served += n;
         z->total_out += n;
     }
@@ -315,7 +357,9 @@ int32_t mz_stream_lzma_close(void *stream) {
     z->wlen = z->wcap = 0;
     z->initialized = 0;
     free(z->in);
-    free(z->out);
+    if (!z->out_borrowed)
+        free(z->out);
+    z->out_borrowed = 0;
     z->in = z->out = NULL;
     z->in_cap = z->out_cap = 0;
     if (z->error != 0)
@@ -393,7 +437,8 @@ void mz_stream_lzma_delete(void **stream) {
     z = (mzhip_lzma *)*stream;
     if (z) {
         free(z->in);
-        free(z->out);
+        if (!z->out_borrowed)
+            free(z->out);
         free(z->wbuf);
         free(z);
     }

@@ -71,3 +71,44 @@ def test_prime_serves_unmodified_reader_loop():
         # after clear the ordinary per-entry device path still works
         _, crc2, _, st2 = hip.zip_read_all(path, cd[:40], nthreads=1)      # own_crc: the driver's extra CRC calls hit the device
         assert (st2 == 0).all() and (crc2 == crc_r[:40]).all()
+
+
+def test_prime_lzma_and_xz_entries():
+    """The same for methods 14 and 95: one launch per codec fills the cache, the unmodified reader loop
+    (mz_stream_lzma_read on the drop-in) is served from it, CRC verification by mz_zip.c still passes."""
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    L = mz.lib()
+    L.mzhip_prime_file.restype = C.c_int64
+    L.mzhip_prime_file.argtypes = [C.c_char_p]
+    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(16)
+    with tempfile.TemporaryDirectory() as tmp:
+        for method in (14, 95):
+            n, size = 40, 120000
+            lens = rnd.randint(0, size + 1, size=n).astype(np.int32)
+            lens[:3] = (0, 1, 65535)
+            offs = rnd.randint(0, len(c) - size, size=n).astype(np.int64)
+            path = os.path.join(tmp, "p%d.zip" % method)
+            ref.zip_write(path, c, offs, lens, method=method, level=6)
+            table = ref.zip_index(path)
+            cd = table[:, 6].copy()
+            out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+            o_ref = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            t_ref, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_ref, out_off=out_off)
+            L.mzhip_prime_clear()
+            cached = L.mzhip_prime_file(path.encode())
+            assert cached == n, (method, cached)
+            t_hip, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_hip, out_off=out_off)
+            ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+            assert (st_r == 0).all() and (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all()
+            assert (o_hip == o_ref).all()
+            assert hits.value == n and miss.value == 0, (method, hits.value, miss.value)
+            print("method %d: reference 1 thread %.3f s, primed drop-in %.3f s (%.1fx)" % (method, t_ref, t_hip, t_ref / t_hip))
+            L.mzhip_prime_clear()
