@@ -73,6 +73,30 @@ MZ_DEV uint32_t mz_clz32(uint32_t v) {
 #endif
 }
 
+/* Length of the common prefix of a[] and b[], at most maxl.  Sixteen bytes per round: the eight dword loads of a
+ * round are issued together, so a typical match (shorter than 16 bytes) costs one memory round trip, not one per
+ * four bytes. */
+MZ_DEV uint32_t mz_match_len(const uint8_t *a, const uint8_t *b, uint32_t maxl) {
+    uint32_t l = 0;
+    while (l + 16u <= maxl) {
+        const uint32_t x0 = mz_load_u32(a + l) ^ mz_load_u32(b + l);
+        const uint32_t x1 = mz_load_u32(a + l + 4u) ^ mz_load_u32(b + l + 4u);
+        const uint32_t x2 = mz_load_u32(a + l + 8u) ^ mz_load_u32(b + l + 8u);
+        const uint32_t x3 = mz_load_u32(a + l + 12u) ^ mz_load_u32(b + l + 12u);
+        if ((x0 | x1 | x2 | x3) == 0u) {
+            l += 16u;
+            continue;
+        }
+        /* first differing byte: little-endian dwords, so the lowest set bit of the first non-zero XOR */
+        const uint32_t x = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3;
+        const uint32_t k = x0 ? 0u : x1 ? 4u : x2 ? 8u : 12u;
+        return l + k + ((31u - mz_clz32(x & (0u - x))) >> 3);
+    }
+    while (l + 4u <= maxl && mz_load_u32(a + l) == mz_load_u32(b + l)) l += 4u;
+    while (l < maxl && a[l] == b[l]) l++;
+    return l;
+}
+
 /* length 3..258 -> symbol 257..285, number and value of extra bits (appnote.txt:2107-2120) */
 MZ_DEV uint32_t mz_len_sym(uint32_t mlen, uint32_t *ex, uint32_t *xv) {
     const uint32_t l = mlen - 3u;
@@ -298,6 +322,11 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
         uint32_t ntokens = 0, skip = 0;
         PV(uint32_t, xbits); /* extra bits of this lane's tokens */
         MZ_LANES { P(xbits) = 0; }
+        PV(uint32_t, vnx); /* the four bytes at this lane's position of the NEXT step, fetched one step ahead */
+        MZ_LANES {
+            const uint32_t pos = blk + (uint32_t)lane;
+            P(vnx) = (pos + 4u <= blk_end) ? mz_load_u32(in + pos) : 0u;
+        }
         for (uint32_t p = blk; p < blk_end; p += 64u) {
             const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u; /* valid positions in this step */
             PV(uint32_t, hh);
@@ -305,7 +334,8 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_LANES {
                 const uint32_t pos = p + (uint32_t)lane;
                 const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
-                const uint32_t v = have4 ? mz_load_u32(in + pos) : 0u;
+                const uint32_t v = P(vnx);
+                P(vnx) = (pos + 68u <= blk_end) ? mz_load_u32(in + pos + 64u) : 0u;
                 const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
                 P(hh) = have4 ? h : 0xFFFFFFFFu;
                 P(cand) = have4 ? (uint32_t)L->u.head[h] : 0u;
@@ -327,9 +357,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - blk) {
                         const uint8_t *a = in + pos, *b = in + (pos - d);
                         const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
-                        uint32_t l = 0;
-                        while (l + 4u <= maxl && mz_load_u32(a + l) == mz_load_u32(b + l)) l += 4u;
-                        while (l < maxl && a[l] == b[l]) l++;
+                        const uint32_t l = mz_match_len(a, b, maxl);
                         if (l >= MZ_DEF_MINMATCH) {
                             mlen = l;
                             dist = d;

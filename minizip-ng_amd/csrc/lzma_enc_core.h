@@ -41,6 +41,11 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
     }
     MZ_WAVE_SYNC();
     uint32_t ntokens = 0, skip = 0;
+    PV(uint32_t, vnx); /* the four bytes at this lane's position of the NEXT step, fetched one step ahead */
+    MZ_LANES {
+        const uint32_t pos = blk + (uint32_t)lane;
+        P(vnx) = (pos + 4u <= blk_end) ? mz_load_u32(in + pos) : 0u;
+    }
     for (uint32_t p = blk; p < blk_end; p += 64u) {
         const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u;
         PV(uint32_t, hh);
@@ -48,7 +53,8 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
         MZ_LANES {
             const uint32_t pos = p + (uint32_t)lane;
             const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
-            const uint32_t v = have4 ? mz_load_u32(in + pos) : 0u;
+            const uint32_t v = P(vnx);
+            P(vnx) = (pos + 68u <= blk_end) ? mz_load_u32(in + pos + 64u) : 0u;
             const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
             P(hh) = have4 ? h : 0xFFFFFFFFu;
             P(cand) = have4 ? (uint32_t)L->head[h] : 0u;
@@ -69,9 +75,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
                 if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - blk) {
                     const uint8_t *a = in + pos, *b = in + (pos - d);
                     const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
-                    uint32_t l = 0;
-                    while (l + 4u <= maxl && mz_load_u32(a + l) == mz_load_u32(b + l)) l += 4u;
-                    while (l < maxl && a[l] == b[l]) l++;
+                    const uint32_t l = mz_match_len(a, b, maxl);
                     if (l >= MZ_DEF_MINMATCH) {
                         mlen = l;
                         dist = d;
