@@ -148,6 +148,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     mz.require_gpu()  # no CPU fallback: fail loudly if the HIP path is unavailable
+    size, n = args.entry_size, args.entries
+    # the worker pool that compresses the synthetic slices forks: do it before this process creates its HIP
+    # context and the RCCL threads
+    c, offs, pays, crcs = make_unique(args.unique, size, 1234 + rank, args.gen_seconds, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -156,8 +160,6 @@ def main():
 
         dist.init_process_group("nccl", device_id=dev)
 
-    size, n = args.entry_size, args.entries
-    c, offs, pays, crcs = make_unique(args.unique, size, 1234 + rank, args.gen_seconds, world)
     U = len(pays)
     # tile the unique slices over this rank's shard; every entry gets its own bytes in HBM
     rnd = np.random.RandomState(99 + rank)
