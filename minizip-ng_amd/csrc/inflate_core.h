@@ -62,7 +62,7 @@ extern unsigned long long mz_stats[16];
  *     literal      : 0x80 | byte << 16                    (already the finished token)
  *     end-of-block : 0x40                                 (already the finished token)
  *     length       : MZ_E_LEN | base << 7 | extra_bits << 16
- *     286, 287     : MZ_E_BAD
+ *     286, 287     : MZ_E_BAD as a descriptor; finished entries hold code length << 16 (an invalid token)
  *     long code    : MZ_E_SUB | sub-table offset << 8 | sub-table index bits   (root table only; the
  *                    sub-table entry, indexed by the next bits of the stream, is one of the above)
  * distance table entry = descriptor + code length in [3:0]; 0 = none:
@@ -91,6 +91,9 @@ MZ_DEV uint32_t mz_dist_ent(uint32_t s) {
     return (ex << 4) | ((1u + ((2u + (s & 1u)) << ex)) << 8);
 }
 MZ_DEV uint32_t mz_clc_ent(uint32_t s) { return s << 4; }
+/* finished table entry: descriptor + code length; the invalid symbols 286 / 287 become an invalid token right here
+ * (0 bits, the code length in [31:16] as "bits the verdict needed"), so the decode loop has no case for them */
+MZ_DEV uint32_t mz_fin_ent(uint32_t e, uint32_t len) { return (e & MZ_E_BAD) ? (len << 16) : e + len; }
 
 /* per-wave LDS scratch */
 typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed and tables are built */
@@ -268,7 +271,7 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
                         (ent_)[_H->offs[_l] + P(_rank)] = _e;                                                  \
                         if (_l <= (uint32_t)(root_)) {                                                         \
                             uint32_t _rv = mz_brev32(_cd) >> (32 - _l);                                        \
-                            for (uint32_t _k = _rv; _k < (1u << (root_)); _k += (1u << _l)) (fast_)[_k] = _e + _l; \
+                            for (uint32_t _k = _rv; _k < (1u << (root_)); _k += (1u << _l)) (fast_)[_k] = mz_fin_ent(_e, _l); \
                         }                                                                                      \
                     }                                                                                          \
                 }                                                                                              \
@@ -343,7 +346,7 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
                         const uint32_t _re = (L_)->lit_fast[_rv & ((1u << MZ_LROOT) - 1)];                     \
                         const uint32_t _of = (_re >> 8) & 0x1FFu, _kb = _re & 7u;                              \
                         for (uint32_t _t = _rv >> MZ_LROOT; _t < (1u << _kb); _t += 1u << (_l - MZ_LROOT))     \
-                            (L_)->lit_sub[_of + _t] = P(_e5)[_j] + _l;                                         \
+                            (L_)->lit_sub[_of + _t] = mz_fin_ent(P(_e5)[_j], _l);                              \
                     }                                                                                          \
                 }                                                                                              \
             }                                                                                                  \
@@ -664,23 +667,25 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
                 PV(uint32_t, tk);
                 PV(uint32_t, g1); /* 4 * successor offset; >= 256: terminal (|0x400 end-of-block, |0x800 invalid) */
-                uint64_t anybad; /* a candidate hit an unused code, 286 / 287, or distance code 30 / 31 */
-                MZ_BALLOT(anybad, P(le) == 0u || (P(le) & MZ_E_BAD) || ((P(le) & MZ_E_LEN) && (P(de) == 0u || (P(de) & MZ_E_LEN))));
+                /* a candidate that hits an unused literal/length code (entry 0), 286 / 287 (finished as an invalid
+                 * token by the table build) or an unused / 30 / 31 distance code ((int)d <= 0) comes out with 0 bits,
+                 * which is what stops the chain; only within 14 bytes of the end of the input does the verdict
+                 * (data error or input exhausted) need the exact number of bits each invalid candidate looked at */
+                const uint32_t avail = total_bits - bitpos;
                 MZ_LANES {
                     const uint32_t e = P(le), d = P(de), nb2 = P(nb2l);
                     const uint32_t dn = d & 15u, dex = mz_bfe(d, 4, 4);
                     const uint32_t dist = mz_bfe(d, 8, 15) + mz_bfe(P(dlo), dn, dex);
                     const uint32_t t_match = (nb2 + dn + dex) | (P(lenl) << 7) | (dist << 16);
-                    P(tk) = (e & MZ_E_LEN) ? t_match : e;
+                    P(tk) = (e & MZ_E_LEN) ? (((int32_t)d > 0) ? t_match : 0u) : e;
                 }
-                if (anybad) { /* complete codes (every dynamic block zlib writes) never come here */
+                if (avail < 64u + 48u) {
                     MZ_LANES {
                         const uint32_t e = P(le), d = P(de), nb2 = P(nb2l);
                         const uint32_t t_badd = ((d == 0u) ? (nb2 + 15u) : (nb2 + (d & 15u))) << 16; /* invalid distance code */
-                        const uint32_t t_bad = (e == 0u) ? (15u << 16) : ((e & 63u) << 16);       /* no code | 286, 287 */
                         uint32_t t = P(tk);
-                        t = ((e & MZ_E_LEN) && (d == 0u || (d & MZ_E_LEN))) ? t_badd : t;
-                        t = (e == 0u || (e & MZ_E_BAD)) ? t_bad : t;
+                        t = ((e & MZ_E_LEN) && (int32_t)d <= 0) ? t_badd : t;
+                        t = (e == 0u) ? (15u << 16) : t; /* no code within 15 bits */
                         P(tk) = t;
                     }
                 }
@@ -697,7 +702,6 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                  * interleaved, so it is five dependent ds_bpermute rounds, no scalar work, and the step's tokens
                  * come out COMPACTED (lane i holds token i).  Offsets are kept multiplied by 4 (the gather's byte
                  * address).  At most 15 tokens retire per step; lane 15 only supplies the continuation offset. */
-                const uint32_t avail = total_bits - bitpos;
                 uint32_t pos, eob = 0, ntok;
                 int32_t chain_err = MZHIP_OK;
                 PV(uint32_t, cpos);
