@@ -47,7 +47,9 @@ extern unsigned long long mz_stats[16];
 #ifndef MZ_LROOT
 #define MZ_LROOT 9 /* literal/length fast-table index bits */
 #endif
+#ifndef MZ_DROOT
 #define MZ_DROOT 8 /* distance fast-table index bits        */
+#endif
 #define MZ_CROOT 7 /* code-length-code table bits (== max)  */
 #ifndef MZ_MLANES_LOG2
 #define MZ_MLANES_LOG2 3 /* lanes that copy one match together in the flush: 2^3 = 8, so 8 matches per round */
