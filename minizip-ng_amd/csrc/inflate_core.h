@@ -45,7 +45,7 @@ extern unsigned long long mz_stats[16];
 #include "wave.h"
 
 #ifndef MZ_LROOT
-#define MZ_LROOT 9 /* literal/length fast-table index bits */
+#define MZ_LROOT 8 /* literal/length fast-table index bits */
 #endif
 #ifndef MZ_DROOT
 #define MZ_DROOT 8 /* distance fast-table index bits        */
@@ -74,7 +74,19 @@ extern unsigned long long mz_stats[16];
 #define MZ_E_LEN 0x80000000u
 #define MZ_E_BAD 0x40000000u
 #define MZ_E_SUB 0x20000000u
-#define MZ_LIT_SUB_ENTRIES 344 /* zlib's enough.c bound for 286 symbols, 9-bit root, 15-bit codes: 852 - 512 = 340 */
+/* Second-level entries a complete canonical literal/length code (<= 286 symbols, <= 15 bits) can need: the maximum of
+ * sum over root prefixes of 2^(longest code in the prefix - root), found by exhaustive dynamic programming over the
+ * code-length counts (the same search as zlib's examples/enough.c; it reproduces zlib's 852 = 512 + 340 for a 9-bit
+ * root and 592 = 64 + 528 for the 6-bit / 30-symbol distance case). */
+#if MZ_LROOT == 8
+#define MZ_LIT_SUB_ENTRIES 404
+#elif MZ_LROOT == 9
+#define MZ_LIT_SUB_ENTRIES 340
+#elif MZ_LROOT == 10
+#define MZ_LIT_SUB_ENTRIES 308
+#else
+#error "MZ_LROOT must be 8, 9 or 10"
+#endif
 
 MZ_DEV uint32_t mz_lit_ent(uint32_t s) {
     if (s < 256u) return 0x80u | (s << 16);

@@ -31,7 +31,7 @@
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
 #ifndef MZ_MIN_WAVES_PER_SIMD
-#define MZ_MIN_WAVES_PER_SIMD 7 /* register budget: 72 VGPRs -> 7 waves per SIMD, 28 per CU (matches the LDS budget: 7 workgroups) */
+#define MZ_MIN_WAVES_PER_SIMD 8 /* register budget: 64 VGPRs -> 8 waves per SIMD, 32 per CU (matches the LDS budget: 8 workgroups) */
 #endif
 
 struct InflateArgs {

@@ -173,3 +173,20 @@ def xz_cases():
     cases.append(("multi-block-sha", b"".join(parts),
                   xz_join([lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_SHA256) for p in parts])))
     return cases
+
+
+def long_code_payloads():
+    """(name, data, raw_deflate): streams whose dynamic Huffman codes reach 13-15 bits and use many symbols, so the
+    decoder's second-level literal/length tables are exercised up to their capacity (zlib Z_HUFFMAN_ONLY / level 9 on
+    data with geometric byte statistics, all 256 byte values present)."""
+    out = []
+    for seed, ratio in ((1, 0.5), (2, 0.6), (3, 0.7), (4, 0.8)):
+        rnd = np.random.RandomState(seed)
+        p = ratio ** np.arange(256, dtype=np.float64)
+        p /= p.sum()
+        perm = rnd.permutation(256)
+        d = perm[rnd.choice(256, size=200000, p=p)].astype(np.uint8).tobytes()
+        d += bytes(range(256)) * 2                      # every byte value at least twice
+        for strat, nm in ((zlib.Z_HUFFMAN_ONLY, "huff"), (zlib.Z_DEFAULT_STRATEGY, "l9")):
+            out.append(("geom%.1f/%s" % (ratio, nm), d, deflate_raw(d, level=9, strategy=strat)))
+    return out

@@ -34,6 +34,17 @@ def test_edge_payloads_batch(gpu):
         assert crc[i] == oracle.crc32(data) == zlib.crc32(data), name
 
 
+def test_long_codes_batch(gpu):
+    """Dynamic codes of 13-15 bits over the full alphabet (second-level tables at capacity, long distance codes)."""
+    cases = synth.long_code_payloads()
+    batch = gpu.make_batch([z for _, _, z in cases], [len(d) + 8 for _, d, _ in cases])
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    h_out = batch["d_out"].cpu().numpy()
+    for i, (name, data, z) in enumerate(cases):
+        assert (status[i], in_used[i], out_len[i], crc[i]) == (0, len(z), len(data), zlib.crc32(data)), name
+        assert gpu.entry_bytes(batch, h_out, i, len(data)) == data, name
+
+
 def test_fixtures_golden(gpu, fixtures):
     ents = [e for e in fixtures if e["method"] == 8]
     batch = gpu.make_batch([e["payload"] for e in ents], [e["usize"] + 4 for e in ents], align=1)

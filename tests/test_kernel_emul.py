@@ -55,8 +55,8 @@ def _run(fn, z, cap, *extra):
 
 
 def test_lds_budget(emu):
-    # 4 waves x inflate slice + CRC table must allow 7 workgroups (28 waves) per 160 KiB CU
-    assert (4 * ((emu.emul_lds_bytes() + 15) // 16 * 16) + 1024) * 7 <= 160 * 1024
+    # 4 waves x inflate slice + CRC table must allow 8 workgroups (32 waves = 8 per SIMD) per 160 KiB CU
+    assert (4 * ((emu.emul_lds_bytes() + 15) // 16 * 16) + 1024) * 8 <= 160 * 1024
     assert emu.emul_lzma_lds_bytes() + 1024 <= 16 * 1024 + 1024
 
 
@@ -112,6 +112,19 @@ def test_inflate_edges(emu):
         so, uo, oo = oracle.inflate_raw(z + b"\x00junk", len(data) + 8)
         assert (st, used, out) == (so, uo, oo) == (0, len(z), data), name
         assert crc == oracle.crc32(data), name
+
+
+def test_inflate_long_codes(emu):
+    """Codes of 13-15 bits over the full alphabet: the second-level tables (capacity = the exhaustive-search bound
+    for the root width, inflate_core.h) and the long-code paths."""
+    n = 0
+    for name, data, z in synth.long_code_payloads():
+        st, used, out, crc = _run(emu.emul_inflate, z, len(data) + 8)
+        assert (st, used, out, crc) == (0, len(z), data, zlib.crc32(data)), name
+        so, uo, oo = oracle.inflate_raw(z, len(data) + 8)
+        assert (so, uo, oo) == (0, len(z), data), name
+        n += 1
+    assert n >= 8
 
 
 def test_inflate_fixtures(emu, fixtures):
