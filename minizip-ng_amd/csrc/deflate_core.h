@@ -43,20 +43,20 @@
 typedef struct mz_deflate_lds {
     union {
         uint16_t head[1 << MZ_DEF_HBITS]; /* pass 1: low 16 bits of the most recent position with this hash */
-        struct {                          /* between the passes: code construction */
+        struct {                          /* after pass 1 (the hash table is dead): code construction and pass 2 */
             uint32_t wt[2 * MZ_DEF_NLIT];     /* node weights: sorted leaves, then internal nodes */
             uint32_t sf[MZ_DEF_NLIT];         /* frequencies as scaled for the current attempt */
             uint16_t parent[2 * MZ_DEF_NLIT];
             uint16_t sym[MZ_DEF_NLIT];        /* sorted position -> symbol */
             uint8_t cl_seq[MZ_DEF_NLIT + MZ_DEF_NDIST + 4]; /* header: code-length alphabet symbols ... */
             uint8_t cl_ext[MZ_DEF_NLIT + MZ_DEF_NDIST + 4]; /* ... and their extra-bit values */
+            uint32_t code[MZ_DEF_NSYM + 1];   /* bit-reversed code | length << 16 */
+            uint32_t first[16];               /* canonical first code per length; bl_count while it is being made */
+            uint32_t stage[104];              /* pass 2: this step's bits (<= 8 + 64 x 48) */
+            uint8_t lens[MZ_DEF_NSYM + 1];
         } hb;
     } u;
-    uint32_t stage[104];          /* pass 2: this step's bits (<= 8 + 64 x 48) */
-    uint32_t freq[MZ_DEF_NSYM + 1]; /* histograms: literal/length, distance, code-length alphabet */
-    uint32_t code[MZ_DEF_NSYM + 1]; /* bit-reversed code | length << 16 */
-    uint32_t first[16];           /* canonical first code per length; bl_count while it is being made */
-    uint8_t lens[MZ_DEF_NSYM + 1];
+    uint32_t freq[MZ_DEF_NSYM + 1]; /* histograms (live during pass 1): literal/length, distance, code-length alphabet */
 } mz_deflate_lds;
 
 typedef struct mz_deflate_result {
@@ -132,12 +132,12 @@ MZ_DEV uint32_t mz_cl_order(uint32_t i) {
 MZ_DEV uint32_t mz_fixed_litlen_bits(uint32_t sym) { return sym < 144u ? 8u : sym < 256u ? 9u : sym < 280u ? 7u : 8u; }
 
 /* Code lengths (<= maxbits) and canonical codes for the n-symbol alphabet at freq[base..]: results in
- * L->lens[base + s] and L->code[base + s] = reversed code | len << 16.  Uses L->u.hb (the hash table is dead). */
+ * L->u.hb.lens[base + s] and L->u.hb.code[base + s] = reversed code | len << 16.  Uses L->u.hb (the hash table is dead). */
 MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t maxbits) {
     MZ_LANE_DECL
     uint32_t *sf = L->u.hb.sf, *wt = L->u.hb.wt;
     uint16_t *parent = L->u.hb.parent, *sym = L->u.hb.sym;
-    uint8_t *lens = L->lens + base;
+    uint8_t *lens = L->u.hb.lens + base;
     PV(uint32_t, cnt);
     MZ_LANES {
         uint32_t c = 0;
@@ -243,21 +243,21 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
     }
     /* canonical codes (appnote.txt:2091-2106): count per length, first code per length, then rank inside the length */
     MZ_LANES {
-        if (lane < 16) L->first[lane] = 0u;
+        if (lane < 16) L->u.hb.first[lane] = 0u;
     }
     MZ_WAVE_SYNC();
     MZ_LANES {
         for (uint32_t s = (uint32_t)lane; s < n; s += 64u)
-            if (lens[s]) MZ_LDS_ATOMIC_INC(&L->first[lens[s]]);
+            if (lens[s]) MZ_LDS_ATOMIC_INC(&L->u.hb.first[lens[s]]);
     }
     MZ_WAVE_SYNC();
     {
         uint32_t c = 0, prev = 0;
         for (uint32_t b = 1; b <= 15u; b++) {
-            const uint32_t nb = MZ_UNIFORM(L->first[b]);
+            const uint32_t nb = MZ_UNIFORM(L->u.hb.first[b]);
             c = (c + prev) << 1;
             prev = nb;
-            MZ_LANES { L->first[b] = c; }
+            MZ_LANES { L->u.hb.first[b] = c; }
         }
         MZ_WAVE_SYNC();
     }
@@ -268,9 +268,9 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
             if (l) {
                 uint32_t idx = 0;
                 for (uint32_t t = 0; t < s; t++) idx += (lens[t] == l) ? 1u : 0u;
-                v = (mz_brev32(L->first[l] + idx) >> (32u - l)) | (l << 16);
+                v = (mz_brev32(L->u.hb.first[l] + idx) >> (32u - l)) | (l << 16);
             }
-            L->code[base + s] = v;
+            L->u.hb.code[base + s] = v;
         }
     }
     MZ_WAVE_SYNC();
@@ -442,13 +442,13 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
         mz_huff_build(L, 0u, MZ_DEF_NLIT, 15u);
         mz_huff_build(L, MZ_DEF_DIST0, MZ_DEF_NDIST, 15u);
         uint32_t nlit = MZ_DEF_NLIT, ndist = MZ_DEF_NDIST;
-        while (nlit > 257u && MZ_UNIFORM(L->lens[nlit - 1u]) == 0u) nlit--;
-        while (ndist > 1u && MZ_UNIFORM(L->lens[MZ_DEF_DIST0 + ndist - 1u]) == 0u) ndist--;
+        while (nlit > 257u && MZ_UNIFORM(L->u.hb.lens[nlit - 1u]) == 0u) nlit--;
+        while (ndist > 1u && MZ_UNIFORM(L->u.hb.lens[MZ_DEF_DIST0 + ndist - 1u]) == 0u) ndist--;
         /* code-length sequence with run-length symbols 16 / 17 / 18 (appnote.txt:2070-2090), wave-uniform */
         uint32_t nseq = 0;
         {
             const uint32_t total = nlit + ndist;
-#define MZ_DEF_LEN_AT(i) MZ_UNIFORM(L->lens[(i) < nlit ? (i) : MZ_DEF_DIST0 + (i) - nlit])
+#define MZ_DEF_LEN_AT(i) MZ_UNIFORM(L->u.hb.lens[(i) < nlit ? (i) : MZ_DEF_DIST0 + (i) - nlit])
 #define MZ_DEF_SEQ(s, x)                                                                   \
     do {                                                                                   \
         const uint32_t _f = MZ_UNIFORM(L->freq[MZ_DEF_CL0 + (s)]) + 1u;                    \
@@ -502,11 +502,11 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             uint32_t cd = 0, cf = 0;
             for (uint32_t s = (uint32_t)lane; s < MZ_DEF_NLIT + MZ_DEF_NDIST; s += 64u) {
                 const uint32_t f = L->freq[s];
-                cd += f * L->lens[s];
+                cd += f * L->u.hb.lens[s];
                 cf += f * (s < MZ_DEF_NLIT ? mz_fixed_litlen_bits(s) : 5u);
             }
             for (uint32_t s = (uint32_t)lane; s < MZ_DEF_NCL; s += 64u)
-                cd += L->freq[MZ_DEF_CL0 + s] * (L->lens[MZ_DEF_CL0 + s] + (s == 16u ? 2u : s == 17u ? 3u : s == 18u ? 7u : 0u));
+                cd += L->freq[MZ_DEF_CL0 + s] * (L->u.hb.lens[MZ_DEF_CL0 + s] + (s == 16u ? 2u : s == 17u ? 3u : s == 18u ? 7u : 0u));
             P(cost_d) = cd;
             P(cost_f) = cf;
         }
@@ -515,7 +515,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
         MZ_WAVE_SUM(fix_bits, cost_f);
         {
             /* HCLEN: code-length code lengths are sent in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 */
-            while (hclen > 4u && MZ_UNIFORM(L->lens[MZ_DEF_CL0 + mz_cl_order(hclen - 1u)]) == 0u) hclen--;
+            while (hclen > 4u && MZ_UNIFORM(L->u.hb.lens[MZ_DEF_CL0 + mz_cl_order(hclen - 1u)]) == 0u) hclen--;
             dyn_bits += 3u + 5u + 5u + 4u + 3u * hclen + extra_total;
             fix_bits += 3u + extra_total;
             const uint32_t blk_len = blk_end - blk;
@@ -545,9 +545,9 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 MZ_PUTBITS(nlit - 257u, 5u);
                 MZ_PUTBITS(ndist - 1u, 5u);
                 MZ_PUTBITS(hclen - 4u, 4u);
-                for (uint32_t i = 0; i < hclen; i++) MZ_PUTBITS(MZ_UNIFORM(L->lens[MZ_DEF_CL0 + mz_cl_order(i)]), 3u);
+                for (uint32_t i = 0; i < hclen; i++) MZ_PUTBITS(MZ_UNIFORM(L->u.hb.lens[MZ_DEF_CL0 + mz_cl_order(i)]), 3u);
                 for (uint32_t i = 0; i < nseq; i++) {
-                    const uint32_t s = MZ_UNIFORM(L->u.hb.cl_seq[i]), c = MZ_UNIFORM(L->code[MZ_DEF_CL0 + s]);
+                    const uint32_t s = MZ_UNIFORM(L->u.hb.cl_seq[i]), c = MZ_UNIFORM(L->u.hb.code[MZ_DEF_CL0 + s]);
                     MZ_PUTBITS(c & 0xFFFFu, c >> 16);
                     if (s >= 16u) MZ_PUTBITS(MZ_UNIFORM(L->u.hb.cl_ext[i]), s == 16u ? 2u : s == 17u ? 3u : 7u);
                 }
@@ -573,7 +573,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                             c = 0xC0u + (s - 280u);
                             n = 8;
                         }
-                        L->code[s] = (mz_brev32(c) >> (32u - n)) | (n << 16);
+                        L->u.hb.code[s] = (mz_brev32(c) >> (32u - n)) | (n << 16);
                     }
                 }
                 MZ_WAVE_SYNC();
@@ -592,15 +592,15 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 if ((uint32_t)lane < nt) {
                     const uint32_t t = tok[t0 + (uint32_t)lane], mlen = t & 511u;
                     if (mlen == 0u) {
-                        const uint32_t c = L->code[t >> 9];
+                        const uint32_t c = L->u.hb.code[t >> 9];
                         b = c & 0xFFFFu;
                         n = c >> 16;
                     } else {
                         uint32_t ex, xv;
-                        const uint32_t c = L->code[mz_len_sym(mlen, &ex, &xv)];
+                        const uint32_t c = L->u.hb.code[mz_len_sym(mlen, &ex, &xv)];
                         b = (c & 0xFFFFu) | ((uint64_t)xv << (c >> 16));
                         n = (c >> 16) + ex;
-                        const uint32_t cd = L->code[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &ex, &xv)];
+                        const uint32_t cd = L->u.hb.code[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &ex, &xv)];
                         b |= (uint64_t)((cd & 0xFFFFu) | (xv << (cd >> 16))) << n;
                         n += (cd >> 16) + ex; /* <= 15 + 5 + 15 + 13 = 48 */
                     }
@@ -612,7 +612,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_INCL_SCAN(tend, tn);
             const uint32_t total = MZ_READLANE(tend, 63);
             MZ_LANES {
-                for (uint32_t i = (uint32_t)lane; i < 104u; i += 64u) L->stage[i] = (i == 0u) ? (uint32_t)acc : 0u;
+                for (uint32_t i = (uint32_t)lane; i < 104u; i += 64u) L->u.hb.stage[i] = (i == 0u) ? (uint32_t)acc : 0u;
             }
             MZ_WAVE_SYNC();
             MZ_LANES {
@@ -621,9 +621,9 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     const uint32_t w = off >> 5, sh = off & 31u;
                     const uint64_t b = ((uint64_t)P(bhi) << 32) | P(blo);
                     const uint64_t v0 = b << sh;
-                    MZ_LDS_ATOMIC_OR(&L->stage[w], (uint32_t)v0);
-                    if (sh + P(tn) > 32u) MZ_LDS_ATOMIC_OR(&L->stage[w + 1u], (uint32_t)(v0 >> 32));
-                    if (sh + P(tn) > 64u) MZ_LDS_ATOMIC_OR(&L->stage[w + 2u], (uint32_t)(b >> (64u - sh)));
+                    MZ_LDS_ATOMIC_OR(&L->u.hb.stage[w], (uint32_t)v0);
+                    if (sh + P(tn) > 32u) MZ_LDS_ATOMIC_OR(&L->u.hb.stage[w + 1u], (uint32_t)(v0 >> 32));
+                    if (sh + P(tn) > 64u) MZ_LDS_ATOMIC_OR(&L->u.hb.stage[w + 2u], (uint32_t)(b >> (64u - sh)));
                 }
             }
             MZ_WAVE_SYNC();
@@ -635,16 +635,16 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
                 MZ_LANES {
                     for (uint32_t i = (uint32_t)lane; i < nbytes; i += 64u)
-                        out[obyte + i] = (uint8_t)(L->stage[i >> 2] >> (8u * (i & 3u)));
+                        out[obyte + i] = (uint8_t)(L->u.hb.stage[i >> 2] >> (8u * (i & 3u)));
                 }
-                acc = (nbit & 7u) ? ((MZ_UNIFORM(L->stage[nbytes >> 2]) >> (8u * (nbytes & 3u))) & ((1u << (nbit & 7u)) - 1u)) : 0u;
+                acc = (nbit & 7u) ? ((MZ_UNIFORM(L->u.hb.stage[nbytes >> 2]) >> (8u * (nbytes & 3u))) & ((1u << (nbit & 7u)) - 1u)) : 0u;
                 nacc = nbit & 7u;
                 obyte += nbytes;
             }
             MZ_WAVE_SYNC();
         }
         {
-            const uint32_t c = MZ_UNIFORM(L->code[256]); /* end of block */
+            const uint32_t c = MZ_UNIFORM(L->u.hb.code[256]); /* end of block */
             MZ_PUTBITS(c & 0xFFFFu, c >> 16);
         }
     }

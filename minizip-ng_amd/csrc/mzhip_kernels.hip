@@ -246,8 +246,8 @@ struct DeflateArgs {
 
 #define MZ_DEF_LDS_STRIDE ((sizeof(mz_deflate_lds) + 15) & ~(size_t)15)
 
-// K4: one wave per piece, 4 waves per workgroup, 11.8 KiB LDS per wave (hash heads / code construction, histograms,
-// code table, bit staging) and 256 KiB of token scratch in HBM per resident wave.
+// K4: one wave per piece, 4 waves per workgroup, 9.3 KiB LDS per wave (hash heads, reused for code construction, code
+// table and bit staging once pass 1 is over; histograms) and 256 KiB of token scratch in HBM per resident wave.
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *crc_tab = (uint32_t *)smem;
@@ -615,7 +615,7 @@ int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE;
     uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
-    uint32_t resident = (uint32_t)c->cu_count * 3u; /* 48 KiB LDS per workgroup -> 3 per CU */
+    uint32_t resident = (uint32_t)c->cu_count * 4u; /* 38.3 KiB LDS per workgroup -> 4 per CU */
     if (!c->d_tok) {
         std::lock_guard<std::mutex> lk(g_mu);
         if (!c->d_tok)
