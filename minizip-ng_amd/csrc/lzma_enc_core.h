@@ -9,7 +9,8 @@
  * Split along what is parallel and what is not:
  *   mz_lz_tokenize   one wave per 64 KiB block, 64 positions per step: the LZ77 parse of deflate_core.h (hash head
  *                    table in LDS, in-place match measurement, lazy rule, greedy selection by pointer doubling);
- *                    tokens (literal | length 4..258 + distance <= 32 KiB, inside the block) go to HBM;
+ *                    the previous 32 KiB of the stream are hashed first so matches may reach back across the block
+ *                    boundary; tokens (literal | length 4..258 + distance <= 32 KiB) go to HBM;
  *   mz_lzma_rc_encode one wave per stream: the adaptive range coder is strictly serial, so the token sequence is
  *                    coded by wave-uniform code with the probability model in LDS; 64 tokens at a time are
  *                    prepared in parallel (positions by prefix sum, the literal context byte and the match byte
@@ -32,7 +33,8 @@ typedef struct mz_lz_tok_lds {
     uint16_t head[1 << MZ_DEF_HBITS];
 } mz_lz_tok_lds;
 
-/* LZ77 parse of in[blk, blk_end) (blk_end - blk <= MZ_DEF_BLOCK); matches stay inside the block.  Returns the
+/* LZ77 parse of in[blk, blk_end) (blk_end - blk <= MZ_DEF_BLOCK) of the stream in[0..); matches may start up to 32 KiB
+ * before blk.  Returns the
  * number of tokens written to tok[]: [8:0] match length (0 = literal), [24:9] distance | literal byte. */
 MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end, uint32_t *tok, mz_lz_tok_lds *L) {
     MZ_LANE_DECL
@@ -40,6 +42,17 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
         for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->head)[i] = 0u;
     }
     MZ_WAVE_SYNC();
+    /* the stream's previous 32 KiB are legal match sources (the dictionary is 64 KiB): enter them into the hash table
+     * first, without producing tokens, so that a block does not start with an empty history */
+    const uint32_t hist = blk > 32768u ? blk - 32768u : 0u;
+    for (uint32_t p = hist; p < blk; p += 64u) {
+        MZ_LANES {
+            const uint32_t pos = p + (uint32_t)lane;
+            if (pos < blk && pos + 4u <= blk_end)
+                L->head[(mz_load_u32(in + pos) * 2654435761u) >> (32 - MZ_DEF_HBITS)] = (uint16_t)pos;
+        }
+        MZ_WAVE_SYNC();
+    }
     uint32_t ntokens = 0, skip = 0;
     PV(uint32_t, vnx); /* the four bytes at this lane's position of the NEXT step, fetched one step ahead */
     MZ_LANES {
@@ -72,7 +85,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
             uint32_t mlen = 0, dist = 0;
             if ((uint32_t)lane < nv) {
                 const uint32_t d = (pos - P(cand)) & 0xFFFFu;
-                if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - blk) {
+                if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - hist) {
                     const uint8_t *a = in + pos, *b = in + (pos - d);
                     const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
                     const uint32_t l = mz_match_len(a, b, maxl);
