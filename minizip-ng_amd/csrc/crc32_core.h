@@ -20,6 +20,7 @@
 
 #define MZ_CRC_POLY 0xEDB88320u
 #define MZ_CRC_TILE 1024u
+#define MZ_CRC_SUPER 4096u /* stand-alone kernel: 64 contiguous bytes per lane per super-tile */
 
 /* constants generated once on the host (mzhip_crc_tables_init) and handed to
  * the kernels; byte_tab is staged into LDS per workgroup. */
@@ -28,6 +29,8 @@ typedef struct mzhip_crc_tables {
     uint32_t kx[32];        /* x^(8*1008) * x^j  mod P, j = 0..31       */
     uint32_t x16[64];       /* x^(128*j) mod P                          */
     uint32_t x1[16];        /* x^(8*j) mod P                            */
+    uint32_t kx4[32];       /* x^(8*4032) * x^j mod P, j = 0..31 (super-tiles of the stand-alone kernel) */
+    uint32_t x64[64];       /* x^(512*j) mod P                          */
 } mzhip_crc_tables;
 
 /* host-side generation (plain arithmetic on 32-bit polynomials) */
@@ -62,6 +65,12 @@ static inline void mzhip_crc_tables_init(mzhip_crc_tables *t) {
     }
     for (int j = 0; j < 64; j++) t->x16[j] = mzhip_xpow8_host(16u * (uint32_t)j);
     for (int j = 0; j < 16; j++) t->x1[j] = mzhip_xpow8_host((uint32_t)j);
+    k = mzhip_xpow8_host(MZ_CRC_SUPER - 64);
+    for (int j = 0; j < 32; j++) {
+        t->kx4[j] = k;
+        k = (k & 1) ? ((k >> 1) ^ MZ_CRC_POLY) : (k >> 1);
+    }
+    for (int j = 0; j < 64; j++) t->x64[j] = mzhip_xpow8_host(64u * (uint32_t)j);
 }
 /* crc(A||B) from crc(A), crc(B), |B| -- 32-bit arithmetic on checksums only */
 static inline uint32_t mzhip_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
@@ -121,6 +130,34 @@ MZ_DEV uint32_t mz_crc_dword(uint32_t r, uint32_t d, const uint32_t *tab) {
         }                                                                                  \
         (done) += MZ_CRC_TILE;                                                             \
     }
+
+/* Stand-alone CRC (k_crc32_batch): super-tiles of 4 KiB in which lane l owns the 64 bytes at 64*l, so the advance by
+ * one GF(2) multiplication (x^(8*4032)) is paid once per 64 bytes of a lane instead of once per 16.  Folds every
+ * complete super-tile of buf[0 .. n) into the per-lane registers; (done) = bytes folded. */
+#define MZ_CRC_FOLD_SUPER(acc, done, buf, n, tab, kx4)                                     \
+    while ((uint64_t)(done) + MZ_CRC_SUPER <= (uint64_t)(n)) {                             \
+        MZ_LANES {                                                                         \
+            const uint8_t *_p = (buf) + (done) + 64u * (uint32_t)lane;                     \
+            uint32_t _r = P(acc);                                                          \
+            if ((done) != 0) _r = mz_gf2_mul_kx(_r, (kx4));                                \
+            for (int _k = 0; _k < 4; _k++) {                                               \
+                uint32_t _q[4];                                                            \
+                __builtin_memcpy(_q, _p + 16 * _k, 16); /* one 16-byte load */             \
+                _r = mz_crc_dword(_r, _q[0], (tab));                                       \
+                _r = mz_crc_dword(_r, _q[1], (tab));                                       \
+                _r = mz_crc_dword(_r, _q[2], (tab));                                       \
+                _r = mz_crc_dword(_r, _q[3], (tab));                                       \
+            }                                                                              \
+            P(acc) = _r;                                                                   \
+        }                                                                                  \
+        (done) += MZ_CRC_SUPER;                                                            \
+    }
+/* collapse the super-tile registers into the raw register after byte (done) - 1 (uniform) */
+#define MZ_CRC_SUPER_REDUCE(reg, acc, tmp, tabs)                                           \
+    do {                                                                                   \
+        MZ_LANES { P(tmp) = mz_gf2_mul(P(acc), (tabs)->x64[63 - lane]); }                  \
+        MZ_WAVE_XOR(reg, tmp);                                                             \
+    } while (0)
 
 /* Finish: buf[0..n) has had its floor(n/1024) tiles folded.  Returns the
  * finished CRC-32 in `result` (uniform). `tmp` is a PV(uint32_t) scratch. */

@@ -101,10 +101,21 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_crc32_batch(CrcArgs a)
         const uint32_t n = a.len[e];
         const uint32_t init = a.init ? a.init[e] : 0u;
         uint32_t acc = (lane == 0) ? ~init : 0u; // register = ~value on entry (mz_crypt.c:81)
-        uint32_t tmp, done = 0, result;
+        uint32_t tmp, done = 0, result, reg = ~init;
         const mzhip_crc_tables *tabs = a.tabs;
-        MZ_CRC_FOLD_TILES(acc, done, buf, n, crc_tab, tabs->kx);
-        MZ_CRC_FINISH_FROM(result, acc, tmp, done, buf, n, crc_tab, tabs, ~init);
+        // 4 KiB super-tiles first (64 contiguous bytes per lane), the remainder with the 1 KiB tiles of the fused epilogues
+        MZ_CRC_FOLD_SUPER(acc, done, buf, n, crc_tab, tabs->kx4);
+        if (done) {
+            MZ_CRC_SUPER_REDUCE(reg, acc, tmp, tabs);
+            acc = (lane == 0) ? reg : 0u;
+        }
+        {
+            const uint8_t *rest = buf + done;
+            const uint32_t nrest = n - done;
+            uint32_t rdone = 0;
+            MZ_CRC_FOLD_TILES(acc, rdone, rest, nrest, crc_tab, tabs->kx);
+            MZ_CRC_FINISH_FROM(result, acc, tmp, rdone, rest, nrest, crc_tab, tabs, reg);
+        }
         a.crc[e] = result; // uniform store
     }
 }

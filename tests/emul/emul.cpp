@@ -129,6 +129,26 @@ extern "C" int32_t emul_lzma_encode(const uint8_t *in, uint32_t in_len, uint32_t
     return r.status;
 }
 
+/* the stand-alone kernel's path: 4 KiB super-tiles, then 1 KiB tiles, then the tail */
+extern "C" uint32_t emul_crc32_super(const uint8_t *buf, uint32_t n, uint32_t init) {
+    ready();
+    uint32_t acc[64], tmp[64], done = 0, result, reg = ~init;
+    for (int l = 0; l < 64; l++) acc[l] = l == 0 ? ~init : 0u;
+    const uint32_t *tab = g_tabs.byte_tab;
+    const mzhip_crc_tables *tabs = &g_tabs;
+    MZ_CRC_FOLD_SUPER(acc, done, buf, n, tab, tabs->kx4);
+    if (done) {
+        MZ_CRC_SUPER_REDUCE(reg, acc, tmp, tabs);
+        for (int l = 0; l < 64; l++) acc[l] = l == 0 ? reg : 0u;
+    }
+    const uint8_t *rest = buf + done;
+    const uint32_t nrest = n - done;
+    uint32_t rdone = 0;
+    MZ_CRC_FOLD_TILES(acc, rdone, rest, nrest, tab, tabs->kx);
+    MZ_CRC_FINISH_FROM(result, acc, tmp, rdone, rest, nrest, tab, tabs, reg);
+    return result;
+}
+
 extern "C" uint32_t emul_lds_bytes(void) { return (uint32_t)sizeof(mz_inflate_lds); }
 
 #include "lzma_core.h"

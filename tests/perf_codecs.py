@@ -1,5 +1,5 @@
 """GPU probe (not a pytest): throughput of K3 (LZMA decode), the .xz kernel, K4 (DEFLATE encode) and the SHA batch
-kernel at config-like shapes.  Usage: python tests/perf_codecs.py [lzma|xz|deflate|sha|lzmaenc|both|all]"""
+kernel at config-like shapes.  Usage: python tests/perf_codecs.py [lzma|xz|deflate|sha|lzmaenc|crc|both|all]"""
 import ctypes as C
 import sys
 import time
@@ -159,3 +159,18 @@ if which in ("lzmaenc", "all"):
             ok = ok and pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == datas[idx[i]]
         print("LZMA encode (%s): %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.3f  ok=%s" % (
             tag, n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), ok), flush=True)
+
+if which in ("crc", "all"):
+    n_total, size = 65536, 65536           # STORE entries: CRC-32 only (mz_crypt_crc32_update over the raw stream)
+    blob = torch.randint(0, 256, (n_total * size,), dtype=torch.uint8, device=dev)      # 4 GiB, HBM-resident
+    off = torch.arange(n_total, dtype=torch.int64, device=dev) * size
+    ln = torch.full((n_total,), size, dtype=torch.int32, device=dev)
+
+    def run6():
+        return mz.crc32_batch(blob, off, ln)
+    ms = timed(run6)
+    crc = mz.u32(run6())
+    h = blob[:size * 3].cpu().numpy()
+    ok = all(int(crc[i]) == zlib.crc32(h[i * size:(i + 1) * size].tobytes()) for i in range(3))
+    print("CRC-32 batch: %d x %d B: %.1f ms  %.1f GiB/s  (%.2f TB/s)  ok=%s" % (n_total, size, ms, n_total * size / 2**30 / (ms / 1e3),
+                                                                         n_total * size / 1e12 / (ms / 1e3), ok), flush=True)

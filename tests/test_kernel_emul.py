@@ -40,6 +40,8 @@ def emu():
     L.emul_crc64.argtypes = [_u8p, C.c_uint64]
     L.emul_sha.restype = None
     L.emul_sha.argtypes = [_u8p, C.c_uint64, C.c_int, _u8p]
+    L.emul_crc32_super.restype = C.c_uint32
+    L.emul_crc32_super.argtypes = [_u8p, C.c_uint32, C.c_uint32]
     L.emul_crc32.restype = C.c_uint32
     L.emul_crc32.argtypes = [_u8p, C.c_uint32]
     return L
@@ -66,6 +68,16 @@ def test_crc_tiles_and_tail(emu):
         d = rnd.bytes(n)
         a = np.frombuffer(d, dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
         assert emu.emul_crc32(a.ctypes.data_as(_u8p), n) == zlib.crc32(d) == oracle.crc32(d), n
+
+
+def test_crc_super_tiles(emu):
+    """The stand-alone CRC kernel's path (4 KiB super-tiles + 1 KiB tiles + tail) with chaining values."""
+    rnd = np.random.RandomState(7)
+    for n in (0, 1, 1023, 4095, 4096, 4097, 8191, 8192, 12288 + 1024 + 5, 65536, 100001, 300000):
+        d = rnd.bytes(n)
+        a = np.frombuffer(d, dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+        for init in (0, 0xDEADBEEF):
+            assert emu.emul_crc32_super(a.ctypes.data_as(_u8p), n, init) == zlib.crc32(d, init), (n, init)
 
 
 def test_adler32_tiles_tail_and_combine(emu):
