@@ -31,6 +31,8 @@ typedef struct mzhip_crc_tables {
     uint32_t x1[16];        /* x^(8*j) mod P                            */
     uint32_t kx4[32];       /* x^(8*4032) * x^j mod P, j = 0..31 (super-tiles of the stand-alone kernel) */
     uint32_t x64[64];       /* x^(512*j) mod P                          */
+    uint32_t mul4[4][256];  /* (v at byte b of the register) * x^(8*4032) mod P: the super-tile advance as four lookups */
+    uint32_t slice[4][256]; /* slicing-by-4 tables: slice[0] = byte_tab, slice[k][i] = slice[k-1][i] advanced by one zero byte */
 } mzhip_crc_tables;
 
 /* host-side generation (plain arithmetic on 32-bit polynomials) */
@@ -71,6 +73,11 @@ static inline void mzhip_crc_tables_init(mzhip_crc_tables *t) {
         k = (k & 1) ? ((k >> 1) ^ MZ_CRC_POLY) : (k >> 1);
     }
     for (int j = 0; j < 64; j++) t->x64[j] = mzhip_xpow8_host(64u * (uint32_t)j);
+    for (int b = 0; b < 4; b++)
+        for (uint32_t n = 0; n < 256; n++) t->mul4[b][n] = mzhip_gf2_mul_host(n << (8 * b), t->kx4[0]);
+    for (uint32_t n = 0; n < 256; n++) t->slice[0][n] = t->byte_tab[n];
+    for (int k2 = 1; k2 < 4; k2++)
+        for (uint32_t n = 0; n < 256; n++) t->slice[k2][n] = (t->slice[k2 - 1][n] >> 8) ^ t->byte_tab[t->slice[k2 - 1][n] & 255];
 }
 /* crc(A||B) from crc(A), crc(B), |B| -- 32-bit arithmetic on checksums only */
 static inline uint32_t mzhip_crc32_combine_host(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
@@ -131,22 +138,31 @@ MZ_DEV uint32_t mz_crc_dword(uint32_t r, uint32_t d, const uint32_t *tab) {
         (done) += MZ_CRC_TILE;                                                             \
     }
 
+/* fold one little-endian dword with the four slicing tables (tab4 = slice[0..3] back to back): four independent
+ * lookups instead of a chain of four */
+MZ_DEV uint32_t mz_crc_dword4(uint32_t r, uint32_t d, const uint32_t *tab4) {
+    const uint32_t x = r ^ d;
+    return tab4[768u + (x & 255u)] ^ tab4[512u + ((x >> 8) & 255u)] ^ tab4[256u + ((x >> 16) & 255u)] ^ tab4[x >> 24];
+}
+
 /* Stand-alone CRC (k_crc32_batch): super-tiles of 4 KiB in which lane l owns the 64 bytes at 64*l, so the advance by
  * one GF(2) multiplication (x^(8*4032)) is paid once per 64 bytes of a lane instead of once per 16.  Folds every
- * complete super-tile of buf[0 .. n) into the per-lane registers; (done) = bytes folded. */
-#define MZ_CRC_FOLD_SUPER(acc, done, buf, n, tab, kx4)                                     \
+ * complete super-tile of buf[0 .. n) into the per-lane registers; (done) = bytes folded.  tab4 = slicing tables,
+ * mul4 = the advance tables, both in LDS. */
+#define MZ_CRC_FOLD_SUPER(acc, done, buf, n, tab4, mul4)                                    \
     while ((uint64_t)(done) + MZ_CRC_SUPER <= (uint64_t)(n)) {                             \
         MZ_LANES {                                                                         \
             const uint8_t *_p = (buf) + (done) + 64u * (uint32_t)lane;                     \
             uint32_t _r = P(acc);                                                          \
-            if ((done) != 0) _r = mz_gf2_mul_kx(_r, (kx4));                                \
+            if ((done) != 0) /* advance over the 4032 bytes of the other lanes: GF(2)-linear, so bytewise tables */ \
+                _r = (mul4)[_r & 255u] ^ (mul4)[256u + ((_r >> 8) & 255u)] ^ (mul4)[512u + ((_r >> 16) & 255u)] ^ (mul4)[768u + (_r >> 24)]; \
             for (int _k = 0; _k < 4; _k++) {                                               \
                 uint32_t _q[4];                                                            \
                 __builtin_memcpy(_q, _p + 16 * _k, 16); /* one 16-byte load */             \
-                _r = mz_crc_dword(_r, _q[0], (tab));                                       \
-                _r = mz_crc_dword(_r, _q[1], (tab));                                       \
-                _r = mz_crc_dword(_r, _q[2], (tab));                                       \
-                _r = mz_crc_dword(_r, _q[3], (tab));                                       \
+                _r = mz_crc_dword4(_r, _q[0], (tab4));                                     \
+                _r = mz_crc_dword4(_r, _q[1], (tab4));                                     \
+                _r = mz_crc_dword4(_r, _q[2], (tab4));                                     \
+                _r = mz_crc_dword4(_r, _q[3], (tab4));                                     \
             }                                                                              \
             P(acc) = _r;                                                                   \
         }                                                                                  \

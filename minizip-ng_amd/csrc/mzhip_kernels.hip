@@ -89,9 +89,14 @@ struct CrcArgs {
 
 // K2 stand-alone: one wave per buffer, same tile folding as the fused epilogue.
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_crc32_batch(CrcArgs a) {
-    __shared__ uint32_t crc_tab[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __shared__ uint32_t crc_tab4[1024]; // slicing-by-4 tables; the first 256 entries are the byte table
+    __shared__ uint32_t crc_mul4[1024]; // the super-tile advance as four lookups
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+        crc_tab4[i] = a.tabs->slice[i >> 8][i & 255];
+        crc_mul4[i] = a.tabs->mul4[i >> 8][i & 255];
+    }
     __syncthreads();
+    const uint32_t *crc_tab = crc_tab4;
     MZ_LANE_DECL
     for (;;) {
         uint32_t e;
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_crc32_batch(CrcArgs a)
         uint32_t tmp, done = 0, result, reg = ~init;
         const mzhip_crc_tables *tabs = a.tabs;
         // 4 KiB super-tiles first (64 contiguous bytes per lane), the remainder with the 1 KiB tiles of the fused epilogues
-        MZ_CRC_FOLD_SUPER(acc, done, buf, n, crc_tab, tabs->kx4);
+        MZ_CRC_FOLD_SUPER(acc, done, buf, n, crc_tab4, crc_mul4);
         if (done) {
             MZ_CRC_SUPER_REDUCE(reg, acc, tmp, tabs);
             acc = (lane == 0) ? reg : 0u;

@@ -136,7 +136,7 @@ extern "C" uint32_t emul_crc32_super(const uint8_t *buf, uint32_t n, uint32_t in
     for (int l = 0; l < 64; l++) acc[l] = l == 0 ? ~init : 0u;
     const uint32_t *tab = g_tabs.byte_tab;
     const mzhip_crc_tables *tabs = &g_tabs;
-    MZ_CRC_FOLD_SUPER(acc, done, buf, n, tab, tabs->kx4);
+    MZ_CRC_FOLD_SUPER(acc, done, buf, n, &g_tabs.slice[0][0], &g_tabs.mul4[0][0]);
     if (done) {
         MZ_CRC_SUPER_REDUCE(reg, acc, tmp, tabs);
         for (int l = 0; l < 64; l++) acc[l] = l == 0 ? reg : 0u;
