@@ -122,3 +122,40 @@ def test_archives_written_through_unmodified_mz_zip(gpu):
         for i in range(n):
             assert o[out_off[i]:out_off[i] + lens[i]].tobytes() == c[offs[i]:offs[i] + lens[i]].tobytes()
             assert crc[i] == zlib.crc32(c[offs[i]:offs[i] + lens[i]].tobytes()) == t[i, 2]
+
+
+def test_full_size_encode_decode_roundtrip_property(gpu):
+    """Size-independent property at config-5 / config-2 scale, all on the device: for 100 000 x 64 KiB entries
+    inflate(deflate(x)) has the length and the CRC-32 of x, the CRC the encoder fused over its input equals the CRC the
+    decoder fused over its output, and both equal zlib's (checked on the unique slices the entries are tiled from)."""
+    import torch
+
+    n_unique, n_total, size = 1024, 100000, 65536
+    datas = synth.slices(n_unique, size, 4321)
+    want_u = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)
+    idx = np.random.RandomState(9).randint(0, n_unique, size=n_total)
+    dev = torch.device("cuda:0")
+    blob = torch.from_numpy(np.frombuffer(b"".join(datas), dtype=np.uint8).copy()).to(dev)
+    in_off = torch.from_numpy(idx.astype(np.int64) * size).to(dev)              # entries share the unique inputs
+    in_len = torch.full((n_total,), size, dtype=torch.int32, device=dev)
+    cap = size + size // 8 + 64
+    z = torch.empty(n_total * cap, dtype=torch.uint8, device=dev)
+    z_off = torch.arange(n_total, dtype=torch.int64, device=dev) * cap
+    z_cap = torch.full((n_total,), cap, dtype=torch.int32, device=dev)
+    z_len, e_crc, e_st = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(3))
+    L = gpu.mz.lib()
+    assert L.mzhip_deflate_batch(blob.data_ptr(), in_off.data_ptr(), in_len.data_ptr(), z.data_ptr(), z_off.data_ptr(),
+                                 z_cap.data_ptr(), None, n_total, z_len.data_ptr(), e_crc.data_ptr(), e_st.data_ptr(),
+                                 None) == 0
+    out = torch.empty(n_total * size, dtype=torch.uint8, device=dev)
+    o_off = torch.arange(n_total, dtype=torch.int64, device=dev) * size
+    o_len, used, d_crc, d_st = gpu.mz.inflate_batch(z, z_off, z_len, out, o_off, in_len)
+    torch.cuda.synchronize()
+    assert int((e_st != 0).sum()) == 0 and int((d_st != 0).sum()) == 0
+    assert bool((o_len == size).all()) and bool((used == z_len).all())
+    assert bool((e_crc == d_crc).all())
+    want = torch.from_numpy(want_u[idx].view(np.int32).copy()).to(dev)
+    assert bool((d_crc == want).all())
+    assert float(z_len.sum()) / (n_total * size) < 0.40
+    for e in (0, n_total // 2, n_total - 1):          # and bytes, on a few entries
+        assert out[e * size:(e + 1) * size].cpu().numpy().tobytes() == datas[idx[e]]
