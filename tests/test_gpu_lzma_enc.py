@@ -135,3 +135,42 @@ def test_archives_written_on_hip_are_extracted_by_the_reference(libs):
             assert (crc_r == t[:, 2].astype(np.uint32)).all() and (ulen_r == lens).all()
             for i in range(n):
                 assert o_ref[out_off[i]:out_off[i] + lens[i]].tobytes() == c[offs[i]:offs[i] + lens[i]].tobytes()
+
+
+def test_encode_decode_roundtrip_property_on_device(gpu):
+    """lzma_decode(lzma_encode(x)) == x at scale, all on the device (K6 -> K3): 9216 x 64 KiB entries, lengths, consumed
+    input and fused CRCs of both directions agree with each other and with zlib's CRC of the unique slices."""
+    import torch
+
+    L = gpu.mz.lib()
+    L.mzhip_lzma_batch.restype = C.c_int32
+    L.mzhip_lzma_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 5
+    n_unique, n_total, size = 512, 9216, 65536
+    datas = synth.slices(n_unique, size, 99)
+    want_u = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)
+    idx = np.random.RandomState(10).randint(0, n_unique, size=n_total)
+    dev = torch.device("cuda:0")
+    blob = torch.from_numpy(np.frombuffer(b"".join(datas), dtype=np.uint8).copy()).to(dev)
+    in_off = torch.from_numpy(idx.astype(np.int64) * size).to(dev)
+    in_len = torch.full((n_total,), size, dtype=torch.int32, device=dev)
+    cap = size + size // 8 + 1024
+    z = torch.empty(n_total * cap, dtype=torch.uint8, device=dev)
+    z_off = torch.arange(n_total, dtype=torch.int64, device=dev) * cap
+    z_cap = torch.full((n_total,), cap, dtype=torch.int32, device=dev)
+    z_len, e_crc, e_st = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(3))
+    assert L.mzhip_lzma_encode_batch(blob.data_ptr(), in_off.data_ptr(), in_len.data_ptr(), size, z.data_ptr(),
+                                     z_off.data_ptr(), z_cap.data_ptr(), None, n_total, z_len.data_ptr(), e_crc.data_ptr(),
+                                     e_st.data_ptr(), None) == 0
+    out = torch.empty(n_total * size, dtype=torch.uint8, device=dev)
+    o_off = torch.arange(n_total, dtype=torch.int64, device=dev) * size
+    o_len, used, d_crc, d_st = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(4))
+    mo = torch.full((n_total,), size, dtype=torch.int64, device=dev)
+    assert L.mzhip_lzma_batch(z.data_ptr(), z_off.data_ptr(), z_len.data_ptr(), out.data_ptr(), o_off.data_ptr(),
+                              in_len.data_ptr(), mo.data_ptr(), n_total, o_len.data_ptr(), used.data_ptr(),
+                              d_crc.data_ptr(), d_st.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int((e_st != 0).sum()) == 0 and int((d_st != 0).sum()) == 0
+    assert bool((o_len == size).all()) and bool((used == z_len).all()) and bool((e_crc == d_crc).all())
+    assert bool((d_crc == torch.from_numpy(want_u[idx].view(np.int32).copy()).to(dev)).all())
+    for e in (0, n_total // 2, n_total - 1):
+        assert out[e * size:(e + 1) * size].cpu().numpy().tobytes() == datas[idx[e]]
