@@ -115,6 +115,9 @@ MZHIP_API uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int
 #define MZH_PROP_COMPRESS_LEVEL 9  /* mz_strm.h:28 */
 #define MZH_PROP_COMPRESS_METHOD 10 /* mz_strm.h:29 */
 #define MZH_PROP_COMPRESS_WINDOW 11 /* mz_strm.h:30 */
+#define MZH_SEEK_SET 0 /* mz.h:58-60 */
+#define MZH_SEEK_CUR 1
+#define MZH_SEEK_END 2
 #define MZH_STAGING_BYTES 32767    /* INT16_MAX staging reads, mz_strm_zlib.c:51,132 */
 
 #ifdef __cplusplus

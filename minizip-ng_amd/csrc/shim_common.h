@@ -9,6 +9,9 @@ int32_t mzhip_prime_lookup(int64_t payload_off, const uint8_t *head, int32_t hea
 /* the same for any primed method (8 DEFLATE, 14 LZMA, 95 XZ) */
 int32_t mzhip_prime_lookup2(int32_t method, int64_t payload_off, const uint8_t *head, int32_t head_len,
                             const uint8_t **data, int64_t *usize, int64_t *csize, uint32_t *crc, const uint32_t **seg_crc);
+/* MZHIP_AUTOPRIME: prime the archive behind a codec stream's base on first use (shim_autoprime.c); no-op otherwise */
+struct mzhip_stream_s;
+void mzhip_autoprime(struct mzhip_stream_s *codec_base);
 /* crc(A||B) from crc(A), crc(B), |B|: arithmetic on checksums, no data bytes involved */
 uint32_t mzhip_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 

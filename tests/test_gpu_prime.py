@@ -112,3 +112,39 @@ def test_prime_lzma_and_xz_entries():
             assert hits.value == n and miss.value == 0, (method, hits.value, miss.value)
             print("method %d: reference 1 thread %.3f s, primed drop-in %.3f s (%.1fx)" % (method, t_ref, t_hip, t_ref / t_hip))
             L.mzhip_prime_clear()
+
+
+def test_autoprime_env(monkeypatch):
+    """MZHIP_AUTOPRIME: no call to mzhip_prime_* at all -- the first read() of the unmodified reader loop images the
+    archive through the reader's own stream, primes it and every entry is then served from the cache."""
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    L = mz.lib()
+    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(26)
+    with tempfile.TemporaryDirectory() as tmp:
+        for method, n, size in ((8, 300, 65536), (14, 20, 100000), (95, 20, 100000)):
+            lens = rnd.randint(0, size + 1, size=n).astype(np.int32)
+            lens[:2] = (1, size)
+            offs = rnd.randint(0, len(c) - size, size=n).astype(np.int64)
+            path = os.path.join(tmp, "a%d.zip" % method)
+            ref.zip_write(path, c, offs, lens, method=method, level=6)
+            cd = ref.zip_index(path)[:, 6].copy()
+            out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+            o_ref = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            _, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_ref, out_off=out_off)
+            L.mzhip_prime_clear()
+            monkeypatch.setenv("MZHIP_AUTOPRIME", "64")
+            _, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_hip, out_off=out_off)
+            monkeypatch.delenv("MZHIP_AUTOPRIME")
+            ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+            assert (st_r == 0).all() and (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all()
+            assert (o_hip == o_ref).all()
+            assert ent.value >= n - 1 and hits.value >= n - 1, (method, ent.value, hits.value, miss.value)
+            L.mzhip_prime_clear()
