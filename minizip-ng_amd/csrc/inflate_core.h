@@ -15,10 +15,13 @@
  *   - Which candidates are real is decided without a serial walk: the successor
  *     function f(l) = l + bits(l) is squared with cross-lane gathers and lane i
  *     composes f^i(0); the step's tokens come out compacted in lanes 0..n-1.
- *     One step retires >= 64 bits of compressed input (about 6 tokens on text).
- *   - Compacted literals scatter in one store; matches (LZ77 back-references)
- *     are copied four at a time, 16 lanes each, overlapping (dist < len) runs
- *     and same-step dependencies falling back to an in-order cooperative copy.
+ *     One step retires about 64 bits of compressed input (4.6 tokens on text).
+ *   - The step's tokens join a queue of up to 64 tokens held one per lane; the
+ *     output phase runs once per ~50 tokens with every lane busy: wave prefix sum
+ *     of the sizes, literals scatter in one store, matches (LZ77 back-references)
+ *     are copied eight at a time, 8 lanes each, as long as every source of a group
+ *     ends before the group's first destination byte; overlapping (dist < len) runs
+ *     and in-group dependencies take an in-order cooperative copy.
  *   - The sliding window IS the output buffer: back-references read bytes this
  *     wave wrote earlier (a wave's vector-memory operations execute in order),
  *     so no 32 KiB LDS window is needed; compressed input is staged through a
@@ -27,7 +30,10 @@
  *     time (crc32_core.h), so the output is never re-read from HBM.
  *   - The kernel is VALU-issue-bound (measured), so the per-lane decode is kept
  *     to 32-bit funnel shifts (v_alignbit), bit-field extracts and table entries
- *     that need no arithmetic.
+ *     that need no arithmetic, and the tables are sized for residency: an 8-bit
+ *     literal/length root plus second-level tables (4.7 KiB of LDS per wave) lets
+ *     eight workgroups = 32 waves share a CU.
+ *   - MZ_STATS (host emulation only) counts flushes / matches / dependent copies.
  *
  * Error classes mirror zlib's as the reference surfaces them
  * (mz_strm_zlib.c:159-189): malformed data -> -3, input exhausted -> -5.
