@@ -47,10 +47,23 @@ MZ_DEV uint32_t mz_sha_word(const uint8_t *p, uint64_t n, uint64_t total_words, 
 /* SHA-256 family: h[] holds the initial value on entry and the digest words on return */
 MZ_DEV void mz_sha256_run(const uint8_t *p, uint64_t n, uint32_t h[8]) {
     const uint64_t blocks = (n + 9 + 63) / 64, total_words = blocks * 16;
+    const uint64_t full = n / 64; /* blocks made of data only: plain 16-byte loads; the padded tail goes word by word */
     for (uint64_t b = 0; b < blocks; b++) {
         uint32_t w[16];
+        if (b < full) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = mz_sha_word(p, n, total_words, b * 16 + (uint64_t)i);
+            for (int i = 0; i < 4; i++) {
+                uint32_t q[4];
+                __builtin_memcpy(q, p + 64 * b + 16 * (uint64_t)i, 16);
+                w[4 * i] = __builtin_bswap32(q[0]);
+                w[4 * i + 1] = __builtin_bswap32(q[1]);
+                w[4 * i + 2] = __builtin_bswap32(q[2]);
+                w[4 * i + 3] = __builtin_bswap32(q[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) w[i] = mz_sha_word(p, n, total_words, b * 16 + (uint64_t)i);
+        }
         uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
 #pragma unroll
         for (int i = 0; i < 64; i++) {
@@ -82,10 +95,23 @@ MZ_DEV void mz_sha256_init(uint32_t h[8], int is224) {
 MZ_DEV void mz_sha1_run(const uint8_t *p, uint64_t n, uint32_t h[5]) {
     const uint64_t blocks = (n + 9 + 63) / 64, total_words = blocks * 16;
     h[0] = 0x67452301; h[1] = 0xEFCDAB89; h[2] = 0x98BADCFE; h[3] = 0x10325476; h[4] = 0xC3D2E1F0;
+    const uint64_t full = n / 64; /* blocks made of data only: plain 16-byte loads; the padded tail goes word by word */
     for (uint64_t b = 0; b < blocks; b++) {
         uint32_t w[16];
+        if (b < full) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = mz_sha_word(p, n, total_words, b * 16 + (uint64_t)i);
+            for (int i = 0; i < 4; i++) {
+                uint32_t q[4];
+                __builtin_memcpy(q, p + 64 * b + 16 * (uint64_t)i, 16);
+                w[4 * i] = __builtin_bswap32(q[0]);
+                w[4 * i + 1] = __builtin_bswap32(q[1]);
+                w[4 * i + 2] = __builtin_bswap32(q[2]);
+                w[4 * i + 3] = __builtin_bswap32(q[3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) w[i] = mz_sha_word(p, n, total_words, b * 16 + (uint64_t)i);
+        }
         uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4];
 #pragma unroll
         for (int i = 0; i < 80; i++) {

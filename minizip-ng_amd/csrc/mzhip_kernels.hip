@@ -224,20 +224,22 @@ struct ShaArgs {
 };
 
 // SHA-1 / SHA-224 / SHA-256 of n buffers: a digest chain is serial, so ONE LANE hashes one buffer (64 per wave).
-__global__ __launch_bounds__(256) void k_sha_batch(ShaArgs a) {
+// One instantiation per algorithm: the unrolled rounds of both families in one kernel cost 177 VGPRs.
+template <int ALG>
+__global__ __launch_bounds__(256, 4) void k_sha_batch(ShaArgs a) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= a.n) return;
     const uint8_t *p = a.buf + a.off[e];
     const uint64_t n = a.len[e];
     uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t words;
-    if (a.algorithm == 20) {
+    if (ALG == 20) {
         mz_sha1_run(p, n, h);
         words = 5;
     } else {
-        mz_sha256_init(h, a.algorithm == 22);
+        mz_sha256_init(h, ALG == 22);
         mz_sha256_run(p, n, h);
-        words = a.algorithm == 22 ? 7 : 8;
+        words = ALG == 22 ? 7 : 8;
     }
     uint32_t *d = (uint32_t *)(a.digest + (size_t)e * 32);
     for (uint32_t i = 0; i < 8; i++) d[i] = i < words ? __builtin_bswap32(h[i]) : 0u;
@@ -601,7 +603,12 @@ int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t
     a.n = n;
     a.algorithm = algorithm;
     a.digest = (uint8_t *)d_digest;
-    hipLaunchKernelGGL(k_sha_batch, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (algorithm == 20)
+        hipLaunchKernelGGL(k_sha_batch<20>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else if (algorithm == 22)
+        hipLaunchKernelGGL(k_sha_batch<22>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(k_sha_batch<23>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
