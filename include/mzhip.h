@@ -109,12 +109,12 @@ MZHIP_API int32_t mzhip_xz_batch(const void *d_in, const uint64_t *d_in_off, con
                                  uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,
                                  int32_t *d_status, void *stream);
 
-/* SHA-1 / SHA-224 / SHA-256 of n buffers ----------------------------- */
+/* SHA-1 / SHA-224 / SHA-256 / SHA-384 / SHA-512 of n buffers ----------------------------- */
 
 /* What the reader's hash verification computes per entry on the CPU: mz_crypt_sha_begin/_update/_end over the
- * decoded bytes (mz_zip_rw.c:409-451,465-466; mz_crypt.h:29-35).  algorithm = MZ_HASH_SHA1 (20), MZ_HASH_SHA224
- * (22) or MZ_HASH_SHA256 (23) (mz.h:127-131).  d_digest receives n x 32 bytes: the digest in its standard byte
- * order followed by zero bytes.  One lane per buffer. */
+ * decoded bytes (mz_zip_rw.c:409-451,465-466; mz_crypt.h:29-35).  algorithm = MZ_HASH_SHA1 (20), SHA224 (22), SHA256
+ * (23), SHA384 (24) or SHA512 (25) (mz.h:127-135).  d_digest receives n x 32 bytes (n x 64 for SHA-384 / SHA-512): the
+ * digest in its standard byte order followed by zero bytes.  One lane per buffer. */
 MZHIP_API int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
                                   uint32_t algorithm, void *d_digest, void *stream);
 

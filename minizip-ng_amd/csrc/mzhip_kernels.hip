@@ -219,8 +219,8 @@ struct ShaArgs {
     const uint64_t *off;
     const uint32_t *len;
     uint32_t n;
-    uint32_t algorithm; // MZ_HASH_SHA1 20, MZ_HASH_SHA224 22, MZ_HASH_SHA256 23 (mz.h:127-131)
-    uint8_t *digest;    // n x 32 bytes, big-endian words, unused tail bytes zero
+    uint32_t algorithm; // MZ_HASH_SHA1 20, SHA224 22, SHA256 23, SHA384 24, SHA512 25 (mz.h:127-135)
+    uint8_t *digest;    // n x 32 bytes (n x 64 for SHA-384 / SHA-512), standard byte order, unused tail bytes zero
 };
 
 // SHA-1 / SHA-224 / SHA-256 of n buffers: a digest chain is serial, so ONE LANE hashes one buffer (64 per wave).
@@ -231,6 +231,14 @@ __global__ __launch_bounds__(256, 4) void k_sha_batch(ShaArgs a) {
     if (e >= a.n) return;
     const uint8_t *p = a.buf + a.off[e];
     const uint64_t n = a.len[e];
+    if (ALG == 24 || ALG == 25) {
+        uint64_t g[8];
+        mz_sha512_init(g, ALG == 24);
+        mz_sha512_run(p, n, g);
+        uint64_t *d8 = (uint64_t *)(a.digest + (size_t)e * 64);
+        for (uint32_t i = 0; i < 8; i++) d8[i] = i < (ALG == 24 ? 6u : 8u) ? __builtin_bswap64(g[i]) : 0ull;
+        return;
+    }
     uint32_t h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t words;
     if (ALG == 20) {
@@ -591,7 +599,7 @@ int32_t mzhip_xz_batch(const void *d_in, const uint64_t *d_in_off, const uint32_
 
 int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n, uint32_t algorithm,
                         void *d_digest, void *stream) {
-    if (algorithm != 20 && algorithm != 22 && algorithm != 23) return MZHIP_STATUS_UNSUPPORTED;
+    if (algorithm != 20 && (algorithm < 22 || algorithm > 25)) return MZHIP_STATUS_UNSUPPORTED;
     if (n == 0) return 0;
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
@@ -605,6 +613,10 @@ int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t
     a.digest = (uint8_t *)d_digest;
     if (algorithm == 20)
         hipLaunchKernelGGL(k_sha_batch<20>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else if (algorithm == 24)
+        hipLaunchKernelGGL(k_sha_batch<24>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else if (algorithm == 25)
+        hipLaunchKernelGGL(k_sha_batch<25>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     else if (algorithm == 22)
         hipLaunchKernelGGL(k_sha_batch<22>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     else

@@ -68,6 +68,14 @@ extern "C" uint64_t emul_crc64(const uint8_t *buf, uint64_t n) {
 }
 
 extern "C" void emul_sha(const uint8_t *buf, uint64_t n, int alg, uint8_t *digest) {
+    if (alg == 24 || alg == 25) {
+        uint64_t g[8];
+        mz_sha512_init(g, alg == 24);
+        mz_sha512_run(buf, n, g);
+        for (int i = 0; i < (alg == 24 ? 6 : 8); i++)
+            for (int k = 0; k < 8; k++) digest[8 * i + k] = (uint8_t)(g[i] >> (56 - 8 * k));
+        return;
+    }
     uint32_t h[8];
     int words = 8;
     if (alg == 20) {

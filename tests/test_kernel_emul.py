@@ -99,12 +99,13 @@ def test_crc64_and_sha_vs_hashlib(emu):
 
     rnd = np.random.RandomState(4)
     kat = b"the quick and lazy fox did his thang"
-    for n in (0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 1000, 4097, 100001):
+    for n in (0, 1, 3, 55, 56, 57, 63, 64, 65, 111, 112, 113, 119, 120, 127, 128, 129, 239, 240, 1000, 4097, 100001):
         d = rnd.bytes(n)
         a = np.frombuffer(d, dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
         assert emu.emul_crc64(a.ctypes.data_as(_u8p), n) == oracle.crc64(d), n
-        for alg, fn in ((20, hashlib.sha1), (22, hashlib.sha224), (23, hashlib.sha256)):
-            out = np.zeros(32, np.uint8)
+        for alg, fn in ((20, hashlib.sha1), (22, hashlib.sha224), (23, hashlib.sha256), (24, hashlib.sha384),
+                        (25, hashlib.sha512)):
+            out = np.zeros(64, np.uint8)
             emu.emul_sha(a.ctypes.data_as(_u8p), n, alg, out.ctypes.data_as(_u8p))
             assert out.tobytes()[:fn().digest_size] == fn(d).digest(), (n, alg)
     a = np.frombuffer(b"123456789", dtype=np.uint8).copy()
@@ -112,8 +113,11 @@ def test_crc64_and_sha_vs_hashlib(emu):
     a = np.frombuffer(kat, dtype=np.uint8).copy()
     for alg, want in ((20, "3efb8392b6cd8e14bd76bd08081521dc73df418c"),
                       (22, "9e444f5f0b6582a923bd48696155f4a2f0d914e044cb64b8729a6600"),
-                      (23, "7a31ea0848525f7ebfeec9ee532bcc5d6d26772427e097b86cf440a56546541c")):
-        out = np.zeros(32, np.uint8)
+                      (23, "7a31ea0848525f7ebfeec9ee532bcc5d6d26772427e097b86cf440a56546541c"),
+                      (24, "e1e42e5977965bb3621231a5df3a1e83c471fa91fde33b6a30c8c4fa0d8be29ba7171c7c9487db91e9ee7e85049f7b41"),
+                      (25, "6627e7643ee7ce633e03f52d22329c3a32597364247c5275d4369985e1518626da46f595ad327667346479d246359b8b381af"
+                           "791ce2ac8c53a4788050eea11fe")):
+        out = np.zeros(64, np.uint8)
         emu.emul_sha(a.ctypes.data_as(_u8p), len(kat), alg, out.ctypes.data_as(_u8p))
         assert out.tobytes()[:len(want) // 2].hex() == want, alg
 
