@@ -372,7 +372,13 @@ struct DeviceCtx {
     bool ready = false;
     mzhip_crc_tables *d_tabs = nullptr;
     uint64_t *d_tab64 = nullptr;
-    uint32_t *d_tok = nullptr; // K4 token scratch, allocated on first use
+    struct ScratchEnt {
+        void *p = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;    // recorded behind the last launch that used the buffer
+        hipStream_t last = nullptr; // ... on this stream
+        bool used = false, held = false;
+    } scratch[8]; // per-launch scratch (K4 / K6 tokens), see scratch_acquire()
     uint32_t *d_counters = nullptr;
     uint32_t next_counter = 0;
     int cu_count = 0;
@@ -425,6 +431,70 @@ int32_t ctx_for_current(DeviceCtx **out) {
         c.ready = true;
     }
     *out = &c;
+    return 0;
+}
+
+// Per-launch device scratch, stream-ordered without the runtime's memory pools.  hipMallocAsync/hipFreeAsync was the
+// first implementation; on this stack (ROCm 7.2, gfx950) the second allocation of a process intermittently came back
+// with the kernels' and copies' early writes wiped (the whole block read as zero afterwards: 16 of 100 fresh processes,
+// profiles/r1/side_measurements.log), so buffers are plain hipMalloc memory cached here.  A buffer is handed out again
+// when the next launch is on the stream that used it last (stream order protects it) or when the event recorded behind
+// its last use has completed; otherwise another buffer is allocated, so concurrent streams never share scratch.
+int32_t scratch_acquire(DeviceCtx *c, size_t bytes, hipStream_t s, int *slot, void **p) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    constexpr int kSlots = (int)(sizeof(c->scratch) / sizeof(c->scratch[0]));
+    int best = -1, empty = -1, victim = -1;
+    for (int i = 0; i < kSlots; i++) {
+        DeviceCtx::ScratchEnt &e = c->scratch[i];
+        if (!e.p) {
+            if (empty < 0) empty = i;
+            continue;
+        }
+        if (e.held) continue;
+        const bool done = !e.used || hipEventQuery(e.ev) == hipSuccess;
+        if (e.cap >= bytes && (done || e.last == s)) {
+            if (best < 0 || e.cap < c->scratch[best].cap) best = i;
+        } else if (done && (victim < 0 || e.cap < c->scratch[victim].cap)) {
+            victim = i; // idle and too small
+        }
+    }
+    if (best < 0) {
+        int i = empty >= 0 ? empty : victim;
+        if (i < 0) { /* every buffer is busy on another stream: wait for one */
+            for (int k = 0; k < kSlots && i < 0; k++)
+                if (!c->scratch[k].held) i = k;
+            if (i < 0) {
+                snprintf(g_err, sizeof(g_err), "scratch: more than %d concurrent launches", kSlots);
+                return -104;
+            }
+            HIP_TRY(hipEventSynchronize(c->scratch[i].ev));
+        }
+        DeviceCtx::ScratchEnt &e = c->scratch[i];
+        if (e.p) {
+            HIP_TRY(hipFree(e.p));
+            e.p = nullptr;
+            e.cap = 0;
+        }
+        const size_t cap = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        HIP_TRY(hipMalloc(&e.p, cap));
+        e.cap = cap;
+        e.used = false;
+        if (!e.ev) HIP_TRY(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+        best = i;
+    }
+    c->scratch[best].held = true;
+    *slot = best;
+    *p = c->scratch[best].p;
+    return 0;
+}
+
+int32_t scratch_release(DeviceCtx *c, int slot, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx::ScratchEnt &e = c->scratch[slot];
+    e.held = false;
+    e.used = true;
+    e.last = s;
+    HIP_TRY(hipEventRecord(e.ev, s));
     return 0;
 }
 
@@ -651,15 +721,17 @@ int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE;
     uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
     uint32_t resident = (uint32_t)c->cu_count * 4u; /* 38.3 KiB LDS per workgroup -> 4 per CU */
-    if (!c->d_tok) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!c->d_tok)
-            HIP_TRY(hipMalloc((void **)&c->d_tok, (size_t)resident * MZ_WAVES_PER_WG * MZ_DEF_BLOCK * sizeof(uint32_t)));
-    }
-    a.tok = c->d_tok;
-    hipLaunchKernelGGL(k_deflate_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const uint32_t grid = wgs < resident ? wgs : resident;
+    int slot = -1;
+    void *scratch = nullptr; /* one token block per resident wave */
+    rc = scratch_acquire(c, (size_t)grid * MZ_WAVES_PER_WG * MZ_DEF_BLOCK * sizeof(uint32_t), s, &slot, &scratch);
+    if (rc) return rc;
+    a.tok = (uint32_t *)scratch;
+    hipLaunchKernelGGL(k_deflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+    const hipError_t le = hipGetLastError();
+    rc = scratch_release(c, slot, s);
+    if (le != hipSuccess) return fail("k_deflate_batch", le);
+    return rc;
 }
 
 int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, uint32_t max_in_len,
@@ -684,14 +756,22 @@ int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, cons
     a.crc = d_crc;
     a.status = d_status;
     a.tabs = c->d_tabs;
-    /* token scratch: 4 bytes per input position of the largest entry, for every entry; stream-ordered */
+    /* token scratch: 4 bytes per input position of the largest entry, for every entry */
     const size_t items = (size_t)n * a.maxb;
+    int slot = -1;
     void *scratch = nullptr;
-    HIP_TRY(hipMallocAsync(&scratch, items * MZ_DEF_BLOCK * sizeof(uint32_t) + items * sizeof(uint32_t) + 64, s));
+    rc = scratch_acquire(c, items * MZ_DEF_BLOCK * sizeof(uint32_t) + items * sizeof(uint32_t) + 64, s, &slot, &scratch);
+    if (rc) return rc;
     a.tok = (uint32_t *)scratch;
     a.ntok = a.tok + items * MZ_DEF_BLOCK;
     a.counter = a.ntok + items; /* two work counters behind the token counts */
-    HIP_TRY(hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), s));
+    {
+        const hipError_t me = hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), s);
+        if (me != hipSuccess) {
+            (void)scratch_release(c, slot, s);
+            return fail("hipMemsetAsync", me);
+        }
+    }
     {
         uint32_t wgs = (uint32_t)((items + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG);
         uint32_t resident = (uint32_t)c->cu_count * 4u; /* 33 KiB LDS per workgroup */
@@ -701,9 +781,10 @@ int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, cons
         uint32_t resident = (uint32_t)c->cu_count * 9u; /* 17 KiB LDS per single-wave workgroup */
         hipLaunchKernelGGL(k_lzma_rc_encode_batch, dim3(n < resident ? n : resident), dim3(64), 0, s, a);
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipFreeAsync(scratch, s));
-    return 0;
+    const hipError_t le = hipGetLastError();
+    rc = scratch_release(c, slot, s);
+    if (le != hipSuccess) return fail("k_lzma_rc_encode_batch", le);
+    return rc;
 }
 
 // ---- host-buffer conveniences (synchronous): staging through one scratch allocation per call

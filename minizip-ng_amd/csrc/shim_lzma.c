@@ -43,6 +43,7 @@ typedef struct mzhip_lzma_s {
     uint8_t *in;
     int64_t in_len, in_cap;
     int8_t base_eof;
+    int32_t base_err; /* base failed after data had arrived: reported only if the stream turns out to need more */
     uint8_t *out;
     int64_t out_len, out_cap, out_served;
     int8_t decoded;
@@ -99,6 +100,7 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->in = z->out = NULL;
     z->in_len = z->in_cap = z->out_len = z->out_cap = z->out_served = 0;
     z->base_eof = z->decoded = 0;
+    z->base_err = 0;
     z->dev_status = 0;
     z->dev_in_used = 0;
     z->next_attempt = 0;
@@ -210,8 +212,13 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         return MZH_DATA_ERROR; /* mz_strm_lzma.c:236-237 */
     while (!z->decoded) {
         int32_t rd = pull_chunk(z);
-        if (rd < 0)
-            return rd;
+        if (rd < 0) {
+            /* a failing base read ends the input; it is the result only if the stream needs more (see shim_zlib.c) */
+            if (z->in_len <= (z->method == MZH_COMPRESS_METHOD_LZMA ? LZMA_MAGIC_SIZE : 0) || z->base_err != 0)
+                return rd;
+            z->base_err = rd;
+            z->base_eof = 1;
+        }
         if (!z->tried_cache) {
             /* was this entry decoded by mzhip_prime_*()?  (payload offset + first payload bytes must agree) */
             z->tried_cache = 1;
@@ -247,6 +254,8 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         z->error = z->dev_status == MZHIP_STATUS_BUF_ERROR ? 10 : 9; /* LZMA_BUF_ERROR : LZMA_DATA_ERROR */
         z->total_in = z->dev_in_used;
         z->total_out = z->out_len;
+        if (z->base_err != 0 && z->dev_status == MZHIP_STATUS_BUF_ERROR)
+            return z->base_err;
         return MZH_DATA_ERROR;
     }
     int32_t n = (int32_t)(avail < size ? avail : size);

@@ -57,6 +57,7 @@ typedef struct mzhip_zlib_s {
     uint8_t *in;       /* compressed bytes pulled from base so far */
     int64_t in_len, in_cap;
     int8_t base_eof;   /* base returned 0 */
+    int32_t base_err;  /* base failed after data had arrived: reported only if the stream turns out to need more */
     uint8_t *out;      /* decoded bytes (host copy) */
     int64_t out_len, out_cap, out_served;
     int8_t decoded;    /* device produced a final verdict */
@@ -111,6 +112,7 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->error = 0;
     free_buffers(z);
     z->base_eof = 0;
+    z->base_err = 0;
     z->decoded = 0;
     z->dev_status = 0;
     z->dev_in_used = 0;
@@ -352,8 +354,16 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
     }
     while (!z->decoded) {
         int32_t rd = pull_chunk(z);
-        if (rd < 0)
-            return rd; /* mz_strm_zlib.c:148-149 */
+        if (rd < 0) {
+            /* mz_strm_zlib.c:148-149 returns a failing base read -- but the reference reads on demand and so never
+             * issues a read its stream does not need, while this side reads ahead of the device's verdict (e.g. past
+             * the last disk of a split archive, mz_strm_split.c:237-241).  What arrived is decoded first; the base
+             * error is the result only if the stream really ends short. */
+            if (z->in_len == 0 || z->base_err != 0)
+                return rd;
+            z->base_err = rd;
+            z->base_eof = 1;
+        }
         if (!z->tried_cache) {
             /* was this entry decoded by mzhip_prime_*()?  (payload offset + first payload bytes must agree) */
             z->tried_cache = 1;
@@ -385,7 +395,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
     int64_t avail = z->out_len - z->out_served;
     if (z->dev_status != 0 && avail < size) {
         /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189) */
-        z->error = z->dev_status;
+        z->error = (z->base_err != 0 && z->dev_status == MZHIP_STATUS_BUF_ERROR) ? z->base_err : z->dev_status;
         z->total_in = z->dev_in_used;
         z->total_out = z->out_len;
         return z->error;
