@@ -150,3 +150,18 @@ def test_cli_gz_ungz(src, tmp_path):
             (w / "out").mkdir()
             _run(unpacker, ["-x", "-d", str(w / "out"), name + ".gz"], str(w))
             assert (w / "out" / name).read_bytes() == data
+
+
+HIP_COMPAT = os.path.join(ROOT, "integration", "_build", "compat_hip")
+REF_COMPAT = os.path.join(ROOT, "oracle", "_ref", "compat_ref")
+
+
+def test_compat_layer(tmp_path):
+    """test/test_compat.cc restated (integration/compat_check.c): the minizip 1.x API -- zipOpen64 ... zipClose,
+    unzOpen ... unzClose -- on the HIP codecs, and each side's archive read by the other."""
+    _need(HIP_COMPAT, REF_COMPAT)
+    for k, (w, r) in enumerate(((HIP_COMPAT, HIP_COMPAT), (HIP_COMPAT, REF_COMPAT), (REF_COMPAT, HIP_COMPAT))):
+        z = str(tmp_path / f"compat{k}.zip")
+        for exe, mode in ((w, "write"), (r, "read")):
+            p = subprocess.run([exe, mode, z], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+            assert p.returncode == 0, f"{os.path.basename(exe)} {mode}: {p.returncode} failed checks\n{p.stdout.decode()}"
