@@ -96,6 +96,7 @@ MZHIP_API uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int
 #define MZH_MEM_ERROR (-4)     /* mz.h:24 */
 #define MZH_BUF_ERROR (-5)     /* mz.h:25 */
 #define MZH_PARAM_ERROR (-102) /* mz.h:31 */
+#define MZH_INTERNAL_ERROR (-104) /* mz.h:33 */
 #define MZH_EXIST_ERROR (-107) /* mz.h:36 */
 #define MZH_SUPPORT_ERROR (-109) /* mz.h:38 */
 #define MZH_OPEN_ERROR (-111)  /* mz.h:40 */

@@ -196,6 +196,21 @@ MZHIP_API int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len);
 MZHIP_API void mzhip_prime_clear(void);
 MZHIP_API void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
 
+/* Write-side prime (SURVEY 8b "Batching", BASELINE config 5) ------------------------------- */
+
+/* Compress n buffers (blob + off[i], len[i]) in one launch per group and keep the streams in a host cache; method 8
+ * (raw DEFLATE) or 14 (ZIP-LZMA payload).  Afterwards the drop-in mz_stream_zlib / mz_stream_lzma WRITE path follows
+ * the bytes the reference's untouched writer loop hands it (mz_zip_writer_add_buffer -> mz_zip_entry_write,
+ * mz_zip.c:2052-2068) against the primed buffers, chunk by chunk and byte for byte; an entry that is exactly one of
+ * them is answered at close() with the cached stream, and the mz_crypt_crc32_update calls on the writer's
+ * 65 535-byte chunks (mz_zip_rw.c:55) with device-computed segment CRCs.  An entry that diverges from a primed buffer
+ * at any point takes the ordinary path.  Buffers shorter than 16 bytes or longer than 8 MiB are not cached.  The
+ * caller keeps the primed buffers valid and unchanged until mzhip_prime_write_clear() (or the next prime of the same
+ * method).  Returns the number of cached buffers or a negative MZ_* code. */
+MZHIP_API int64_t mzhip_prime_write(int32_t method, const uint8_t *blob, const uint64_t *off, const uint32_t *len, uint32_t n);
+MZHIP_API void mzhip_prime_write_clear(void);
+MZHIP_API void mzhip_prime_write_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
+
 /* Geometry the last launch used (for reports): workgroups, waves per workgroup, LDS bytes per workgroup. */
 MZHIP_API void mzhip_inflate_launch_geometry(uint32_t n, uint32_t *grid, uint32_t *waves_per_wg, uint32_t *lds_bytes);
 

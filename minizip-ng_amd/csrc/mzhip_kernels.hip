@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 #include <stdlib.h>
 #include <stdio.h>
@@ -1410,6 +1411,303 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup(int64_t payload
 // checksums only: crc(A||B) from crc(A), crc(B), |B| (shared with shim_crc32.c)
 __attribute__((visibility("hidden"))) uint32_t mzhip_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
     return mzhip_crc32_combine_host(crc_a, crc_b, len_b);
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Write-side prime (SURVEY 8b "Batching", config 5): compress many buffers in ONE launch per group ahead of the
+// reference's untouched writer loop (mz_zip_writer_add_buffer -> mz_zip_entry_write -> mz_stream_zlib_write ->
+// mz_crypt_crc32_update, one entry at a time).  The codec stream's WRITE side follows the bytes it is handed against
+// the primed buffers (exact comparison, chunk by chunk); when an entry turns out to be one of them, close() emits the
+// cached stream instead of launching, and the CRC updates of the 65 535-byte writer chunks (mz_zip_rw.c:55) are
+// answered from device-computed segment CRCs.  Anything that diverges from the primed bytes falls back to the
+// ordinary path with nothing lost.  The caller keeps the primed buffers alive and unchanged until the clear.
+
+namespace {
+struct WPrimed {
+    const uint8_t *src;
+    uint32_t len, out_len, crc;
+    uint64_t out_off;
+    int64_t seg0;
+};
+struct WPrimeCache {
+    std::vector<WPrimed> ents;
+    std::unordered_multimap<uint64_t, uint32_t> by_key;
+    std::vector<uint32_t> seg_crc;
+    std::vector<uint8_t *> outs; // one host buffer per launch group
+    uint64_t hits = 0, misses = 0;
+};
+WPrimeCache g_wprime[3]; // methods 8, 14 (95 not primed: its container is laid out per entry on the host)
+std::mutex g_wprime_mu;
+
+int wprime_slot(int32_t method) { return method == 8 ? 0 : method == 14 ? 1 : -1; }
+
+// key of an entry's first writer chunk: its length and its first and last 16 bytes
+uint64_t wprime_key(const uint8_t *p, uint32_t n) {
+    uint64_t a = 0, b = 0, c = 0, d = 0;
+    memcpy(&a, p, 8);
+    memcpy(&b, p + 8, 8);
+    memcpy(&c, p + n - 16, 8);
+    memcpy(&d, p + n - 8, 8);
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+    h = (h ^ a) * 0xFF51AFD7ED558CCDull;
+    h = (h ^ (h >> 32) ^ b) * 0xC4CEB9FE1A85EC53ull;
+    h = (h ^ (h >> 29) ^ c) * 0xFF51AFD7ED558CCDull;
+    h = (h ^ (h >> 32) ^ d) * 0xC4CEB9FE1A85EC53ull;
+    return h ^ (h >> 31);
+}
+
+void wprime_clear_locked(WPrimeCache &w) {
+    for (uint8_t *p : w.outs) free(p);
+    w = WPrimeCache();
+}
+} // namespace
+
+extern "C" {
+
+void mzhip_prime_write_clear(void) {
+    std::lock_guard<std::mutex> lk(g_wprime_mu);
+    for (WPrimeCache &w : g_wprime) wprime_clear_locked(w);
+}
+
+void mzhip_prime_write_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses) {
+    std::lock_guard<std::mutex> lk(g_wprime_mu);
+    uint64_t e = 0, h = 0, m = 0;
+    for (const WPrimeCache &w : g_wprime) {
+        e += w.ents.size();
+        h += w.hits;
+        m += w.misses;
+    }
+    if (entries) *entries = e;
+    if (hits) *hits = h;
+    if (misses) *misses = m;
+}
+
+int64_t mzhip_prime_write(int32_t method, const uint8_t *blob, const uint64_t *off, const uint32_t *len, uint32_t n) {
+    const int slot = wprime_slot(method);
+    if (slot < 0 || (!blob && n) || (n && (!off || !len))) return -102; /* MZ_PARAM_ERROR */
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    const uint32_t kMaxLen = 8u << 20; /* what the WRITE shims hold before their first launch */
+    const uint32_t piece = 64u << 10, pcap = piece + piece / 8 + 64;
+    WPrimeCache fresh;
+    // launch groups: bounded input bytes and bounded token scratch
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < n; i++)
+        if (len[i] >= 16u && len[i] <= kMaxLen) ids.push_back(i);
+    size_t g0 = 0;
+    while (g0 < ids.size()) {
+        size_t g1 = g0;
+        uint64_t in_bytes = 0, units = 0;
+        uint32_t maxlen = 0;
+        while (g1 < ids.size()) {
+            const uint32_t l = len[ids[g1]];
+            const uint32_t ml = l > maxlen ? l : maxlen;
+            const uint64_t u = method == 8 ? units + (l + piece - 1) / piece
+                                           : (uint64_t)(g1 - g0 + 1) * ((ml + piece - 1) / piece);
+            if (g1 > g0 && (in_bytes + l > ((uint64_t)1 << 30) || u > 32768u)) break;
+            in_bytes += (l + 63u) & ~63u;
+            units = u;
+            maxlen = ml;
+            g1++;
+        }
+        const uint32_t gn = (uint32_t)(g1 - g0);
+        // descriptors: method 8 = one per 64 KiB piece, method 14 = one per entry
+        std::vector<uint64_t> in_off, out_off, seg_off;
+        std::vector<uint32_t> in_len, out_cap, seg_len, first_unit(gn + 1);
+        std::vector<uint8_t> fin;
+        uint64_t ipos = 0, opos = 0;
+        std::vector<uint64_t> ent_in(gn);
+        for (uint32_t e = 0; e < gn; e++) {
+            const uint32_t l = len[ids[g0 + e]];
+            ent_in[e] = ipos;
+            first_unit[e] = (uint32_t)in_off.size();
+            if (method == 8) {
+                for (uint32_t o = 0; o < l; o += piece) {
+                    in_off.push_back(ipos + o);
+                    in_len.push_back(l - o < piece ? l - o : piece);
+                    out_off.push_back(opos);
+                    out_cap.push_back(pcap);
+                    fin.push_back(o + piece >= l ? 1 : 0);
+                    opos += pcap;
+                }
+            } else {
+                const uint32_t cap = l + l / 8 + 1024;
+                in_off.push_back(ipos);
+                in_len.push_back(l);
+                out_off.push_back(opos);
+                out_cap.push_back(cap);
+                opos += (cap + 63u) & ~63u;
+            }
+            for (uint32_t o = 0; o < l; o += kSeg) {
+                seg_off.push_back(ipos + o);
+                seg_len.push_back(l - o < kSeg ? l - o : kSeg);
+            }
+            ipos += (l + 63u) & ~63u;
+        }
+        first_unit[gn] = (uint32_t)in_off.size();
+        const uint32_t nu = (uint32_t)in_off.size(), ns = (uint32_t)seg_off.size();
+        const uint64_t out_base = ipos; /* outputs behind the inputs in one allocation */
+        for (uint64_t &o : out_off) o += out_base;
+        const size_t meta = (size_t)nu * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 1) + (size_t)ns * (8 + 4 + 4) + 256;
+        Scratch d_data, d_meta;
+        HIP_TRY(hipMalloc(&d_data.p, out_base + opos + 64));
+        HIP_TRY(hipMalloc(&d_meta.p, meta));
+        {   /* the group's inputs in their padded device layout, one transfer */
+            uint8_t *stage = (uint8_t *)malloc(ipos + 64);
+            if (!stage) return -4;
+            for (uint32_t e = 0; e < gn; e++) memcpy(stage + ent_in[e], blob + off[ids[g0 + e]], len[ids[g0 + e]]);
+            const hipError_t ce = hipMemcpy(d_data.p, stage, ipos, hipMemcpyHostToDevice);
+            free(stage);
+            if (ce != hipSuccess) return fail("hipMemcpy (buffers to prime)", ce);
+        }
+        uint8_t *m = (uint8_t *)d_meta.p;
+        uint64_t *d_in_off = (uint64_t *)m, *d_out_off = d_in_off + nu, *d_seg_off = d_out_off + nu;
+        uint32_t *d_in_len = (uint32_t *)(d_seg_off + ns), *d_out_cap = d_in_len + nu, *d_out_len = d_out_cap + nu,
+                 *d_crc = d_out_len + nu;
+        int32_t *d_status = (int32_t *)(d_crc + nu);
+        uint32_t *d_seg_len = (uint32_t *)(d_status + nu), *d_seg_crc = d_seg_len + ns;
+        uint8_t *d_fin = (uint8_t *)(d_seg_crc + ns);
+        HIP_TRY(hipMemcpy(d_in_off, in_off.data(), (size_t)nu * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_out_off, out_off.data(), (size_t)nu * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_in_len, in_len.data(), (size_t)nu * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_out_cap, out_cap.data(), (size_t)nu * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_seg_off, seg_off.data(), (size_t)ns * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_seg_len, seg_len.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
+        if (method == 8) {
+            HIP_TRY(hipMemcpy(d_fin, fin.data(), nu, hipMemcpyHostToDevice));
+            rc = mzhip_deflate_batch(d_data.p, d_in_off, d_in_len, d_data.p, d_out_off, d_out_cap, d_fin, nu, d_out_len, d_crc,
+                                     d_status, nullptr);
+        } else {
+            rc = mzhip_lzma_encode_batch(d_data.p, d_in_off, d_in_len, maxlen, d_data.p, d_out_off, d_out_cap, nullptr, nu,
+                                         d_out_len, d_crc, d_status, nullptr);
+        }
+        if (rc) return rc;
+        rc = mzhip_crc32_batch(d_data.p, d_seg_off, d_seg_len, ns, nullptr, d_seg_crc, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<uint32_t> h_len(nu), h_crc(nu), h_seg(ns);
+        std::vector<int32_t> h_st(nu);
+        HIP_TRY(hipMemcpy(h_len.data(), d_out_len, (size_t)nu * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_crc.data(), d_crc, (size_t)nu * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_st.data(), d_status, (size_t)nu * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(h_seg.data(), d_seg_crc, (size_t)ns * 4, hipMemcpyDeviceToHost));
+        // one transfer of the whole output region, then the pieces are closed up on the host
+        uint8_t *raw = (uint8_t *)malloc(opos + 64);
+        if (!raw) return -4;
+        hipError_t he = hipMemcpy(raw, (uint8_t *)d_data.p + out_base, opos, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) {
+            free(raw);
+            return fail("hipMemcpy (primed streams)", he);
+        }
+        uint64_t packed = 0;
+        for (uint32_t u = 0; u < nu; u++) packed += h_len[u];
+        uint8_t *host_out = (uint8_t *)malloc(packed + 64);
+        if (!host_out) {
+            free(raw);
+            return -4;
+        }
+        uint64_t w = 0;
+        int64_t seg_at = (int64_t)fresh.seg_crc.size(), seg_i = 0;
+        for (uint32_t e = 0; e < gn; e++) {
+            const uint32_t i = ids[g0 + e], l = len[i];
+            const uint32_t nseg = (l + kSeg - 1) / kSeg;
+            bool ok = true;
+            uint32_t crc = 0;
+            const uint64_t w0 = w;
+            for (uint32_t u = first_unit[e]; u < first_unit[e + 1]; u++) {
+                if (h_st[u] != 0 || h_len[u] > out_cap[u]) ok = false;
+                if (!ok) break;
+                memcpy(host_out + w, raw + (out_off[u] - out_base), h_len[u]);
+                w += h_len[u];
+                crc = (u == first_unit[e]) ? h_crc[u] : mzhip_crc32_combine_host(crc, h_crc[u], in_len[u]);
+            }
+            if (ok) {
+                WPrimed pe;
+                pe.src = blob + off[i];
+                pe.len = l;
+                pe.out_off = w0;
+                pe.out_len = (uint32_t)(w - w0);
+                pe.crc = crc;
+                pe.seg0 = seg_at + seg_i;
+                // out_off is relative to this group's buffer: remember which one through the pointer table
+                pe.out_off |= (uint64_t)fresh.outs.size() << 48;
+                fresh.by_key.emplace(wprime_key(pe.src, l < kSeg ? l : kSeg), (uint32_t)fresh.ents.size());
+                fresh.ents.push_back(pe);
+            } else {
+                w = w0; /* not cached: the ordinary path and its exact behaviour */
+            }
+            seg_i += nseg;
+        }
+        fresh.seg_crc.insert(fresh.seg_crc.end(), h_seg.begin(), h_seg.end());
+        fresh.outs.push_back(host_out);
+        free(raw);
+        g0 = g1;
+    }
+    std::lock_guard<std::mutex> lk(g_wprime_mu);
+    wprime_clear_locked(g_wprime[slot]);
+    g_wprime[slot] = std::move(fresh);
+    return (int64_t)g_wprime[slot].ents.size();
+}
+
+// Used by the WRITE shims.  *id < 0: does a primed buffer start with these `size` bytes?  *id >= 0: do the bytes at
+// `pos` of that buffer continue with them?  Returns 1 on a match; *have_crc says whether the chunk is one of the
+// buffer's 65 535-byte segments, whose CRC-32 the device already computed.
+__attribute__((visibility("hidden"))) int32_t mzhip_wprime_track(int32_t method, int64_t *id, int64_t pos, const uint8_t *buf,
+                                                                 int32_t size, uint32_t *chunk_crc, int32_t *have_crc) {
+    const int slot = wprime_slot(method);
+    *have_crc = 0;
+    if (slot < 0 || size <= 0) return 0;
+    std::lock_guard<std::mutex> lk(g_wprime_mu);
+    WPrimeCache &w = g_wprime[slot];
+    if (w.ents.empty()) return 0;
+    const WPrimed *e = nullptr;
+    if (*id < 0) {
+        if (pos != 0 || size < 16) return 0;
+        auto range = w.by_key.equal_range(wprime_key(buf, (uint32_t)size));
+        for (auto it = range.first; it != range.second; ++it) {
+            const WPrimed &c = w.ents[it->second];
+            const uint32_t first = c.len < kSeg ? c.len : kSeg;
+            if (first == (uint32_t)size && memcmp(c.src, buf, (size_t)size) == 0) {
+                *id = (int64_t)it->second;
+                e = &c;
+                break;
+            }
+        }
+        if (!e) {
+            w.misses++;
+            return 0;
+        }
+    } else {
+        if ((uint64_t)*id >= w.ents.size()) return 0;
+        e = &w.ents[(size_t)*id];
+        if (pos + size > (int64_t)e->len || memcmp(e->src + pos, buf, (size_t)size) != 0) return 0;
+    }
+    if (pos % kSeg == 0 && ((uint32_t)size == kSeg || pos + size == (int64_t)e->len)) {
+        *chunk_crc = w.seg_crc[(size_t)(e->seg0 + pos / kSeg)];
+        *have_crc = 1;
+    }
+    return 1;
+}
+
+// The primed buffer behind `id`: its bytes (for a stream that diverged and must fall back), and -- when the entry
+// ended exactly at the buffer's end (pos == len) -- the cached stream.  Returns 1 if the stream may be emitted.
+__attribute__((visibility("hidden"))) int32_t mzhip_wprime_result(int32_t method, int64_t id, int64_t pos, const uint8_t **src,
+                                                                  const uint8_t **out, uint32_t *out_len) {
+    const int slot = wprime_slot(method);
+    if (slot < 0) return 0;
+    std::lock_guard<std::mutex> lk(g_wprime_mu);
+    WPrimeCache &w = g_wprime[slot];
+    if (id < 0 || (uint64_t)id >= w.ents.size()) return 0;
+    const WPrimed &e = w.ents[(size_t)id];
+    *src = e.src;
+    if (pos != (int64_t)e.len) return 0;
+    *out = w.outs[(size_t)(e.out_off >> 48)] + (e.out_off & (((uint64_t)1 << 48) - 1));
+    *out_len = e.out_len;
+    w.hits++;
+    return 1;
 }
 
 } // extern "C"

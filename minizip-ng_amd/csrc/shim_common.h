@@ -12,6 +12,11 @@ int32_t mzhip_prime_lookup2(int32_t method, int64_t payload_off, const uint8_t *
 /* MZHIP_AUTOPRIME: prime the archive behind a codec stream's base on first use (shim_autoprime.c); no-op otherwise */
 struct mzhip_stream_s;
 void mzhip_autoprime(struct mzhip_stream_s *codec_base);
+/* write-side prime (mzhip_prime_write): follow the bytes a WRITE stream is handed against the primed buffers */
+int32_t mzhip_wprime_track(int32_t method, int64_t *id, int64_t pos, const uint8_t *buf, int32_t size, uint32_t *chunk_crc,
+                           int32_t *have_crc);
+int32_t mzhip_wprime_result(int32_t method, int64_t id, int64_t pos, const uint8_t **src, const uint8_t **out,
+                            uint32_t *out_len);
 /* crc(A||B) from crc(A), crc(B), |B|: arithmetic on checksums, no data bytes involved */
 uint32_t mzhip_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 

@@ -44,6 +44,9 @@ typedef struct mzhip_lzma_s {
     int64_t in_len, in_cap;
     int8_t base_eof;
     int32_t base_err; /* base failed after data had arrived: reported only if the stream turns out to need more */
+    /* write side, mzhip_prime_write: the entry so far equals bytes [0, wp_pos) of primed buffer wp_id */
+    int64_t wp_id, wp_pos;
+    int8_t wp_off;
     uint8_t *out;
     int64_t out_len, out_cap, out_served;
     int8_t decoded;
@@ -101,6 +104,9 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->in_len = z->in_cap = z->out_len = z->out_cap = z->out_served = 0;
     z->base_eof = z->decoded = 0;
     z->base_err = 0;
+    z->wp_id = -1;
+    z->wp_pos = 0;
+    z->wp_off = 0;
     z->dev_status = 0;
     z->dev_in_used = 0;
     z->next_attempt = 0;
@@ -287,10 +293,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
 
 #define MZH_LZMA_WRITE_LIMIT ((int64_t)1 << 30) /* one stream = one launch: the entry is held in host memory */
 
-int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
-    mzhip_lzma *z = (mzhip_lzma *)stream;
-    if (size <= 0)
-        return size;
+static int32_t collect(mzhip_lzma *z, const void *buf, int64_t size) {
     if (z->wlen + size > MZH_LZMA_WRITE_LIMIT)
         return MZH_MEM_ERROR;
     if (z->wlen + size > z->wcap) {
@@ -305,6 +308,51 @@ int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
     }
     memcpy(z->wbuf + z->wlen, buf, (size_t)size);
     z->wlen += size;
+    return MZH_OK;
+}
+
+/* the entry stopped following its primed buffer (mzhip_prime_write): what it shared with it is collected after all */
+static int32_t leave_primed(mzhip_lzma *z) {
+    int32_t err = MZH_OK;
+    if (z->wp_id >= 0) {
+        const uint8_t *src = NULL, *out = NULL;
+        uint32_t out_len = 0;
+        (void)mzhip_wprime_result(z->method, z->wp_id, -1, &src, &out, &out_len);
+        if (!src)
+            return MZH_INTERNAL_ERROR; /* the cache was cleared under a stream that was following it */
+        err = collect(z, src, z->wp_pos);
+    }
+    z->wp_id = -1;
+    z->wp_off = 1;
+    return err;
+}
+
+int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
+    mzhip_lzma *z = (mzhip_lzma *)stream;
+    if (size <= 0)
+        return size;
+    if (!z->wp_off) {
+        uint32_t crc = 0;
+        int32_t have_crc = 0;
+        if ((z->wp_id >= 0 || z->total_in == 0) &&
+            mzhip_wprime_track(z->method, &z->wp_id, z->wp_pos, (const uint8_t *)buf, size, &crc, &have_crc) == 1) {
+            z->wp_pos += size;
+            z->total_in += size;
+            if (have_crc) { /* answers the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) */
+                mzhip_last_served.buf = buf;
+                mzhip_last_served.size = size;
+                mzhip_last_served.crc = crc;
+                mzhip_last_served.valid = 1;
+            }
+            return size;
+        }
+        int32_t err = leave_primed(z);
+        if (err != MZH_OK)
+            return err;
+    }
+    int32_t err = collect(z, buf, size);
+    if (err != MZH_OK)
+        return err;
     z->total_in += size; /* mz_strm_lzma.c:322 */
     return size;
 }
@@ -321,6 +369,25 @@ static int32_t base_write(mzhip_stream *base, const void *buf, int32_t size) {
 
 /* code everything collected and hand it to base in staging-sized writes (mz_strm_lzma.c:244-248) */
 static int32_t finish_write(mzhip_lzma *z) {
+    if (z->wp_id >= 0) {
+        const uint8_t *src = NULL, *pout = NULL;
+        uint32_t pout_len = 0;
+        if (mzhip_wprime_result(z->method, z->wp_id, z->wp_pos, &src, &pout, &pout_len) == 1) {
+            /* the entry is exactly a primed buffer: its stream was coded in the batch */
+            z->wp_id = -1;
+            uint32_t pos = 0;
+            while (pos < pout_len) {
+                int32_t n = (int32_t)(pout_len - pos < MZH_STAGING_BYTES ? pout_len - pos : MZH_STAGING_BYTES);
+                if (base_write(z->stream.base, pout + pos, n) != n)
+                    return MZH_WRITE_ERROR;
+                pos += (uint32_t)n;
+            }
+            z->total_out += pout_len;
+            return MZH_OK;
+        }
+        if (leave_primed(z) != MZH_OK) /* a proper prefix of a primed buffer */
+            return MZH_MEM_ERROR;
+    }
     uint32_t cap = (uint32_t)(z->wlen + z->wlen / 8 + 4096 + (z->wlen / 49152 + 1) * 8);
     uint8_t *out = (uint8_t *)malloc(cap);
     if (!out)

@@ -64,6 +64,9 @@ typedef struct mzhip_zlib_s {
     int32_t dev_status;
     int64_t dev_in_used;
     int64_t next_attempt; /* try the device again once in_len reaches this */
+    /* write side, mzhip_prime_write: the entry so far equals bytes [0, wp_pos) of primed buffer wp_id */
+    int64_t wp_id, wp_pos;
+    int8_t wp_off; /* this entry is not (or no longer) following a primed buffer */
     int8_t tried_cache, out_borrowed; /* prime cache: looked up once; out points into the cache */
     int64_t base_pos0;                /* base position at the first read = payload offset */
     const uint32_t *seg_crc;          /* GPU CRCs of the 65 535-byte segments of a primed entry */
@@ -113,6 +116,9 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     free_buffers(z);
     z->base_eof = 0;
     z->base_err = 0;
+    z->wp_id = -1;
+    z->wp_pos = 0;
+    z->wp_off = 0;
     z->decoded = 0;
     z->dev_status = 0;
     z->dev_in_used = 0;
@@ -511,10 +517,8 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
 
 #define MZH_WRITE_SEGMENT (8 << 20) /* bytes collected per device launch (128 pieces of 64 KiB) */
 
-int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
-    mzhip_zlib *z = (mzhip_zlib *)stream;
-    const uint8_t *p = (const uint8_t *)buf;
-    int32_t left = size;
+/* bytes into the segment buffer, launching whenever it is full */
+static int32_t collect(mzhip_zlib *z, const uint8_t *p, int64_t left) {
     while (left > 0) {
         if (z->wcap == 0) {
             z->wbuf = (uint8_t *)malloc(MZH_WRITE_SEGMENT);
@@ -523,7 +527,7 @@ int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
             z->wcap = MZH_WRITE_SEGMENT;
         }
         int64_t room = z->wcap - z->wlen;
-        int32_t n = (int32_t)(left < room ? left : room);
+        int64_t n = left < room ? left : room;
         memcpy(z->wbuf + z->wlen, p, (size_t)n);
         z->wlen += n;
         p += n;
@@ -534,6 +538,50 @@ int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
                 return err;
         }
     }
+    return MZH_OK;
+}
+
+/* the entry stopped following its primed buffer: what it shared with it goes down the ordinary path */
+static int32_t leave_primed(mzhip_zlib *z) {
+    int32_t err = MZH_OK;
+    if (z->wp_id >= 0) {
+        const uint8_t *src = NULL, *out = NULL;
+        uint32_t out_len = 0;
+        (void)mzhip_wprime_result(8, z->wp_id, -1, &src, &out, &out_len);
+        if (!src)
+            return MZH_INTERNAL_ERROR; /* the cache was cleared under a stream that was following it */
+        err = collect(z, src, z->wp_pos);
+    }
+    z->wp_id = -1;
+    z->wp_off = 1;
+    return err;
+}
+
+int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
+    mzhip_zlib *z = (mzhip_zlib *)stream;
+    if (size > 0 && z->wrap == 0 && !z->wp_off) {
+        /* mzhip_prime_write: is this entry, so far, one of the buffers that were compressed ahead of time? */
+        uint32_t crc = 0;
+        int32_t have_crc = 0;
+        if ((z->wp_id >= 0 || z->total_in == 0) &&
+            mzhip_wprime_track(8, &z->wp_id, z->wp_pos, (const uint8_t *)buf, size, &crc, &have_crc) == 1) {
+            z->wp_pos += size;
+            z->total_in += size;
+            if (have_crc) { /* the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) is answered from the cache */
+                mzhip_last_served.buf = buf;
+                mzhip_last_served.size = size;
+                mzhip_last_served.crc = crc;
+                mzhip_last_served.valid = 1;
+            }
+            return size;
+        }
+        int32_t err = leave_primed(z);
+        if (err != MZH_OK)
+            return err;
+    }
+    int32_t err = collect(z, (const uint8_t *)buf, size);
+    if (err != MZH_OK)
+        return err;
     z->total_in += size; /* mz_strm_zlib.c:261 */
     return size;
 }
@@ -552,8 +600,18 @@ int32_t mz_stream_zlib_seek(void *stream, int64_t offset, int32_t origin) {
 
 int32_t mz_stream_zlib_close(void *stream) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
-    if (z->mode & MZH_OPEN_MODE_WRITE)
-        flush_segment(z, 1); /* deflate(Z_FINISH) + flush, return value ignored like mz_strm_zlib.c:287-288 */
+    if (z->mode & MZH_OPEN_MODE_WRITE) {
+        const uint8_t *src = NULL, *out = NULL;
+        uint32_t out_len = 0;
+        if (z->wp_id >= 0 && mzhip_wprime_result(8, z->wp_id, z->wp_pos, &src, &out, &out_len) == 1) {
+            push_to_base(z, out, out_len); /* the entry is exactly a primed buffer: its stream was coded in the batch */
+        } else {
+            if (z->wp_id >= 0)
+                leave_primed(z); /* a proper prefix of a primed buffer */
+            flush_segment(z, 1); /* deflate(Z_FINISH) + flush, return value ignored like mz_strm_zlib.c:287-288 */
+        }
+        z->wp_id = -1;
+    }
     z->initialized = 0;
     free(z->in);
     if (!z->out_borrowed)
