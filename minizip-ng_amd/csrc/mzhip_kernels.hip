@@ -379,7 +379,7 @@ struct DeviceCtx {
         hipEvent_t ev = nullptr;    // recorded behind the last launch that used the buffer
         hipStream_t last = nullptr; // ... on this stream
         bool used = false, held = false;
-    } scratch[8]; // per-launch scratch (K4 / K6 tokens), see scratch_acquire()
+    } scratch[32]; // per-launch scratch (K4 / K6 tokens) and the host-buffer calls' staging, see scratch_acquire()
     uint32_t *d_counters = nullptr;
     uint32_t next_counter = 0;
     int cu_count = 0;
@@ -797,6 +797,20 @@ struct Scratch {
         if (p) (void)hipFree(p);
     }
 };
+// Staging of the synchronous host-buffer calls: a buffer of the scratch cache instead of a hipMalloc / hipFree pair
+// per call (hipFree alone is a device-wide synchronisation); released when the call returns, after its own sync.
+struct Staging {
+    DeviceCtx *c = nullptr;
+    int slot = -1;
+    void *p = nullptr;
+    int32_t get(DeviceCtx *ctx, size_t bytes) {
+        c = ctx;
+        return scratch_acquire(ctx, bytes, nullptr, &slot, &p);
+    }
+    ~Staging() {
+        if (slot >= 0) (void)scratch_release(c, slot, nullptr);
+    }
+};
 } // namespace
 
 int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
@@ -807,8 +821,9 @@ int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, ui
     // layout: [meta 64 B][in (16-aligned)][out]
     const size_t in_pad = ((size_t)in_len + 15) & ~(size_t)15;
     const size_t total = 64 + in_pad + out_cap + 16;
-    Scratch sc;
-    HIP_TRY(hipMalloc(&sc.p, total));
+    Staging sc;
+    rc = sc.get(c, total);
+    if (rc) return rc;
     uint8_t *base = (uint8_t *)sc.p;
     struct Meta {
         uint64_t in_off, out_off;
@@ -855,8 +870,9 @@ static int32_t lzma_family_host(int xz, const uint8_t *in, uint32_t in_len, uint
     if (rc) return rc;
     const size_t in_pad = ((size_t)in_len + 15) & ~(size_t)15;
     const size_t total = 64 + in_pad + out_cap + 16;
-    Scratch sc;
-    HIP_TRY(hipMalloc(&sc.p, total));
+    Staging sc;
+    rc = sc.get(c, total);
+    if (rc) return rc;
     uint8_t *base = (uint8_t *)sc.p;
     struct Meta {
         uint64_t in_off, out_off;
@@ -903,8 +919,9 @@ int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out,
     if (rc) return rc;
     const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
     const uint32_t cap = in_len + in_len / 8 + 1024;
-    Scratch sc;
-    HIP_TRY(hipMalloc(&sc.p, 64 + in_pad + cap));
+    Staging sc;
+    rc = sc.get(c, 64 + in_pad + cap);
+    if (rc) return rc;
     uint8_t *base = (uint8_t *)sc.p;
     struct Meta {
         uint64_t in_off, out_off;
@@ -945,8 +962,9 @@ int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     const size_t meta = (size_t)np * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 1) + 64;
     const size_t meta_pad = (meta + 63) & ~(size_t)63;
     const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
-    Scratch sc;
-    HIP_TRY(hipMalloc(&sc.p, meta_pad + in_pad + (size_t)np * pcap + 64));
+    Staging sc;
+    rc = sc.get(c, meta_pad + in_pad + (size_t)np * pcap + 64);
+    if (rc) return rc;
     uint8_t *base = (uint8_t *)sc.p;
     std::vector<uint8_t> hm(meta_pad, 0);
     uint64_t *h_in_off = (uint64_t *)hm.data(), *h_out_off = h_in_off + np;
@@ -1055,8 +1073,9 @@ int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, 
     const size_t meta = (size_t)np * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4 + 1);
     const size_t meta_pad = (meta + 63) & ~(size_t)63;
     const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
-    Scratch sc;
-    HIP_TRY(hipMalloc(&sc.p, meta_pad + in_pad + (size_t)np * pcap));
+    Staging sc;
+    rc = sc.get(c, meta_pad + in_pad + (size_t)np * pcap);
+    if (rc) return rc;
     uint8_t *base = (uint8_t *)sc.p;
     uint8_t *hm = (uint8_t *)calloc(1, meta_pad);
     if (!hm) return -4;
@@ -1133,9 +1152,9 @@ uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
     const uint32_t nseg = (uint32_t)((size + seg - 1) / seg);
     const size_t meta = (size_t)nseg * (8 + 4 + 4);
     const size_t meta_pad = (meta + 63) & ~(size_t)63;
-    Scratch sc;
-    if (hipMalloc(&sc.p, meta_pad + size) != hipSuccess) {
-        fprintf(stderr, "mzhip: hipMalloc failed in mz_crypt_crc32_update\n");
+    Staging sc;
+    if (sc.get(c, meta_pad + size) != 0) {
+        fprintf(stderr, "mzhip: device allocation failed in mz_crypt_crc32_update (%s)\n", g_err);
         abort();
     }
     uint8_t *base = (uint8_t *)sc.p;
