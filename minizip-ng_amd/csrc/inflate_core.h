@@ -57,6 +57,12 @@ extern unsigned long long mz_stats[16];
 #define MZ_DROOT 8 /* distance fast-table index bits        */
 #endif
 #define MZ_CROOT 7 /* code-length-code table bits (== max)  */
+#ifndef MZ_SPAN_DW
+#define MZ_SPAN_DW 8 /* span-parallel decode (see mz_span_token): dwords of compressed stream per lane, 0 = off */
+#endif
+#define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
+#define MZ_SPAN_TOK_CAP 4096u        /* tokens one window may hand over (global scratch per wave, 16 KiB) */
+#define MZ_SPAN_MAX_PASS 6u
 #ifndef MZ_MLANES_LOG2
 #define MZ_MLANES_LOG2 3 /* lanes that copy one match together in the flush: 2^3 = 8, so 8 matches per round */
 #endif
@@ -130,6 +136,9 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
     uint32_t ring[130]; /* 512 B of compressed stream: aligned dword j of the entry at ring[j & 127]; entries 128, 129
                            mirror 0, 1 so that a window read is one address plus constant offsets */
     uint16_t mslot[64]; /* 4 * lane id of this step's match tokens, compacted */
+#if MZ_SPAN_DW
+    uint32_t win[65 * MZ_SPAN_RS]; /* span path: the window's dword d at win[(d / MZ_SPAN_DW) * MZ_SPAN_RS + d % MZ_SPAN_DW] */
+#endif
 } mz_inflate_body_scratch;
 
 typedef struct mz_inflate_lds {
@@ -405,10 +414,156 @@ static const uint8_t mz_k_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 __device__ static const uint8_t mz_k_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 #endif
 
+
+#if MZ_SPAN_DW
+/* Span-parallel decode.  A DEFLATE token walk started at an arbitrary bit falls in step with the true token
+ * sequence after 8.5 tokens on average (text at zlib level 6: 88 % of the walks within 256 bits, 98 % within 512,
+ * profiles/r1/side_measurements.log), so instead of decoding 64 candidate offsets of ONE 64-bit window per step the
+ * wave gives every lane its own span of 32 * MZ_SPAN_DW bits and lets all lanes walk token by token:
+ *   pass 1    lane i walks from the first bit of span i until it crosses into span i + 1 (lane 0 starts at the true
+ *             cursor);
+ *   pass 2..  lane i restarts from where lane i - 1 crossed; when no start moves any more the walks are the true parse;
+ *   emit      one more walk writes the tokens (same format as the step loop's) to a per-wave scratch in stream order,
+ *             and the shared flush consumes them 64 at a time.
+ * Every lane does useful work in the final walks, where the step loop keeps ~5 of 64 candidates.  Anything unusual
+ * -- an invalid code on the true path, the end of the input closer than a span -- stays with the step loop, which
+ * owns the exact error verdicts: the span path only ever commits a prefix of verified tokens.
+ *
+ * One token at window-relative bit `rel`: the same table walk as phase 1 of the step loop. */
+MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *win, uint32_t rel) {
+    const uint32_t d = rel >> 5;
+    const uint32_t a = (d / MZ_SPAN_DW) * MZ_SPAN_RS + (d % MZ_SPAN_DW);
+    const uint32_t d0 = win[a], d1 = win[a + 1u], d2 = win[a + 2u];
+    const uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
+    uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
+    if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
+    if (!(e & MZ_E_LEN)) return e; /* literal, end of block, or an invalid code (0 bits) */
+    const uint32_t nb = e & 63u, ex = mz_bfe(e, 16, 4);
+    const uint32_t lenl = mz_bfe(e, 7, 9) + mz_bfe(mz_funnel(w1, w0, nb), 0, ex);
+    const uint32_t nb2 = nb + ex;
+    const uint32_t dl = mz_funnel(w1, w0, nb2);
+    uint32_t dd = L->dist_fast[dl & ((1u << MZ_DROOT) - 1u)];
+    if (dd == 0u) dd = mz_long_code(dl, MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
+    if ((int32_t)dd <= 0) return 0u; /* unused / 30 / 31 distance code */
+    const uint32_t dn = dd & 15u, dex = mz_bfe(dd, 4, 4);
+    const uint32_t dist = mz_bfe(dd, 8, 15) + mz_bfe(dl, dn, dex);
+    return (nb2 + dn + dex) | (lenl << 7) | (dist << 16);
+}
+#endif
+
+/* Flush of the token queue tq (qn tokens, lane i = i-th token): shared by the step loop and the span path. */
+#define MZ_FLUSH_QUEUE()                                                                                                              \
+    do {                                                                                                                              \
+            /* phase 4 (flush): queued tokens -> output offsets by a wave prefix sum; literals scatter in                             \
+             * one store */                                                                                                           \
+            PV(uint32_t, olen);                                                                                                       \
+            PV(uint32_t, oend);                                                                                                       \
+            MZ_LANES {                                                                                                                \
+                if ((uint32_t)lane >= qn) P(tq) = 0u;                                                                                 \
+                P(olen) = mz_bfe(P(tq), 7, 9);                                                                                        \
+            }                                                                                                                         \
+            MZ_STAT(4, qn);                                                                                                           \
+            MZ_STAT(6, 1);                                                                                                            \
+            qn = 0;                                                                                                                   \
+            MZ_INCL_SCAN(oend, olen);                                                                                                 \
+            const uint32_t total = MZ_READLANE(oend, 63);                                                                             \
+            if (total > out_cap - out_pos) {                                                                                          \
+                /* which comes first in stream order: the token that does not fit, or a match that reaches before the                 \
+                 * start of the entry (inflate checks the distance before it copies)? */                                              \
+                uint64_t over_m, far_m;                                                                                               \
+                MZ_BALLOT(over_m, P(oend) > out_cap - out_pos);                                                                       \
+                MZ_BALLOT(far_m, P(olen) > 1u && (P(tq) >> 16) > out_pos + P(oend) - P(olen));                                        \
+                const uint32_t fo = mz_ctz64(over_m);                                                                                 \
+                status = (far_m & ((fo >= 63u) ? ~0ull : ((2ull << fo) - 1ull))) ? MZHIP_DATA_ERROR : MZHIP_OUT_FULL;                 \
+                goto finish;                                                                                                          \
+            }                                                                                                                         \
+            uint64_t matm;                                                                                                            \
+            MZ_BALLOT(matm, P(olen) > 1u);                                                                                            \
+            MZ_LANES {                                                                                                                \
+                if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tq) >> 16);                                              \
+            }                                                                                                                         \
+            MZ_WAVE_SYNC();                                                                                                           \
+                                                                                                                                      \
+            /* LZ77 back-references, in stream order.  Eight matches at a time, 8 lanes each (one gather of                           \
+             * the match descriptors, one load, one store) as long as every source of the group ends at or                            \
+             * before the group's first destination byte -- everything earlier is complete: all literals of                           \
+             * the queue, every earlier match.  The first match of a group that reads inside the group (or                            \
+             * overlaps itself, or reaches before the entry) goes through the in-order cooperative path. */                           \
+            if (matm) {                                                                                                               \
+                const uint32_t nmatch = mz_popc64(matm);                                                                              \
+                uint32_t done_m = 0;                                                                                                  \
+                MZ_LANES {                                                                                                            \
+                    if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);                 \
+                }                                                                                                                     \
+                MZ_WAVE_SYNC();                                                                                                       \
+                MZ_STAT(0, 1); MZ_STAT(1, nmatch);                                                                                    \
+                while (done_m < nmatch) {                                                                                             \
+                    MZ_STAT(2, 1);                                                                                                    \
+                    PV(uint32_t, msrc);                                                                                               \
+                    PV(uint32_t, mtk);                                                                                                \
+                    PV(uint32_t, mend);                                                                                               \
+                    MZ_LANES {                                                                                                        \
+                        const uint32_t g = done_m + ((uint32_t)lane >> MZ_MLANES_LOG2);                                               \
+                        P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 256u;                                                    \
+                    }                                                                                                                 \
+                    MZ_GATHER4(mtk, tq, P(msrc));                                                                                     \
+                    MZ_GATHER4(mend, oend, P(msrc));                                                                                  \
+                    MZ_LANES {                                                                                                        \
+                        if (P(msrc) >= 256u) { P(mtk) = 0; P(mend) = 0; }                                                             \
+                    }                                                                                                                 \
+                    /* group start = destination offset of its first match (lanes 0..15 hold it) */                                   \
+                    const uint32_t gs = MZ_READLANE(mend, 0) - mz_bfe(MZ_READLANE(mtk, 0), 7, 9);                                     \
+                    uint64_t dep;                                                                                                     \
+                    MZ_BALLOT(dep, P(mend) > (P(mtk) >> 16) + gs ||                                                                   \
+                                       (P(mtk) >> 16) > out_pos + P(mend) - mz_bfe(P(mtk), 7, 9));                                    \
+                    /* matches of the group before the first dependent one */                                                         \
+                    const uint32_t nind = dep ? (mz_ctz64(dep) >> MZ_MLANES_LOG2) : (64u >> MZ_MLANES_LOG2);                          \
+                    if (nind) {                                                                                                       \
+                        MZ_LANES {                                                                                                    \
+                            if (P(msrc) < 256u && ((uint32_t)lane >> MZ_MLANES_LOG2) < nind) {                                        \
+                                const uint32_t ln = mz_bfe(P(mtk), 7, 9), dist = P(mtk) >> 16;                                        \
+                                const uint32_t dst = out_pos + P(mend) - ln;                                                          \
+                                for (uint32_t i = (uint32_t)lane & ((1u << MZ_MLANES_LOG2) - 1u); i < ln; i += 1u << MZ_MLANES_LOG2)  \
+                                    out[dst + i] = out[dst - dist + i];                                                               \
+                            }                                                                                                         \
+                        }                                                                                                             \
+                        MZ_WAVE_SYNC();                                                                                               \
+                        done_m += nind;                                                                                               \
+                    }                                                                                                                 \
+                    if (dep && done_m < nmatch) {                                                                                     \
+                        MZ_STAT(3, 1);                                                                                                \
+                        /* in-order cooperative copy of the dependent match (64 bytes per instruction) */                             \
+                        const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]) >> 2;                                                    \
+                        const uint32_t t = MZ_READLANE(tq, tl);                                                                       \
+                        const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;                                                          \
+                        const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;                                                    \
+                        if (dist > dst) {                                                                                             \
+                            status = MZHIP_DATA_ERROR; /* invalid distance too far back */                                            \
+                            goto finish;                                                                                              \
+                        }                                                                                                             \
+                        const uint8_t *src = out + (dst - dist);                                                                      \
+                        if (dist >= ln) {                                                                                             \
+                            MZ_LANES {                                                                                                \
+                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i];                            \
+                            }                                                                                                         \
+                        } else { /* overlapping run: byte i repeats with period dist */                                               \
+                            MZ_LANES {                                                                                                \
+                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i % dist];                     \
+                            }                                                                                                         \
+                        }                                                                                                             \
+                        MZ_WAVE_SYNC();                                                                                               \
+                        done_m++;                                                                                                     \
+                    }                                                                                                                 \
+                }                                                                                                                     \
+            }                                                                                                                         \
+            out_pos += total;                                                                                                         \
+            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);                                                    \
+    } while (0)
+
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                             mz_inflate_result *res) {
+                             uint32_t *tokbuf, mz_inflate_result *res) {
     MZ_LANE_DECL
     const uint32_t total_bits = in_len * 8u; /* in_len < 2^28, checked below */
     const uint32_t in_mis = (uint32_t)((uintptr_t)in & 3u);
@@ -610,27 +765,148 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
         {
             uint32_t *ring = L->u.b.ring;
             const uint32_t pbase = 8u * in_mis; /* bit offset of `in` inside its aligned dword */
-            uint32_t ring_hi;                   /* blocks < ring_hi are in the ring; block ring_hi is in wpre */
+            uint32_t ring_hi = 0;               /* blocks < ring_hi are in the ring; block ring_hi is in wpre */
+            uint32_t ring_valid = 0;            /* the ring is (re)loaded on entry to the step loop: the span path moves the cursor */
             PV(uint32_t, wpre);
-            {
-                const uint32_t blk = (bitpos + pbase) >> 11; /* 2048 bits per block */
-                MZ_LANES {
-                    const uint32_t da = mz_load_stream_dword(in_al, in_mis, in_len, blk * 64u + (uint32_t)lane);
-                    const uint32_t db = mz_load_stream_dword(in_al, in_mis, in_len, (blk + 1u) * 64u + (uint32_t)lane);
-                    ring[((blk & 1u) << 6) + (uint32_t)lane] = da;
-                    ring[(((blk + 1u) & 1u) << 6) + (uint32_t)lane] = db;
-                    if (lane < 2) ring[128 + lane] = (blk & 1u) ? db : da; /* mirror of ring[0], ring[1] */
-                    P(wpre) = mz_load_stream_dword(in_al, in_mis, in_len, (blk + 2u) * 64u + (uint32_t)lane);
-                }
-                ring_hi = blk + 2u;
-                MZ_WAVE_SYNC();
-            }
 
             PV(uint32_t, tq); /* token queue: lane i = i-th pending token of this flush interval */
             uint32_t qn = 0;
             MZ_LANES { P(tq) = 0u; }
 
+#if MZ_SPAN_DW
+            uint32_t span_skip = 0;
+#endif
             for (;;) {
+#if MZ_SPAN_DW
+                {
+                    const uint32_t S = 32u * MZ_SPAN_DW;
+                    const uint32_t remain = total_bits - bitpos;
+                    /* lanes whose every token lies inside the input (a token is at most 48 bits) */
+                    uint32_t nact = (remain > 64u) ? (remain - 64u) / S : 0u;
+                    if (nact > 64u) nact = 64u;
+                    if (tokbuf && qn == 0u && !span_skip && nact >= 2u) {
+                        uint32_t *win = L->u.b.win;
+                        const uint32_t wpos = bitpos + pbase;
+                        const uint32_t wb = wpos >> 5, woff = wpos & 31u;
+                        const uint32_t ndw = MZ_SPAN_DW * nact + 3u;
+                        MZ_LANES {
+                            for (uint32_t d = (uint32_t)lane; d < ndw; d += 64u) {
+                                const uint32_t v = mz_load_stream_dword(in_al, in_mis, in_len, wb + d);
+                                const uint32_t row = d / MZ_SPAN_DW, k = d % MZ_SPAN_DW;
+                                win[row * MZ_SPAN_RS + k] = v;
+                                if (k < 2u && row > 0u) win[(row - 1u) * MZ_SPAN_RS + MZ_SPAN_DW + k] = v;
+                            }
+                        }
+                        MZ_WAVE_SYNC();
+                        PV(uint32_t, sst); /* where this lane's walk starts (window-relative bit) */
+                        PV(uint32_t, sxe); /* where it crossed into the next span */
+                        PV(uint32_t, scn); /* tokens it walked over */
+                        PV(uint32_t, sfl); /* 0 crossed, 1 stopped behind an end-of-block, 2 stopped at an invalid code */
+                        PV(uint32_t, pxe);
+                        PV(uint32_t, pfl);
+                        MZ_LANES { P(sst) = woff + (uint32_t)lane * S; }
+                        uint32_t pass = 0;
+                        uint64_t moved;
+                        do {
+                            MZ_LANES {
+                                uint32_t q = P(sst), n = 0, f = 2;
+                                if ((uint32_t)lane < nact) {
+                                    const uint32_t lim = woff + ((uint32_t)lane + 1u) * S;
+                                    f = 0;
+                                    while (q < lim) {
+                                        const uint32_t t = mz_span_token(L, win, q);
+                                        const uint32_t nb = t & 63u;
+                                        if (nb == 0u) {
+                                            f = 2;
+                                            break;
+                                        }
+                                        n++;
+                                        q += nb;
+                                        if (t & 64u) {
+                                            f = 1;
+                                            break;
+                                        }
+                                    }
+                                }
+                                P(sxe) = q;
+                                P(scn) = n;
+                                P(sfl) = f;
+                            }
+                            MZ_GATHER4(pxe, sxe, (4u * ((uint32_t)lane - 1u)) & 255u);
+                            MZ_GATHER4(pfl, sfl, (4u * ((uint32_t)lane - 1u)) & 255u);
+                            MZ_BALLOT(moved, lane > 0 && (uint32_t)lane < nact && P(pfl) == 0u && P(pxe) != P(sst));
+                            MZ_LANES {
+                                if (lane > 0 && (uint32_t)lane < nact && P(pfl) == 0u) P(sst) = P(pxe);
+                            }
+                            pass++;
+                        } while (moved && pass < MZ_SPAN_MAX_PASS);
+                        /* verified prefix: lane i's walk is the true parse iff every lane before it crossed cleanly
+                         * and handed it the start it actually used in the last pass */
+                        uint64_t brk;
+                        MZ_BALLOT(brk, lane > 0 && ((uint32_t)lane >= nact || P(pfl) != 0u || ((moved >> lane) & 1ull)));
+                        uint32_t m = brk ? mz_ctz64(brk) : 64u;
+                        PV(uint32_t, sin);
+                        PV(uint32_t, scm);
+                        MZ_LANES { P(scm) = ((uint32_t)lane < m) ? P(scn) : 0u; }
+                        MZ_INCL_SCAN(sin, scm);
+                        {
+                            uint64_t fit;
+                            MZ_BALLOT(fit, (uint32_t)lane < m && P(sin) <= MZ_SPAN_TOK_CAP);
+                            m = mz_popc64(fit); /* the scan is monotone: the lanes that fit are a prefix */
+                        }
+                        const uint32_t T = m ? MZ_READLANE(sin, m - 1u) : 0u;
+                        MZ_STAT(8, 1); MZ_STAT(9, pass); MZ_STAT(10, T); MZ_STAT(11, m);
+                        if (T == 0u) {
+                            span_skip = 1; /* the very first token is the problem: the step loop has the verdict */
+                        } else {
+                            MZ_LANES {
+                                if ((uint32_t)lane < m) {
+                                    uint32_t q = P(sst), n = P(sin) - P(scn);
+                                    const uint32_t lim = woff + ((uint32_t)lane + 1u) * S;
+                                    while (q < lim) {
+                                        const uint32_t t = mz_span_token(L, win, q);
+                                        const uint32_t nb = t & 63u;
+                                        if (nb == 0u) break;
+                                        tokbuf[n++] = t;
+                                        q += nb;
+                                        if (t & 64u) break;
+                                    }
+                                }
+                            }
+                            MZ_WAVE_SYNC();
+                            const uint32_t endrel = MZ_READLANE(sxe, m - 1u);
+                            const uint32_t span_eob = (MZ_READLANE(sfl, m - 1u) == 1u) ? 1u : 0u;
+                            bitpos += endrel - woff;
+                            ring_valid = 0;
+                            for (uint32_t j = 0; j < T; j += 64u) {
+                                const uint32_t c = (T - j < 64u) ? (T - j) : 64u;
+                                MZ_LANES { P(tq) = ((uint32_t)lane < c) ? tokbuf[j + (uint32_t)lane] : 0u; }
+                                qn = c;
+                                MZ_FLUSH_QUEUE();
+                            }
+                            MZ_WAVE_SYNC(); /* the scratch is rewritten by the next window */
+                            if (span_eob) break;
+                            if (MZ_READLANE(sfl, m - 1u) == 2u) span_skip = 1; /* an invalid code is next */
+                            continue;
+                        }
+                    }
+                    span_skip = 0;
+                }
+#endif
+                if (!ring_valid) {
+                    const uint32_t blk = (bitpos + pbase) >> 11; /* 2048 bits per block */
+                    MZ_LANES {
+                        const uint32_t da = mz_load_stream_dword(in_al, in_mis, in_len, blk * 64u + (uint32_t)lane);
+                        const uint32_t db = mz_load_stream_dword(in_al, in_mis, in_len, (blk + 1u) * 64u + (uint32_t)lane);
+                        ring[((blk & 1u) << 6) + (uint32_t)lane] = da;
+                        ring[(((blk + 1u) & 1u) << 6) + (uint32_t)lane] = db;
+                        if (lane < 2) ring[128 + lane] = (blk & 1u) ? db : da; /* mirror of ring[0], ring[1] */
+                        P(wpre) = mz_load_stream_dword(in_al, in_mis, in_len, (blk + 2u) * 64u + (uint32_t)lane);
+                    }
+                    ring_hi = blk + 2u;
+                    ring_valid = 1;
+                    MZ_WAVE_SYNC();
+                }
                 const uint32_t pbit = bitpos + pbase;
                 if ((pbit >> 11) + 1u >= ring_hi) {
                     /* the cursor entered the newest block: retire the oldest, start the next fetch */
@@ -807,104 +1083,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
                 if (qn + 15u <= 64u && !eob && chain_err == MZHIP_OK) continue;
 
-                /* phase 4 (flush): queued tokens -> output offsets by a wave prefix sum; literals scatter in
-                 * one store */
-                PV(uint32_t, olen);
-                PV(uint32_t, oend);
-                MZ_LANES {
-                    if ((uint32_t)lane >= qn) P(tq) = 0u;
-                    P(olen) = mz_bfe(P(tq), 7, 9);
-                }
-                MZ_STAT(4, qn);
-                MZ_STAT(6, 1);
-                qn = 0;
-                MZ_INCL_SCAN(oend, olen);
-                const uint32_t total = MZ_READLANE(oend, 63);
-                if (total > out_cap - out_pos) {
-                    status = MZHIP_OUT_FULL;
-                    goto finish;
-                }
-                uint64_t matm;
-                MZ_BALLOT(matm, P(olen) > 1u);
-                MZ_LANES {
-                    if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tq) >> 16);
-                }
-                MZ_WAVE_SYNC();
-
-                /* LZ77 back-references, in stream order.  Eight matches at a time, 8 lanes each (one gather of
-                 * the match descriptors, one load, one store) as long as every source of the group ends at or
-                 * before the group's first destination byte -- everything earlier is complete: all literals of
-                 * the queue, every earlier match.  The first match of a group that reads inside the group (or
-                 * overlaps itself, or reaches before the entry) goes through the in-order cooperative path. */
-                if (matm) {
-                    const uint32_t nmatch = mz_popc64(matm);
-                    uint32_t done_m = 0;
-                    MZ_LANES {
-                        if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);
-                    }
-                    MZ_WAVE_SYNC();
-                    MZ_STAT(0, 1); MZ_STAT(1, nmatch);
-                    while (done_m < nmatch) {
-                        MZ_STAT(2, 1);
-                        PV(uint32_t, msrc);
-                        PV(uint32_t, mtk);
-                        PV(uint32_t, mend);
-                        MZ_LANES {
-                            const uint32_t g = done_m + ((uint32_t)lane >> MZ_MLANES_LOG2);
-                            P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 256u;
-                        }
-                        MZ_GATHER4(mtk, tq, P(msrc));
-                        MZ_GATHER4(mend, oend, P(msrc));
-                        MZ_LANES {
-                            if (P(msrc) >= 256u) { P(mtk) = 0; P(mend) = 0; }
-                        }
-                        /* group start = destination offset of its first match (lanes 0..15 hold it) */
-                        const uint32_t gs = MZ_READLANE(mend, 0) - mz_bfe(MZ_READLANE(mtk, 0), 7, 9);
-                        uint64_t dep;
-                        MZ_BALLOT(dep, P(mend) > (P(mtk) >> 16) + gs ||
-                                           (P(mtk) >> 16) > out_pos + P(mend) - mz_bfe(P(mtk), 7, 9));
-                        /* matches of the group before the first dependent one */
-                        const uint32_t nind = dep ? (mz_ctz64(dep) >> MZ_MLANES_LOG2) : (64u >> MZ_MLANES_LOG2);
-                        if (nind) {
-                            MZ_LANES {
-                                if (P(msrc) < 256u && ((uint32_t)lane >> MZ_MLANES_LOG2) < nind) {
-                                    const uint32_t ln = mz_bfe(P(mtk), 7, 9), dist = P(mtk) >> 16;
-                                    const uint32_t dst = out_pos + P(mend) - ln;
-                                    for (uint32_t i = (uint32_t)lane & ((1u << MZ_MLANES_LOG2) - 1u); i < ln; i += 1u << MZ_MLANES_LOG2)
-                                        out[dst + i] = out[dst - dist + i];
-                                }
-                            }
-                            MZ_WAVE_SYNC();
-                            done_m += nind;
-                        }
-                        if (dep && done_m < nmatch) {
-                            MZ_STAT(3, 1);
-                            /* in-order cooperative copy of the dependent match (64 bytes per instruction) */
-                            const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]) >> 2;
-                            const uint32_t t = MZ_READLANE(tq, tl);
-                            const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;
-                            const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;
-                            if (dist > dst) {
-                                status = MZHIP_DATA_ERROR; /* invalid distance too far back */
-                                goto finish;
-                            }
-                            const uint8_t *src = out + (dst - dist);
-                            if (dist >= ln) {
-                                MZ_LANES {
-                                    for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i];
-                                }
-                            } else { /* overlapping run: byte i repeats with period dist */
-                                MZ_LANES {
-                                    for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i % dist];
-                                }
-                            }
-                            MZ_WAVE_SYNC();
-                            done_m++;
-                        }
-                    }
-                }
-                out_pos += total;
-                MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);
+                MZ_FLUSH_QUEUE();
                 if (chain_err != MZHIP_OK) {
                     status = chain_err;
                     goto finish;

@@ -32,7 +32,7 @@
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
 #ifndef MZ_MIN_WAVES_PER_SIMD
-#define MZ_MIN_WAVES_PER_SIMD 8 /* register budget: 64 VGPRs -> 8 waves per SIMD, 32 per CU (matches the LDS budget: 8 workgroups) */
+#define MZ_MIN_WAVES_PER_SIMD 5 /* register budget: 96 VGPRs -> 5 waves per SIMD, 20 per CU (matches the LDS budget: 5 workgroups) */
 #endif
 
 struct InflateArgs {
@@ -49,6 +49,7 @@ struct InflateArgs {
     int32_t *status;
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
+    uint32_t *tok; // span path: MZ_SPAN_TOK_CAP tokens of scratch per resident wave (null = step loop only)
 };
 
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_batch(InflateArgs a) {
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
     MZ_LANE_DECL
     const int wave = threadIdx.x >> 6;
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
+    uint32_t *tokbuf = a.tok ? a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_SPAN_TOK_CAP : nullptr;
     for (;;) {
         uint32_t e;
         MZ_WAVE_FETCH_ADD(e, a.counter);
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
         const uint64_t io = a.in_off[e], oo = a.out_off[e];
         const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
-        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, &r);
+        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, tokbuf, &r);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -569,9 +571,22 @@ int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     a.tabs = c->d_tabs;
     HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE;
-    hipLaunchKernelGGL(k_inflate_batch, dim3(grid_for(c, n)), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const uint32_t grid = grid_for(c, n);
+    a.tok = nullptr;
+#if MZ_SPAN_DW
+    int slot = -1;
+    void *scratch = nullptr;
+    rc = scratch_acquire(c, (size_t)grid * MZ_WAVES_PER_WG * MZ_SPAN_TOK_CAP * sizeof(uint32_t), s, &slot, &scratch);
+    if (rc) return rc;
+    a.tok = (uint32_t *)scratch;
+#endif
+    hipLaunchKernelGGL(k_inflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+    const hipError_t le = hipGetLastError();
+#if MZ_SPAN_DW
+    rc = scratch_release(c, slot, s);
+#endif
+    if (le != hipSuccess) return fail("k_inflate_batch", le);
+    return rc;
 }
 
 int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,

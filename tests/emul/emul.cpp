@@ -8,7 +8,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* emul_inflate() runs the product configuration (span path on); emul_inflate_steps() the step loop alone */
 #include "inflate_core.h"
+#if defined(MZ_STATS)
+unsigned long long mz_stats[16];
+extern "C" unsigned long long *emul_stats() { return mz_stats; }
+#endif
 
 static mzhip_crc_tables g_tabs;
 static int g_ready;
@@ -26,7 +31,25 @@ extern "C" int32_t emul_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out
     mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_inflate_result r;
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, &r);
+    uint32_t *tok = (uint32_t *)malloc(MZ_SPAN_TOK_CAP * sizeof(uint32_t));
+    memset(tok, 0x5A, MZ_SPAN_TOK_CAP * sizeof(uint32_t));
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, tok, &r);
+    free(tok);
+    free(L);
+    *out_len = r.out_len;
+    *in_used = r.in_used;
+    *crc = r.crc;
+    return r.status;
+}
+
+/* the step loop alone (no token scratch => the span path is off) */
+extern "C" int32_t emul_inflate_steps(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                                      uint32_t *in_used, uint32_t *crc) {
+    ready();
+    mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
+    memset(L, 0xA5, sizeof(*L));
+    mz_inflate_result r;
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, (uint32_t *)0, &r);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;

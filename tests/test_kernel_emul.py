@@ -28,6 +28,7 @@ def emu():
                     os.path.join(ROOT, "tests", "emul", "emul.cpp"), "-o", so], check=True)
     L = C.CDLL(so)
     L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_inflate_steps.argtypes = L.emul_inflate.argtypes
     L.emul_lzma.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
     L.emul_xz.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.c_int64] + [C.POINTER(C.c_uint32)] * 3
     L.emul_lzma_encode.argtypes = [_u8p, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -57,8 +58,9 @@ def _run(fn, z, cap, *extra):
 
 
 def test_lds_budget(emu):
-    # 4 waves x inflate slice + CRC table must allow 8 workgroups (32 waves = 8 per SIMD) per 160 KiB CU
-    assert (4 * ((emu.emul_lds_bytes() + 15) // 16 * 16) + 1024) * 8 <= 160 * 1024
+    # 4 waves x inflate slice (tables + the span path's window) + CRC table must allow 5 workgroups
+    # (20 waves = 5 per SIMD, the kernel's launch bound) per 160 KiB CU
+    assert (4 * ((emu.emul_lds_bytes() + 15) // 16 * 16) + 1024) * 5 <= 160 * 1024
     assert emu.emul_lzma_lds_bytes() + 1024 <= 16 * 1024 + 1024
 
 
@@ -389,3 +391,42 @@ def test_inflate_differential_fuzz(emu):
         else:
             n_err += 1
     assert n_ok > 20 and n_err > 100
+
+
+def test_inflate_span_and_step_paths(emu):
+    """K1 has two decode front ends feeding one flush: the span path (every lane walks its own 256-bit span, then the
+    walks are chained) and the step loop (64 candidate offsets of one 64-bit window), which also owns the last span of
+    a stream and every error verdict.  Both must agree with the oracle on streams long enough for the span path to
+    engage, including corrupted and truncated ones and tight output caps."""
+    import random
+
+    c = synth.corpus()
+    rnd = random.Random(99)
+    bases = []
+    for lvl, strat, n in ((6, zlib.Z_DEFAULT_STRATEGY, 65536), (1, zlib.Z_DEFAULT_STRATEGY, 30000), (9, zlib.Z_FILTERED, 65536),
+                          (6, zlib.Z_FIXED, 20000), (6, zlib.Z_HUFFMAN_ONLY, 9000), (6, zlib.Z_RLE, 40000)):
+        o = rnd.randrange(0, len(c) - n)
+        co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 9, strat)
+        bases.append(co.compress(c[o:o + n]) + co.flush())
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    bases.append(co.compress(bytes(rnd.randrange(256) for _ in range(3000)) + c[:30000]) + co.flush())   # several blocks
+    n_ok = 0
+    for it in range(500):
+        z = bytearray(rnd.choice(bases))
+        kind = it % 5
+        if kind == 0:
+            z[rnd.randrange(len(z))] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            del z[rnd.randrange(1, len(z)):]
+        elif kind == 2:
+            z[rnd.randrange(len(z))] = rnd.randrange(256)
+        z = bytes(z)
+        cap = rnd.choice((120000, 120000, 5000, 66000))
+        so, uo, oo = oracle.inflate_raw(z, cap)
+        for fn in (emu.emul_inflate, emu.emul_inflate_steps):
+            st, used, out, crc = _run(fn, z, cap)
+            assert st == so, (it, kind, st, so, fn is emu.emul_inflate)
+            if so == 0:
+                assert (used, out) == (uo, oo) and crc == oracle.crc32(oo), (it, kind)
+        n_ok += so == 0
+    assert n_ok > 150
