@@ -451,114 +451,6 @@ MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *win, uint
 }
 #endif
 
-/* Flush of the token queue tq (qn tokens, lane i = i-th token): shared by the step loop and the span path. */
-#define MZ_FLUSH_QUEUE()                                                                                                              \
-    do {                                                                                                                              \
-            /* phase 4 (flush): queued tokens -> output offsets by a wave prefix sum; literals scatter in                             \
-             * one store */                                                                                                           \
-            PV(uint32_t, olen);                                                                                                       \
-            PV(uint32_t, oend);                                                                                                       \
-            MZ_LANES {                                                                                                                \
-                if ((uint32_t)lane >= qn) P(tq) = 0u;                                                                                 \
-                P(olen) = mz_bfe(P(tq), 7, 9);                                                                                        \
-            }                                                                                                                         \
-            MZ_STAT(4, qn);                                                                                                           \
-            MZ_STAT(6, 1);                                                                                                            \
-            qn = 0;                                                                                                                   \
-            MZ_INCL_SCAN(oend, olen);                                                                                                 \
-            const uint32_t total = MZ_READLANE(oend, 63);                                                                             \
-            if (total > out_cap - out_pos) {                                                                                          \
-                /* which comes first in stream order: the token that does not fit, or a match that reaches before the                 \
-                 * start of the entry (inflate checks the distance before it copies)? */                                              \
-                uint64_t over_m, far_m;                                                                                               \
-                MZ_BALLOT(over_m, P(oend) > out_cap - out_pos);                                                                       \
-                MZ_BALLOT(far_m, P(olen) > 1u && (P(tq) >> 16) > out_pos + P(oend) - P(olen));                                        \
-                const uint32_t fo = mz_ctz64(over_m);                                                                                 \
-                status = (far_m & ((fo >= 63u) ? ~0ull : ((2ull << fo) - 1ull))) ? MZHIP_DATA_ERROR : MZHIP_OUT_FULL;                 \
-                goto finish;                                                                                                          \
-            }                                                                                                                         \
-            uint64_t matm;                                                                                                            \
-            MZ_BALLOT(matm, P(olen) > 1u);                                                                                            \
-            MZ_LANES {                                                                                                                \
-                if (P(olen) == 1u) out[out_pos + P(oend) - 1u] = (uint8_t)(P(tq) >> 16);                                              \
-            }                                                                                                                         \
-            MZ_WAVE_SYNC();                                                                                                           \
-                                                                                                                                      \
-            /* LZ77 back-references, in stream order.  Eight matches at a time, 8 lanes each (one gather of                           \
-             * the match descriptors, one load, one store) as long as every source of the group ends at or                            \
-             * before the group's first destination byte -- everything earlier is complete: all literals of                           \
-             * the queue, every earlier match.  The first match of a group that reads inside the group (or                            \
-             * overlaps itself, or reaches before the entry) goes through the in-order cooperative path. */                           \
-            if (matm) {                                                                                                               \
-                const uint32_t nmatch = mz_popc64(matm);                                                                              \
-                uint32_t done_m = 0;                                                                                                  \
-                MZ_LANES {                                                                                                            \
-                    if (P(olen) > 1u) L->u.b.mslot[mz_popc64(matm & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);                 \
-                }                                                                                                                     \
-                MZ_WAVE_SYNC();                                                                                                       \
-                MZ_STAT(0, 1); MZ_STAT(1, nmatch);                                                                                    \
-                while (done_m < nmatch) {                                                                                             \
-                    MZ_STAT(2, 1);                                                                                                    \
-                    PV(uint32_t, msrc);                                                                                               \
-                    PV(uint32_t, mtk);                                                                                                \
-                    PV(uint32_t, mend);                                                                                               \
-                    MZ_LANES {                                                                                                        \
-                        const uint32_t g = done_m + ((uint32_t)lane >> MZ_MLANES_LOG2);                                               \
-                        P(msrc) = (g < nmatch) ? (uint32_t)L->u.b.mslot[g] : 256u;                                                    \
-                    }                                                                                                                 \
-                    MZ_GATHER4(mtk, tq, P(msrc));                                                                                     \
-                    MZ_GATHER4(mend, oend, P(msrc));                                                                                  \
-                    MZ_LANES {                                                                                                        \
-                        if (P(msrc) >= 256u) { P(mtk) = 0; P(mend) = 0; }                                                             \
-                    }                                                                                                                 \
-                    /* group start = destination offset of its first match (lanes 0..15 hold it) */                                   \
-                    const uint32_t gs = MZ_READLANE(mend, 0) - mz_bfe(MZ_READLANE(mtk, 0), 7, 9);                                     \
-                    uint64_t dep;                                                                                                     \
-                    MZ_BALLOT(dep, P(mend) > (P(mtk) >> 16) + gs ||                                                                   \
-                                       (P(mtk) >> 16) > out_pos + P(mend) - mz_bfe(P(mtk), 7, 9));                                    \
-                    /* matches of the group before the first dependent one */                                                         \
-                    const uint32_t nind = dep ? (mz_ctz64(dep) >> MZ_MLANES_LOG2) : (64u >> MZ_MLANES_LOG2);                          \
-                    if (nind) {                                                                                                       \
-                        MZ_LANES {                                                                                                    \
-                            if (P(msrc) < 256u && ((uint32_t)lane >> MZ_MLANES_LOG2) < nind) {                                        \
-                                const uint32_t ln = mz_bfe(P(mtk), 7, 9), dist = P(mtk) >> 16;                                        \
-                                const uint32_t dst = out_pos + P(mend) - ln;                                                          \
-                                for (uint32_t i = (uint32_t)lane & ((1u << MZ_MLANES_LOG2) - 1u); i < ln; i += 1u << MZ_MLANES_LOG2)  \
-                                    out[dst + i] = out[dst - dist + i];                                                               \
-                            }                                                                                                         \
-                        }                                                                                                             \
-                        MZ_WAVE_SYNC();                                                                                               \
-                        done_m += nind;                                                                                               \
-                    }                                                                                                                 \
-                    if (dep && done_m < nmatch) {                                                                                     \
-                        MZ_STAT(3, 1);                                                                                                \
-                        /* in-order cooperative copy of the dependent match (64 bytes per instruction) */                             \
-                        const uint32_t tl = MZ_UNIFORM(L->u.b.mslot[done_m]) >> 2;                                                    \
-                        const uint32_t t = MZ_READLANE(tq, tl);                                                                       \
-                        const uint32_t ln = (t >> 7) & 511u, dist = t >> 16;                                                          \
-                        const uint32_t dst = out_pos + MZ_READLANE(oend, tl) - ln;                                                    \
-                        if (dist > dst) {                                                                                             \
-                            status = MZHIP_DATA_ERROR; /* invalid distance too far back */                                            \
-                            goto finish;                                                                                              \
-                        }                                                                                                             \
-                        const uint8_t *src = out + (dst - dist);                                                                      \
-                        if (dist >= ln) {                                                                                             \
-                            MZ_LANES {                                                                                                \
-                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i];                            \
-                            }                                                                                                         \
-                        } else { /* overlapping run: byte i repeats with period dist */                                               \
-                            MZ_LANES {                                                                                                \
-                                for (uint32_t i = (uint32_t)lane; i < ln; i += 64u) out[dst + i] = src[i % dist];                     \
-                            }                                                                                                         \
-                        }                                                                                                             \
-                        MZ_WAVE_SYNC();                                                                                               \
-                        done_m++;                                                                                                     \
-                    }                                                                                                                 \
-                }                                                                                                                     \
-            }                                                                                                                         \
-            out_pos += total;                                                                                                         \
-            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);                                                    \
-    } while (0)
 
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
@@ -882,7 +774,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                                 const uint32_t c = (T - j < 64u) ? (T - j) : 64u;
                                 MZ_LANES { P(tq) = ((uint32_t)lane < c) ? tokbuf[j + (uint32_t)lane] : 0u; }
                                 qn = c;
-                                MZ_FLUSH_QUEUE();
+#include "inflate_flush.inc"
                             }
                             MZ_WAVE_SYNC(); /* the scratch is rewritten by the next window */
                             if (span_eob) break;
@@ -1083,7 +975,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
                 if (qn + 15u <= 64u && !eob && chain_err == MZHIP_OK) continue;
 
-                MZ_FLUSH_QUEUE();
+#include "inflate_flush.inc"
                 if (chain_err != MZHIP_OK) {
                     status = chain_err;
                     goto finish;
