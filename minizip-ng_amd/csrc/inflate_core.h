@@ -63,6 +63,9 @@ extern unsigned long long mz_stats[16];
 #define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
 #define MZ_SPAN_TOK_CAP 4096u        /* tokens one window may hand over (global scratch per wave, 16 KiB) */
 #define MZ_SPAN_MAX_PASS 6u
+#ifndef MZ_STAGED_FLUSH
+#define MZ_STAGED_FLUSH 0 /* assemble each flush batch in LDS (needs the span window's space: MZ_SPAN_DW > 0) */
+#endif
 #ifndef MZ_MLANES_LOG2
 #define MZ_MLANES_LOG2 3 /* lanes that copy one match together in the flush: 2^3 = 8, so 8 matches per round */
 #endif

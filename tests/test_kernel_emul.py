@@ -393,7 +393,22 @@ def test_inflate_differential_fuzz(emu):
     assert n_ok > 20 and n_err > 100
 
 
-def test_inflate_span_and_step_paths(emu):
+@pytest.fixture(scope="module")
+def emu_staged():
+    """The same emulation with the staged flush (MZ_STAGED_FLUSH=1: batches assembled in LDS), an opt-in build."""
+    out = os.path.join(ROOT, "tests", "emul", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libemul_staged.so")
+    subprocess.run(["g++", "-O1", "-g", "-Wno-unknown-pragmas", "-DMZHIP_HOST_EMUL", "-DMZ_STAGED_FLUSH=1",
+                    "-I" + os.path.join(ROOT, "minizip-ng_amd", "csrc"), "-shared", "-fPIC",
+                    os.path.join(ROOT, "tests", "emul", "emul.cpp"), "-o", so], check=True)
+    L = C.CDLL(so)
+    L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
+    L.emul_inflate_steps.argtypes = L.emul_inflate.argtypes
+    return L
+
+
+def test_inflate_span_and_step_paths(emu, emu_staged):
     """K1 has two decode front ends feeding one flush: the span path (every lane walks its own 256-bit span, then the
     walks are chained) and the step loop (64 candidate offsets of one 64-bit window), which also owns the last span of
     a stream and every error verdict.  Both must agree with the oracle on streams long enough for the span path to
@@ -410,8 +425,11 @@ def test_inflate_span_and_step_paths(emu):
         bases.append(co.compress(c[o:o + n]) + co.flush())
     co = zlib.compressobj(6, zlib.DEFLATED, -15)
     bases.append(co.compress(bytes(rnd.randrange(256) for _ in range(3000)) + c[:30000]) + co.flush())   # several blocks
+    for d in (bytes(70000), b"abc" * 20000, c[:500] * 100, b"ab" * 300 + c[:2000] + b"x" * 5000):    # runs, short periods
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        bases.append(co.compress(d) + co.flush())
     n_ok = 0
-    for it in range(500):
+    for it in range(700):
         z = bytearray(rnd.choice(bases))
         kind = it % 5
         if kind == 0:
@@ -423,9 +441,9 @@ def test_inflate_span_and_step_paths(emu):
         z = bytes(z)
         cap = rnd.choice((120000, 120000, 5000, 66000))
         so, uo, oo = oracle.inflate_raw(z, cap)
-        for fn in (emu.emul_inflate, emu.emul_inflate_steps):
+        for k, fn in enumerate((emu.emul_inflate, emu.emul_inflate_steps, emu_staged.emul_inflate, emu_staged.emul_inflate_steps)):
             st, used, out, crc = _run(fn, z, cap)
-            assert st == so, (it, kind, st, so, fn is emu.emul_inflate)
+            assert st == so, (it, kind, st, so, k)
             if so == 0:
                 assert (used, out) == (uo, oo) and crc == oracle.crc32(oo), (it, kind)
         n_ok += so == 0
