@@ -48,13 +48,16 @@ def emu():
     return L
 
 
-def _run(fn, z, cap, *extra):
-    a = np.frombuffer(z, dtype=np.uint8).copy() if len(z) else np.zeros(1, np.uint8)
-    out = np.zeros(cap + 1, np.uint8)
+def _run(fn, z, cap, *extra, mis=0, omis=0):
+    """mis / omis: byte misalignment of the input / output pointers handed to the core (0..3)"""
+    a = np.zeros(len(z) + 8, np.uint8)
+    a[mis:mis + len(z)] = np.frombuffer(z, dtype=np.uint8)
+    out = np.zeros(cap + 8, np.uint8)
     ol, iu, crc = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    st = fn(a.ctypes.data_as(_u8p), len(z), out.ctypes.data_as(_u8p), cap, *extra, C.byref(ol), C.byref(iu),
-            C.byref(crc))
-    return st, iu.value, out[:ol.value].tobytes(), crc.value
+    pin = C.cast(a.ctypes.data + mis, _u8p)
+    pout = C.cast(out.ctypes.data + omis, _u8p)
+    st = fn(pin, len(z), pout, cap, *extra, C.byref(ol), C.byref(iu), C.byref(crc))
+    return st, iu.value, out[omis:omis + ol.value].tobytes(), crc.value
 
 
 def test_lds_budget(emu):
@@ -442,7 +445,7 @@ def test_inflate_span_and_step_paths(emu, emu_staged):
         cap = rnd.choice((120000, 120000, 5000, 66000))
         so, uo, oo = oracle.inflate_raw(z, cap)
         for k, fn in enumerate((emu.emul_inflate, emu.emul_inflate_steps, emu_staged.emul_inflate, emu_staged.emul_inflate_steps)):
-            st, used, out, crc = _run(fn, z, cap)
+            st, used, out, crc = _run(fn, z, cap, mis=it % 4, omis=(it // 4) % 4)
             assert st == so, (it, kind, st, so, k)
             if so == 0:
                 assert (used, out) == (uo, oo) and crc == oracle.crc32(oo), (it, kind)
