@@ -9,30 +9,31 @@
  *   - Huffman tables are built by the whole wave (histogram -> canonical first
  *     codes -> ranked symbols -> LDS lookup tables whose 32-bit entries are
  *     ready-made tokens / operand descriptors), see MZ_BUILD_HUFF.
- *   - Symbol decode is SPECULATIVE AND PARALLEL: in every step lane l decodes
- *     the complete token (literal | length+distance | end-of-block) that would
- *     start at bit cursor+l, for all 64 bit offsets at once.
- *   - Which candidates are real is decided without a serial walk: the successor
- *     function f(l) = l + bits(l) is squared with cross-lane gathers and lane i
- *     composes f^i(0); the step's tokens come out compacted in lanes 0..n-1.
- *     One step retires about 64 bits of compressed input (4.6 tokens on text).
- *   - The step's tokens join a queue of up to 64 tokens held one per lane; the
- *     output phase runs once per ~50 tokens with every lane busy: wave prefix sum
- *     of the sizes, literals scatter in one store, matches (LZ77 back-references)
- *     are copied eight at a time, 8 lanes each, as long as every source of a group
- *     ends before the group's first destination byte; overlapping (dist < len) runs
- *     and in-group dependencies take an in-order cooperative copy.
+ *   - Two decode front ends produce the same 32-bit tokens:
+ *       SPAN PATH (mz_span_token, the default for all but the tail of a stream): every lane walks its own
+ *       256-bit span of the compressed stream token by token; a walk started at an arbitrary bit meets the
+ *       true token sequence after ~8 tokens, so chaining the walks (each lane restarts where its left
+ *       neighbour crossed into its span) converges to the true parse in ~2.6 passes; one more walk emits
+ *       the tokens in stream order.  Every lane does useful work.
+ *       STEP LOOP (the last span of a stream, and every error verdict): lane l decodes the complete token
+ *       that would start at bit cursor+l, for all 64 bit offsets at once; which candidates are real is
+ *       decided without a serial walk: f(l) = l + bits(l) is squared with cross-lane gathers and lane i
+ *       composes f^i(0).  One step retires about 64 bits of input (4.6 tokens on text).
+ *   - Tokens are handed to the flush (inflate_flush.inc) 64 at a time, one per lane: wave prefix sum
+ *     of the sizes, literals scatter in one store, matches (LZ77 back-references) are copied eight at a
+ *     time, 8 lanes each, as long as every source of a group ends before the group's first destination
+ *     byte; overlapping (dist < len) runs and in-group dependencies take an in-order cooperative copy.
+ *     MZ_STAGED_FLUSH assembles the batch in LDS instead and stores it once (opt-in build).
  *   - The sliding window IS the output buffer: back-references read bytes this
  *     wave wrote earlier (a wave's vector-memory operations execute in order),
  *     so no 32 KiB LDS window is needed; compressed input is staged through a
  *     512-byte LDS ring with a register-held prefetch.
  *   - CRC-32 is folded from the freshly written output one 1 KiB tile at a
  *     time (crc32_core.h), so the output is never re-read from HBM.
- *   - The kernel is VALU-issue-bound (measured), so the per-lane decode is kept
- *     to 32-bit funnel shifts (v_alignbit), bit-field extracts and table entries
- *     that need no arithmetic, and the tables are sized for residency: an 8-bit
- *     literal/length root plus second-level tables (4.7 KiB of LDS per wave) lets
- *     eight workgroups = 32 waves share a CU.
+ *   - The per-lane decode is kept to 32-bit funnel shifts (v_alignbit), bit-field extracts and table
+ *     entries that need no arithmetic, and the tables are sized for residency: an 8-bit literal/length
+ *     root plus second-level tables (4.7 KiB of LDS per wave) and the 2.8 KiB span window let five
+ *     workgroups = 20 waves share a CU (the step loop alone: eight workgroups, VALU-issue-bound).
  *   - MZ_STATS (host emulation only) counts flushes / matches / dependent copies.
  *
  * Error classes mirror zlib's as the reference surfaces them
