@@ -64,6 +64,9 @@ extern unsigned long long mz_stats[16];
 #define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
 #define MZ_SPAN_TOK_CAP 4096u        /* tokens one window may hand over (global scratch per wave, 16 KiB) */
 #define MZ_SPAN_MAX_PASS 6u
+#ifndef MZ_LDS_COMPACT
+#define MZ_LDS_COMPACT 0 /* ring / match slots / span window / staging share one LDS area (see mz_inflate_body_scratch) */
+#endif
 #ifndef MZ_STAGED_FLUSH
 #define MZ_STAGED_FLUSH 0 /* assemble each flush batch in LDS (needs the span window's space: MZ_SPAN_DW > 0) */
 #endif
@@ -136,6 +139,21 @@ typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed a
     uint8_t clc_len[20]; /* lengths of the code-length code */
 } mz_inflate_hdr_scratch;
 
+#if MZ_LDS_COMPACT
+/* Compact layout (opt-in, with MZ_SPAN_DW and MZ_STAGED_FLUSH): ONE area whose uses never overlap in time.  The span
+ * window's rows grow from the front; the step loop's ring (130 dwords) and the match slots (32 dwords) sit at the back;
+ * the staged flush assembles its batch in the front part that the ring does not reach.  While lanes walk their spans
+ * the ring is dead (it is reloaded on re-entry to the step loop) and no flush is running, so the window may cover
+ * everything. */
+#define MZ_BODY_DW (65 * MZ_SPAN_RS)
+typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
+    uint32_t area[MZ_BODY_DW];
+} mz_inflate_body_scratch;
+#define MZ_L_WIN(L_) ((L_)->u.b.area)
+#define MZ_L_RING(L_) ((L_)->u.b.area + (MZ_BODY_DW - 162))
+#define MZ_L_MSLOT(L_) ((uint16_t *)((L_)->u.b.area + (MZ_BODY_DW - 32)))
+#define MZ_L_STG_BYTES (4u * (MZ_BODY_DW - 162))
+#else
 typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
     uint32_t ring[130]; /* 512 B of compressed stream: aligned dword j of the entry at ring[j & 127]; entries 128, 129
                            mirror 0, 1 so that a window read is one address plus constant offsets */
@@ -144,6 +162,11 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
     uint32_t win[65 * MZ_SPAN_RS]; /* span path: the window's dword d at win[(d / MZ_SPAN_DW) * MZ_SPAN_RS + d % MZ_SPAN_DW] */
 #endif
 } mz_inflate_body_scratch;
+#define MZ_L_WIN(L_) ((L_)->u.b.win)
+#define MZ_L_RING(L_) ((L_)->u.b.ring)
+#define MZ_L_MSLOT(L_) ((L_)->u.b.mslot)
+#define MZ_L_STG_BYTES ((uint32_t)sizeof(((mz_inflate_lds *)0)->u.b.win))
+#endif
 
 typedef struct mz_inflate_lds {
     uint32_t lit_fast[1 << MZ_LROOT];
@@ -659,7 +682,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
          * block prefetched into a VGPR one block ahead), so the per-step window fetch is three
          * ds_read_b32 and no global-memory latency sits on the critical path. */
         {
-            uint32_t *ring = L->u.b.ring;
+            uint32_t *ring = MZ_L_RING(L);
             const uint32_t pbase = 8u * in_mis; /* bit offset of `in` inside its aligned dword */
             uint32_t ring_hi = 0;               /* blocks < ring_hi are in the ring; block ring_hi is in wpre */
             uint32_t ring_valid = 0;            /* the ring is (re)loaded on entry to the step loop: the span path moves the cursor */
@@ -681,7 +704,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     uint32_t nact = (remain > 64u) ? (remain - 64u) / S : 0u;
                     if (nact > 64u) nact = 64u;
                     if (tokbuf && qn == 0u && !span_skip && nact >= 2u) {
-                        uint32_t *win = L->u.b.win;
+                        uint32_t *win = MZ_L_WIN(L);
                         const uint32_t wpos = bitpos + pbase;
                         const uint32_t wb = wpos >> 5, woff = wpos & 31u;
                         const uint32_t ndw = MZ_SPAN_DW * nact + 3u;
@@ -694,6 +717,9 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                             }
                         }
                         MZ_WAVE_SYNC();
+#if MZ_LDS_COMPACT
+                        ring_valid = 0; /* the window covers the ring's place */
+#endif
                         PV(uint32_t, sst); /* where this lane's walk starts (window-relative bit) */
                         PV(uint32_t, sxe); /* where it crossed into the next span */
                         PV(uint32_t, scn); /* tokens it walked over */
@@ -956,10 +982,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         }
                     }
                     MZ_LANES {
-                        if ((sel >> lane) & 1u) L->u.b.mslot[mz_popc64(sel & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);
+                        if ((sel >> lane) & 1u) MZ_L_MSLOT(L)[mz_popc64(sel & ((1ull << lane) - 1ull))] = (uint16_t)(4 * lane);
                     }
                     MZ_WAVE_SYNC();
-                    MZ_LANES { P(cpos) = ((uint32_t)lane < ntok) ? (uint32_t)L->u.b.mslot[lane & 15] : 0x1000u; }
+                    MZ_LANES { P(cpos) = ((uint32_t)lane < ntok) ? (uint32_t)MZ_L_MSLOT(L)[lane & 15] : 0x1000u; }
                     MZ_WAVE_SYNC();
                 }
                 bitpos += pos;

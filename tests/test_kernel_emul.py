@@ -396,19 +396,25 @@ def test_inflate_differential_fuzz(emu):
     assert n_ok > 20 and n_err > 100
 
 
-@pytest.fixture(scope="module")
-def emu_staged():
-    """The same emulation with the staged flush (MZ_STAGED_FLUSH=1: batches assembled in LDS), an opt-in build."""
+def _build_variant(tag, flags):
     out = os.path.join(ROOT, "tests", "emul", "_build")
     os.makedirs(out, exist_ok=True)
-    so = os.path.join(out, "libemul_staged.so")
-    subprocess.run(["g++", "-O1", "-g", "-Wno-unknown-pragmas", "-DMZHIP_HOST_EMUL", "-DMZ_STAGED_FLUSH=1",
-                    "-I" + os.path.join(ROOT, "minizip-ng_amd", "csrc"), "-shared", "-fPIC",
+    so = os.path.join(out, "libemul_%s.so" % tag)
+    subprocess.run(["g++", "-O1", "-g", "-Wno-unknown-pragmas", "-DMZHIP_HOST_EMUL"] + flags +
+                   ["-I" + os.path.join(ROOT, "minizip-ng_amd", "csrc"), "-shared", "-fPIC",
                     os.path.join(ROOT, "tests", "emul", "emul.cpp"), "-o", so], check=True)
     L = C.CDLL(so)
     L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
     L.emul_inflate_steps.argtypes = L.emul_inflate.argtypes
     return L
+
+
+@pytest.fixture(scope="module")
+def emu_staged():
+    """Opt-in K1 builds in the same emulation: the staged flush (batches assembled in LDS), and the compact LDS layout
+    with 192-bit spans that admits a sixth workgroup per CU."""
+    return [_build_variant("staged", ["-DMZ_STAGED_FLUSH=1"]),
+            _build_variant("compact6", ["-DMZ_SPAN_DW=6", "-DMZ_STAGED_FLUSH=1", "-DMZ_LDS_COMPACT=1"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
@@ -444,7 +450,10 @@ def test_inflate_span_and_step_paths(emu, emu_staged):
         z = bytes(z)
         cap = rnd.choice((120000, 120000, 5000, 66000))
         so, uo, oo = oracle.inflate_raw(z, cap)
-        for k, fn in enumerate((emu.emul_inflate, emu.emul_inflate_steps, emu_staged.emul_inflate, emu_staged.emul_inflate_steps)):
+        fns = [emu.emul_inflate, emu.emul_inflate_steps]
+        for v in emu_staged:
+            fns += [v.emul_inflate, v.emul_inflate_steps]
+        for k, fn in enumerate(fns):
             st, used, out, crc = _run(fn, z, cap, mis=it % 4, omis=(it // 4) % 4)
             assert st == so, (it, kind, st, so, k)
             if so == 0:
