@@ -64,6 +64,9 @@ extern unsigned long long mz_stats[16];
 #define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
 #define MZ_SPAN_TOK_CAP 4096u        /* tokens one window may hand over (global scratch per wave, 16 KiB) */
 #define MZ_SPAN_MAX_PASS 6u
+#ifndef MZ_TOK_PREFETCH
+#define MZ_TOK_PREFETCH 0 /* span path: fetch the next flush batch's tokens one batch ahead */
+#endif
 #ifndef MZ_LDS_COMPACT
 #define MZ_LDS_COMPACT 0 /* ring / match slots / span window / staging share one LDS area (see mz_inflate_body_scratch) */
 #endif
@@ -800,9 +803,20 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                             const uint32_t span_eob = (MZ_READLANE(sfl, m - 1u) == 1u) ? 1u : 0u;
                             bitpos += endrel - woff;
                             ring_valid = 0;
+#if MZ_TOK_PREFETCH
+                            PV(uint32_t, tqn); /* the next batch's tokens are fetched while this one is flushed */
+                            MZ_LANES { P(tqn) = ((uint32_t)lane < T) ? tokbuf[(uint32_t)lane] : 0u; }
+#endif
                             for (uint32_t j = 0; j < T; j += 64u) {
                                 const uint32_t c = (T - j < 64u) ? (T - j) : 64u;
+#if MZ_TOK_PREFETCH
+                                MZ_LANES {
+                                    P(tq) = ((uint32_t)lane < c) ? P(tqn) : 0u;
+                                    P(tqn) = (j + 64u + (uint32_t)lane < T) ? tokbuf[j + 64u + (uint32_t)lane] : 0u;
+                                }
+#else
                                 MZ_LANES { P(tq) = ((uint32_t)lane < c) ? tokbuf[j + (uint32_t)lane] : 0u; }
+#endif
                                 qn = c;
 #include "inflate_flush.inc"
                             }

@@ -10,6 +10,9 @@ VARIANTS=(
   "staged_c8  STAGED=1 COMPACT=1"
   "staged_s6w6 SPAN=6 WAVES=6 STAGED=1 COMPACT=1"
   "staged_s6w5 SPAN=6 WAVES=5 STAGED=1 COMPACT=1"
+  "staged2   STAGED=2"
+  "staged2_pf STAGED=2 PREFETCH=1"
+  "staged2_pf_s6w6 SPAN=6 WAVES=6 STAGED=2 COMPACT=1 PREFETCH=1"
   "staged_m2 STAGED=1 MLANES=2"
   "steploop SPAN=0 WAVES=8"
 )

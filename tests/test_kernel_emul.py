@@ -414,6 +414,7 @@ def emu_staged():
     """Opt-in K1 builds in the same emulation: the staged flush (batches assembled in LDS), and the compact LDS layout
     with 192-bit spans that admits a sixth workgroup per CU."""
     return [_build_variant("staged", ["-DMZ_STAGED_FLUSH=1"]),
+            _build_variant("staged2", ["-DMZ_STAGED_FLUSH=2", "-DMZ_TOK_PREFETCH=1"]),
             _build_variant("compact6", ["-DMZ_SPAN_DW=6", "-DMZ_STAGED_FLUSH=1", "-DMZ_LDS_COMPACT=1"])]
 
 
