@@ -5,7 +5,7 @@
 # counter (never combined with other trace domains).  Copy what should be judged into profiles/<round>/.
 set -u
 tag=${1:-run}
-what=${2:-all}   # all | bench | stats | FETCH_SIZE | WRITE_SIZE
+what=${2:-all}   # all | bench | stats | FETCH_SIZE | WRITE_SIZE | SQ (instruction mix and wait cycles, not part of `all`)
 T=${MZ_COLLECT_TIMEOUT:-300}  # a pass that outlives this is killed (rocprofv3 has hung here once)
 root=$PWD
 out=$root/gpurun_out/$tag
@@ -24,5 +24,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 $T rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$lc" -o pmc --output-format csv -- $cmd > "$out/pmc_$lc.log" 2>&1
   find "$out/pmc_$lc" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|k_inflate_batch" "$1" > "$2"' _ {} "$out/pmc_$lc.csv" \;
 done
+if [ $what = SQ ]; then
+  # instruction mix and stall picture of the dominant kernel; a pass per counter group (never with other trace domains);
+  # MZ_SQ_CMD overrides the workload (default: the short probe, one launch is enough for counters)
+  sqcmd=${MZ_SQ_CMD:-python $root/tests/perf_probe.py}
+  i=0
+  for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR"; do
+    i=$((i+1))
+    timeout -k 10 $T rocprofv3 --kernel-trace --pmc $grp -d "$out/pmc_sq$i" -o pmc --output-format csv -- $sqcmd > "$out/pmc_sq$i.log" 2>&1
+    find "$out/pmc_sq$i" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|k_inflate_batch" "$1" > "$2"' _ {} "$out/pmc_sq$i.csv" \;
+  done
+fi
 ls -la "$out"
 head -3 "$out/kernel_stats.csv"
