@@ -1,0 +1,113 @@
+// mock_device.cpp -- TEST INFRASTRUCTURE: the host-buffer entry points of include/mzhip.h implemented on the 64-lane
+// HOST EMULATION of the device cores (emul.cpp), so that the C shims (shim_zlib.c, shim_lzma.c, shim_crc32.c,
+// shim_autoprime.c -- the code that mirrors mz_strm_zlib.c / mz_strm_lzma.c call for call) can be exercised behind the
+// reference's unmodified zip layer in a container WITHOUT a GPU.  tests/emul/Makefile links it into
+// tests/emul/_build/libmockdrop.so, which only tests/test_shims_emul.py loads.  It is never part of libmzhip.so: the
+// product has no CPU path, and a GPU box runs the same tests against the real device (tests/test_gpu_dropin.py,
+// test_gpu_wrappers.py).  What it cannot cover: the prime caches and the .xz writer, whose host code lives in
+// mzhip_kernels.hip.
+#include "emul.cpp"
+
+#include "../../include/mzhip.h"
+
+#define MOCK_API extern "C" __attribute__((visibility("default")))
+
+MOCK_API int32_t mzhip_device_count(void) { return 1; }
+MOCK_API int32_t mzhip_init(int32_t) { return 0; }
+MOCK_API const char *mzhip_last_error(void) { return ""; }
+MOCK_API const char *mzhip_version(void) { return "mock (host emulation of the device cores)"; }
+
+MOCK_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                                     uint32_t *in_used, uint32_t *crc, uint32_t *adler) {
+    uint32_t ol = 0, iu = 0, k = 0;
+    const uint8_t dummy = 0;
+    const int32_t st = emul_inflate(in ? in : &dummy, in_len, out, out_cap, &ol, &iu, &k);
+    if (out_len) *out_len = ol;
+    if (in_used) *in_used = iu;
+    if (crc) *crc = k;
+    if (adler) *adler = emul_adler32(out, ol);
+    return st;
+}
+MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                                    uint32_t *in_used, uint32_t *crc) {
+    return mzhip_inflate_host2(in, in_len, out, out_cap, out_len, in_used, crc, nullptr);
+}
+
+// one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host2 does)
+MOCK_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
+                                     uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
+    const uint32_t piece = 64u << 10;
+    const uint32_t np = in_len ? (in_len + piece - 1) / piece : 1u;
+    uint32_t total = 0, k = 0, ad = 1;
+    const uint8_t dummy = 0;
+    for (uint32_t i = 0; i < np; i++) {
+        const uint32_t off = in_len ? i * piece : 0u, len = in_len - off < piece ? in_len - off : piece;
+        uint32_t ol = 0, pc = 0;
+        const int32_t st = emul_deflate(in_len ? in + off : &dummy, len, out + total, out_cap - total, (i + 1 == np && final) ? 1u : 0u, &ol, &pc);
+        if (st) return st;
+        total += ol;
+        k = i == 0 ? pc : mzhip_crc32_combine_host(k, pc, len);
+        if (adler) ad = mzhip_adler32_combine_host(ad, emul_adler32(in_len ? in + off : &dummy, len), len);
+    }
+    if (out_len) *out_len = total;
+    if (crc) *crc = k;
+    if (adler) *adler = ad;
+    return 0;
+}
+MOCK_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
+                                    uint32_t *out_len, uint32_t *crc) {
+    return mzhip_deflate_host2(in, in_len, final, out, out_cap, out_len, crc, nullptr);
+}
+
+MOCK_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                                 uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    uint32_t ol = 0, iu = 0, k = 0;
+    const int32_t st = emul_lzma(in, in_len, out, out_cap, max_out, &ol, &iu, &k);
+    if (out_len) *out_len = ol;
+    if (in_used) *in_used = iu;
+    if (crc) *crc = k;
+    return st;
+}
+MOCK_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                               uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    uint32_t ol = 0, iu = 0, k = 0;
+    const int32_t st = emul_xz(in, in_len, out, out_cap, max_out, &ol, &iu, &k);
+    if (out_len) *out_len = ol;
+    if (in_used) *in_used = iu;
+    if (crc) *crc = k;
+    return st;
+}
+MOCK_API int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                                        uint32_t *crc) {
+    const uint8_t dummy = 0;
+    return emul_lzma_encode(in ? in : &dummy, in_len, 0u, out, out_cap, out_len, crc);
+}
+MOCK_API int32_t mzhip_xz_encode_host(const uint8_t *, uint32_t, uint8_t *, uint32_t, uint32_t *, uint32_t *) {
+    return MZHIP_STATUS_UNSUPPORTED; /* the .xz container is laid out by host code inside mzhip_kernels.hip */
+}
+
+MOCK_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
+    uint32_t v = value;
+    for (size_t pos = 0; pos < size;) { /* the emulated kernel takes 32-bit lengths */
+        const size_t n = size - pos < ((size_t)1 << 30) ? size - pos : ((size_t)1 << 30);
+        v = emul_crc32_super(buf + pos, (uint32_t)n, v);
+        pos += n;
+    }
+    return v;
+}
+extern "C" uint32_t mzhip_crc32_combine(uint32_t a, uint32_t b, uint64_t len_b) { return mzhip_crc32_combine_host(a, b, len_b); }
+extern "C" uint32_t mzhip_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b) { return mzhip_adler32_combine_host(a, b, len_b); }
+
+// prime caches: not available here (their host code lives in mzhip_kernels.hip); every lookup misses
+MOCK_API int64_t mzhip_prime_file(const char *) { return -109; }
+MOCK_API int64_t mzhip_prime_mem(const uint8_t *, uint64_t) { return -109; }
+MOCK_API void mzhip_prime_clear(void) {}
+extern "C" int32_t mzhip_prime_lookup2(int32_t, int64_t, const uint8_t *, int32_t, const uint8_t **, int64_t *, int64_t *, uint32_t *,
+                                       const uint32_t **) { return 0; }
+extern "C" int32_t mzhip_prime_lookup(int64_t, const uint8_t *, int32_t, const uint8_t **, int64_t *, int64_t *, uint32_t *,
+                                      const uint32_t **) { return 0; }
+extern "C" int32_t mzhip_wprime_track(int32_t, int64_t *, int64_t, const uint8_t *, int32_t, uint32_t *, int32_t *have_crc) {
+    *have_crc = 0;
+    return 0;
+}
+extern "C" int32_t mzhip_wprime_result(int32_t, int64_t, int64_t, const uint8_t **, const uint8_t **, uint32_t *) { return 0; }

@@ -1,0 +1,94 @@
+"""CPU tests of the C SHIMS (minizip-ng_amd/csrc/shim_*.c -- the code that mirrors mz_strm_zlib.c / mz_strm_lzma.c /
+mz_crypt_crc32_update call for call) behind the reference's unmodified zip layer, in a container without a GPU.
+
+tests/emul/_build/libmockdrop.so links the shims against tests/emul/mock_device.cpp, which implements the
+host-buffer entry points of include/mzhip.h on the 64-lane HOST EMULATION of the device cores (the same headers the
+HIP build compiles).  The test bodies are the GPU tests' own (tests/test_gpu_dropin.py, tests/test_gpu_wrappers.py),
+run here against the mock instead of the device; a GPU box runs them against the real thing.  Test infrastructure
+only: nothing here is part of, or loaded by, the product."""
+import os
+import subprocess
+
+import pytest
+
+import oracle
+from tests import test_gpu_dropin as D
+from tests import test_gpu_wrappers as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "emul", "_build", "libmockdrop.so")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    if os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul")], check=True, capture_output=True)
+    if not os.path.exists(MOCK) or not oracle.have_ref():
+        pytest.skip("tests/emul/_build/libmockdrop.so / oracle/_ref/libmzref.so need the reference sources at build time")
+    return oracle.MzDriver(MOCK), oracle.ref()
+
+
+def test_crc32_symbol(libs):
+    D.test_crc32_symbol(libs)
+
+
+def test_zlib_stream_parity(libs):
+    D.test_zlib_stream_parity(libs)
+
+
+def test_zlib_stream_error_parity(libs):
+    D.test_zlib_stream_error_parity(libs)
+
+
+def test_lzma_stream_parity(libs):
+    D.test_lzma_stream_parity(libs)
+
+
+def test_archives_through_unmodified_mz_zip(libs):
+    D.test_archives_through_unmodified_mz_zip(libs)
+
+
+def test_wrapped_read_parity(libs):
+    W.test_wrapped_read_parity(libs)
+
+
+def test_gzip_optional_header_fields(libs):
+    W.test_gzip_optional_header_fields(libs)
+
+
+def test_wrapper_error_parity(libs):
+    W.test_wrapper_error_parity(libs)
+
+
+def test_unsupported_windows_are_refused(libs):
+    W.test_unsupported_windows_are_refused(libs)
+
+
+def test_wrapped_write_roundtrip(libs):
+    W.test_wrapped_write_roundtrip(libs)
+
+
+# ---- the reference's CLI matrix (tests/test_gpu_cli.py) with minizip.c / minigzip.c linked against the mock
+
+from tests import test_gpu_cli as K  # noqa: E402
+
+MOCK_ZIP = os.path.join(ROOT, "tests", "emul", "_build", "minizip_mock")
+MOCK_GZ = os.path.join(ROOT, "tests", "emul", "_build", "minigzip_mock")
+cli_src = K.src           # the module-scoped fixture that lays out the stand-in test files
+
+
+@pytest.mark.parametrize("fname,fargs", K.FLAVOURS, ids=[f[0] for f in K.FLAVOURS])
+@pytest.mark.parametrize("mname,marg", K.METHODS[:3], ids=[m[0] for m in K.METHODS[:3]])     # raw, deflate, lzma
+def test_cli_matrix_on_mock(libs, cli_src, tmp_path, mname, marg, fname, fargs):
+    if not (os.path.exists(MOCK_ZIP) and os.path.exists(K.REF_ZIP)):
+        pytest.skip("CLI binaries need the reference sources at build time")
+    if fname == "zipcd" and mname == "raw":
+        pytest.skip("CMakeLists.txt:813-816: the raw method is left out of the -z flavour")
+    K._matrix(MOCK_ZIP, K.REF_ZIP, cli_src, tmp_path, mname, marg, fname, fargs)
+
+
+def test_cli_gz_ungz_on_mock(libs, cli_src, tmp_path, monkeypatch):
+    if not (os.path.exists(MOCK_GZ) and os.path.exists(K.REF_GZ)):
+        pytest.skip("CLI binaries need the reference sources at build time")
+    monkeypatch.setattr(K, "HIP_GZ", MOCK_GZ)
+    K.test_cli_gz_ungz(cli_src, tmp_path)
