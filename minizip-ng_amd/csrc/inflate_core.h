@@ -13,7 +13,7 @@
  *       SPAN PATH (mz_span_token, the default for all but the tail of a stream): every lane walks its own
  *       256-bit span of the compressed stream token by token; a walk started at an arbitrary bit meets the
  *       true token sequence after ~8 tokens, so chaining the walks (each lane restarts where its left
- *       neighbour crossed into its span) converges to the true parse in ~2.6 passes; one more walk emits
+ *       neighbour crossed into its span) converges to the true parse in ~3.7 passes; one more walk emits
  *       the tokens in stream order.  Every lane does useful work.
  *       STEP LOOP (the last span of a stream, and every error verdict): lane l decodes the complete token
  *       that would start at bit cursor+l, for all 64 bit offsets at once; which candidates are real is
