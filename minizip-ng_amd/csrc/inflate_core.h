@@ -62,19 +62,22 @@ extern unsigned long long mz_stats[16];
 #define MZ_SPAN_DW 8 /* span-parallel decode (see mz_span_token): dwords of compressed stream per lane, 0 = off */
 #endif
 #define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
-#define MZ_SPAN_TOK_CAP 4096u        /* tokens one window may hand over (global scratch per wave, 16 KiB) */
 #define MZ_SPAN_MAX_PASS 6u
-#ifndef MZ_TOK_PREFETCH
-#define MZ_TOK_PREFETCH 0 /* span path: fetch the next flush batch's tokens one batch ahead */
+#ifndef MZ_POOL_BYTES
+#define MZ_POOL_BYTES 3520u /* span path: LDS pool of one window chunk = staging bytes of its output (from the front,
+                               at most 4 KiB), a pending bit per byte, its back-reference list, 4 bytes each (from the back) */
 #endif
-#ifndef MZ_LDS_COMPACT
-#define MZ_LDS_COMPACT 0 /* ring / match slots / span window / staging share one LDS area (see mz_inflate_body_scratch) */
+#ifndef MZ_NEAR_SLOTS
+#define MZ_NEAR_SLOTS 2 /* span path: back-references per lane in one batch of the near pass (1 or 2) */
 #endif
-#ifndef MZ_STAGED_FLUSH
-#define MZ_STAGED_FLUSH 0 /* assemble each flush batch in LDS (needs the span window's space: MZ_SPAN_DW > 0) */
+#ifndef MZ_LDS_PAD
+#define MZ_LDS_PAD 0
+#endif
+#ifndef MZ_ABLATE
+#define MZ_ABLATE 0 /* measurement builds only (wrong output): 1 no match copies, 2 no far loads, 4 no CRC, 8 no store */
 #endif
 #ifndef MZ_MLANES_LOG2
-#define MZ_MLANES_LOG2 3 /* lanes that copy one match together in the flush: 2^3 = 8, so 8 matches per round */
+#define MZ_MLANES_LOG2 3 /* step-loop flush: lanes that copy one match together: 2^3 = 8, so 8 matches per round */
 #endif
 
 /* ---- table entry formats (32-bit) -------------------------------------------------------------
@@ -142,36 +145,33 @@ typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed a
     uint8_t clc_len[20]; /* lengths of the code-length code */
 } mz_inflate_hdr_scratch;
 
-#if MZ_LDS_COMPACT
-/* Compact layout (opt-in, with MZ_SPAN_DW and MZ_STAGED_FLUSH): ONE area whose uses never overlap in time.  The span
- * window's rows grow from the front; the step loop's ring (130 dwords) and the match slots (32 dwords) sit at the back;
- * the staged flush assembles its batch in the front part that the ring does not reach.  While lanes walk their spans
- * the ring is dead (it is reloaded on re-entry to the step loop) and no flush is running, so the window may cover
- * everything. */
-#define MZ_BODY_DW (65 * MZ_SPAN_RS)
 typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
-    uint32_t area[MZ_BODY_DW];
-} mz_inflate_body_scratch;
-#define MZ_L_WIN(L_) ((L_)->u.b.area)
-#define MZ_L_RING(L_) ((L_)->u.b.area + (MZ_BODY_DW - 162))
-#define MZ_L_MSLOT(L_) ((uint16_t *)((L_)->u.b.area + (MZ_BODY_DW - 32)))
-#define MZ_L_STG_BYTES (4u * (MZ_BODY_DW - 162))
-#else
-typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
-    uint32_t ring[130]; /* 512 B of compressed stream: aligned dword j of the entry at ring[j & 127]; entries 128, 129
-                           mirror 0, 1 so that a window read is one address plus constant offsets */
-    uint16_t mslot[64]; /* 4 * lane id of this step's match tokens, compacted */
+    union { /* first: the pool's 16-byte chunks line up with 16-byte stores (the struct sits on a 16-byte boundary) */
+        struct {
+            uint32_t ring[130]; /* step loop: 512 B of compressed stream: aligned dword j of the entry at ring[j & 127];
+                                   entries 128, 129 mirror 0, 1 so that a window read is one address plus constant offsets */
+            uint16_t mslot[64]; /* step-loop flush: 4 * lane id of this step's match tokens, compacted */
+        } s;
+#if MZ_SPAN_DW
+        uint32_t pool[MZ_POOL_BYTES / 4]; /* span path (never live together with the step loop's ring) */
+#endif
+    } x;
 #if MZ_SPAN_DW
     uint32_t win[65 * MZ_SPAN_RS]; /* span path: the window's dword d at win[(d / MZ_SPAN_DW) * MZ_SPAN_RS + d % MZ_SPAN_DW] */
 #endif
 } mz_inflate_body_scratch;
-#define MZ_L_WIN(L_) ((L_)->u.b.win)
-#define MZ_L_RING(L_) ((L_)->u.b.ring)
-#define MZ_L_MSLOT(L_) ((L_)->u.b.mslot)
-#define MZ_L_STG_BYTES ((uint32_t)sizeof(((mz_inflate_lds *)0)->u.b.win))
+#if MZ_SPAN_DW
+typedef char mz_pool_is_16_byte_granular[(MZ_POOL_BYTES % 16u == 0u && MZ_POOL_BYTES < 65536u) ? 1 : -1];
 #endif
+#define MZ_L_WIN(L_) ((L_)->u.b.win)
+#define MZ_L_RING(L_) ((L_)->u.b.x.s.ring)
+#define MZ_L_MSLOT(L_) ((L_)->u.b.x.s.mslot)
 
 typedef struct mz_inflate_lds {
+    union { /* first member: 16-byte aligned like the struct itself */
+        mz_inflate_hdr_scratch h;
+        mz_inflate_body_scratch b;
+    } u;
     uint32_t lit_fast[1 << MZ_LROOT];
     uint32_t dist_fast[1 << MZ_DROOT];
     uint32_t lit_sub[MZ_LIT_SUB_ENTRIES]; /* second-level tables for literal/length codes longer than the root
@@ -179,10 +179,9 @@ typedef struct mz_inflate_lds {
     uint32_t dist_ent[32]; /* distance descriptors in canonical (length, symbol) order, for codes > root */
     uint16_t dist_lim[16]; /* left-justified 15-bit upper bound of the distance codes of each length */
     int16_t dist_delta[16]; /* rank offset - first code, per length */
-    union {
-        mz_inflate_hdr_scratch h;
-        mz_inflate_body_scratch b;
-    } u;
+#if MZ_LDS_PAD
+    uint32_t pad[MZ_LDS_PAD / 4]; /* measurement builds only: occupancy study */
+#endif
 } mz_inflate_lds;
 
 typedef struct mz_inflate_result {
@@ -446,6 +445,43 @@ __device__ static const uint8_t mz_k_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10,
 
 
 #if MZ_SPAN_DW
+/* bits [sh, sh + n) of a 64-bit window as two words, 0 <= sh <= 31, 1 <= n <= 32 (the pending bits of one piece) */
+MZ_DEV void mz_bitrange(uint32_t sh, uint32_t n, uint32_t *m0, uint32_t *m1) {
+    const uint32_t full = 0xFFFFFFFFu >> (32u - n);
+    *m0 = full << sh;
+    *m1 = (full >> 1) >> (31u - sh);
+}
+/* n <= 32 bytes from src to dst; the two ranges do not overlap; every load is issued before the first store, so a
+ * source in global memory costs one round trip */
+MZ_DEV void mz_copy32(uint8_t *dst, const uint8_t *src, uint32_t n) {
+    uint64_t v[4] = {0, 0, 0, 0};
+    uint32_t t4 = 0, t2 = 0, t1 = 0;
+    const uint32_t n8 = n & ~7u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++)
+        if (8u * k + 8u <= n) v[k] = mz_ld8(src + 8u * k);
+    if (n & 4u) t4 = mz_ld4(src + n8);
+    if (n & 2u) t2 = mz_ld2(src + n8 + (n & 4u));
+    if (n & 1u) t1 = src[n - 1u];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++)
+        if (8u * k + 8u <= n) mz_st8(dst + 8u * k, v[k]);
+    if (n & 4u) mz_st4(dst + n8, t4);
+    if (n & 2u) mz_st2(dst + n8 + (n & 4u), t2);
+    if (n & 1u) dst[n - 1u] = (uint8_t)t1;
+}
+/* the same inside the staging area, where the source may end less than n (but at least 8) bytes in front of the
+ * destination: 8-byte steps in order, each one reading only what the steps before it (or earlier pieces) wrote */
+MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
+    const uint32_t n8 = n & ~7u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++)
+        if (8u * k + 8u <= n) mz_st8(dst + 8u * k, mz_ld8(src + 8u * k));
+    if (n & 4u) mz_st4(dst + n8, mz_ld4(src + n8));
+    if (n & 2u) mz_st2(dst + n8 + (n & 4u), mz_ld2(src + n8 + (n & 4u)));
+    if (n & 1u) dst[n - 1u] = src[n - 1u];
+}
+
 /* Span-parallel decode.  A DEFLATE token walk started at an arbitrary bit falls in step with the true token
  * sequence after 8.5 tokens on average (text at zlib level 6: 88 % of the walks within 256 bits, 98 % within 512,
  * profiles/r1/side_measurements.log), so instead of decoding 64 candidate offsets of ONE 64-bit window per step the
@@ -485,7 +521,7 @@ MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *win, uint
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                             uint32_t *tokbuf, mz_inflate_result *res) {
+                             uint32_t use_span, mz_inflate_result *res) {
     MZ_LANE_DECL
     const uint32_t total_bits = in_len * 8u; /* in_len < 2^28, checked below */
     const uint32_t in_mis = (uint32_t)((uintptr_t)in & 3u);
@@ -696,7 +732,8 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_LANES { P(tq) = 0u; }
 
 #if MZ_SPAN_DW
-            uint32_t span_skip = 0;
+            uint32_t span_skip = 0;     /* the step loop takes the next step (it owns the exact verdicts) */
+            uint32_t span_on = use_span; /* cleared for the rest of the block when a window cannot be committed here */
 #endif
             for (;;) {
 #if MZ_SPAN_DW
@@ -706,7 +743,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     /* lanes whose every token lies inside the input (a token is at most 48 bits) */
                     uint32_t nact = (remain > 64u) ? (remain - 64u) / S : 0u;
                     if (nact > 64u) nact = 64u;
-                    if (tokbuf && qn == 0u && !span_skip && nact >= 2u) {
+                    if (span_on && qn == 0u && !span_skip && nact >= 2u) {
                         uint32_t *win = MZ_L_WIN(L);
                         const uint32_t wpos = bitpos + pbase;
                         const uint32_t wb = wpos >> 5, woff = wpos & 31u;
@@ -720,12 +757,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                             }
                         }
                         MZ_WAVE_SYNC();
-#if MZ_LDS_COMPACT
-                        ring_valid = 0; /* the window covers the ring's place */
-#endif
+                        ring_valid = 0; /* the pool covers the ring's place */
                         PV(uint32_t, sst); /* where this lane's walk starts (window-relative bit) */
                         PV(uint32_t, sxe); /* where it crossed into the next span */
-                        PV(uint32_t, scn); /* tokens it walked over */
+                        PV(uint32_t, sby); /* bytes its tokens produce */
+                        PV(uint32_t, smc); /* back-references among them */
                         PV(uint32_t, sfl); /* 0 crossed, 1 stopped behind an end-of-block, 2 stopped at an invalid code */
                         PV(uint32_t, pxe);
                         PV(uint32_t, pfl);
@@ -734,7 +770,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         uint64_t moved;
                         do {
                             MZ_LANES {
-                                uint32_t q = P(sst), n = 0, f = 2;
+                                uint32_t q = P(sst), nby = 0, nmc = 0, f = 2;
                                 if ((uint32_t)lane < nact) {
                                     const uint32_t lim = woff + ((uint32_t)lane + 1u) * S;
                                     f = 0;
@@ -745,7 +781,9 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                                             f = 2;
                                             break;
                                         }
-                                        n++;
+                                        const uint32_t ln = mz_bfe(t, 7, 9);
+                                        nby += ln;
+                                        nmc += (ln > 1u) ? (ln + 31u) >> 5 : 0u; /* list entries: pieces of <= 32 bytes */
                                         q += nb;
                                         if (t & 64u) {
                                             f = 1;
@@ -754,7 +792,8 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                                     }
                                 }
                                 P(sxe) = q;
-                                P(scn) = n;
+                                P(sby) = nby;
+                                P(smc) = nmc;
                                 P(sfl) = f;
                             }
                             MZ_GATHER4(pxe, sxe, (4u * ((uint32_t)lane - 1u)) & 255u);
@@ -770,61 +809,8 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         uint64_t brk;
                         MZ_BALLOT(brk, lane > 0 && ((uint32_t)lane >= nact || P(pfl) != 0u || ((moved >> lane) & 1ull)));
                         uint32_t m = brk ? mz_ctz64(brk) : 64u;
-                        PV(uint32_t, sin);
-                        PV(uint32_t, scm);
-                        MZ_LANES { P(scm) = ((uint32_t)lane < m) ? P(scn) : 0u; }
-                        MZ_INCL_SCAN(sin, scm);
-                        {
-                            uint64_t fit;
-                            MZ_BALLOT(fit, (uint32_t)lane < m && P(sin) <= MZ_SPAN_TOK_CAP);
-                            m = mz_popc64(fit); /* the scan is monotone: the lanes that fit are a prefix */
-                        }
-                        const uint32_t T = m ? MZ_READLANE(sin, m - 1u) : 0u;
-                        MZ_STAT(8, 1); MZ_STAT(9, pass); MZ_STAT(10, T); MZ_STAT(11, m);
-                        if (T == 0u) {
-                            span_skip = 1; /* the very first token is the problem: the step loop has the verdict */
-                        } else {
-                            MZ_LANES {
-                                if ((uint32_t)lane < m) {
-                                    uint32_t q = P(sst), n = P(sin) - P(scn);
-                                    const uint32_t lim = woff + ((uint32_t)lane + 1u) * S;
-                                    while (q < lim) {
-                                        const uint32_t t = mz_span_token(L, win, q);
-                                        const uint32_t nb = t & 63u;
-                                        if (nb == 0u) break;
-                                        tokbuf[n++] = t;
-                                        q += nb;
-                                        if (t & 64u) break;
-                                    }
-                                }
-                            }
-                            MZ_WAVE_SYNC();
-                            const uint32_t endrel = MZ_READLANE(sxe, m - 1u);
-                            const uint32_t span_eob = (MZ_READLANE(sfl, m - 1u) == 1u) ? 1u : 0u;
-                            bitpos += endrel - woff;
-                            ring_valid = 0;
-#if MZ_TOK_PREFETCH
-                            PV(uint32_t, tqn); /* the next batch's tokens are fetched while this one is flushed */
-                            MZ_LANES { P(tqn) = ((uint32_t)lane < T) ? tokbuf[(uint32_t)lane] : 0u; }
-#endif
-                            for (uint32_t j = 0; j < T; j += 64u) {
-                                const uint32_t c = (T - j < 64u) ? (T - j) : 64u;
-#if MZ_TOK_PREFETCH
-                                MZ_LANES {
-                                    P(tq) = ((uint32_t)lane < c) ? P(tqn) : 0u;
-                                    P(tqn) = (j + 64u + (uint32_t)lane < T) ? tokbuf[j + 64u + (uint32_t)lane] : 0u;
-                                }
-#else
-                                MZ_LANES { P(tq) = ((uint32_t)lane < c) ? tokbuf[j + (uint32_t)lane] : 0u; }
-#endif
-                                qn = c;
-#include "inflate_flush.inc"
-                            }
-                            MZ_WAVE_SYNC(); /* the scratch is rewritten by the next window */
-                            if (span_eob) break;
-                            if (MZ_READLANE(sfl, m - 1u) == 2u) span_skip = 1; /* an invalid code is next */
-                            continue;
-                        }
+                        MZ_STAT(8, 1); MZ_STAT(9, pass);
+#include "inflate_window.inc"
                     }
                     span_skip = 0;
                 }
@@ -1036,8 +1022,13 @@ finish:
     if (res->in_used > in_len) res->in_used = in_len;
     {
         uint32_t crc;
+#if MZ_ABLATE & 4
+        crc = 0;
+        (void)crc_tmp;
+#else
         MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);
         MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, out, out_pos, crc_tab, tabs);
+#endif
         res->crc = crc;
     }
 }

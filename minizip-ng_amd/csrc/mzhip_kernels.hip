@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -27,7 +28,9 @@
 #include "xz_core.h"
 #include "lzma_enc_core.h"
 
+#ifndef MZ_WAVES_PER_WG
 #define MZ_WAVES_PER_WG 4
+#endif
 #define MZ_CRC_TAB_BYTES 1024
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
@@ -49,7 +52,6 @@ struct InflateArgs {
     int32_t *status;
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
-    uint32_t *tok; // span path: MZ_SPAN_TOK_CAP tokens of scratch per resident wave (null = step loop only)
 };
 
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_batch(InflateArgs a) {
@@ -60,7 +62,6 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
     MZ_LANE_DECL
     const int wave = threadIdx.x >> 6;
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
-    uint32_t *tokbuf = a.tok ? a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_SPAN_TOK_CAP : nullptr;
     for (;;) {
         uint32_t e;
         MZ_WAVE_FETCH_ADD(e, a.counter);
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
         const uint64_t io = a.in_off[e], oo = a.out_off[e];
         const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
-        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, tokbuf, &r);
+        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, 1u, &r);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -572,21 +573,10 @@ int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE;
     const uint32_t grid = grid_for(c, n);
-    a.tok = nullptr;
-#if MZ_SPAN_DW
-    int slot = -1;
-    void *scratch = nullptr;
-    rc = scratch_acquire(c, (size_t)grid * MZ_WAVES_PER_WG * MZ_SPAN_TOK_CAP * sizeof(uint32_t), s, &slot, &scratch);
-    if (rc) return rc;
-    a.tok = (uint32_t *)scratch;
-#endif
     hipLaunchKernelGGL(k_inflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
     const hipError_t le = hipGetLastError();
-#if MZ_SPAN_DW
-    rc = scratch_release(c, slot, s);
-#endif
     if (le != hipSuccess) return fail("k_inflate_batch", le);
-    return rc;
+    return 0;
 }
 
 int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
@@ -1216,25 +1206,38 @@ struct PrimedEntry {
     int32_t status;
     int64_t seg0; // index of this entry's first segment CRC
     int32_t method;
-    uint8_t head[16];
+    int32_t head_len;
+    uint8_t head[256]; // the first payload bytes: a stream must present the same ones to be served
 };
-struct PrimeCache {
+// One primed archive.  Generations are reference-counted: an open stream that is being served from one pins it, so a
+// later prime / clear (another archive, another thread, MZHIP_AUTOPRIME) never frees memory a stream still reads.
+struct PrimeGen {
     std::vector<PrimedEntry> entries; // sorted by payload_off
     std::vector<uint32_t> seg_crc;
     uint8_t *out = nullptr;
+    uint64_t zip_len = 0, ident = 0; // archive identity: length + hash of its central directory and end records
+    ~PrimeGen() { free(out); }
+};
+struct PrimeCache {
+    std::vector<std::shared_ptr<PrimeGen>> gens; // newest first, at most kMaxGens
     uint64_t hits = 0, misses = 0;
 };
 PrimeCache g_prime;
 std::mutex g_prime_mu;
 constexpr uint32_t kSeg = 65535u;
+constexpr size_t kMaxGens = 8;
+
+uint64_t fnv1a64(const uint8_t *p, uint64_t n, uint64_t h = 0xCBF29CE484222325ull) {
+    for (uint64_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
 } // namespace
 
 extern "C" {
 
 void mzhip_prime_clear(void) {
     std::lock_guard<std::mutex> lk(g_prime_mu);
-    free(g_prime.out);
-    g_prime = PrimeCache();
+    g_prime = PrimeCache(); // generations pinned by open streams live until those streams let go
 }
 
 int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
@@ -1252,7 +1255,8 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     uint64_t total_out = 0;
     for (int64_t i = 0; i < n; i++) {
         const int64_t *t = &table[(size_t)i * 8];
-        if ((t[0] != 8 && t[0] != 14 && t[0] != 95) || (t[1] & 1) || t[7] < 0 || t[3] >= (1ll << 28) || t[4] >= (1ll << 31))
+        if ((t[0] != 8 && t[0] != 14 && t[0] != 95) || (t[1] & 1) || t[7] < 0 || t[3] < 0 || t[4] < 0 ||
+            t[3] >= (1ll << 28) || t[4] >= (1ll << 31) || (uint64_t)t[7] > zip_len || (uint64_t)t[3] > zip_len - (uint64_t)t[7])
             continue;
         PrimedEntry e;
         memset(&e, 0, sizeof(e));
@@ -1261,7 +1265,8 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
         e.csize = t[3];
         e.usize = t[4];
         e.out_off = (int64_t)total_out;
-        memcpy(e.head, zip + t[7], (size_t)(t[3] < 16 ? t[3] : 16));
+        e.head_len = (int32_t)(t[3] < (int64_t)sizeof(e.head) ? t[3] : (int64_t)sizeof(e.head));
+        memcpy(e.head, zip + t[7], (size_t)e.head_len);
         ents.push_back(e);
         in_off.push_back((uint64_t)t[7]);
         in_len.push_back((uint32_t)t[3]);
@@ -1372,15 +1377,28 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
         ents[i].status = 0;
         good.push_back(ents[i]);
     }
-    std::lock_guard<std::mutex> lk(g_prime_mu);
-    free(g_prime.out);
-    g_prime = PrimeCache();
-    g_prime.entries = std::move(good); // index order == payload order for archives written front to back
-    std::sort(g_prime.entries.begin(), g_prime.entries.end(),
+    auto gen = std::make_shared<PrimeGen>();
+    gen->entries = std::move(good); // index order == payload order for archives written front to back
+    std::sort(gen->entries.begin(), gen->entries.end(),
               [](const PrimedEntry &a, const PrimedEntry &b) { return a.payload_off < b.payload_off; });
-    g_prime.seg_crc = std::move(h_segcrc);
-    g_prime.out = h_out;
-    return (int64_t)g_prime.entries.size();
+    gen->seg_crc = std::move(h_segcrc);
+    gen->out = h_out;
+    gen->zip_len = zip_len;
+    {
+        /* identity = length + hash of everything from the first central-directory record to the end of the file */
+        const uint64_t cd0 = (uint64_t)table[6];
+        gen->ident = fnv1a64(zip + cd0, zip_len - cd0);
+    }
+    const int64_t n_good = (int64_t)gen->entries.size();
+    std::lock_guard<std::mutex> lk(g_prime_mu);
+    auto &gens = g_prime.gens;
+    for (size_t i = 0; i < gens.size();) { /* a re-prime of the same archive replaces its generation */
+        if (gens[i]->zip_len == gen->zip_len && gens[i]->ident == gen->ident) gens.erase(gens.begin() + (long)i);
+        else i++;
+    }
+    gens.insert(gens.begin(), std::move(gen));
+    if (gens.size() > kMaxGens) gens.resize(kMaxGens);
+    return n_good;
 }
 
 int64_t mzhip_prime_file(const char *path) {
@@ -1399,47 +1417,56 @@ int64_t mzhip_prime_file(const char *path) {
 
 void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses) {
     std::lock_guard<std::mutex> lk(g_prime_mu);
-    if (entries) *entries = g_prime.entries.size();
+    if (entries) {
+        *entries = 0;
+        for (const auto &g : g_prime.gens) *entries += g->entries.size();
+    }
     if (hits) *hits = g_prime.hits;
     if (misses) *misses = g_prime.misses;
 }
 
-// Used by shim_zlib.c: is the entry whose payload starts at `payload_off` (first bytes `head`) primed?
-// On a hit returns 1 and the cached output / sizes / CRCs (pointers stay valid until the next prime/clear).
-__attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup2(int32_t method, int64_t payload_off, const uint8_t *head,
-                                                                  int32_t head_len, const uint8_t **data,
+// Used by the READ shims: is the entry whose payload starts at `payload_off` primed?  The stream presents the payload
+// bytes it has pulled so far (`head`, at least min(csize, 16) of them) and, when the zip layer set one, its
+// TOTAL_IN_MAX (= the entry's compressed size, mz_zip.c:1829); offset, method, compressed size and up to 256 leading
+// payload bytes must all agree.  On a hit returns 1, the cached output / sizes / CRCs, and *pin: a reference that keeps
+// the generation alive until the stream hands it back with mzhip_prime_unpin() (close / delete / re-open).
+__attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup3(int32_t method, int64_t payload_off, const uint8_t *head,
+                                                                  int32_t head_len, int64_t max_total_in, const uint8_t **data,
                                                                   int64_t *usize, int64_t *csize, uint32_t *crc,
-                                                                  const uint32_t **seg_crc) {
+                                                                  const uint32_t **seg_crc, void **pin) {
     std::lock_guard<std::mutex> lk(g_prime_mu);
-    if (g_prime.entries.empty()) return 0;
-    size_t lo = 0, hi = g_prime.entries.size();
-    while (lo < hi) {
-        size_t mid = (lo + hi) / 2;
-        if (g_prime.entries[mid].payload_off < payload_off) lo = mid + 1; else hi = mid;
+    *pin = nullptr;
+    if (g_prime.gens.empty()) return 0;
+    for (const std::shared_ptr<PrimeGen> &g : g_prime.gens) {
+        const std::vector<PrimedEntry> &ents = g->entries;
+        size_t lo = 0, hi = ents.size();
+        while (lo < hi) {
+            size_t mid = (lo + hi) / 2;
+            if (ents[mid].payload_off < payload_off) lo = mid + 1; else hi = mid;
+        }
+        if (lo == ents.size() || ents[lo].payload_off != payload_off) continue;
+        const PrimedEntry &e = ents[lo];
+        const int32_t need = e.head_len < 16 ? e.head_len : 16;
+        const int32_t cmp = head_len < e.head_len ? head_len : e.head_len;
+        if (e.method != method || head_len < need || memcmp(head, e.head, (size_t)cmp) != 0) continue;
+        if (max_total_in > 0 && max_total_in != e.csize) continue;
+        g_prime.hits++;
+        *data = g->out + e.out_off;
+        *usize = e.usize;
+        *csize = e.csize;
+        *crc = e.crc;
+        *seg_crc = g->seg_crc.data() + e.seg0;
+        *pin = new std::shared_ptr<PrimeGen>(g);
+        return 1;
     }
-    if (lo == g_prime.entries.size() || g_prime.entries[lo].payload_off != payload_off) {
-        g_prime.misses++;
-        return 0;
-    }
-    const PrimedEntry &e = g_prime.entries[lo];
-    const int32_t cmp = (int32_t)(e.csize < 16 ? e.csize : 16);
-    if (e.method != method || head_len < cmp || memcmp(head, e.head, (size_t)cmp) != 0) {
-        g_prime.misses++;
-        return 0;
-    }
-    g_prime.hits++;
-    *data = g_prime.out + e.out_off;
-    *usize = e.usize;
-    *csize = e.csize;
-    *crc = e.crc;
-    *seg_crc = g_prime.seg_crc.data() + e.seg0;
-    return 1;
+    g_prime.misses++;
+    return 0;
 }
 
-__attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup(int64_t payload_off, const uint8_t *head, int32_t head_len,
-                                                                 const uint8_t **data, int64_t *usize, int64_t *csize,
-                                                                 uint32_t *crc, const uint32_t **seg_crc) {
-    return mzhip_prime_lookup2(8, payload_off, head, head_len, data, usize, csize, crc, seg_crc);
+__attribute__((visibility("hidden"))) void mzhip_prime_unpin(void *pin) {
+    if (!pin) return;
+    std::lock_guard<std::mutex> lk(g_prime_mu); // the last reference may free the generation
+    delete (std::shared_ptr<PrimeGen> *)pin;
 }
 
 // checksums only: crc(A||B) from crc(A), crc(B), |B| (shared with shim_crc32.c)

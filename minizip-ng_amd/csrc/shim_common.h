@@ -3,12 +3,13 @@
 #define MZHIP_SHIM_COMMON_H
 #include <stdint.h>
 
-/* prime cache lookup (mzhip_kernels.hip): 1 = hit */
-int32_t mzhip_prime_lookup(int64_t payload_off, const uint8_t *head, int32_t head_len, const uint8_t **data,
-                           int64_t *usize, int64_t *csize, uint32_t *crc, const uint32_t **seg_crc);
-/* the same for any primed method (8 DEFLATE, 14 LZMA, 95 XZ) */
-int32_t mzhip_prime_lookup2(int32_t method, int64_t payload_off, const uint8_t *head, int32_t head_len,
-                            const uint8_t **data, int64_t *usize, int64_t *csize, uint32_t *crc, const uint32_t **seg_crc);
+/* prime cache lookup (mzhip_kernels.hip): 1 = hit, for any primed method (8 DEFLATE, 14 LZMA, 95 XZ).  `head` = the
+ * payload bytes pulled so far, `max_total_in` = the stream's TOTAL_IN_MAX (<= 0: unknown).  On a hit *pin keeps the
+ * cached generation alive; hand it back with mzhip_prime_unpin() when the stream stops reading from `data`. */
+int32_t mzhip_prime_lookup3(int32_t method, int64_t payload_off, const uint8_t *head, int32_t head_len, int64_t max_total_in,
+                            const uint8_t **data, int64_t *usize, int64_t *csize, uint32_t *crc, const uint32_t **seg_crc,
+                            void **pin);
+void mzhip_prime_unpin(void *pin);
 /* MZHIP_AUTOPRIME: prime the archive behind a codec stream's base on first use (shim_autoprime.c); no-op otherwise */
 struct mzhip_stream_s;
 void mzhip_autoprime(struct mzhip_stream_s *codec_base);
@@ -31,8 +32,24 @@ typedef struct mzhip_served_s {
     int32_t size;
     uint32_t crc;
     int32_t valid;
+    uint8_t first[8], last[8]; /* the buffer's first and last bytes at the time it was served (size >= 8: else both = first `size`) */
 } mzhip_served;
 extern __thread mzhip_served mzhip_last_served;
+/* record / drop the hint; every shim read, write and open drops it first, so it only ever describes the bytes the
+ * immediately preceding codec call produced */
+static inline void mzhip_served_set(const void *buf, int32_t size, uint32_t crc) {
+    const uint8_t *p = (const uint8_t *)buf;
+    const int32_t k = size < 8 ? size : 8;
+    mzhip_last_served.buf = buf;
+    mzhip_last_served.size = size;
+    mzhip_last_served.crc = crc;
+    for (int32_t i = 0; i < 8; i++) {
+        mzhip_last_served.first[i] = i < k ? p[i] : 0;
+        mzhip_last_served.last[i] = i < k ? p[size - k + i] : 0;
+    }
+    mzhip_last_served.valid = 1;
+}
+static inline void mzhip_served_drop(void) { mzhip_last_served.valid = 0; }
 
 #define MZHIP_PRIME_SEGMENT 65535 /* the reader's buffer size, mz_zip_rw.c:55 */
 #endif

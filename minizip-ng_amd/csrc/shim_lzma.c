@@ -54,6 +54,7 @@ typedef struct mzhip_lzma_s {
     int64_t dev_in_used;
     int64_t next_attempt;
     int8_t tried_cache, out_borrowed; /* prime cache: looked up once; out points into the cache */
+    void *prime_pin;                  /* keeps the cached generation alive while out points into it */
     int64_t base_pos0;                /* base position at open = payload offset */
     const uint32_t *seg_crc;          /* GPU CRCs of the 65 535-byte segments of a primed entry */
     /* write side: the whole entry is collected, coded at close() */
@@ -90,12 +91,15 @@ static int32_t grow_in(mzhip_lzma *z, int64_t need) {
 
 int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
+    mzhip_served_drop();
     (void)path;
     z->total_in = z->total_out = 0;
     z->error = 0;
     free(z->in);
     if (!z->out_borrowed)
         free(z->out);
+    mzhip_prime_unpin(z->prime_pin);
+    z->prime_pin = NULL;
     z->out_borrowed = 0;
     z->tried_cache = 0;
     z->seg_crc = NULL;
@@ -214,6 +218,7 @@ static int32_t attempt_decode(mzhip_lzma *z) {
 
 int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
+    mzhip_served_drop();
     if (z->error != 0)
         return MZH_DATA_ERROR; /* mz_strm_lzma.c:236-237 */
     while (!z->decoded) {
@@ -233,9 +238,9 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
             int64_t usize = 0, csize = 0;
             uint32_t crc = 0;
             if (z->base_pos0 >= 0 &&
-                mzhip_prime_lookup2(z->method, z->base_pos0, z->in, (int32_t)(z->in_len < 16 ? z->in_len : 16), &data, &usize,
-                                    &csize, &crc, &z->seg_crc) == 1 &&
-                (z->max_total_in <= 0 || z->max_total_in >= csize) && (z->max_total_out < 0 || z->max_total_out >= usize)) {
+                mzhip_prime_lookup3(z->method, z->base_pos0, z->in, (int32_t)(z->in_len < 256 ? z->in_len : 256), z->max_total_in,
+                                    &data, &usize, &csize, &crc, &z->seg_crc, &z->prime_pin) == 1 &&
+                (z->max_total_out < 0 || z->max_total_out >= usize)) {
                 z->out = (uint8_t *)(uintptr_t)data;
                 z->out_borrowed = 1;
                 z->out_len = usize;
@@ -270,10 +275,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: its device-computed CRC answers the mz_crypt_crc32_update that follows */
-            mzhip_last_served.buf = buf;
-            mzhip_last_served.size = n;
-            mzhip_last_served.crc = z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT];
-            mzhip_last_served.valid = 1;
+            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT]);
         }
         z->out_served += n;
         z->total_out += n;
@@ -329,6 +331,7 @@ static int32_t leave_primed(mzhip_lzma *z) {
 
 int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
+    mzhip_served_drop();
     if (size <= 0)
         return size;
     if (!z->wp_off) {
@@ -339,10 +342,7 @@ int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
             z->wp_pos += size;
             z->total_in += size;
             if (have_crc) { /* answers the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) */
-                mzhip_last_served.buf = buf;
-                mzhip_last_served.size = size;
-                mzhip_last_served.crc = crc;
-                mzhip_last_served.valid = 1;
+                mzhip_served_set(buf, size, crc);
             }
             return size;
         }
@@ -436,6 +436,8 @@ int32_t mz_stream_lzma_close(void *stream) {
     free(z->in);
     if (!z->out_borrowed)
         free(z->out);
+    mzhip_prime_unpin(z->prime_pin);
+    z->prime_pin = NULL;
     z->out_borrowed = 0;
     z->in = z->out = NULL;
     z->in_cap = z->out_cap = 0;
@@ -516,6 +518,8 @@ void mz_stream_lzma_delete(void **stream) {
         free(z->in);
         if (!z->out_borrowed)
             free(z->out);
+        mzhip_prime_unpin(z->prime_pin);
+        z->prime_pin = NULL;
         free(z->wbuf);
         free(z);
     }

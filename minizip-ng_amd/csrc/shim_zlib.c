@@ -68,6 +68,7 @@ typedef struct mzhip_zlib_s {
     int64_t wp_id, wp_pos;
     int8_t wp_off; /* this entry is not (or no longer) following a primed buffer */
     int8_t tried_cache, out_borrowed; /* prime cache: looked up once; out points into the cache */
+    void *prime_pin;                  /* keeps the cached generation alive while out points into it */
     int64_t base_pos0;                /* base position at the first read = payload offset */
     const uint32_t *seg_crc;          /* GPU CRCs of the 65 535-byte segments of a primed entry */
     int32_t wrap;      /* 0 raw, 1 zlib, 2 gzip (resolved from window_bits; 3 = detect, resolved by the header) */
@@ -100,6 +101,8 @@ static void free_buffers(mzhip_zlib *z) {
     free(z->in);
     if (!z->out_borrowed)
         free(z->out);
+    mzhip_prime_unpin(z->prime_pin);
+    z->prime_pin = NULL;
     z->out_borrowed = 0;
     free(z->wbuf);
     z->in = z->out = z->wbuf = NULL;
@@ -109,6 +112,7 @@ static void free_buffers(mzhip_zlib *z) {
 
 int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
+    mzhip_served_drop();
     (void)path;
     z->total_in = 0;
     z->total_out = 0;
@@ -350,6 +354,7 @@ static int32_t attempt_decode(mzhip_zlib *z) {
 
 int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
+    mzhip_served_drop();
     if (z->error != 0)
         return z->error; /* mz_strm_zlib.c:186-189 */
 
@@ -377,9 +382,9 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             const uint8_t *data = NULL;
             int64_t usize = 0, csize = 0;
             uint32_t crc = 0;
-            if (z->wrap == 0 && z->base_pos0 >= 0 && mzhip_prime_lookup(z->base_pos0, z->in, (int32_t)(z->in_len < 16 ? z->in_len : 16),
-                                                         &data, &usize, &csize, &crc, &z->seg_crc) == 1 &&
-                (z->max_total_in <= 0 || z->max_total_in >= csize)) {
+            if (z->wrap == 0 && z->base_pos0 >= 0 &&
+                mzhip_prime_lookup3(8, z->base_pos0, z->in, (int32_t)(z->in_len < 256 ? z->in_len : 256), z->max_total_in, &data,
+                                    &usize, &csize, &crc, &z->seg_crc, &z->prime_pin) == 1) {
                 z->out = (uint8_t *)(uintptr_t)data;
                 z->out_borrowed = 1;
                 z->out_len = usize;
@@ -412,10 +417,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: remember its device-computed CRC for the mz_crypt_crc32_update that follows */
-            mzhip_last_served.buf = buf;
-            mzhip_last_served.size = n;
-            mzhip_last_served.crc = z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT];
-            mzhip_last_served.valid = 1;
+            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT]);
         }
         z->out_served += n;
         z->total_out += n;
@@ -559,6 +561,7 @@ static int32_t leave_primed(mzhip_zlib *z) {
 
 int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
+    mzhip_served_drop();
     if (size > 0 && z->wrap == 0 && !z->wp_off) {
         /* mzhip_prime_write: is this entry, so far, one of the buffers that were compressed ahead of time? */
         uint32_t crc = 0;
@@ -568,10 +571,7 @@ int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
             z->wp_pos += size;
             z->total_in += size;
             if (have_crc) { /* the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) is answered from the cache */
-                mzhip_last_served.buf = buf;
-                mzhip_last_served.size = size;
-                mzhip_last_served.crc = crc;
-                mzhip_last_served.valid = 1;
+                mzhip_served_set(buf, size, crc);
             }
             return size;
         }
@@ -616,6 +616,8 @@ int32_t mz_stream_zlib_close(void *stream) {
     free(z->in);
     if (!z->out_borrowed)
         free(z->out);
+    mzhip_prime_unpin(z->prime_pin);
+    z->prime_pin = NULL;
     z->out_borrowed = 0;
     free(z->wbuf);
     z->in = z->out = z->wbuf = NULL;
@@ -691,6 +693,8 @@ void mz_stream_zlib_delete(void **stream) {
         free(z->in);
         if (!z->out_borrowed)
             free(z->out);
+        mzhip_prime_unpin(z->prime_pin);
+        z->prime_pin = NULL;
         free(z->wbuf);
         free(z);
     }

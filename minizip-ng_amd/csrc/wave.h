@@ -61,6 +61,7 @@
 #define MZ_LDS_ATOMIC_INC(ptr) (++*(ptr))
 #define MZ_LDS_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
 #define MZ_LDS_ATOMIC_MAX(ptr, v) (*(ptr) = (*(ptr) > (v)) ? *(ptr) : (v))
+#define MZ_LDS_ATOMIC_AND(ptr, v) (*(ptr) &= (v))
 /* dst[lane] = src[idx(lane)] -- a cross-lane gather (ds_bpermute on the device) */
 #define MZ_GATHER(dst, src, idx_expr)                                \
     do {                                                             \
@@ -141,6 +142,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
 #define MZ_LDS_ATOMIC_INC(ptr) atomicAdd((ptr), 1u)
 #define MZ_LDS_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
 #define MZ_LDS_ATOMIC_MAX(ptr, v) atomicMax((ptr), (v))
+#define MZ_LDS_ATOMIC_AND(ptr, v) atomicAnd((ptr), (v))
 #define MZ_GATHER(dst, src, idx_expr) ((dst) = (uint32_t)__shfl((int)(src), (int)(idx_expr), 64))
 #define MZ_GATHER4(dst, src, byteidx_expr) ((dst) = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(byteidx_expr), (int)(src)))
 /* inclusive wave64 prefix sum on the DPP network: Kogge-Stone inside each row of 16 lanes
@@ -163,6 +165,16 @@ MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 MZ_DEV uint32_t mz_brev32(uint32_t v) { return __brev(v); }
 
 #endif
+
+/* Byte-granular moves of 1 / 2 / 4 / 8 bytes at ANY address (LDS or global): gfx950 serves unaligned ds_read/ds_write
+ * b16..b64 and global loads / stores natively (hipcc emits the single instruction for these memcpys); the host
+ * emulation is plain memcpy. */
+MZ_DEV uint64_t mz_ld8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+MZ_DEV uint32_t mz_ld4(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+MZ_DEV uint32_t mz_ld2(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+MZ_DEV void mz_st8(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+MZ_DEV void mz_st4(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+MZ_DEV void mz_st2(uint8_t *p, uint32_t v) { uint16_t w = (uint16_t)v; __builtin_memcpy(p, &w, 2); }
 
 /* status words shared by every kernel; numerically the zlib / MZ_* codes the
  * reference surfaces (mz.h:20-26, mz_strm_zlib.c:186-189). */

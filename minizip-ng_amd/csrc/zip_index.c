@@ -18,6 +18,9 @@ static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); 
 static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 static uint64_t rd64(const uint8_t *p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
 
+/* [off, off + len) lies inside a buffer of `total` bytes -- written so that nothing wraps */
+static int fits(uint64_t off, uint64_t len, uint64_t total) { return off <= total && len <= total - off; }
+
 #define SIG_LOCAL 0x04034b50u   /* mz_zip.c:59 */
 #define SIG_CD 0x02014b50u      /* mz_zip.c:60 */
 #define SIG_EOCD 0x06054b50u    /* mz_zip.c:61 */
@@ -46,18 +49,18 @@ int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table
         if (eocd < 20 || rd32(zip + eocd - 20) != SIG_LOC64)
             return -103;
         uint64_t e64 = rd64(zip + eocd - 20 + 8);
-        if (e64 + 56 > zip_len || rd32(zip + e64) != SIG_EOCD64)
+        if (!fits(e64, 56, zip_len) || rd32(zip + e64) != SIG_EOCD64)
             return -103;
         n_entries = rd64(zip + e64 + 32);
         cd_size = rd64(zip + e64 + 40);
         cd_off = rd64(zip + e64 + 48);
     }
-    if (cd_off + cd_size > zip_len)
+    if (!fits(cd_off, cd_size, zip_len))
         return -103;
     uint64_t p = cd_off;
     int64_t n = 0;
     for (uint64_t k = 0; k < n_entries; k++) {
-        if (p + 46 > zip_len || rd32(zip + p) != SIG_CD)
+        if (!fits(p, 46, zip_len) || rd32(zip + p) != SIG_CD)
             return -103;
         const uint8_t *h = zip + p;
         uint64_t flag = rd16(h + 8), method = rd16(h + 10), crc = rd32(h + 16);
@@ -65,7 +68,7 @@ int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table
         uint32_t fn = rd16(h + 28), ex = rd16(h + 30), cm = rd16(h + 32);
         uint64_t disk = rd16(h + 34);
         uint64_t loff = rd32(h + 42);
-        if (p + 46 + fn + ex + cm > zip_len)
+        if (!fits(p, 46ull + fn + ex + cm, zip_len))
             return -103;
         /* ZIP64 extended information: only the fields that overflowed, in this fixed order (appnote 4.5.3) */
         const uint8_t *x = h + 46 + fn, *xe = x + ex;
@@ -82,12 +85,16 @@ int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table
             }
             x += 4 + sz;
         }
+        /* a ZIP64 field that does not fit the reference's int64_t members is a format error there too
+         * (mz_zip.c:328-339: `< 0` after the 64-bit read) */
+        if ((usize | csize | loff) >> 63)
+            return -103;
         int64_t payload = -1;
-        if (loff + 30 <= zip_len && rd32(zip + loff) == SIG_LOCAL) {
+        if (fits(loff, 30, zip_len) && rd32(zip + loff) == SIG_LOCAL) {
             uint64_t lfn = rd16(zip + loff + 26), lex = rd16(zip + loff + 28);
-            payload = (int64_t)(loff + 30 + lfn + lex);
-            if ((uint64_t)payload + csize > zip_len)
-                payload = -1;
+            uint64_t pay = loff + 30 + lfn + lex; /* loff <= zip_len - 30: no wrap */
+            if (fits(pay, csize, zip_len))
+                payload = (int64_t)pay;
         }
         if (n < max_entries && table) {
             int64_t *t = table + n * 8;

@@ -31,10 +31,7 @@ extern "C" int32_t emul_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out
     mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_inflate_result r;
-    uint32_t *tok = (uint32_t *)malloc(MZ_SPAN_TOK_CAP * sizeof(uint32_t));
-    memset(tok, 0x5A, MZ_SPAN_TOK_CAP * sizeof(uint32_t));
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, tok, &r);
-    free(tok);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, &r);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;
@@ -42,14 +39,14 @@ extern "C" int32_t emul_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out
     return r.status;
 }
 
-/* the step loop alone (no token scratch => the span path is off) */
+/* the step loop alone (the span path is off) */
 extern "C" int32_t emul_inflate_steps(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                                       uint32_t *in_used, uint32_t *crc) {
     ready();
     mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_inflate_result r;
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, (uint32_t *)0, &r);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 0u, &r);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;

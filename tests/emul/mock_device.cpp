@@ -102,10 +102,12 @@ extern "C" uint32_t mzhip_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b
 MOCK_API int64_t mzhip_prime_file(const char *) { return -109; }
 MOCK_API int64_t mzhip_prime_mem(const uint8_t *, uint64_t) { return -109; }
 MOCK_API void mzhip_prime_clear(void) {}
-extern "C" int32_t mzhip_prime_lookup2(int32_t, int64_t, const uint8_t *, int32_t, const uint8_t **, int64_t *, int64_t *, uint32_t *,
-                                       const uint32_t **) { return 0; }
-extern "C" int32_t mzhip_prime_lookup(int64_t, const uint8_t *, int32_t, const uint8_t **, int64_t *, int64_t *, uint32_t *,
-                                      const uint32_t **) { return 0; }
+extern "C" int32_t mzhip_prime_lookup3(int32_t, int64_t, const uint8_t *, int32_t, int64_t, const uint8_t **, int64_t *, int64_t *,
+                                       uint32_t *, const uint32_t **, void **pin) {
+    *pin = nullptr;
+    return 0;
+}
+extern "C" void mzhip_prime_unpin(void *) {}
 extern "C" int32_t mzhip_wprime_track(int32_t, int64_t *, int64_t, const uint8_t *, int32_t, uint32_t *, int32_t *have_crc) {
     *have_crc = 0;
     return 0;

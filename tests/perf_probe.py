@@ -6,7 +6,9 @@ import zlib
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from tests import gpu_util, synth  # noqa: E402
 
 n_unique = int(sys.argv[1]) if len(sys.argv) > 1 else 512

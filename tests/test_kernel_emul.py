@@ -61,9 +61,9 @@ def _run(fn, z, cap, *extra, mis=0, omis=0):
 
 
 def test_lds_budget(emu):
-    # 4 waves x inflate slice (tables + the span path's window) + CRC table must allow 5 workgroups
-    # (20 waves = 5 per SIMD, the kernel's launch bound) per 160 KiB CU
-    assert (4 * ((emu.emul_lds_bytes() + 15) // 16 * 16) + 1024) * 5 <= 160 * 1024
+    # 4 waves x inflate slice (tables + the span path's window + the window's staging / match-list pool) + CRC table
+    # must allow 2 workgroups (8 waves = 2 per SIMD, the kernel's launch bound) per 160 KiB CU
+    assert (4 * ((emu.emul_lds_bytes() + 15) // 16 * 16) + 1024) * 2 <= 160 * 1024
     assert emu.emul_lzma_lds_bytes() + 1024 <= 16 * 1024 + 1024
 
 
@@ -411,15 +411,15 @@ def _build_variant(tag, flags):
 
 @pytest.fixture(scope="module")
 def emu_staged():
-    """Opt-in K1 builds in the same emulation: the staged flush (batches assembled in LDS), and the compact LDS layout
-    with 192-bit spans that admits a sixth workgroup per CU."""
-    return [_build_variant("staged", ["-DMZ_STAGED_FLUSH=1"]),
-            _build_variant("staged2", ["-DMZ_STAGED_FLUSH=2", "-DMZ_TOK_PREFETCH=1"]),
-            _build_variant("compact6", ["-DMZ_SPAN_DW=6", "-DMZ_STAGED_FLUSH=1", "-DMZ_LDS_COMPACT=1"])]
+    """Other K1 geometries in the same emulation: 192-bit spans with a smaller pool (the tuning builds), and pools so
+    small that windows are cut short or handed back to the step loop all the time."""
+    return [_build_variant("s6", ["-DMZ_SPAN_DW=6", "-DMZ_POOL_BYTES=4608u"]),
+            _build_variant("tiny", ["-DMZ_POOL_BYTES=2048u", "-DMZ_NEAR_SLOTS=1"]),
+            _build_variant("s4tiny", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=1024u"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
-    """K1 has two decode front ends feeding one flush: the span path (every lane walks its own 256-bit span, then the
+    """K1 has two decode front ends: the span path (every lane walks its own 256-bit span, then the
     walks are chained) and the step loop (64 candidate offsets of one 64-bit window), which also owns the last span of
     a stream and every error verdict.  Both must agree with the oracle on streams long enough for the span path to
     engage, including corrupted and truncated ones and tight output caps."""
