@@ -44,10 +44,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def measured_traffic(n, size):
-    """HBM bytes per launch from the committed PMC passes (profiles/r1/hbm_traffic.json), only when they were
+    """HBM bytes per launch from the committed PMC passes (profiles/r2/hbm_traffic.json), only when they were
     taken on this very workload; counters cannot be collected from inside a timed run."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1", "hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2", "hbm_traffic.json")) as f:
             t = json.load(f)
         if n == 100000 and size == 65536:
             return t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]

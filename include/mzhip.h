@@ -170,6 +170,11 @@ MZHIP_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_
                                       uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t *adler);
 MZHIP_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
                                       uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler);
+/* mz_crypt_crc32_update on a host buffer (mz_crypt.c:35-92: chaining value in, chaining value out).  Buffers of
+ * MZHIP_CRC_HOST_BELOW bytes or more are reduced on the device (K2); smaller ones -- the reference calls the symbol
+ * per byte from mz_strm_pkcrypt.c:79,86 -- are folded on the host with the same generated tables.  Never aborts: if
+ * the device is unusable the value is still exact and the failure is reported by the next codec-stream call. */
+#define MZHIP_CRC_HOST_BELOW 4096u
 MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size);
 
 /* Archive index (host, C) --------------------------------------------------------------- */

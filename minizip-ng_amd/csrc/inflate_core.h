@@ -64,11 +64,14 @@ extern unsigned long long mz_stats[16];
 #define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
 #define MZ_SPAN_MAX_PASS 6u
 #ifndef MZ_POOL_BYTES
-#define MZ_POOL_BYTES 3520u /* span path: LDS pool of one window chunk = staging bytes of its output (from the front,
+#define MZ_POOL_BYTES 3264u /* span path: LDS pool of one window chunk = staging bytes of its output (from the front,
                                at most 4 KiB), a pending bit per byte, its back-reference list, 4 bytes each (from the back) */
 #endif
+#ifndef MZ_EMIT_MIN_LANES
+#define MZ_EMIT_MIN_LANES 12u /* span path: verified lanes worth a commit while other lanes are still converging */
+#endif
 #ifndef MZ_NEAR_SLOTS
-#define MZ_NEAR_SLOTS 2 /* span path: back-references per lane in one batch of the near pass (1 or 2) */
+#define MZ_NEAR_SLOTS 1 /* span path: pieces per lane in one batch of the near pass (1 or 2) */
 #endif
 #ifndef MZ_LDS_PAD
 #define MZ_LDS_PAD 0
@@ -161,24 +164,27 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
 #endif
 } mz_inflate_body_scratch;
 #if MZ_SPAN_DW
-typedef char mz_pool_is_16_byte_granular[(MZ_POOL_BYTES % 16u == 0u && MZ_POOL_BYTES < 65536u) ? 1 : -1];
+typedef char mz_pool_is_16_byte_granular[(MZ_POOL_BYTES % 16u == 0u && MZ_POOL_BYTES < 65536u && (MZ_LIT_SUB_ENTRIES % 4) == 0 &&
+                                          ((1 << MZ_LROOT) % 4) == 0) ? 1 : -1];
 #endif
 #define MZ_L_WIN(L_) ((L_)->u.b.win)
 #define MZ_L_RING(L_) ((L_)->u.b.x.s.ring)
 #define MZ_L_MSLOT(L_) ((L_)->u.b.x.s.mslot)
 
-typedef struct mz_inflate_lds {
-    union { /* first member: 16-byte aligned like the struct itself */
-        mz_inflate_hdr_scratch h;
-        mz_inflate_body_scratch b;
-    } u;
+typedef struct mz_inflate_lds { /* sits on a 16-byte boundary; every member below starts on one */
     uint32_t lit_fast[1 << MZ_LROOT];
     uint32_t dist_fast[1 << MZ_DROOT];
-    uint32_t lit_sub[MZ_LIT_SUB_ENTRIES]; /* second-level tables for literal/length codes longer than the root
-                                             (during the build: descriptors in canonical order) */
     uint32_t dist_ent[32]; /* distance descriptors in canonical (length, symbol) order, for codes > root */
     uint16_t dist_lim[16]; /* left-justified 15-bit upper bound of the distance codes of each length */
     int16_t dist_delta[16]; /* rank offset - first code, per length */
+    uint32_t lit_sub[MZ_LIT_SUB_ENTRIES]; /* second-level tables for literal/length codes longer than the root
+                                             (during the build: descriptors in canonical order).  Sized for the worst
+                                             code; the entries a block does not use extend the span path's pool, which
+                                             follows directly (u.b.x.pool) */
+    union {
+        mz_inflate_hdr_scratch h;
+        mz_inflate_body_scratch b;
+    } u;
 #if MZ_LDS_PAD
     uint32_t pad[MZ_LDS_PAD / 4]; /* measurement builds only: occupancy study */
 #endif
@@ -346,7 +352,7 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
  *   A  long symbols (<= 5 per lane, kept in registers) atomicMax their length into the root entry;
  *   B  a prefix sum over the 512 root entries hands out sub-table offsets, root entry <- MZ_E_SUB | off | bits;
  *   C  the sub-tables are filled (shorter codes of a group replicated). */
-#define MZ_BUILD_LIT_SUB(err_out, L_)                                                                          \
+#define MZ_BUILD_LIT_SUB(err_out, used_out, L_)                                                                         \
     do {                                                                                                       \
         mz_inflate_hdr_scratch *_H = &(L_)->u.h;                                                               \
         const uint32_t _lo = MZ_UNIFORM(_H->offs[MZ_LROOT + 1]);                                               \
@@ -383,6 +389,7 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
         MZ_INCL_SCAN(_szend, _sz);                                                                             \
         const uint32_t _total = MZ_READLANE(_szend, 63);                                                       \
         (err_out) = (_total > MZ_LIT_SUB_ENTRIES) ? 1 : 0;                                                     \
+        (used_out) = _total;                                                                                   \
         if (!(err_out)) {                                                                                      \
             MZ_LANES {                                                                                         \
                 for (int _j = lane; _j < MZ_LIT_SUB_ENTRIES; _j += 64) (L_)->lit_sub[_j] = 0u;                 \
@@ -586,6 +593,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
 
         int32_t left;
         uint32_t maxlen;
+        uint32_t sub_used = MZ_LIT_SUB_ENTRIES; /* second-level entries this block's literal/length code occupies */
         if (btype == 1) {
             /* fixed code, appnote.txt:2050-2059 */
             MZ_LANES {
@@ -597,7 +605,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                           (int16_t *)0);
             {
                 int suberr;
-                MZ_BUILD_LIT_SUB(suberr, L);
+                MZ_BUILD_LIT_SUB(suberr, sub_used, L);
                 (void)suberr; /* the fixed code has no literal/length code longer than 9 bits */
             }
             MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_ent, mz_dist_ent,
@@ -702,7 +710,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
             {
                 int suberr;
-                MZ_BUILD_LIT_SUB(suberr, L);
+                MZ_BUILD_LIT_SUB(suberr, sub_used, L);
                 if (suberr) { /* cannot happen for a complete code (zlib enough.c bound) */
                     status = MZHIP_DATA_ERROR;
                     goto finish;
@@ -758,58 +766,6 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         }
                         MZ_WAVE_SYNC();
                         ring_valid = 0; /* the pool covers the ring's place */
-                        PV(uint32_t, sst); /* where this lane's walk starts (window-relative bit) */
-                        PV(uint32_t, sxe); /* where it crossed into the next span */
-                        PV(uint32_t, sby); /* bytes its tokens produce */
-                        PV(uint32_t, smc); /* back-references among them */
-                        PV(uint32_t, sfl); /* 0 crossed, 1 stopped behind an end-of-block, 2 stopped at an invalid code */
-                        PV(uint32_t, pxe);
-                        PV(uint32_t, pfl);
-                        MZ_LANES { P(sst) = woff + (uint32_t)lane * S; }
-                        uint32_t pass = 0;
-                        uint64_t moved;
-                        do {
-                            MZ_LANES {
-                                uint32_t q = P(sst), nby = 0, nmc = 0, f = 2;
-                                if ((uint32_t)lane < nact) {
-                                    const uint32_t lim = woff + ((uint32_t)lane + 1u) * S;
-                                    f = 0;
-                                    while (q < lim) {
-                                        const uint32_t t = mz_span_token(L, win, q);
-                                        const uint32_t nb = t & 63u;
-                                        if (nb == 0u) {
-                                            f = 2;
-                                            break;
-                                        }
-                                        const uint32_t ln = mz_bfe(t, 7, 9);
-                                        nby += ln;
-                                        nmc += (ln > 1u) ? (ln + 31u) >> 5 : 0u; /* list entries: pieces of <= 32 bytes */
-                                        q += nb;
-                                        if (t & 64u) {
-                                            f = 1;
-                                            break;
-                                        }
-                                    }
-                                }
-                                P(sxe) = q;
-                                P(sby) = nby;
-                                P(smc) = nmc;
-                                P(sfl) = f;
-                            }
-                            MZ_GATHER4(pxe, sxe, (4u * ((uint32_t)lane - 1u)) & 255u);
-                            MZ_GATHER4(pfl, sfl, (4u * ((uint32_t)lane - 1u)) & 255u);
-                            MZ_BALLOT(moved, lane > 0 && (uint32_t)lane < nact && P(pfl) == 0u && P(pxe) != P(sst));
-                            MZ_LANES {
-                                if (lane > 0 && (uint32_t)lane < nact && P(pfl) == 0u) P(sst) = P(pxe);
-                            }
-                            pass++;
-                        } while (moved && pass < MZ_SPAN_MAX_PASS);
-                        /* verified prefix: lane i's walk is the true parse iff every lane before it crossed cleanly
-                         * and handed it the start it actually used in the last pass */
-                        uint64_t brk;
-                        MZ_BALLOT(brk, lane > 0 && ((uint32_t)lane >= nact || P(pfl) != 0u || ((moved >> lane) & 1ull)));
-                        uint32_t m = brk ? mz_ctz64(brk) : 64u;
-                        MZ_STAT(8, 1); MZ_STAT(9, pass);
 #include "inflate_window.inc"
                     }
                     span_skip = 0;

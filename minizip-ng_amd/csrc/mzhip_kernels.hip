@@ -35,7 +35,7 @@
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
 #ifndef MZ_MIN_WAVES_PER_SIMD
-#define MZ_MIN_WAVES_PER_SIMD 5 /* register budget: 96 VGPRs -> 5 waves per SIMD, 20 per CU (matches the LDS budget: 5 workgroups) */
+#define MZ_MIN_WAVES_PER_SIMD 4 /* register budget: 128 VGPRs -> 4 waves per SIMD, 16 per CU (matches the LDS budget: 4 workgroups) */
 #endif
 
 struct InflateArgs {
@@ -1144,12 +1144,45 @@ __attribute__((visibility("hidden"))) uint32_t mzhip_adler32_combine(uint32_t ad
     return mzhip_adler32_combine_host(ad1, ad2, len2);
 }
 
+// Host side of mz_crypt_crc32_update.  Buffers below MZHIP_CRC_HOST_BELOW bytes are folded right here with the
+// product's own slicing-by-4 tables (the same mzhip_crc_tables the kernels use): a launch plus two PCIe round trips for
+// a few bytes helps nobody, and the reference calls this symbol one byte at a time from mz_strm_pkcrypt.c:79,86.
+// Larger buffers go to K2 on the device.  The symbol has no error channel (mz_crypt.h:20), so a device failure neither
+// aborts the host process nor corrupts the value: the bytes are folded on the host, and the failure is latched for the
+// next codec-stream call of this thread to report (mzhip_take_crc_fault, checked by the READ / WRITE shims).
+namespace {
+const mzhip_crc_tables *host_crc_tables() {
+    static mzhip_crc_tables t;
+    static std::once_flag once;
+    std::call_once(once, [] { mzhip_crc_tables_init(&t); });
+    return &t;
+}
+uint32_t crc32_fold_host(uint32_t value, const uint8_t *p, size_t n) {
+    const mzhip_crc_tables *t = host_crc_tables();
+    uint32_t r = ~value; /* register inverted on entry and exit, mz_crypt.c:81,90 */
+    while (n && ((uintptr_t)p & 3u)) {
+        r = t->byte_tab[(r ^ *p++) & 255u] ^ (r >> 8);
+        n--;
+    }
+    for (; n >= 4; n -= 4, p += 4) {
+        uint32_t d;
+        memcpy(&d, p, 4);
+        const uint32_t x = r ^ d; /* little-endian host */
+        r = t->slice[3][x & 255u] ^ t->slice[2][(x >> 8) & 255u] ^ t->slice[1][(x >> 16) & 255u] ^ t->slice[0][x >> 24];
+    }
+    while (n--) r = t->byte_tab[(r ^ *p++) & 255u] ^ (r >> 8);
+    return ~r;
+}
+thread_local int32_t g_crc_fault = 0;
+} // namespace
+
 uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
     if (size == 0) return value;
+    if (size < MZHIP_CRC_HOST_BELOW) return crc32_fold_host(value, buf, size);
     DeviceCtx *c = nullptr;
     if (ctx_for_current(&c)) {
-        fprintf(stderr, "mzhip: no usable HIP device for mz_crypt_crc32_update (%s)\n", g_err);
-        abort(); /* the CRC symbol has no error channel (mz_crypt.h:20); never fall back silently */
+        g_crc_fault = -1; /* MZ_STREAM_ERROR: no usable HIP device (mzhip_last_error has the reason) */
+        return crc32_fold_host(value, buf, size);
     }
     // segments of 256 KiB, one wave each; segment CRCs are chained with x^(8*len) shifts
     // (32-bit arithmetic on checksums only, no byte is touched on the host).
@@ -1158,35 +1191,43 @@ uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
     const size_t meta = (size_t)nseg * (8 + 4 + 4);
     const size_t meta_pad = (meta + 63) & ~(size_t)63;
     Staging sc;
-    if (sc.get(c, meta_pad + size) != 0) {
-        fprintf(stderr, "mzhip: device allocation failed in mz_crypt_crc32_update (%s)\n", g_err);
-        abort();
-    }
-    uint8_t *base = (uint8_t *)sc.p;
     uint64_t *h_off = (uint64_t *)malloc(meta_pad);
-    uint32_t *h_len = (uint32_t *)(h_off + nseg);
-    uint32_t *h_crc = h_len + nseg;
-    for (uint32_t i = 0; i < nseg; i++) {
-        h_off[i] = meta_pad + (uint64_t)i * seg;
-        size_t left = size - (size_t)i * seg;
-        h_len[i] = (uint32_t)(left < seg ? left : seg);
-    }
-    bool ok = hipMemcpy(base, h_off, meta, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemcpy(base + meta_pad, buf, size, hipMemcpyHostToDevice) == hipSuccess;
-    uint64_t *d_off = (uint64_t *)base;
-    uint32_t *d_len = (uint32_t *)(d_off + nseg);
-    uint32_t *d_crc = d_len + nseg;
-    ok = ok && mzhip_crc32_batch(base, d_off, d_len, nseg, nullptr, d_crc, nullptr) == 0;
-    ok = ok && hipDeviceSynchronize() == hipSuccess;
-    ok = ok && hipMemcpy(h_crc, d_crc, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) {
-        fprintf(stderr, "mzhip: device failure in mz_crypt_crc32_update (%s)\n", g_err);
-        abort();
-    }
+    bool ok = h_off != nullptr && sc.get(c, meta_pad + size) == 0;
     uint32_t v = value;
-    for (uint32_t i = 0; i < nseg; i++) v = mzhip_crc32_combine_host(v, h_crc[i], h_len[i]);
+    if (ok) {
+        uint8_t *base = (uint8_t *)sc.p;
+        uint32_t *h_len = (uint32_t *)(h_off + nseg);
+        uint32_t *h_crc = h_len + nseg;
+        for (uint32_t i = 0; i < nseg; i++) {
+            h_off[i] = meta_pad + (uint64_t)i * seg;
+            size_t left = size - (size_t)i * seg;
+            h_len[i] = (uint32_t)(left < seg ? left : seg);
+        }
+        ok = hipMemcpy(base, h_off, meta, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(base + meta_pad, buf, size, hipMemcpyHostToDevice) == hipSuccess;
+        uint64_t *d_off = (uint64_t *)base;
+        uint32_t *d_len = (uint32_t *)(d_off + nseg);
+        uint32_t *d_crc = d_len + nseg;
+        ok = ok && mzhip_crc32_batch(base, d_off, d_len, nseg, nullptr, d_crc, nullptr) == 0;
+        ok = ok && hipDeviceSynchronize() == hipSuccess;
+        ok = ok && hipMemcpy(h_crc, d_crc, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+        if (ok)
+            for (uint32_t i = 0; i < nseg; i++) v = mzhip_crc32_combine_host(v, h_crc[i], h_len[i]);
+    }
     free(h_off);
+    if (!ok) {
+        if (!g_err[0]) snprintf(g_err, sizeof(g_err), "device failure in mz_crypt_crc32_update");
+        g_crc_fault = -1;
+        return crc32_fold_host(value, buf, size);
+    }
     return v;
+}
+
+// the failure a mz_crypt_crc32_update of this thread could not report (0 = none); reading clears it
+__attribute__((visibility("hidden"))) int32_t mzhip_take_crc_fault(void) {
+    const int32_t f = g_crc_fault;
+    g_crc_fault = 0;
+    return f;
 }
 
 } // extern "C"

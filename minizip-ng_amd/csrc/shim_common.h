@@ -18,6 +18,8 @@ int32_t mzhip_wprime_track(int32_t method, int64_t *id, int64_t pos, const uint8
                            int32_t *have_crc);
 int32_t mzhip_wprime_result(int32_t method, int64_t id, int64_t pos, const uint8_t **src, const uint8_t **out,
                             uint32_t *out_len);
+/* the device failure a mz_crypt_crc32_update of this thread could not report (the symbol has no error channel); 0 = none */
+int32_t mzhip_take_crc_fault(void);
 /* crc(A||B) from crc(A), crc(B), |B|: arithmetic on checksums, no data bytes involved */
 uint32_t mzhip_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 

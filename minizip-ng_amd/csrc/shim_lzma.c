@@ -219,6 +219,8 @@ static int32_t attempt_decode(mzhip_lzma *z) {
 int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
     mzhip_served_drop();
+    if (z->error == 0 && mzhip_take_crc_fault() != 0)
+        z->error = MZH_STREAM_ERROR; /* a checksum call before this one met a device failure */
     if (z->error != 0)
         return MZH_DATA_ERROR; /* mz_strm_lzma.c:236-237 */
     while (!z->decoded) {
@@ -332,6 +334,10 @@ static int32_t leave_primed(mzhip_lzma *z) {
 int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
     mzhip_served_drop();
+    if (mzhip_take_crc_fault() != 0) { /* a checksum call before this one met a device failure */
+        z->error = MZH_STREAM_ERROR;
+        return MZH_STREAM_ERROR;
+    }
     if (size <= 0)
         return size;
     if (!z->wp_off) {

@@ -355,6 +355,8 @@ static int32_t attempt_decode(mzhip_zlib *z) {
 int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
     mzhip_served_drop();
+    if (z->error == 0 && mzhip_take_crc_fault() != 0)
+        z->error = MZH_STREAM_ERROR; /* a checksum call before this one met a device failure */
     if (z->error != 0)
         return z->error; /* mz_strm_zlib.c:186-189 */
 
@@ -562,6 +564,10 @@ static int32_t leave_primed(mzhip_zlib *z) {
 int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
     mzhip_served_drop();
+    if (mzhip_take_crc_fault() != 0) { /* a checksum call before this one met a device failure */
+        z->error = MZH_STREAM_ERROR;
+        return MZH_STREAM_ERROR;
+    }
     if (size > 0 && z->wrap == 0 && !z->wp_off) {
         /* mzhip_prime_write: is this entry, so far, one of the buffers that were compressed ahead of time? */
         uint32_t crc = 0;

@@ -29,6 +29,7 @@
 #include <string.h>
 #define MZ_DEV static inline
 #define MZ_LANE_DECL
+#define MZ_NOUNROLL
 #define MZ_LANES for (int lane = 0; lane < 64; ++lane)
 #define PV(type, name) type name[64]
 #define PV2(type, name, n) type name[64][n] /* small per-lane array */
@@ -103,6 +104,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
 #include <hip/hip_runtime.h>
 #define MZ_DEV __device__ __forceinline__
 #define MZ_LANE_DECL const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#define MZ_NOUNROLL _Pragma("nounroll")
 #define MZ_LANES
 #define PV(type, name) type name
 #define PV2(type, name, n) type name[n]

@@ -5,14 +5,11 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "d8w8_k1 SLOTS=1"
-  "d8w8_k2 SLOTS=2"
-  "d8p6_w12_k1 POOL=6144 WPG=2 WAVES=3 SLOTS=1"
-  "d6p4608_w14_k1 SPAN=6 POOL=4608 WPG=2 WAVES=4 SLOTS=1"
-  "d6p3520_w16_k1 SPAN=6 POOL=3520 WPG=2 WAVES=4 SLOTS=1"
-  "d6p3520_w16_k2 SPAN=6 POOL=3520 WPG=2 WAVES=4 SLOTS=2"
-  "abl_d6_nonear SPAN=6 POOL=3520 WPG=2 WAVES=4 SLOTS=1 ABLATE=1"
-  "abl_d6_walkemit SPAN=6 POOL=3520 WPG=2 WAVES=4 SLOTS=1 ABLATE=15"
+  "f8p3008_w16 SPAN=8 POOL=3008 WPG=2 WAVES=4"
+  "f7p3264_w16 SPAN=7 POOL=3264 WPG=2 WAVES=4"
+  "f8p3456_w16_wpg4 SPAN=8 POOL=3264 WPG=4 WAVES=4"
+  "abl_f8_walkemit SPAN=8 POOL=3008 WPG=2 WAVES=4 ABLATE=15"
+  "abl_f8_nocrc SPAN=8 POOL=3008 WPG=2 WAVES=4 ABLATE=4"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}

@@ -8,6 +8,8 @@ import re
 
 import pytest
 
+import oracle
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 mz = importlib.import_module("minizip-ng_amd")
 
@@ -105,3 +107,58 @@ def test_no_gpu_means_loud_failure(lib):
         mz.require_gpu()
     with pytest.raises(mz.MzHipError):
         mz.inflate_host(b"\x03\x00", 16)
+
+
+def test_crc32_small_calls_stay_on_the_host(lib):
+    """mz_crypt_crc32_update below MZHIP_CRC_HOST_BELOW bytes is folded on the host with the product's own tables
+    (the reference calls it once per byte from mz_strm_pkcrypt.c:79,86 with a ~-wrapped state): no device, no abort,
+    same chaining contract (mz_crypt.c:81,90).  Runs with or without a GPU."""
+    import os
+    import time
+    import zlib
+
+    f = lib.mz_crypt_crc32_update
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint32, C.c_char_p, C.c_int32]
+    data = os.urandom(100000)
+    t0 = time.time()
+    v = 0
+    for i in range(len(data)):
+        v = f(v, data[i:i + 1], 1)
+    dt = time.time() - t0
+    assert v == zlib.crc32(data)
+    assert dt < 2.0, dt          # ~0.5 us per call is ctypes; a launch per byte would take minutes
+    # the pkcrypt pattern: the state travels inverted between calls (mz_strm_pkcrypt.c:75-89)
+    k = 0x12345678
+    for b in data[:2000]:
+        k = (~f(~k & 0xFFFFFFFF, bytes([b]), 1)) & 0xFFFFFFFF
+    want = 0x12345678
+    for b in data[:2000]:
+        want = (~zlib.crc32(bytes([b]), ~want & 0xFFFFFFFF)) & 0xFFFFFFFF
+    assert k == want
+    for n in (0, 1, 2, 3, 5, 17, 255, 4095):
+        assert f(123, data[7:7 + n], n) == zlib.crc32(data[7:7 + n], 123), n
+    if oracle.have_ref():
+        r = oracle.ref()
+        for n in (1, 3, 4095):
+            assert f(77, data[:n], n) == r.crc32(data[:n], 77)
+
+
+def test_crc32_without_device_is_exact_and_latched(lib):
+    """No usable device and a large buffer: the symbol has no error channel, so the value is still exact (host fold) and
+    the failure is recorded (mzhip_last_error; the next codec-stream call of the thread returns MZ_STREAM_ERROR) instead
+    of aborting the process."""
+    import os
+    import zlib
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    f = lib.mz_crypt_crc32_update
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint32, C.c_char_p, C.c_int32]
+    data = os.urandom(70000)
+    assert f(5, data, len(data)) == zlib.crc32(data, 5)
+    lib.mzhip_last_error.restype = C.c_char_p
+    assert lib.mzhip_last_error()          # the reason is on record; a codec stream cannot even be opened without a device

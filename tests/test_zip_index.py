@@ -106,3 +106,59 @@ def test_hash_extrafield_parse():
     assert alg.tolist() == [23, 0, 23, 20] and dsz.tolist() == [32, 0, 32, 20]
     assert dig[0, :32].tobytes() == hashlib.sha256(d).digest() == dig[2, :32].tobytes()
     assert dig[3, :20].tobytes() == hashlib.sha1(d).digest()
+
+
+def test_index_crafted_sizes_do_not_wrap():
+    """Archive-supplied 64-bit fields must never wrap the bounds checks: a ZIP64 extra field that claims
+    2^64 - 1 compressed bytes, a local-header offset near 2^64, a ZIP64 end record offset near 2^64 -- each is either
+    rejected with MZ_FORMAT_ERROR (negative as int64: the reference does the same, mz_zip.c:328-339) or indexed with
+    payload = -1 (points outside the file), never with a negative size and a valid payload offset."""
+    import io
+    import struct
+    import zipfile
+
+    mz = importlib.import_module("minizip-ng_amd")
+    buf = io.BytesIO()
+    with zipfile.ZipFile(buf, "w", zipfile.ZIP_DEFLATED) as z:
+        z.writestr("a.txt", b"hello hello hello hello hello")
+    raw = bytearray(buf.getvalue())
+    cd = raw.rfind(b"PK\x01\x02")
+    eocd = raw.rfind(b"PK\x05\x06")
+    fn, ex, cm = struct.unpack_from("<HHH", raw, cd + 28)
+    assert ex == 0 and cm == 0
+
+    def with_zip64_extra(usize=None, csize=None, loff=None):
+        """rewrite the single CD record with 0xFFFFFFFF markers and a ZIP64 extended-information field"""
+        r = bytearray(raw[:eocd])
+        fields = b""
+        if usize is not None:
+            struct.pack_into("<I", r, cd + 24, 0xFFFFFFFF)
+            fields += struct.pack("<Q", usize)
+        if csize is not None:
+            struct.pack_into("<I", r, cd + 20, 0xFFFFFFFF)
+            fields += struct.pack("<Q", csize)
+        if loff is not None:
+            struct.pack_into("<I", r, cd + 42, 0xFFFFFFFF)
+            fields += struct.pack("<Q", loff)
+        extra = struct.pack("<HH", 1, len(fields)) + fields
+        struct.pack_into("<H", r, cd + 30, len(extra))
+        r = r[:cd + 46 + fn] + extra + r[cd + 46 + fn:]
+        e = bytearray(raw[eocd:])
+        struct.pack_into("<I", e, 12, len(r) - cd)      # size of the central directory
+        return bytes(r + e)
+
+    for kw in (dict(csize=0xFFFFFFFFFFFFFFFF), dict(usize=0xFFFFFFFFFFFFFFFF), dict(loff=0xFFFFFFFFFFFFFFF0),
+               dict(csize=0x8000000000000000), dict(loff=0x8000000000000010)):
+        with pytest.raises(mz.MzHipError):
+            archive.index_bytes(with_zip64_extra(**kw))
+    # sizes that fit int64 but not the file: indexed, but the payload is marked unusable
+    for kw in (dict(csize=1 << 40), dict(loff=(1 << 62) + 5)):
+        t = archive.index_bytes(with_zip64_extra(**kw))
+        assert len(t) == 1 and t[0, archive.COL_PAYLOAD] == -1 and (t[0, :6] >= 0).all()
+    # ZIP64 end-of-central-directory locator pointing near 2^64
+    r = bytearray(raw)
+    struct.pack_into("<H", r, eocd + 10, 0xFFFF)
+    loc = struct.pack("<IIQI", 0x07064B50, 0, 0xFFFFFFFFFFFFFFF0, 1)
+    bad = bytes(r[:eocd]) + loc + bytes(r[eocd:])
+    with pytest.raises(mz.MzHipError):
+        archive.index_bytes(bad)
