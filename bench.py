@@ -1,35 +1,45 @@
 #!/usr/bin/env python3
-"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+"""bench.py -- the benchmarks of BASELINE.json on MI355X.
 
-metric  : decompressed GiB/s (whole job) + CRC32 match rate, 100k x 64 KiB DEFLATE entries
-workload: BASELINE.json configs[1] -- DEFLATE level-6 raw streams (wbits -15, memLevel 8: exactly what the
-          reference writer emits, mz_strm_zlib.c:87) of 64 KiB "enwik-slice"-like text entries, 100 000 entries
-          per GPU, inflate + fused CRC-32 on the device (mzhip_inflate_batch), inputs and outputs resident in HBM.
-step    : ONE pass of the hot path over the whole batch = one k_inflate_batch launch decoding every entry of
-          this rank's shard, the per-entry CRC/status comparison against the central-directory values, and (N>1)
-          the RCCL gather of the per-entry {crc, status} words to rank 0 -- the only collective on the path.
-scaling : weak (every rank owns its own 100k-entry shard; entries are independent, no data-path exchange).
+  python bench.py [--gpus N --steps K --warmup W] [--config 2|3|4|5] [--scaling strong|weak]
 
-Synthetic data (no network, no enwik): entries are 64 KiB slices of the English prose shipped with CPython
-(pydoc_data.topics, 460 KB; zlib-6 ratio ~0.31).  Level-6 compression costs ~2.4 ms per entry on one core, so a
-bounded number of UNIQUE slices is compressed (all host cores, <= --gen-seconds) and tiled to the full entry
-count; every entry still has its own copy of its compressed bytes and its own output region in HBM (2.0 GiB in,
-6.1 GiB out per GPU), so no cache can serve one entry's bytes to another.
+config 2 (default, the headline): DEFLATE level-6 100 000 x 64 KiB entries, inflate + fused CRC-32 (k_inflate_batch)
+config 3: DEFLATE level-6 1 000 000 x 8 KiB entries, same kernel (the small-entry shape of the 8-GPU sharding config)
+config 4: LZMA (ZIP method 14, preset 6, EOS marker) 10 000 x 1 MiB entries, range decode + fused CRC-32 (k_lzma_batch)
+config 5: DEFLATE compress (level 1) of 100 000 x 64 KiB buffers + CRC-32 of the input (k_deflate_batch)
+
+step    : ONE pass of the hot path over the whole batch = one batch launch over every entry of this rank's shard, the
+          per-entry CRC / status comparison against the central-directory values and (N > 1) the RCCL gather of the
+          per-entry {crc, status} words -- the only collective on the path.  Inputs and outputs are resident in HBM.
+scaling : strong by default, as north_star states it: ONE entry table (100 000 entries for config 2) is cut into N
+          contiguous slices balanced by compressed + uncompressed bytes (archive.shard_bounds), rank r decodes slice r.
+          --scaling weak gives every rank its own full-size table.
+data    : synthetic, SURVEY 8(d): entries are slices of C = appnote.txt || appnote.iz.txt || alice29.txt of the reference
+          tree (oracle/_ref/corpus.bin, built by oracle/make_corpus.py; CPython's pydoc prose when it did not travel);
+          config 4 uses the seeded order-2 word-Markov expansion of C.  Level-6 compression costs ~2.4 ms per entry on
+          one core, so a bounded number of UNIQUE slices is compressed (all host cores, <= --gen-seconds) with exactly
+          the reference writer's parameters (mz_strm_zlib.c:87: raw, 32 KiB window, memLevel 8 -- the cpu_baseline leg
+          checks that the reference writer emits the same bytes) and tiled to the full entry count; every entry still
+          has its own copy of its compressed bytes and its own output region in HBM.
 
 Besides the contract fields the JSON line carries
-  roofline     : the dominant kernel (k_inflate_batch) against the 8 TB/s HBM roofline; achieved = algorithmic bytes
-                 (compressed bytes read once + decompressed bytes written once) / mean launch duration,
-                 measured with HIP events on the launch stream inside the timed region;
-  cpu_baseline : the UNMODIFIED reference path (oracle/_ref: mz_zip_entry_read -> mz_stream_zlib_read -> zlib
-                 inflate + mz_crypt_crc32_update + CRC verify) on the host cores of the same box, on a bounded
-                 sample of the same entries.  Rank 0, N=1 only.
+  roofline     : the dominant kernel against the 8 TB/s HBM roofline; achieved = algorithmic bytes (compressed bytes
+                 read once + decompressed bytes written once) / mean launch duration, measured with HIP
+                 events on the launch stream inside the timed region (max over ranks);
+  cpu_baseline : the UNMODIFIED reference path (oracle/_ref) on the host cores of the same box, on a bounded sample of
+                 the same workload.  Rank 0, N = 1 only;
+  legs         : (config 2, N = 1) SURVEY 8(d) i-iii: kernel only / H2D of the compressed bytes + kernel + D2H of
+                 {crc, len, status} from pinned host memory / the reference's unmodified mz_zip_reader loop on the
+                 drop-in library (prime + vtbl shims) into host buffers, GiB/s of decompressed bytes each.
 """
 import argparse
+import ctypes as C
 import importlib
 import json
 import multiprocessing as mp
 import os
 import random
+import struct
 import sys
 import tempfile
 import time
@@ -42,14 +52,29 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
+CONFIGS = {
+    2: dict(entries=100000, size=65536, codec="inflate", kernel="k_inflate_batch", unique=8192,
+            metric="decompressed GiB/s (whole node) + CRC32 match rate, 100k x 64KiB DEFLATE entries",
+            workload="BASELINE.json configs[1]: DEFLATE level-6 %d x %d B entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
+    3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=16384,
+            metric="decompressed GiB/s (whole node) + CRC32 match rate, 1M x 8KiB DEFLATE entries",
+            workload="BASELINE.json configs[2]: DEFLATE level-6 %d x %d B small entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
+    4: dict(entries=10000, size=1 << 20, codec="lzma", kernel="k_lzma_batch", unique=16,
+            metric="decompressed GiB/s (whole node) + CRC32 match rate, 10k x 1MiB LZMA entries",
+            workload="BASELINE.json configs[3]: LZMA (method 14, preset 6) %d x %d B entries, range decode + fused CRC32 (mzhip_lzma_batch), device-resident"),
+    5: dict(entries=100000, size=65536, codec="deflate", kernel="k_deflate_batch", unique=8192,
+            metric="compressed-input GiB/s (whole node) + round-trip match rate, 100k x 64KiB DEFLATE level-1 compress",
+            workload="BASELINE.json configs[4]: DEFLATE compress level 1 of %d x %d B buffers + CRC32 of the input (mzhip_deflate_batch), device-resident"),
+}
 
-def measured_traffic(n, size):
-    """HBM bytes per launch from the committed PMC passes (profiles/r2/hbm_traffic.json), only when they were
-    taken on this very workload; counters cannot be collected from inside a timed run."""
+
+def measured_traffic(cfg, n, size):
+    """HBM bytes per launch from the committed PMC passes (profiles/r2/hbm_traffic.json), only when they were taken on
+    this very workload; counters cannot be collected from inside a timed run."""
     try:
         with open(os.path.join(ROOT, "profiles", "r2", "hbm_traffic.json")) as f:
             t = json.load(f)
-        if n == 100000 and size == 65536:
+        if cfg == 2 and n == 100000 and size == 65536:
             return t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -57,125 +82,76 @@ def measured_traffic(n, size):
 
 
 def corpus():
-    import pydoc_data.topics as t
+    from tests import synth
 
-    return "".join(t.topics[k] for k in sorted(t.topics)).encode()
+    return synth.bench_corpus()
 
 
 _C = None
+_LEVEL = 6
 
 
 def _compress_one(off_size):
-    global _C
-    if _C is None:
-        _C = corpus()
     off, size = off_size
     d = _C[off:off + size]
-    co = zlib.compressobj(6, zlib.DEFLATED, -15, 8)  # == deflateInit2(level, Z_DEFLATED, -15, 8, default)
+    co = zlib.compressobj(_LEVEL, zlib.DEFLATED, -15, 8)  # == deflateInit2(level, Z_DEFLATED, -15, 8, default)
     return co.compress(d) + co.flush(), zlib.crc32(d)
 
 
-def make_unique(n_unique, size, seed, gen_seconds, world=1):
-    c = corpus()
+def _pool_init(c, level):
+    global _C, _LEVEL
+    _C, _LEVEL = c, level
+
+
+def make_unique_deflate(c, n_unique, size, seed, gen_seconds, world):
     rnd = random.Random(seed)
     offs = [(rnd.randrange(len(c) - size), size) for _ in range(n_unique)]
     procs = max(1, min((os.cpu_count() or 1) // max(world, 1), 64))  # ranks share the host cores
     t0 = time.time()
     out = []
-    with mp.Pool(procs) as pool:
+    with mp.Pool(procs, initializer=_pool_init, initargs=(c, 6)) as pool:
         for r in pool.imap(_compress_one, offs, chunksize=8):
             out.append(r)
             if time.time() - t0 > gen_seconds and len(out) >= 256:
                 pool.terminate()
                 break
     offs = offs[:len(out)]
-    return c, offs, [p for p, _ in out], np.array([k for _, k in out], dtype=np.uint32)
+    return offs, [p for p, _ in out], np.array([k for _, k in out], dtype=np.uint32)
 
 
-def cpu_baseline(c, offs, size, want_crc, cores):
-    """Time the unmodified reference path on the host cores (oracle/_ref)."""
-    import oracle
+def _lzma_one(d):
+    import lzma
 
-    if not oracle.have_ref():
-        return None
-    ref = oracle.ref()
-    n = min(len(offs), 2048)
-    blob = np.frombuffer(c, dtype=np.uint8)
-    o = np.array([x[0] for x in offs[:n]], dtype=np.int64)
-    ln = np.full(n, size, dtype=np.int32)
-    tmp = tempfile.mkdtemp(prefix="mzhip_bench_")
-    path = os.path.join(tmp, "sample.zip")
-    ref.zip_write(path, blob, o, ln, method=8, level=6)  # the reference writer itself (mz_zip_rw.c:1546)
-    table = ref.zip_index(path)
-    cd = table[:, 6].copy()
-    passes, total_s, best = 0, 0.0, None
-    while total_s < 4.0 and passes < 400:
-        sec, crc, ulen, st = ref.zip_read_all(path, cd, nthreads=cores, own_crc=False)
-        assert (st == 0).all() and (ulen == size).all() and (crc == want_crc[:n]).all()
-        passes += 1
-        total_s += sec
-        best = sec if best is None else min(best, sec)
-    # one single-thread pass on a slice for the per-core figure
-    k = min(n, 256)
-    sec1, _, _, st1 = ref.zip_read_all(path, cd[:k], nthreads=1, own_crc=False)
-    os.remove(path)
-    os.rmdir(tmp)
-    gib = n * size / 2**30
-    return dict(value=round(gib * passes / total_s, 4), unit="GiB/s", cores=cores, kind="reference",
-                sample="%d x %d B DEFLATE-6 entries written by the reference writer, %d passes of mz_zip_entry_read "
-                       "(zlib 1.2.11 inflate + crc32 + CRC verify) with %d threads; 1-thread: %.3f GiB/s" % (
-                           n, size, passes, cores, k * size / 2**30 / sec1))
+    # what the reference writer emits for method 14 (mz_strm_lzma.c:94-104,250-265, mz_zip.c:1984): the 4-byte ZIP-LZMA
+    # header (version 5.2, properties size 5), the 5 properties bytes, the raw LZMA1 stream of preset 6 with the end marker
+    raw = lzma.compress(d, format=lzma.FORMAT_ALONE, filters=[dict(id=lzma.FILTER_LZMA1, preset=6)])
+    assert raw[5:13] == b"\xff" * 8  # .lzma alone = props(5) + size(8, unknown) + stream + end marker
+    return bytes([5, 2, 5, 0]) + raw[:5] + raw[13:], zlib.crc32(d)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--entries", type=int, default=100000, help="entries per GPU")
-    ap.add_argument("--entry-size", type=int, default=65536)
-    ap.add_argument("--unique", type=int, default=8192, help="max unique compressed slices to generate")
-    ap.add_argument("--gen-seconds", type=float, default=45.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def make_unique_lzma(datas, world):
+    procs = max(1, min((os.cpu_count() or 1) // max(world, 1), len(datas)))
+    with mp.Pool(procs) as pool:
+        out = pool.map(_lzma_one, datas)
+    return [p for p, _ in out], np.array([k for _, k in out], dtype=np.uint32)
 
-    import torch
 
-    mz = importlib.import_module("minizip-ng_amd")
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    mz.require_gpu()  # no CPU fallback: fail loudly if the HIP path is unavailable
-    size, n = args.entry_size, args.entries
-    # the worker pool that compresses the synthetic slices forks: do it before this process creates its HIP
-    # context and the RCCL threads
-    c, offs, pays, crcs = make_unique(args.unique, size, 1234 + rank, args.gen_seconds, world)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=dev)
-
-    U = len(pays)
-    # tile the unique slices over this rank's shard; every entry gets its own bytes in HBM
-    rnd = np.random.RandomState(99 + rank)
-    pick = rnd.randint(0, U, size=n)
+def device_blob(torch, dev, pays, pick, align=16):
+    """every entry gets its own copy of its bytes: gather 16-byte granules on the host, one H2D copy"""
     plen = np.array([len(p) for p in pays], dtype=np.int64)
     in_len = plen[pick]
+    n = len(pick)
+    pad = (in_len + align - 1) // align * align
     in_off = np.zeros(n, dtype=np.int64)
-    np.cumsum(((in_len + 15) // 16 * 16)[:-1], out=in_off[1:])
-    total_in = int(in_off[-1] + (in_len[-1] + 15) // 16 * 16)
-    uoff = np.zeros(U, dtype=np.int64)
-    np.cumsum(((plen + 15) // 16 * 16)[:-1], out=uoff[1:])
-    ublob = np.zeros(int(uoff[-1] + (plen[-1] + 15) // 16 * 16), dtype=np.uint8)
+    np.cumsum(pad[:-1], out=in_off[1:])
+    total_in = int(in_off[-1] + pad[-1]) if n else align
+    upad = (plen + align - 1) // align * align
+    uoff = np.zeros(len(pays), dtype=np.int64)
+    np.cumsum(upad[:-1], out=uoff[1:])
+    ublob = np.zeros(int(uoff[-1] + upad[-1]), dtype=np.uint8)
     for i, p in enumerate(pays):
         ublob[uoff[i]:uoff[i] + len(p)] = np.frombuffer(p, dtype=np.uint8)
-    # every entry gets its own copy of its compressed bytes: gather 16-byte granules on the host, one H2D copy
-    gran = ((in_len + 15) // 16).astype(np.int64)
+    gran = (pad // 16).astype(np.int64)
     gstart = np.concatenate(([0], np.cumsum(gran)[:-1]))
     u16 = ublob.view(np.dtype((np.void, 16)))
     h_in = np.empty(total_in // 16, dtype=u16.dtype)
@@ -185,32 +161,327 @@ def main():
         g0, g1 = int(gstart[lo]), int(gstart[hi - 1] + gran[hi - 1])
         src = np.repeat(uoff[pick[lo:hi]] // 16 - gstart[lo:hi], gran[lo:hi]) + np.arange(g0, g1)
         h_in[g0:g1] = u16[src]
-    d_in = torch.from_numpy(h_in.view(np.uint8)).to(dev)
-    for e in (0, n // 3, n // 2, n - 1):  # the device input really is the compressed stream
-        assert d_in[in_off[e]:in_off[e] + in_len[e]].cpu().numpy().tobytes() == pays[pick[e]]
-    del h_in, u16
-    d_in_off = torch.from_numpy(in_off).to(dev)
-    d_in_len = torch.from_numpy(in_len.astype(np.int32)).to(dev)
-    d_out = torch.empty(n * size, dtype=torch.uint8, device=dev)
-    d_out_off = torch.arange(n, dtype=torch.int64, device=dev) * size
-    d_out_cap = torch.full((n,), size, dtype=torch.int32, device=dev)
-    want_crc = torch.from_numpy(crcs[pick].view(np.int32).copy()).to(dev)  # the central directory's CRCs
-    algo_bytes = int(in_len.sum()) + n * size
+    h_u8 = h_in.view(np.uint8)
+    d_in = torch.from_numpy(h_u8).to(dev)
+    return d_in, h_u8, in_off, in_len
 
-    gathered = torch.empty(world * n * 2, dtype=torch.int32, device=dev) if world > 1 else None
+
+# ---------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline_inflate(c, offs, size, pays, want_crc, cores, keep_path=None):
+    """The unmodified reference reader on the host cores (oracle/_ref): mz_zip_entry_read -> mz_stream_zlib_read ->
+    zlib inflate + mz_crypt_crc32_update + CRC verify, one reader handle per thread."""
+    import oracle
+
+    if not oracle.have_ref():
+        return None
+    ref = oracle.ref()
+    n = min(len(offs), 2048 if size >= 65536 else 16384)
+    blob = np.frombuffer(c, dtype=np.uint8)
+    o = np.array([x[0] for x in offs[:n]], dtype=np.int64)
+    ln = np.full(n, size, dtype=np.int32)
+    tmp = tempfile.mkdtemp(prefix="mzhip_bench_")
+    path = keep_path or os.path.join(tmp, "sample.zip")
+    ref.zip_write(path, blob, o, ln, method=8, level=6)  # the reference writer itself (mz_zip_rw.c:1546)
+    table = ref.zip_index(path)
+    raw = open(path, "rb").read()
+    same = all(raw[int(table[i, 7]):int(table[i, 7] + table[i, 3])] == pays[i] for i in range(0, n, max(1, n // 64)))
+    cd = table[:, 6].copy()
+    passes, total_s = 0, 0.0
+    while total_s < 4.0 and passes < 400:
+        sec, crc, ulen, st = ref.zip_read_all(path, cd, nthreads=cores, own_crc=False)
+        assert (st == 0).all() and (ulen == size).all() and (crc == want_crc[:n]).all()
+        passes += 1
+        total_s += sec
+    k = min(n, 256)
+    sec1, _, _, _ = ref.zip_read_all(path, cd[:k], nthreads=1, own_crc=False)
+    if not keep_path:
+        os.remove(path)
+        os.rmdir(tmp)
+    gib = n * size / 2**30
+    return dict(value=round(gib * passes / total_s, 4), unit="GiB/s", cores=cores, kind="reference",
+                sample="%d x %d B DEFLATE-6 entries written by the reference writer (payload bytes %s the bench's streams), "
+                       "%d passes of mz_zip_entry_read (zlib 1.2.11 inflate + crc32 + CRC verify) with %d threads; "
+                       "1-thread: %.3f GiB/s" % (n, size, "identical to" if same else "DIFFER from", passes, cores,
+                                                 k * size / 2**30 / sec1))
+
+
+def cpu_baseline_lzma(datas, cores):
+    """The reference LZMA reader (mz_stream_lzma_read -> liblzma 5.2.5).  Its encoder runs at ~2 MB/s, so 8 entries are
+    written by the reference writer and their payloads replicated into a 2 x cores-entry archive."""
+    import oracle
+
+    if not oracle.have_ref():
+        return None
+    ref = oracle.ref()
+    size = len(datas[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        k = min(8, len(datas))
+        blob = np.frombuffer(b"".join(datas[:k]), dtype=np.uint8)
+        small = os.path.join(tmp, "s.zip")
+        ref.zip_write(small, blob, np.arange(k, dtype=np.int64) * size, np.full(k, size, dtype=np.int32), method=14, level=6)
+        st = ref.zip_index(small)
+        raw = open(small, "rb").read()
+        n = max(2 * cores, 64)
+        path = os.path.join(tmp, "l.zip")
+        with open(path, "wb") as f:
+            cd = []
+            for i in range(n):
+                m, flag, crc, cs, us, _, _, po = (int(v) for v in st[i % k])
+                name = b"e/%06d" % i
+                f.write(struct.pack("<IHHHHHIIIHH", 0x04034B50, 63, flag & ~8, m, 0, 0x21, crc & 0xFFFFFFFF, cs, us, len(name), 0))
+                cd.append(struct.pack("<IHHHHHHIIIHHHHHII", 0x02014B50, 0x033F, 63, flag & ~8, m, 0, 0x21, crc & 0xFFFFFFFF, cs,
+                                      us, len(name), 0, 0, 0, 0, 0, f.tell() - 30) + name)
+                f.write(name + raw[po:po + cs])
+            cd_off = f.tell()
+            f.write(b"".join(cd))
+            f.write(struct.pack("<IHHHHIIH", 0x06054B50, 0, 0, n, n, f.tell() - cd_off, cd_off, 0))
+        tab = ref.zip_index(path)
+        sec, crc, ulen, stt = ref.zip_read_all(path, tab[:, 6].copy(), nthreads=cores, own_crc=False)
+        assert (stt == 0).all()
+        sec1, _, ulen1, _ = ref.zip_read_all(path, tab[:4, 6].copy(), nthreads=1, own_crc=False)
+        return dict(value=round(float(ulen.sum()) / 2**30 / sec, 4), unit="GiB/s", cores=cores, kind="reference",
+                    sample="%d x %d B method-14 entries (8 written by the reference writer, preset 6, ratio %.3f, replicated), "
+                           "one pass of mz_zip_entry_read (liblzma 5.2.5 + crc32 + CRC verify) with %d threads; 1-thread: %.3f GiB/s"
+                           % (n, size, tab[:, 3].sum() / tab[:, 4].sum(), cores, float(ulen1.sum()) / 2**30 / sec1))
+
+
+def cpu_baseline_deflate(c, offs, size, cores):
+    """The reference writer at level 1 (mz_zip_writer_add_buffer -> mz_stream_zlib_write -> zlib deflate + crc32),
+    one archive per thread."""
+    import threading
+
+    import oracle
+
+    if not oracle.have_ref():
+        return None
+    ref = oracle.ref()
+    per = 1000
+    blob = np.frombuffer(c, dtype=np.uint8)
+    o = np.array([offs[i % len(offs)][0] for i in range(per)], dtype=np.int64)
+    ln = np.full(per, size, dtype=np.int32)
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for th in (1, cores):
+            ts = [threading.Thread(target=ref.zip_write, args=(os.path.join(tmp, "w%d.zip" % i), blob, o, ln, 8, 1)) for i in range(th)]
+            t0 = time.time()
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            res[th] = per * th * size / 2**30 / (time.time() - t0)
+            ratio = os.path.getsize(os.path.join(tmp, "w0.zip")) / (per * size)
+    return dict(value=round(res[cores], 4), unit="GiB/s", cores=cores, kind="reference",
+                sample="%d x %d B buffers per thread through mz_zip_writer_add_buffer at level 1 (zlib 1.2.11 deflate + crc32, "
+                       "archive ratio %.3f), %d threads = %d archives; 1-thread: %.3f GiB/s" % (per, size, ratio, cores, cores, res[1]))
+
+
+# ---------------------------------------------------------------------------------------------- config-2 legs
+def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel_gib, sample_zip):
+    """SURVEY 8(d) (i)-(iii).  (ii) and (iii) run on bounded samples; all figures are decompressed GiB/s."""
+    out = {"kernel": round(kernel_gib, 2)}
+    n = min(len(in_len), 20000)
+    end = int(in_off[n - 1] + (in_len[n - 1] + 15) // 16 * 16)
+    hp = torch.from_numpy(h_in[:end]).pin_memory()
+    d_in = torch.empty(end, dtype=torch.uint8, device=dev)
+    d_off = torch.from_numpy(in_off[:n]).to(dev)
+    d_len = torch.from_numpy(in_len[:n].astype(np.int32)).to(dev)
+    d_out = torch.empty(n * size, dtype=torch.uint8, device=dev)
+    d_oo = torch.arange(n, dtype=torch.int64, device=dev) * size
+    d_oc = torch.full((n,), size, dtype=torch.int32, device=dev)
+    h_res = torch.empty((3, n), dtype=torch.int32).pin_memory()
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d_in.copy_(hp, non_blocking=True)
+        out_len, in_used, crc, status = mz.inflate_batch(d_in, d_off, d_len, d_out, d_oo, d_oc)
+        h_res.copy_(torch.stack((crc, out_len, status)), non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    ok = bool((h_res[2].numpy() == 0).all() and (h_res[0].numpy().view(np.uint32) == want_crc_np[:n]).all())
+    out["h2d_kernel_d2hcrc"] = round(n * size / 2**30 / best, 2) if ok else None
+    out["h2d_kernel_d2hcrc_sample"] = "%d entries, pinned host memory, best of 3" % n
+    # (iii) the reference's unmodified reader loop on the drop-in library: mzhip_prime_file + mz_zip_reader_* into host buffers
+    drop = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+    out["vtbl_end_to_end"] = None
+    if sample_zip and os.path.exists(sample_zip) and os.path.exists(drop):
+        D = C.CDLL(drop)
+        L = mz.lib()
+        L.mzhip_prime_file.restype = C.c_int64
+        L.mzhip_prime_file.argtypes = [C.c_char_p]
+        D.mz_zip_reader_create.restype = C.c_void_p
+        for f in ("mz_zip_reader_open_file", "mz_zip_reader_goto_first_entry", "mz_zip_reader_goto_next_entry",
+                  "mz_zip_reader_entry_save_buffer", "mz_zip_reader_close"):
+            getattr(D, f).restype = C.c_int32
+        D.mz_zip_reader_open_file.argtypes = [C.c_void_p, C.c_char_p]
+        D.mz_zip_reader_goto_first_entry.argtypes = [C.c_void_p]
+        D.mz_zip_reader_goto_next_entry.argtypes = [C.c_void_p]
+        D.mz_zip_reader_entry_save_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        D.mz_zip_reader_close.argtypes = [C.c_void_p]
+        D.mz_zip_reader_delete.argtypes = [C.POINTER(C.c_void_p)]
+        buf = C.create_string_buffer(size)
+        best, cnt = None, 0
+        for _ in range(2):
+            t0 = time.perf_counter()
+            L.mzhip_prime_clear()
+            primed = L.mzhip_prime_file(sample_zip.encode())
+            h = C.c_void_p(D.mz_zip_reader_create())
+            cnt, err = 0, D.mz_zip_reader_open_file(h, sample_zip.encode())
+            if err == 0:
+                err = D.mz_zip_reader_goto_first_entry(h)
+            while err == 0:
+                if D.mz_zip_reader_entry_save_buffer(h, buf, size) != 0:  # decode + CRC verification (mz_zip.c:2116-2128)
+                    cnt = -1
+                    break
+                cnt += 1
+                err = D.mz_zip_reader_goto_next_entry(h)
+            D.mz_zip_reader_close(h)
+            D.mz_zip_reader_delete(C.byref(h))
+            dt = time.perf_counter() - t0
+            if cnt > 0 and (best is None or dt < best):
+                best = dt
+        L.mzhip_prime_clear()
+        if best and cnt > 0:
+            out["vtbl_end_to_end"] = round(cnt * size / 2**30 / best, 3)
+            out["vtbl_end_to_end_sample"] = ("%d entries: mzhip_prime_file (index + H2D + one launch + D2H of every byte) + the "
+                                             "unmodified mz_zip_reader_entry_save_buffer loop on libmzhipdrop.so, one host thread, "
+                                             "%d entries primed, best of 2" % (cnt, primed))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"))
+    ap.add_argument("--entries", type=int, default=0, help="entries of the table (strong) / per GPU (weak); 0 = the config's")
+    ap.add_argument("--entry-size", type=int, default=0)
+    ap.add_argument("--unique", type=int, default=0, help="max unique compressed slices to generate")
+    ap.add_argument("--gen-seconds", type=float, default=45.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+
+    mz = importlib.import_module("minizip-ng_amd")
+    archive = importlib.import_module("minizip-ng_amd.archive")
+    from tests import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    mz.require_gpu()  # no CPU fallback: fail loudly if the HIP path is unavailable
+    size = args.entry_size or cfg["size"]
+    n_table = args.entries or cfg["entries"]
+    n_unique = args.unique or cfg["unique"]
+    strong = args.scaling == "strong"
+    c, cdesc = corpus()
+    # the worker pool that compresses the synthetic slices forks: do it before this process creates its HIP context
+    # and the RCCL threads.  Strong scaling: every rank derives the SAME table (same seeds); weak: its own.
+    seed = 1234 if strong else 1234 + rank
+    offs = datas = None
+    if cfg["codec"] == "lzma":
+        datas = synth.markov_entries(n_unique, size, seed, c)
+        pays, crcs = make_unique_lzma(datas, world)
+    else:
+        offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world)
+    U = len(pays)
+    rnd = np.random.RandomState(99 if strong else 99 + rank)
+    pick_all = rnd.randint(0, U, size=n_table)
+    plen = np.array([len(p) for p in pays], dtype=np.int64)
+    lo, hi = 0, n_table
+    bounds = None
+    if strong and world > 1:
+        table = np.zeros((n_table, 8), dtype=np.int64)
+        table[:, archive.COL_CSIZE] = plen[pick_all]
+        table[:, archive.COL_USIZE] = size
+        bounds = archive.shard_bounds(table, world)  # contiguous slices balanced by compressed + uncompressed bytes
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    pick = pick_all[lo:hi]
+    n = len(pick)
+    max_shard = int(np.diff(bounds).max()) if bounds is not None else n
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    L = mz.lib()
+    want_crc_np = crcs[pick]
+    want_crc = torch.from_numpy(want_crc_np.view(np.int32).copy()).to(dev)  # the central directory's CRCs
+    if cfg["codec"] in ("inflate", "lzma"):
+        d_in, h_in, in_off, in_len = device_blob(torch, dev, pays, pick)
+        for e in (0, n // 3, n // 2, n - 1):  # the device input really is the compressed stream
+            assert d_in[in_off[e]:in_off[e] + in_len[e]].cpu().numpy().tobytes() == pays[pick[e]]
+        d_in_off = torch.from_numpy(in_off).to(dev)
+        d_in_len = torch.from_numpy(in_len.astype(np.int32)).to(dev)
+        d_out = torch.empty(n * size, dtype=torch.uint8, device=dev)
+        d_out_off = torch.arange(n, dtype=torch.int64, device=dev) * size
+        d_out_cap = torch.full((n,), size, dtype=torch.int32, device=dev)
+        algo_bytes = int(in_len.sum()) + n * size
+        ratio = float(in_len.sum()) / (n * size)
+        if cfg["codec"] == "lzma":
+            L.mzhip_lzma_batch.restype = C.c_int32
+            L.mzhip_lzma_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 5
+            r_len, r_used, r_crc, r_st = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(4))
+            d_max = torch.full((n,), size, dtype=torch.int64, device=dev)  # TOTAL_OUT_MAX, as mz_zip.c:1833-1846 sets it
+    else:
+        srcs = [c[o:o + size] for o, _ in offs]
+        d_src, h_src, in_off, in_len = device_blob(torch, dev, srcs, pick)
+        cap = size + size // 8 + 64
+        d_in_off = torch.from_numpy(in_off).to(dev)
+        d_in_len = torch.from_numpy(in_len.astype(np.int32)).to(dev)
+        d_out = torch.empty(n * cap, dtype=torch.uint8, device=dev)
+        d_out_off = torch.arange(n, dtype=torch.int64, device=dev) * cap
+        d_out_cap = torch.full((n,), cap, dtype=torch.int32, device=dev)
+        L.mzhip_deflate_batch.restype = C.c_int32
+        L.mzhip_deflate_batch.argtypes = [C.c_void_p] * 7 + [C.c_uint32] + [C.c_void_p] * 4
+        r_len, r_crc, r_st = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+        algo_bytes = None  # known once the compressed sizes are
+
+    gathered = torch.empty(world * max_shard * 2, dtype=torch.int32, device=dev) if world > 1 else None
+    mine = torch.zeros(max_shard * 2, dtype=torch.int32, device=dev) if world > 1 else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     stats = {}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        if cfg["codec"] == "inflate":
+            return mz.inflate_batch(d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap)
+        if cfg["codec"] == "lzma":
+            rc = L.mzhip_lzma_batch(d_in.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), d_out.data_ptr(),
+                                    d_out_off.data_ptr(), d_out_cap.data_ptr(), d_max.data_ptr(), n, r_len.data_ptr(),
+                                    r_used.data_ptr(), r_crc.data_ptr(), r_st.data_ptr(), C.c_void_p(stream))
+            assert rc == 0, rc
+            return r_len, r_used, r_crc, r_st
+        rc = L.mzhip_deflate_batch(d_src.data_ptr(), d_in_off.data_ptr(), d_in_len.data_ptr(), d_out.data_ptr(),
+                                   d_out_off.data_ptr(), d_out_cap.data_ptr(), None, n, r_len.data_ptr(), r_crc.data_ptr(),
+                                   r_st.data_ptr(), C.c_void_p(stream))
+        assert rc == 0, rc
+        return r_len, None, r_crc, r_st
 
     def step(i_timed=None):
         if i_timed is not None:
             ev[i_timed][0].record()
-        out_len, in_used, crc, status = mz.inflate_batch(d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap)
+        out_len, in_used, crc, status = launch()
         if i_timed is not None:
             ev[i_timed][1].record()
-        ok = (crc == want_crc) & (status == 0) & (out_len == size) & (in_used == d_in_len)
+        if cfg["codec"] == "deflate":
+            ok = (crc == want_crc) & (status == 0) & (out_len > 0)
+        else:
+            ok = (crc == want_crc) & (status == 0) & (out_len == size) & (in_used == d_in_len)
         stats["match"] = ok.sum()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, torch.stack((crc, status)).reshape(-1))
+            mine[:2 * n] = torch.stack((crc, status)).reshape(-1)
+            dist.all_gather_into_tensor(gathered, mine)
 
     for _ in range(args.warmup):
         step()
@@ -229,54 +500,76 @@ def main():
     match = int(stats["match"].item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    # byte-exact spot check of the output buffer against the source slices (outside the timed region)
-    h = {}
-    for e in range(0, n, max(1, n // 64)):
-        got = d_out[e * size:(e + 1) * size].cpu().numpy().tobytes()
-        o = offs[pick[e]][0]
-        h[e] = got == c[o:o + size]
-    bytes_ok = all(h.values())
+    # byte-exact spot check of the output buffer (outside the timed region)
+    bytes_ok = True
+    if cfg["codec"] == "deflate":
+        ol = r_len.cpu().numpy().astype(np.int64)
+        algo_bytes = int(ol.sum()) + n * size
+        ratio = float(ol.sum()) / (n * size)
+        for e in range(0, n, max(1, n // 64)):
+            z = d_out[e * cap:e * cap + int(ol[e])].cpu().numpy().tobytes()
+            bytes_ok = bytes_ok and zlib.decompress(z, -15) == srcs[pick[e]]  # round trip through zlib's inflate
+    else:
+        for e in range(0, n, max(1, n // 64)):
+            got = d_out[e * size:(e + 1) * size].cpu().numpy().tobytes()
+            want = datas[pick[e]] if datas is not None else c[offs[pick[e]][0]:offs[pick[e]][0] + size]
+            bytes_ok = bytes_ok and got == want
 
+    total_entries = n
+    algo_all = float(algo_bytes)
     if world > 1:
-        t = torch.tensor([elapsed, float(match), kernel_ms], dtype=torch.float64, device=dev)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0].item())
-        match = int(tsum[1].item())
-        kernel_ms = float(tmax[2].item())
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s = torch.tensor([float(match), float(n), float(algo_bytes), float(bytes_ok)], dtype=torch.float64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
+        match, total_entries, algo_all = int(s[0].item()), int(s[1].item()), float(s[2].item())
+        bytes_ok = int(s[3].item()) == world
 
     if rank == 0:
-        total_entries = n * world
         value = total_entries * size * args.steps / elapsed / 2**30
-        achieved = algo_bytes / (kernel_ms / 1e3) / 1e9
-        geo = (mz.C.c_uint32(), mz.C.c_uint32(), mz.C.c_uint32())
-        mz.lib().mzhip_inflate_launch_geometry(n, *(mz.C.byref(g) for g in geo))
+        achieved = algo_all / world / (kernel_ms / 1e3) / 1e9  # per GPU: the slowest rank's launch over an average shard
         line = {
-            "metric": "decompressed GiB/s (whole node) + CRC32 match rate, 100k x 64KiB DEFLATE entries",
-            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic: %d x %d B slices of CPython's pydoc prose (zlib level 6 raw, ratio %.3f); %d unique "
-                    "slices tiled to %d entries per GPU, each entry with its own bytes in HBM" % (
-                        n, size, float(in_len.sum()) / (n * size), U, n),
+            "metric": cfg["metric"], "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic: %d x %d B %s of %s (%s, ratio %.3f); %d unique tiled to %d entries%s, each entry with its own "
+                    "bytes in HBM" % (n_table, size, "order-2 word-Markov expansions" if datas is not None else "slices", cdesc,
+                                      {"inflate": "zlib level 6 raw", "lzma": "LZMA preset 6 + end marker",
+                                       "deflate": "compressed here at level 1"}[cfg["codec"]], ratio, U, n_table,
+                                      "" if strong else " per GPU"),
             "crc32_match_rate": match / total_entries, "bytes_spot_check": bool(bytes_ok),
-            "config": {"workload": "BASELINE.json configs[1]: DEFLATE level-6 %d x %d B entries per GPU, inflate + "
-                                   "fused CRC32 (mzhip_inflate_batch), device-resident" % (n, size),
-                       "entries_per_gpu": n, "entry_bytes": size, "sharding": "independent entries per rank; "
-                       "RCCL all_gather of per-entry {crc,status} only" if world > 1 else "single GPU",
-                       "launch": {"workgroups": geo[0].value, "waves_per_wg": geo[1].value, "lds_bytes_per_wg": geo[2].value}},
+            "config": {"workload": cfg["workload"] % (n_table, size), "config": args.config,
+                       "entries_total": total_entries, "entries_rank0": n, "entry_bytes": size,
+                       "sharding": ("one entry table, contiguous slices balanced by c+u bytes (archive.shard_bounds), "
+                                    if strong else "independent table per rank, ") +
+                                   "RCCL all_gather of per-entry {crc,status} only" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(n, size),
-                         "kernel": "k_inflate_batch", "kernel_ms": round(kernel_ms, 3),
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.config, n, size),
+                         "kernel": cfg["kernel"], "kernel_ms": round(kernel_ms, 3),
+                         "algorithmic_bytes_per_launch": int(algo_all / world), "per_gpu": True},
         }
+        if cfg["codec"] == "inflate":
+            geo = (C.c_uint32(), C.c_uint32(), C.c_uint32())
+            L.mzhip_inflate_launch_geometry(n, *(C.byref(g) for g in geo))
+            line["config"]["launch"] = {"workgroups": geo[0].value, "waves_per_wg": geo[1].value, "lds_bytes_per_wg": geo[2].value}
+        sample_zip = None
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
-            cb = cpu_baseline(c, offs, size, crcs, cores)
+            if cfg["codec"] == "inflate":
+                sample_zip = os.path.join(tempfile.mkdtemp(prefix="mzhip_bench_"), "sample.zip")
+                cb = cpu_baseline_inflate(c, offs, size, pays, crcs, cores, keep_path=sample_zip)
+            elif cfg["codec"] == "lzma":
+                cb = cpu_baseline_lzma(datas, cores)
+            else:
+                cb = cpu_baseline_deflate(c, offs, size, cores)
             if cb is not None:
                 line["cpu_baseline"] = cb
+        if world == 1 and args.config == 2 and not args.no_legs:
+            line["legs"] = legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, value, sample_zip)
+        if sample_zip and os.path.exists(sample_zip):
+            os.remove(sample_zip)
+            os.rmdir(os.path.dirname(sample_zip))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

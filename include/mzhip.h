@@ -198,6 +198,16 @@ MZHIP_API int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int6
  * its exact error behaviour).  Returns the number of cached entries or a negative MZ_* code. */
 MZHIP_API int64_t mzhip_prime_file(const char *path);
 MZHIP_API int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len);
+/* The same over several devices of the node (the host side of the sharded path in C): the entries are
+ * independent (mz_zip.c:1682-1863 builds a fresh codec per entry), so the entry table is cut into ndev contiguous
+ * slices balanced by compressed + uncompressed bytes (mzhip_shard_bounds) and ONE HOST THREAD PER SLICE decodes it on
+ * device devices[i]: only the byte range of the archive that holds the slice's payloads goes to that device, nothing
+ * crosses between devices, the per-entry results are merged on the host into one cache generation.  devices == NULL:
+ * devices 0 .. ndev-1; ndev <= 0: every visible device.  A device may be listed more than once. */
+MZHIP_API int64_t mzhip_prime_file_multi(const char *path, const int32_t *devices, int32_t ndev);
+MZHIP_API int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_t *devices, int32_t ndev);
+/* bounds[0 .. world]: slice r = entries [bounds[r], bounds[r+1]) of an mzhip_zip_index_mem table (8 x int64 per entry) */
+MZHIP_API void mzhip_shard_bounds(const int64_t *table, int64_t n, int32_t world, int64_t *bounds);
 MZHIP_API void mzhip_prime_clear(void);
 MZHIP_API void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
 

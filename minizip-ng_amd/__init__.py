@@ -21,7 +21,8 @@ BATCH_SYMBOLS = [
     "mzhip_sha_batch", "mzhip_inflate_host", "mzhip_inflate_host2", "mzhip_lzma_host", "mzhip_xz_host",
     "mzhip_deflate_host", "mzhip_deflate_host2", "mzhip_crc32_host", "mzhip_inflate_launch_geometry",
     "mzhip_zip_index_mem", "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_clear", "mzhip_prime_stats",
-    "mzhip_prime_write", "mzhip_prime_write_clear", "mzhip_prime_write_stats",
+    "mzhip_prime_write", "mzhip_prime_write_clear", "mzhip_prime_write_stats", "mzhip_prime_file_multi",
+    "mzhip_prime_mem_multi", "mzhip_shard_bounds",
 ]
 
 _u64p, _u32p, _i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)

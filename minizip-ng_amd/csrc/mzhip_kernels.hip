@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <memory>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include <stdlib.h>
@@ -1281,85 +1283,55 @@ void mzhip_prime_clear(void) {
     g_prime = PrimeCache(); // generations pinned by open streams live until those streams let go
 }
 
-int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
+} // extern "C"
+
+namespace {
+// One slice of the primed entries, decoded on the CURRENT device of the calling thread: H2D of the byte range of the
+// archive that holds the slice's payloads, one launch per codec, D2H of the outputs into the shared host buffer.
+// ents[lo..hi) are in archive order; results land in the shared per-entry arrays at the same indices.
+int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const std::vector<int64_t> &max_out_all, size_t lo,
+                    size_t hi, uint8_t *h_out, uint32_t *r_len, uint32_t *r_used, uint32_t *r_crc, int32_t *r_st,
+                    std::vector<uint32_t> &seg_crc_all) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
-    int64_t n = mzhip_zip_index_mem(zip, zip_len, nullptr, 0);
-    if (n <= 0) return n;
-    std::vector<int64_t> table((size_t)n * 8);
-    mzhip_zip_index_mem(zip, zip_len, table.data(), n);
-    std::vector<PrimedEntry> ents;
-    std::vector<uint64_t> in_off, out_off;
-    std::vector<uint32_t> in_len, out_cap;
-    std::vector<int64_t> max_out;
-    uint64_t total_out = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const int64_t *t = &table[(size_t)i * 8];
-        if ((t[0] != 8 && t[0] != 14 && t[0] != 95) || (t[1] & 1) || t[7] < 0 || t[3] < 0 || t[4] < 0 ||
-            t[3] >= (1ll << 28) || t[4] >= (1ll << 31) || (uint64_t)t[7] > zip_len || (uint64_t)t[3] > zip_len - (uint64_t)t[7])
-            continue;
-        PrimedEntry e;
-        memset(&e, 0, sizeof(e));
-        e.method = (int32_t)t[0];
-        e.payload_off = t[7];
-        e.csize = t[3];
-        e.usize = t[4];
-        e.out_off = (int64_t)total_out;
-        e.head_len = (int32_t)(t[3] < (int64_t)sizeof(e.head) ? t[3] : (int64_t)sizeof(e.head));
-        memcpy(e.head, zip + t[7], (size_t)e.head_len);
-        ents.push_back(e);
-        in_off.push_back((uint64_t)t[7]);
-        in_len.push_back((uint32_t)t[3]);
-        out_off.push_back(total_out);
-        out_cap.push_back((uint32_t)t[4]);
-        /* TOTAL_OUT_MAX as mz_zip.c:1833-1846 sets it: the uncompressed size when the EOS flag is set */
-        max_out.push_back((t[0] != 8 && (t[1] & 2)) ? t[4] : -1);
-        total_out += ((uint64_t)t[4] + 15) & ~15ull;
-    }
-    const uint32_t k = (uint32_t)ents.size();
+    const uint32_t k = (uint32_t)(hi - lo);
     if (k == 0) return 0;
-    {
-        /* group the launch arrays by method (8, 14, 95): one batch launch per codec */
-        std::vector<uint32_t> order(k);
-        for (uint32_t i = 0; i < k; i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ents[a].method < ents[b].method; });
-        std::vector<PrimedEntry> e2(k);
-        std::vector<uint64_t> io(k), oo(k);
-        std::vector<uint32_t> il(k), oc(k);
-        std::vector<int64_t> mo(k);
-        for (uint32_t i = 0; i < k; i++) {
-            e2[i] = ents[order[i]];
-            io[i] = in_off[order[i]];
-            oo[i] = out_off[order[i]];
-            il[i] = in_len[order[i]];
-            oc[i] = out_cap[order[i]];
-            mo[i] = max_out[order[i]];
-        }
-        ents.swap(e2);
-        in_off.swap(io);
-        out_off.swap(oo);
-        in_len.swap(il);
-        out_cap.swap(oc);
-        max_out.swap(mo);
+    uint64_t zlo = UINT64_MAX, zhi = 0;
+    for (size_t i = lo; i < hi; i++) {
+        zlo = std::min(zlo, (uint64_t)ents[i].payload_off);
+        zhi = std::max(zhi, (uint64_t)(ents[i].payload_off + ents[i].csize));
     }
-    // segments for the chunked CRC updates
-    std::vector<uint64_t> seg_off;
-    std::vector<uint32_t> seg_len;
+    const int64_t out_base = ents[lo].out_off;
+    const uint64_t out_bytes = (uint64_t)(ents[hi - 1].out_off - out_base) + (((uint64_t)ents[hi - 1].usize + 15) & ~15ull);
+    /* group the launch arrays by method (8, 14, 95): one batch launch per codec */
+    std::vector<uint32_t> order(k);
+    for (uint32_t i = 0; i < k; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ents[lo + a].method < ents[lo + b].method; });
+    std::vector<uint64_t> in_off(k), out_off(k), seg_off;
+    std::vector<uint32_t> in_len(k), out_cap(k), seg_len;
+    std::vector<int64_t> max_out(k), seg_first(k);
     for (uint32_t i = 0; i < k; i++) {
-        ents[i].seg0 = (int64_t)seg_off.size();
+        const PrimedEntry &e = ents[lo + order[i]];
+        in_off[i] = (uint64_t)e.payload_off - zlo;
+        in_len[i] = (uint32_t)e.csize;
+        out_off[i] = (uint64_t)(e.out_off - out_base);
+        out_cap[i] = (uint32_t)e.usize;
+        max_out[i] = max_out_all[lo + order[i]];
+    }
+    // segments for the chunked CRC updates, in archive order (seg0 was assigned by the caller)
+    for (size_t i = lo; i < hi; i++)
         for (int64_t o = 0; o < ents[i].usize; o += kSeg) {
-            seg_off.push_back((uint64_t)ents[i].out_off + (uint64_t)o);
+            seg_off.push_back((uint64_t)(ents[i].out_off - out_base) + (uint64_t)o);
             seg_len.push_back((uint32_t)(ents[i].usize - o < kSeg ? ents[i].usize - o : kSeg));
         }
-    }
     const uint32_t ns = (uint32_t)seg_off.size();
     const size_t meta = (size_t)k * (8 + 8 + 8 + 4 + 4 + 4 + 4 + 4 + 4) + (size_t)ns * (8 + 4 + 4) + 256;
     Scratch d_zip, d_out, d_meta;
-    HIP_TRY(hipMalloc(&d_zip.p, zip_len + 16));
-    HIP_TRY(hipMalloc(&d_out.p, total_out + 16));
+    HIP_TRY(hipMalloc(&d_zip.p, zhi - zlo + 16));
+    HIP_TRY(hipMalloc(&d_out.p, out_bytes + 16));
     HIP_TRY(hipMalloc(&d_meta.p, meta));
-    HIP_TRY(hipMemcpy(d_zip.p, zip, zip_len, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_zip.p, zip + zlo, zhi - zlo, hipMemcpyHostToDevice));
     uint8_t *m = (uint8_t *)d_meta.p;
     uint64_t *d_in_off = (uint64_t *)m, *d_out_off = d_in_off + k, *d_seg_off = d_out_off + k;
     int64_t *d_max_out = (int64_t *)(d_seg_off + ns);
@@ -1378,13 +1350,14 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     }
     for (uint32_t g0 = 0; g0 < k;) {
         uint32_t g1 = g0;
-        while (g1 < k && ents[g1].method == ents[g0].method) g1++;
+        const int32_t method = ents[lo + order[g0]].method;
+        while (g1 < k && ents[lo + order[g1]].method == method) g1++;
         const uint32_t gn = g1 - g0;
-        if (ents[g0].method == 8)
+        if (method == 8)
             rc = mzhip_inflate_batch(d_zip.p, d_in_off + g0, d_in_len + g0, d_out.p, d_out_off + g0, d_out_cap + g0, gn,
                                      d_out_len + g0, d_in_used + g0, d_crc + g0, d_status + g0, nullptr);
         else
-            rc = lzma_family_batch(ents[g0].method == 95, d_zip.p, d_in_off + g0, d_in_len + g0, d_out.p, d_out_off + g0,
+            rc = lzma_family_batch(method == 95, d_zip.p, d_in_off + g0, d_in_len + g0, d_out.p, d_out_off + g0,
                                    d_out_cap + g0, d_max_out + g0, gn, d_out_len + g0, d_in_used + g0, d_crc + g0,
                                    d_status + g0, nullptr);
         if (rc) return rc;
@@ -1395,26 +1368,129 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
         if (rc) return rc;
     }
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<uint32_t> h_len(k), h_used(k), h_crc(k), h_segcrc(ns);
+    std::vector<uint32_t> h_len(k), h_used(k), h_crc(k);
     std::vector<int32_t> h_st(k);
     HIP_TRY(hipMemcpy(h_len.data(), d_out_len, k * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_used.data(), d_in_used, k * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_crc.data(), d_crc, k * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_st.data(), d_status, k * 4, hipMemcpyDeviceToHost));
-    if (ns) HIP_TRY(hipMemcpy(h_segcrc.data(), d_seg_crc, ns * 4, hipMemcpyDeviceToHost));
+    if (ns) HIP_TRY(hipMemcpy(seg_crc_all.data() + ents[lo].seg0, d_seg_crc, ns * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_out + out_base, d_out.p, out_bytes, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < k; i++) {
+        const size_t g = lo + order[i];
+        r_len[g] = h_len[i];
+        r_used[g] = h_used[i];
+        r_crc[g] = h_crc[i];
+        r_st[g] = h_st[i];
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" {
+
+void mzhip_shard_bounds(const int64_t *table, int64_t n, int32_t world, int64_t *bounds) {
+    /* contiguous slices balanced by compressed + uncompressed bytes (+ 64 per entry): the rule of archive.shard_bounds */
+    if (world < 1) world = 1;
+    double total = 0;
+    for (int64_t i = 0; i < n; i++) total += (double)(table[i * 8 + 3] + table[i * 8 + 4] + 64);
+    bounds[0] = 0;
+    double cum = 0;
+    int64_t i = 0;
+    for (int32_t r = 1; r < world; r++) {
+        const double target = total * r / world;
+        while (i < n && cum < target) {
+            cum += (double)(table[i * 8 + 3] + table[i * 8 + 4] + 64);
+            i++;
+        }
+        /* numpy.searchsorted(cum, target, 'left') over the cumulative sums that start with 0: first index with cum >= target */
+        bounds[r] = i;
+    }
+    bounds[world] = n;
+}
+
+int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_t *devices, int32_t ndev) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    std::vector<int32_t> devs;
+    if (ndev <= 0) {
+        const int32_t nd = mzhip_device_count();
+        if (nd <= 0) return -104;
+        for (int32_t d = 0; d < nd; d++) devs.push_back(d);
+    } else {
+        for (int32_t i = 0; i < ndev; i++) devs.push_back(devices ? devices[i] : i);
+    }
+    int64_t n = mzhip_zip_index_mem(zip, zip_len, nullptr, 0);
+    if (n <= 0) return n;
+    std::vector<int64_t> table((size_t)n * 8);
+    mzhip_zip_index_mem(zip, zip_len, table.data(), n);
+    std::vector<PrimedEntry> ents;
+    std::vector<int64_t> max_out, wtab;
+    uint64_t total_out = 0;
+    int64_t nseg = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t *t = &table[(size_t)i * 8];
+        if ((t[0] != 8 && t[0] != 14 && t[0] != 95) || (t[1] & 1) || t[7] < 0 || t[3] < 0 || t[4] < 0 ||
+            t[3] >= (1ll << 28) || t[4] >= (1ll << 31) || (uint64_t)t[7] > zip_len || (uint64_t)t[3] > zip_len - (uint64_t)t[7])
+            continue;
+        PrimedEntry e;
+        memset(&e, 0, sizeof(e));
+        e.method = (int32_t)t[0];
+        e.payload_off = t[7];
+        e.csize = t[3];
+        e.usize = t[4];
+        e.out_off = (int64_t)total_out;
+        e.seg0 = nseg;
+        e.head_len = (int32_t)(t[3] < (int64_t)sizeof(e.head) ? t[3] : (int64_t)sizeof(e.head));
+        memcpy(e.head, zip + t[7], (size_t)e.head_len);
+        ents.push_back(e);
+        /* TOTAL_OUT_MAX as mz_zip.c:1833-1846 sets it: the uncompressed size when the EOS flag is set */
+        max_out.push_back((t[0] != 8 && (t[1] & 2)) ? t[4] : -1);
+        wtab.insert(wtab.end(), t, t + 8);
+        total_out += ((uint64_t)t[4] + 15) & ~15ull;
+        nseg += (t[4] + kSeg - 1) / kSeg;
+    }
+    const size_t k = ents.size();
+    if (k == 0) return 0;
     uint8_t *h_out = (uint8_t *)malloc(total_out + 16);
     if (!h_out) return -4;
-    hipError_t he = hipMemcpy(h_out, d_out.p, total_out, hipMemcpyDeviceToHost);
-    if (he != hipSuccess) {
-        free(h_out);
-        return fail("hipMemcpy (primed output)", he);
+    std::vector<uint32_t> r_len(k), r_used(k), r_crc(k), seg_crc((size_t)nseg);
+    std::vector<int32_t> r_st(k, -1);
+    const int32_t world = (int32_t)std::min<size_t>(devs.size(), k);
+    std::vector<int64_t> bounds((size_t)world + 1);
+    mzhip_shard_bounds(wtab.data(), (int64_t)k, world, bounds.data());
+    std::vector<int32_t> rcs((size_t)world, 0);
+    std::vector<std::string> errs((size_t)world);
+    auto work = [&](int32_t r) {
+        hipError_t he = hipSetDevice(devs[(size_t)r]);
+        if (he != hipSuccess) {
+            rcs[(size_t)r] = fail("hipSetDevice", he);
+        } else {
+            rcs[(size_t)r] = prime_slice(zip, ents, max_out, (size_t)bounds[(size_t)r], (size_t)bounds[(size_t)r + 1], h_out,
+                                         r_len.data(), r_used.data(), r_crc.data(), r_st.data(), seg_crc);
+        }
+        if (rcs[(size_t)r]) errs[(size_t)r] = g_err;
+    };
+    if (world == 1 && devs[0] == cur) {
+        work(0);
+    } else { /* one host thread per device: the host side of the sharded path is C */
+        std::vector<std::thread> th;
+        for (int32_t r = 0; r < world; r++) th.emplace_back(work, r);
+        for (auto &t : th) t.join();
+        (void)hipSetDevice(cur);
     }
+    for (int32_t r = 0; r < world; r++)
+        if (rcs[(size_t)r]) {
+            snprintf(g_err, sizeof(g_err), "%s", errs[(size_t)r].c_str());
+            free(h_out);
+            return rcs[(size_t)r];
+        }
     std::vector<PrimedEntry> good;
-    for (uint32_t i = 0; i < k; i++) {
+    for (size_t i = 0; i < k; i++) {
         // only entries that decoded cleanly, to their declared sizes, are served from the cache;
         // everything else goes through the ordinary per-entry path and its exact error behaviour
-        if (h_st[i] != 0 || h_len[i] != (uint32_t)ents[i].usize || h_used[i] != (uint32_t)ents[i].csize) continue;
-        ents[i].crc = h_crc[i];
+        if (r_st[i] != 0 || r_len[i] != (uint32_t)ents[i].usize || r_used[i] != (uint32_t)ents[i].csize) continue;
+        ents[i].crc = r_crc[i];
         ents[i].status = 0;
         good.push_back(ents[i]);
     }
@@ -1422,7 +1498,7 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     gen->entries = std::move(good); // index order == payload order for archives written front to back
     std::sort(gen->entries.begin(), gen->entries.end(),
               [](const PrimedEntry &a, const PrimedEntry &b) { return a.payload_off < b.payload_off; });
-    gen->seg_crc = std::move(h_segcrc);
+    gen->seg_crc = std::move(seg_crc);
     gen->out = h_out;
     gen->zip_len = zip_len;
     {
@@ -1442,7 +1518,14 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     return n_good;
 }
 
-int64_t mzhip_prime_file(const char *path) {
+int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    const int32_t d = (int32_t)cur;
+    return mzhip_prime_mem_multi(zip, zip_len, &d, 1);
+}
+
+static int64_t prime_file_on(const char *path, const int32_t *devices, int32_t ndev, int multi) {
     FILE *f = fopen(path, "rb");
     if (!f) return -111; /* MZ_OPEN_ERROR */
     fseeko(f, 0, SEEK_END);
@@ -1450,11 +1533,16 @@ int64_t mzhip_prime_file(const char *path) {
     fseeko(f, 0, SEEK_SET);
     uint8_t *buf = (uint8_t *)malloc((size_t)(len > 0 ? len : 1));
     int64_t rc = -115; /* MZ_READ_ERROR */
-    if (buf && len > 0 && fread(buf, 1, (size_t)len, f) == (size_t)len) rc = mzhip_prime_mem(buf, (uint64_t)len);
+    if (buf && len > 0 && fread(buf, 1, (size_t)len, f) == (size_t)len)
+        rc = multi ? mzhip_prime_mem_multi(buf, (uint64_t)len, devices, ndev) : mzhip_prime_mem(buf, (uint64_t)len);
     free(buf);
     fclose(f);
     return rc;
 }
+
+int64_t mzhip_prime_file_multi(const char *path, const int32_t *devices, int32_t ndev) { return prime_file_on(path, devices, ndev, 1); }
+
+int64_t mzhip_prime_file(const char *path) { return prime_file_on(path, nullptr, 0, 0); }
 
 void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses) {
     std::lock_guard<std::mutex> lk(g_prime_mu);

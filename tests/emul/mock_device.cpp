@@ -102,6 +102,8 @@ extern "C" uint32_t mzhip_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b
 MOCK_API int64_t mzhip_prime_file(const char *) { return -109; }
 MOCK_API int64_t mzhip_prime_mem(const uint8_t *, uint64_t) { return -109; }
 MOCK_API void mzhip_prime_clear(void) {}
+MOCK_API int64_t mzhip_prime_file_multi(const char *, const int32_t *, int32_t) { return -109; }
+MOCK_API int64_t mzhip_prime_mem_multi(const uint8_t *, uint64_t, const int32_t *, int32_t) { return -109; }
 extern "C" int32_t mzhip_prime_lookup3(int32_t, int64_t, const uint8_t *, int32_t, int64_t, const uint8_t **, int64_t *, int64_t *,
                                        uint32_t *, const uint32_t **, void **pin) {
     *pin = nullptr;

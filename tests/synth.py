@@ -15,6 +15,46 @@ def corpus():
     return "".join(t.topics[k] for k in sorted(t.topics)).encode()
 
 
+def bench_corpus():
+    """(bytes, description): the SURVEY 8(d) corpus when oracle/_ref/corpus.bin travelled (built by
+    oracle/make_corpus.py from the reference tree), else the CPython prose above."""
+    import os
+
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "corpus.bin")
+    if os.path.exists(p):
+        return open(p, "rb").read(), "appnote.txt || appnote.iz.txt || alice29.txt of the reference tree (SURVEY 8d)"
+    return corpus(), "CPython's pydoc prose (oracle/_ref/corpus.bin absent)"
+
+
+def markov_entries(n_unique, size, seed=3, text=None, jump=0.45):
+    """Seeded order-2 word-Markov expansion of the corpus (mandatory for config 4: the corpus is only
+    ~470 KB, so 1 MiB entries tiled from slices would repeat inside LZMA's dictionary).  `jump` = probability of leaving
+    the chain at a word: 0.45 gives liblzma preset 6 a ratio of ~0.25 on the SURVEY corpus (0.15 without jumps)."""
+    rnd = random.Random(seed)
+    words = (text if text is not None else corpus()).split()
+    nxt = {}
+    for a, b, c in zip(words, words[1:], words[2:]):
+        nxt.setdefault((a, b), []).append(c)
+    keys = list(nxt)
+    out = []
+    for _ in range(n_unique):
+        a, b = keys[rnd.randrange(len(keys))]
+        parts, total = [a, b], len(a) + len(b) + 2
+        while total < size + 64:                         # a few words more than needed: the slice below is exactly `size`
+            cand = nxt.get((a, b))
+            if not cand or rnd.random() < jump:          # dead end, or a jump: keeps phrases short enough for an LZMA ratio of ~0.25
+                a, b = keys[rnd.randrange(len(keys))]
+                parts += [a, b]
+                total += len(a) + len(b) + 2
+                continue
+            c = cand[rnd.randrange(len(cand))]
+            parts.append(c)
+            total += len(c) + 1
+            a, b = b, c
+        out.append(b" ".join(parts)[:size])
+    return out
+
+
 def slices(n, size, seed=1234):
     c = corpus()
     rnd = random.Random(seed)

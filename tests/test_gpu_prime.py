@@ -148,3 +148,60 @@ def test_autoprime_env(monkeypatch):
             assert (o_hip == o_ref).all()
             assert ent.value >= n - 1 and hits.value >= n - 1, (method, ent.value, hits.value, miss.value)
             L.mzhip_prime_clear()
+
+
+def test_prime_multi_device_slices_and_generations():
+    """mzhip_prime_file_multi: the entry table is cut into slices (mzhip_shard_bounds), one host thread per slice decodes
+    it on its device -- here three slices on the one visible device, which exercises the sharding, the per-slice byte
+    ranges and the merge exactly as three devices would.  Two archives stay primed side by side (one cache generation
+    each, pinned by the streams that read from them): interleaved reads of both are served, and clearing the cache
+    while nothing is open leaves the ordinary path intact."""
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    L = mz.lib()
+    L.mzhip_prime_file_multi.restype = C.c_int64
+    L.mzhip_prime_file_multi.argtypes = [C.c_char_p, C.c_void_p, C.c_int32]
+    L.mzhip_prime_file.restype = C.c_int64
+    L.mzhip_prime_file.argtypes = [C.c_char_p]
+    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(36)
+    with tempfile.TemporaryDirectory() as tmp:
+        paths, cds, lens_all, refs = [], [], [], []
+        for a, (n, size) in enumerate(((700, 40000), (300, 90000))):
+            lens = rnd.randint(0, size + 1, size=n).astype(np.int32)
+            lens[:3] = (0, 1, 65535)
+            offs = rnd.randint(0, len(c) - size, size=n).astype(np.int64)
+            path = os.path.join(tmp, "m%d.zip" % a)
+            # mixed methods in one archive: the slices must group their launches by codec
+            ref.zip_write(path, c, offs, lens, method=8, level=6)
+            table = ref.zip_index(path)
+            cd = table[:, 6].copy()
+            out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+            o_ref = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            _, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_ref, out_off=out_off)
+            assert (st_r == 0).all()
+            paths.append(path); cds.append(cd); lens_all.append((lens, out_off)); refs.append((crc_r, ulen_r, o_ref))
+        L.mzhip_prime_clear()
+        devs = (C.c_int32 * 3)(0, 0, 0)
+        n0 = L.mzhip_prime_file_multi(paths[0].encode(), devs, 3)
+        n1 = L.mzhip_prime_file(paths[1].encode())                     # second generation; the first one stays
+        assert n0 >= 699 and n1 >= 299, (n0, n1)
+        ent = C.c_uint64()
+        L.mzhip_prime_stats(C.byref(ent), None, None)
+        assert ent.value == n0 + n1
+        for a in (0, 1, 0):                                            # interleaved: both generations serve
+            lens, out_off = lens_all[a]
+            o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            _, crc_h, ulen_h, st_h = hip.zip_read_all(paths[a], cds[a], nthreads=1, own_crc=False, out=o_hip, out_off=out_off)
+            assert (st_h == 0).all() and (crc_h == refs[a][0]).all() and (ulen_h == refs[a][1]).all()
+            assert (o_hip == refs[a][2]).all()
+        hits, miss = C.c_uint64(), C.c_uint64()
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        assert hits.value >= 2 * n0 + n1 - 6 and miss.value == 0, (hits.value, miss.value)
+        L.mzhip_prime_clear()
+        _, crc2, _, st2 = hip.zip_read_all(paths[1], cds[1][:20], nthreads=1, own_crc=False)
+        assert (st2 == 0).all() and (crc2 == refs[1][0][:20]).all()

@@ -1,4 +1,4 @@
-"""CPU test of the N>1 path (world_size 2, gloo): contiguous sharding of the entry table + the one collective
+"""CPU test of the N>1 path (world_size 2 and 4, gloo): contiguous sharding of the entry table + the one collective
 (all-gather of the per-entry {crc, out_len, status} words).  The per-entry work itself is done by the ORACLE
 here -- this is a test of the host-side distribution logic, which is device-independent; on the GPU box the
 same functions carry the results of mzhip_inflate_batch (bench.py --gpus N, DeviceArchive)."""
@@ -41,8 +41,13 @@ def _worker(rank, world, port, zpath, outdir):
     raw = open(zpath, "rb").read()
     res = np.zeros((hi - lo, 3), dtype=np.int64)
     for i in range(lo, hi):
-        p, cs, us = (int(table[i, k]) for k in (archive.COL_PAYLOAD, archive.COL_CSIZE, archive.COL_USIZE))
-        st, used, out = oracle.inflate_raw(raw[p:p + cs], us + 8)
+        m, p, cs, us = (int(table[i, k]) for k in (archive.COL_METHOD, archive.COL_PAYLOAD, archive.COL_CSIZE, archive.COL_USIZE))
+        if m == 8:
+            st, used, out = oracle.inflate_raw(raw[p:p + cs], us + 8)
+        elif m == 14:
+            st, used, out = oracle.lzma_zip_decode(raw[p:p + cs], us + 8, us)
+        else:                                          # STORE: the CRC-only path
+            st, used, out = 0, cs, raw[p:p + cs]
         res[i - lo] = (oracle.crc32(out), len(out), st if used == cs else -5)
     full = archive.gather_results(torch.from_numpy(res), world).numpy()
     ok = bool((full[:, 0] == table[:, archive.COL_CRC]).all() and (full[:, 1] == table[:, archive.COL_USIZE]).all()
@@ -71,3 +76,35 @@ def test_two_rank_shard_and_gather():
         assert all(r["ok"] and r["n"] == 301 for r in rs)
         assert rs[0]["lo"] == 0 and rs[0]["hi"] == rs[1]["lo"] and rs[1]["hi"] == 301
         assert 0 < rs[0]["hi"] < 301
+
+
+def test_four_rank_ragged_mixed_methods():
+    """Four ranks over a table that mixes DEFLATE, LZMA and STORE entries of very uneven sizes (a few entries carry most
+    of the bytes): the slices still tile the table, stay balanced by bytes rather than by count, and the gather returns
+    every row in table order on every rank."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, ROOT)
+    from tests import synth
+
+    archive = importlib.import_module("minizip-ng_amd.archive")
+    c = synth.corpus()
+    rnd = np.random.RandomState(11)
+    with tempfile.TemporaryDirectory() as tmp:
+        zpath = os.path.join(tmp, "m.zip")
+        with zipfile.ZipFile(zpath, "w") as z:
+            for i in range(257):
+                size = int(rnd.choice((0, 1, 300, 5000, 60000, 300000), p=(0.05, 0.05, 0.4, 0.3, 0.15, 0.05)))
+                o = int(rnd.randint(0, len(c) - size - 1))
+                method = (zipfile.ZIP_DEFLATED, zipfile.ZIP_LZMA, zipfile.ZIP_STORED)[i % 3]
+                z.writestr(zipfile.ZipInfo("e/%04d" % i), c[o:o + size], compress_type=method)
+        table = archive.index_file(zpath)
+        assert set(table[:, archive.COL_METHOD].tolist()) == {0, 8, 14}
+        world = 4
+        mp.spawn(_worker, args=(world, _free_port(), zpath, tmp), nprocs=world, join=True)
+        rs = [json.load(open(os.path.join(tmp, "r%d.json" % r))) for r in range(world)]
+        assert all(r["ok"] and r["n"] == 257 for r in rs)
+        assert rs[0]["lo"] == 0 and rs[-1]["hi"] == 257 and all(rs[r]["hi"] == rs[r + 1]["lo"] for r in range(world - 1))
+        w = (table[:, archive.COL_CSIZE] + table[:, archive.COL_USIZE] + 64).astype(float)
+        loads = [w[r["lo"]:r["hi"]].sum() for r in rs]
+        assert max(loads) <= sum(loads) / world + w.max()      # no slice is off by more than one entry's weight
