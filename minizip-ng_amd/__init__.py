@@ -22,7 +22,7 @@ BATCH_SYMBOLS = [
     "mzhip_deflate_host", "mzhip_deflate_host2", "mzhip_crc32_host", "mzhip_inflate_launch_geometry",
     "mzhip_zip_index_mem", "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_clear", "mzhip_prime_stats",
     "mzhip_prime_write", "mzhip_prime_write_clear", "mzhip_prime_write_stats", "mzhip_prime_file_multi",
-    "mzhip_prime_mem_multi", "mzhip_shard_bounds",
+    "mzhip_prime_mem_multi", "mzhip_shard_bounds", "mzhip_deflate_batch_level", "mzhip_deflate_host_level",
 ]
 
 _u64p, _u32p, _i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)

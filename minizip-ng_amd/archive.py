@@ -21,6 +21,7 @@ import numpy as np
 _mz = importlib.import_module("minizip-ng_amd")
 
 COL_METHOD, COL_FLAG, COL_CRC, COL_CSIZE, COL_USIZE, COL_LOCAL, COL_CDPOS, COL_PAYLOAD = range(8)
+MZ_FORMAT_ERROR = -103
 MZ_CRC_ERROR = -105       # mz.h:34
 MZ_SUPPORT_ERROR = -109   # mz.h:38
 MZ_ZIP_EXTENSION_HASH = 0x1A51   # mz.h:113
@@ -137,6 +138,11 @@ class DeviceArchive:
         status = np.full(n, MZ_SUPPORT_ERROR, dtype=np.int32)
         if (t[:, COL_PAYLOAD] < 0).any():
             raise _mz.MzHipError("entry without a usable local header")
+        # sizes come from the archive: nothing negative, nothing that reaches past the file image (the indexer already
+        # refuses both; a table handed in from elsewhere is checked again here before it becomes device offsets)
+        flen = int(self.h_file.size)
+        if n and ((t[:, COL_CSIZE] < 0).any() or (usize < 0).any() or (t[:, COL_PAYLOAD] + t[:, COL_CSIZE] > flen).any()):
+            raise _mz.MzHipError("entry sizes outside the archive")
         L = _mz.lib()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -176,8 +182,14 @@ class DeviceArchive:
                                              r_crc.data_ptr(), stream)
                     r_len = d_in_len.clone()
                     r_used = d_in_len.clone()
+                    # a stored entry's two sizes must agree (the slot was sized from the uncompressed one): anything
+                    # else is a format error and nothing is copied for it
+                    same = t[sel, COL_CSIZE] == usize[sel]
+                    r_st = dev_i32(np.where(same, 0, MZ_FORMAT_ERROR))
                     if keep_output:
                         for j, e in enumerate(sel):   # host-driven D2D copies: STORE is the CPU-plumbing config
+                            if not same[j]:
+                                continue
                             c0, cl = int(t[e, COL_PAYLOAD]), int(t[e, COL_CSIZE])
                             d_out[out_off[e]:out_off[e] + cl] = self.d_file[c0:c0 + cl]
                 if rc != 0:

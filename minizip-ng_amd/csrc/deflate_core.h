@@ -297,9 +297,13 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
  * byte).  final == 0: non-final blocks followed by an empty stored block, so that pieces of one stream can be
  * concatenated on byte boundaries.  tok = this wave's token scratch (MZ_DEF_BLOCK words).  All arguments
  * wave-uniform. */
+/* ways / xhead: the match finder keeps the `ways` most recent positions of every hash bucket (1 = the fast class: zlib
+ * levels 1-3; MZ_DEF_WAYS_BEST = the default class: levels 4-9 and -1, mz_strm_zlib.c:87,339-343).  Way 0 is L->u.head;
+ * ways 1.. are xhead[(w - 1) << MZ_DEF_HBITS | hash], extra LDS behind the wave's mz_deflate_lds (may be NULL for 1). */
+#define MZ_DEF_WAYS_BEST 4u
 MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
                              uint32_t *tok, mz_deflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                             mz_deflate_result *res) {
+                             uint32_t ways, uint16_t *xhead, mz_deflate_result *res) {
     MZ_LANE_DECL
     int32_t status = MZHIP_OK;
     uint32_t obyte = 0; /* whole bytes already written to out */
@@ -316,6 +320,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
         /* ================= pass 1: tokens and histograms ================= */
         MZ_LANES {
             for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->u.head)[i] = 0u;
+            for (uint32_t i = (uint32_t)lane; i < (ways - 1u) * ((1u << MZ_DEF_HBITS) / 2u); i += 64u) ((uint32_t *)xhead)[i] = 0u;
             for (uint32_t i = (uint32_t)lane; i <= MZ_DEF_NSYM; i += 64u) L->freq[i] = 0u;
         }
         MZ_WAVE_SYNC();
@@ -331,6 +336,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u; /* valid positions in this step */
             PV(uint32_t, hh);
             PV(uint32_t, cand);
+            PV2(uint32_t, candx, MZ_DEF_WAYS_BEST - 1u); /* the older positions of the bucket (ways > 1) */
             MZ_LANES {
                 const uint32_t pos = p + (uint32_t)lane;
                 const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
@@ -339,10 +345,18 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
                 P(hh) = have4 ? h : 0xFFFFFFFFu;
                 P(cand) = have4 ? (uint32_t)L->u.head[h] : 0u;
+                for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++)
+                    P(candx)[w - 1u] = (have4 && w < ways) ? (uint32_t)xhead[((w - 1u) << MZ_DEF_HBITS) | h] : 0u;
             }
             MZ_WAVE_SYNC();
             MZ_LANES {
-                if (P(hh) != 0xFFFFFFFFu) L->u.head[P(hh)] = (uint16_t)(p + (uint32_t)lane);
+                if (P(hh) != 0xFFFFFFFFu) {
+                    /* the bucket shifts by one: lanes that share a bucket write the same older entries, one of them
+                     * wins way 0 */
+                    for (uint32_t w = MZ_DEF_WAYS_BEST - 1u; w >= 1u; w--)
+                        if (w < ways) xhead[((w - 1u) << MZ_DEF_HBITS) | P(hh)] = (uint16_t)(w == 1u ? P(cand) : P(candx)[w - 2u]);
+                    L->u.head[P(hh)] = (uint16_t)(p + (uint32_t)lane);
+                }
             }
             MZ_WAVE_SYNC();
             PV(uint32_t, pk); /* [8:0] match length (0 = literal), [24:9] distance | literal byte */
@@ -351,16 +365,18 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_LANES {
                 const uint32_t pos = p + (uint32_t)lane;
                 uint32_t mlen = 0, dist = 0;
-                if ((uint32_t)lane < nv) {
-                    const uint32_t d = (pos - P(cand)) & 0xFFFFu;
-                    /* the head table is cleared per block, so a candidate never precedes the block */
-                    if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - blk) {
-                        const uint8_t *a = in + pos, *b = in + (pos - d);
-                        const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
-                        const uint32_t l = mz_match_len(a, b, maxl);
-                        if (l >= MZ_DEF_MINMATCH) {
-                            mlen = l;
-                            dist = d;
+                if ((uint32_t)lane < nv && P(hh) != 0xFFFFFFFFu) {
+                    const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
+                    for (uint32_t w = 0; w < MZ_DEF_WAYS_BEST; w++) { /* most recent first: a tie keeps the shorter distance */
+                        if (w >= ways) break;
+                        const uint32_t d = (pos - (w ? P(candx)[w - 1u] : P(cand))) & 0xFFFFu;
+                        /* the head table is cleared per block, so a candidate never precedes the block */
+                        if (d >= 1u && d <= 32768u && d <= pos - blk && d != dist) {
+                            const uint32_t l = mz_match_len(in + pos, in + (pos - d), maxl);
+                            if (l >= MZ_DEF_MINMATCH && l > mlen) {
+                                mlen = l;
+                                dist = d;
+                            }
                         }
                     }
                 }
@@ -370,10 +386,14 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             /* lazy evaluation (what zlib does from level 4 up): a match yields to a longer one starting at the
              * next position -- this position then goes out as a literal */
             PV(uint32_t, pkn);
+            PV(uint32_t, pkn2);
             MZ_GATHER4(pkn, pk, 4u * ((uint32_t)lane + 1u));
+            MZ_GATHER4(pkn2, pk, 4u * ((uint32_t)lane + 2u));
             MZ_LANES {
                 uint32_t mlen = P(pk) & 511u;
                 if (mlen && (uint32_t)lane + 1u < nv && (P(pkn) & 511u) > mlen) mlen = 0u;
+                /* the default class also looks two positions ahead (two literals must buy more than one byte) */
+                if (ways > 1u && mlen && (uint32_t)lane + 2u < nv && (P(pkn2) & 511u) > mlen + 1u) mlen = 0u;
                 P(pk) = mlen ? P(pk) : (P(lit) << 9);
                 const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
                 P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);

@@ -274,12 +274,15 @@ struct DeflateArgs {
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
     uint32_t *tok; // token scratch: MZ_DEF_BLOCK words per resident wave
+    uint32_t ways; // hash-bucket depth of the match finder: 1 (levels 1-3) or MZ_DEF_WAYS_BEST (levels 4-9, -1)
 };
 
 #define MZ_DEF_LDS_STRIDE ((sizeof(mz_deflate_lds) + 15) & ~(size_t)15)
 
 // K4: one wave per piece, 4 waves per workgroup, 9.3 KiB LDS per wave (hash heads, reused for code construction, code
-// table and bit staging once pass 1 is over; histograms) and 256 KiB of token scratch in HBM per resident wave.
+// table and bit staging once pass 1 is over; histograms) and 256 KiB of token scratch in HBM per resident wave.  The
+// default compression class adds (MZ_DEF_WAYS_BEST - 1) x 8 KiB of older bucket entries per wave behind those.
+#define MZ_DEF_XHEAD_BYTES ((MZ_DEF_WAYS_BEST - 1u) * (sizeof(uint16_t) << MZ_DEF_HBITS))
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *crc_tab = (uint32_t *)smem;
@@ -288,6 +291,8 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateA
     MZ_LANE_DECL
     const int wave = threadIdx.x >> 6;
     mz_deflate_lds *L = (mz_deflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_DEF_LDS_STRIDE);
+    uint16_t *xhead = a.ways > 1u ? (uint16_t *)(smem + MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE + wave * MZ_DEF_XHEAD_BYTES)
+                                  : nullptr;
     for (;;) {
         uint32_t e;
         MZ_WAVE_FETCH_ADD(e, a.counter);
@@ -298,7 +303,8 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateA
         const uint32_t fin = a.final_flag ? MZ_UNIFORM((uint32_t)a.final_flag[e]) : 1u;
         mz_deflate_result r;
         mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
-                         a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs, &r);
+                         a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs,
+                         MZ_UNIFORM(a.ways), xhead, &r);
         a.out_len[e] = r.out_len;
         a.crc[e] = r.crc;
         a.status[e] = r.status;
@@ -385,7 +391,12 @@ struct DeviceCtx {
         hipStream_t last = nullptr; // ... on this stream
         bool used = false, held = false;
     } scratch[32]; // per-launch scratch (K4 / K6 tokens) and the host-buffer calls' staging, see scratch_acquire()
-    uint32_t *d_counters = nullptr;
+    uint32_t *d_counters = nullptr; // MZ_NUM_COUNTERS work-queue heads, see CounterLease
+    struct CounterSlot {
+        hipEvent_t ev = nullptr;    // recorded behind the last launch that used the counter
+        hipStream_t last = nullptr; // ... on this stream
+        bool used = false, held = false;
+    } cslots[MZ_NUM_COUNTERS];
     uint32_t next_counter = 0;
     int cu_count = 0;
     int inflate_wgs_per_cu = 1;
@@ -425,7 +436,7 @@ int32_t ctx_for_current(DeviceCtx **out) {
         mzhip_crc64_table_init(t64);
         HIP_TRY(hipMalloc((void **)&c.d_tab64, sizeof(t64)));
         HIP_TRY(hipMemcpy(c.d_tab64, t64, sizeof(t64), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc((void **)&c.d_counters, MZ_NUM_COUNTERS * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&c.d_counters, 2 * MZ_NUM_COUNTERS * sizeof(uint32_t)));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         c.cu_count = prop.multiProcessorCount;
@@ -504,12 +515,55 @@ int32_t scratch_release(DeviceCtx *c, int slot, hipStream_t s) {
     return 0;
 }
 
-uint32_t *take_counter(DeviceCtx *c) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    uint32_t *p = c->d_counters + (c->next_counter % MZ_NUM_COUNTERS);
-    c->next_counter++;
-    return p;
-}
+// The work-queue head of one launch.  The batch entry points are asynchronous on caller-supplied streams, so a counter
+// may only be handed out again when the launch that used it last is known to be over: the next launch is on the same
+// stream (stream order puts its memset behind that kernel) or the event recorded behind it has completed.  Otherwise
+// another slot is taken; with every slot busy on other streams the oldest one is waited for.
+struct CounterLease {
+    DeviceCtx *c = nullptr;
+    hipStream_t s = nullptr;
+    int idx = -1;
+    uint32_t *p = nullptr;
+    int32_t get(DeviceCtx *ctx, hipStream_t st) {
+        c = ctx;
+        s = st;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            for (uint32_t k = 0; k < MZ_NUM_COUNTERS && idx < 0; k++) {
+                const uint32_t i = (c->next_counter + k) % MZ_NUM_COUNTERS;
+                DeviceCtx::CounterSlot &e = c->cslots[i];
+                if (e.held) continue;
+                if (!e.used || e.last == s || hipEventQuery(e.ev) == hipSuccess) idx = (int)i;
+            }
+            if (idx < 0) { /* every counter is busy on another stream: wait for one that is not being set up right now */
+                for (uint32_t k = 0; k < MZ_NUM_COUNTERS && idx < 0; k++) {
+                    const uint32_t i = (c->next_counter + k) % MZ_NUM_COUNTERS;
+                    if (!c->cslots[i].held) idx = (int)i;
+                }
+                if (idx < 0) {
+                    snprintf(g_err, sizeof(g_err), "more than %d launches being set up at once", MZ_NUM_COUNTERS);
+                    return -104;
+                }
+                HIP_TRY(hipEventSynchronize(c->cslots[idx].ev));
+            }
+            c->cslots[idx].held = true;
+            c->next_counter = (uint32_t)idx + 1u;
+        }
+        p = c->d_counters + 2 * idx; /* two words per slot: the LZMA encoder's two kernels each have a head */
+        HIP_TRY(hipMemsetAsync(p, 0, 2 * sizeof(uint32_t), s));
+        return 0;
+    }
+    ~CounterLease() {
+        if (idx < 0) return;
+        std::lock_guard<std::mutex> lk(g_mu);
+        DeviceCtx::CounterSlot &e = c->cslots[idx];
+        if (!e.ev && hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) e.ev = nullptr;
+        if (e.ev) (void)hipEventRecord(e.ev, s);
+        e.used = e.ev != nullptr;
+        e.last = s;
+        e.held = false;
+    }
+};
 
 uint32_t grid_for(const DeviceCtx *c, uint32_t n) {
     uint32_t wgs_needed = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
@@ -570,9 +624,11 @@ int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     a.in_used = d_in_used;
     a.crc = d_crc;
     a.status = d_status;
-    a.counter = take_counter(c);
+    CounterLease lease;
+    rc = lease.get(c, s);
+    if (rc) return rc;
+    a.counter = lease.p;
     a.tabs = c->d_tabs;
-    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE;
     const uint32_t grid = grid_for(c, n);
     hipLaunchKernelGGL(k_inflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
@@ -595,9 +651,11 @@ int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *d_off, const uint32
     a.n = n;
     a.init = d_init;
     a.crc = d_crc;
-    a.counter = take_counter(c);
+    CounterLease lease;
+    rc = lease.get(c, s);
+    if (rc) return rc;
+    a.counter = lease.p;
     a.tabs = c->d_tabs;
-    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_crc32_batch, dim3(grid_for(c, n)), dim3(MZ_WAVES_PER_WG * 64), 0, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -617,9 +675,11 @@ int32_t mzhip_adler32_batch(const void *d_buf, const uint64_t *d_off, const uint
     a.n = n;
     a.init = nullptr;
     a.crc = d_adler;
-    a.counter = take_counter(c);
+    CounterLease lease;
+    rc = lease.get(c, s);
+    if (rc) return rc;
+    a.counter = lease.p;
     a.tabs = c->d_tabs;
-    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     hipLaunchKernelGGL(k_adler32_batch, dim3(grid_for(c, n)), dim3(MZ_WAVES_PER_WG * 64), 0, s, a);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -646,10 +706,12 @@ static int32_t lzma_family_batch(int xz, const void *d_in, const uint64_t *d_in_
     a.in_used = d_in_used;
     a.crc = d_crc;
     a.status = d_status;
-    a.counter = take_counter(c);
+    CounterLease lease;
+    rc = lease.get(c, s);
+    if (rc) return rc;
+    a.counter = lease.p;
     a.tabs = c->d_tabs;
     a.tab64 = c->d_tab64;
-    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
     /* 16 KiB LDS per wave -> 10 single-wave workgroups per CU (K3); 17.6 KiB -> 8 (.xz) */
     uint32_t resident = (uint32_t)c->cu_count * (xz ? 8u : 10u);
     uint32_t grid = n < resident ? n : resident;
@@ -706,6 +768,13 @@ int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t
 int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                             const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_final, uint32_t n,
                             uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    return mzhip_deflate_batch_level(d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_final, n, 1, d_out_len, d_crc,
+                                     d_status, stream);
+}
+
+int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                                  const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_final, uint32_t n,
+                                  int32_t level, uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream) {
     if (n == 0) return 0;
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
@@ -723,12 +792,22 @@ int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     a.out_len = d_out_len;
     a.crc = d_crc;
     a.status = d_status;
-    a.counter = take_counter(c);
+    CounterLease lease;
+    rc = lease.get(c, s);
+    if (rc) return rc;
+    a.counter = lease.p;
     a.tabs = c->d_tabs;
-    HIP_TRY(hipMemsetAsync(a.counter, 0, sizeof(uint32_t), s));
-    const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE;
+    /* compression classes (mz_strm_zlib.c:87 hands `level` to deflateInit2): 0-3 fast = one candidate per hash bucket,
+     * everything else (4-9, and -1 = Z_DEFAULT_COMPRESSION) = MZ_DEF_WAYS_BEST candidates + a two-position lazy rule */
+    a.ways = (level >= 0 && level <= 3) ? 1u : MZ_DEF_WAYS_BEST;
+    const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
+    static std::once_flag big_lds;
+    std::call_once(big_lds, [] { /* the default class needs 134 KiB of dynamic LDS per workgroup */
+        (void)hipFuncSetAttribute((const void *)k_deflate_batch, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + MZ_DEF_XHEAD_BYTES)));
+    });
     uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
-    uint32_t resident = (uint32_t)c->cu_count * 4u; /* 38.3 KiB LDS per workgroup -> 4 per CU */
+    uint32_t resident = (uint32_t)c->cu_count * (a.ways > 1u ? 1u : 4u); /* 38.3 / 134 KiB LDS per workgroup -> 4 / 1 per CU */
     const uint32_t grid = wgs < resident ? wgs : resident;
     int slot = -1;
     void *scratch = nullptr; /* one token block per resident wave */
@@ -1071,6 +1150,11 @@ int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, u
 // stored block so the pieces concatenate on byte boundaries; the last piece is final iff `final`.
 int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
                             uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
+    return mzhip_deflate_host_level(in, in_len, final, 1, out, out_cap, out_len, crc, adler);
+}
+
+int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, uint8_t *out,
+                                 uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -1112,8 +1196,8 @@ int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, 
     int32_t *d_status = (int32_t *)(d_crc + np);
     uint32_t *d_adler = (uint32_t *)(d_status + np);
     uint8_t *d_final = (uint8_t *)(d_adler + np);
-    rc = mzhip_deflate_batch(base, d_in_off, d_in_len, base, d_out_off, d_out_cap, d_final, np, d_out_len, d_crc,
-                             d_status, nullptr);
+    rc = mzhip_deflate_batch_level(base, d_in_off, d_in_len, base, d_out_off, d_out_cap, d_final, np, level, d_out_len, d_crc,
+                                   d_status, nullptr);
     if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -104;
     /* zlib wrapper: Adler-32 of the same pieces, one wave each, combined below from the checksums alone */
     if (rc == 0 && adler) rc = mzhip_adler32_batch(base, d_in_off, d_in_len, np, d_adler, nullptr);

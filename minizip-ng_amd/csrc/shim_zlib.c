@@ -488,8 +488,8 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
     if (!out)
         return MZH_MEM_ERROR;
     uint32_t out_len = 0, crc = 0, adler = 1;
-    int32_t st = mzhip_deflate_host2(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, out, cap, &out_len, &crc,
-                                     z->wrap == 1 ? &adler : NULL);
+    int32_t st = mzhip_deflate_host_level(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, z->level, out, cap, &out_len, &crc,
+                                          z->wrap == 1 ? &adler : NULL); /* the level goes where mz_strm_zlib.c:87 hands it */
     if (st != 0) {
         free(out);
         z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */

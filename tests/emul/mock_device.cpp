@@ -34,8 +34,8 @@ MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t 
 }
 
 // one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host2 does)
-MOCK_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
-                                     uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
+MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, uint8_t *out,
+                                          uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
     const uint32_t piece = 64u << 10;
     const uint32_t np = in_len ? (in_len + piece - 1) / piece : 1u;
     uint32_t total = 0, k = 0, ad = 1;
@@ -43,7 +43,7 @@ MOCK_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_
     for (uint32_t i = 0; i < np; i++) {
         const uint32_t off = in_len ? i * piece : 0u, len = in_len - off < piece ? in_len - off : piece;
         uint32_t ol = 0, pc = 0;
-        const int32_t st = emul_deflate(in_len ? in + off : &dummy, len, out + total, out_cap - total, (i + 1 == np && final) ? 1u : 0u, &ol, &pc);
+        const int32_t st = ((level >= 0 && level <= 3) ? emul_deflate : emul_deflate_best)(in_len ? in + off : &dummy, len, out + total, out_cap - total, (i + 1 == np && final) ? 1u : 0u, &ol, &pc);
         if (st) return st;
         total += ol;
         k = i == 0 ? pc : mzhip_crc32_combine_host(k, pc, len);
@@ -53,6 +53,10 @@ MOCK_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_
     if (crc) *crc = k;
     if (adler) *adler = ad;
     return 0;
+}
+MOCK_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
+                                     uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
+    return mzhip_deflate_host_level(in, in_len, final, 1, out, out_cap, out_len, crc, adler);
 }
 MOCK_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
                                     uint32_t *out_len, uint32_t *crc) {

@@ -168,3 +168,40 @@ def test_hash_extrafield_verification(env):
         r = da.decode(verify_hash=True)
         assert r["status"].tolist() == [0, 0, archive.MZ_CRC_ERROR, archive.MZ_SUPPORT_ERROR, 0, 0, 0, 0, 0]
         assert da.decode()["status"].tolist() == [0] * 9           # without the check every entry is fine
+
+
+def test_store_entry_with_disagreeing_sizes_is_refused():
+    """A crafted STORE entry whose compressed size exceeds its uncompressed size: its output slot is sized
+    from the uncompressed size, so copying `csize` bytes would run over the neighbours' decoded bytes.  It must come out
+    as MZ_FORMAT_ERROR with nothing copied, and the entries around it must be intact."""
+    import io
+    import struct
+    import zipfile
+
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    archive = importlib.import_module("minizip-ng_amd.archive")
+    datas = [bytes([65 + i]) * (100 + 10 * i) for i in range(6)]
+    buf = io.BytesIO()
+    with zipfile.ZipFile(buf, "w", zipfile.ZIP_STORED) as z:
+        for i, d in enumerate(datas):
+            z.writestr("s%d" % i, d)
+    raw = bytearray(buf.getvalue())
+    # entry 2: claim 40 more compressed bytes than there are uncompressed ones (central directory and local header)
+    p = 0
+    for _ in range(3):
+        p = raw.index(b"PK\x01\x02", p + 1)
+    csize, = struct.unpack_from("<I", raw, p + 20)
+    struct.pack_into("<I", raw, p + 20, csize + 40)
+    loff, = struct.unpack_from("<I", raw, p + 42)
+    struct.pack_into("<I", raw, loff + 18, csize + 40)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "bad_store.zip")
+        open(path, "wb").write(raw)
+        da = archive.DeviceArchive(path)
+        r = da.decode()
+        assert r["status"][2] == -103 and not r["ok"][2]
+        h = r["out"].cpu().numpy()
+        for i in (0, 1, 3, 4, 5):
+            assert r["status"][i] == 0 and r["ok"][i]
+            assert h[r["out_off"][i]:r["out_off"][i] + len(datas[i])].tobytes() == datas[i]

@@ -3,6 +3,7 @@
 output is not a format property, so parity = the reference side (oracle restatement, zlib 1.2.11, the compiled
 reference's mz_stream_zlib READ) inflates the bytes back to the input and every CRC agrees."""
 import ctypes as C
+import importlib
 import os
 import tempfile
 import zlib
@@ -159,3 +160,61 @@ def test_full_size_encode_decode_roundtrip_property(gpu):
     assert float(z_len.sum()) / (n_total * size) < 0.40
     for e in (0, n_total // 2, n_total - 1):          # and bytes, on a few entries
         assert out[e * size:(e + 1) * size].cpu().numpy().tobytes() == datas[idx[e]]
+
+
+@pytest.mark.parametrize("level", [1, 6, 9, -1])
+def test_compress_level_is_honoured(gpu, level):
+    """COMPRESS_LEVEL reaches the match finder (the reference hands it to deflateInit2, mz_strm_zlib.c:87,339-343):
+    levels 1-3 take the fast class, everything else (4-9, -1) four candidates per hash bucket.  Same round-trip bar at
+    every level -- the REFERENCE's inflate returns the input -- plus a ratio bar per class on 64 KiB slices of the
+    bench corpus (zlib 1.2.11 on the same slices: level 1 0.355, level 6 0.297)."""
+    import torch
+
+    L = gpu.mz.lib()
+    L.mzhip_deflate_batch_level.restype = C.c_int32
+    L.mzhip_deflate_batch_level.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_int32] + [C.c_void_p] * 4
+    text, _ = synth.bench_corpus()
+    rnd = np.random.RandomState(77)
+    datas = [text[o:o + 65536] for o in rnd.randint(0, len(text) - 65536, size=400)]
+    datas += [b"", b"abc", b"A" * 70000, text[:100], text[:200000], rnd.bytes(3000)]
+    caps = [len(d) + len(d) // 8 + 64 for d in datas]
+    b = gpu.make_batch(datas, caps)
+    n = len(datas)
+    dev = b["d_in"].device
+    out_len, crc, status = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
+    rc = L.mzhip_deflate_batch_level(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(), b["d_out"].data_ptr(),
+                                     b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None, n, level, out_len.data_ptr(),
+                                     crc.data_ptr(), status.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    h = b["d_out"].cpu().numpy()
+    ol = out_len.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    zs = [gpu.entry_bytes(b, h, i, int(ol[i])) for i in range(n)]
+    ref = oracle.ref() if oracle.have_ref() else None
+    for i, d in enumerate(datas):
+        assert zlib.decompress(zs[i], -15) == d and gpu.mz.u32(crc)[i] == zlib.crc32(d), (level, i)
+        if ref is not None and i % 25 == 0:
+            r = ref.stream_decode(8, zs[i], len(d) + 64, chunk=16384)          # mz_stream_zlib_read of the reference
+            assert r["out"] == d and r["error"] == 0 and r["total_in"] == len(zs[i]), (level, i)
+    ratio = sum(len(z) for z in zs[:400]) / (400 * 65536)
+    print("level %d: ratio %.4f" % (level, ratio))
+    assert ratio <= (0.36 if 1 <= level <= 3 else 0.32), (level, ratio)
+
+
+def test_stream_level_property_changes_the_output():
+    """MZ_STREAM_PROP_COMPRESS_LEVEL through the drop-in stream: level 9 output is smaller than level 1 output, both
+    decode on the reference."""
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    text, _ = synth.bench_corpus()
+    d = text[:300000]
+    z1, i1 = hip.stream_encode(8, d, level=1, chunk=65535)
+    z9, i9 = hip.stream_encode(8, d, level=9, chunk=65535)
+    assert i1["error"] == 0 and i9["error"] == 0 and len(z9) < 0.95 * len(z1)
+    for z in (z1, z9):
+        r = ref.stream_decode(8, z, len(d) + 64, chunk=16384)
+        assert r["out"] == d and r["error"] == 0 and r["total_in"] == len(z)

@@ -461,3 +461,24 @@ def test_inflate_span_and_step_paths(emu, emu_staged):
                 assert (used, out) == (uo, oo) and crc == oracle.crc32(oo), (it, kind)
         n_ok += so == 0
     assert n_ok > 150
+
+
+def test_deflate_default_class_roundtrip(emu):
+    """K4's default compression class (levels 4-9, -1: four candidates per hash bucket, two-position lazy rule) in the
+    emulation: zlib inflates the bytes back, and they are smaller than the fast class's."""
+    emu.emul_deflate_best.argtypes = emu.emul_deflate.argtypes
+    text, _ = synth.bench_corpus()
+    rnd = np.random.RandomState(12)
+    datas = [text[o:o + 65536] for o in rnd.randint(0, len(text) - 65536, size=6)]
+    datas += [b"", b"a", b"abcabcabcabc" * 300, bytes(70000), text[:200000], rnd.bytes(4000), b"ab" * 40000]
+    tot = {"fast": 0, "best": 0}
+    for d in datas:
+        a = np.frombuffer(d, dtype=np.uint8).copy() if d else np.zeros(1, np.uint8)
+        for name, fn in (("fast", emu.emul_deflate), ("best", emu.emul_deflate_best)):
+            out = np.zeros(len(d) + len(d) // 8 + 1000, np.uint8)
+            ol, crc = C.c_uint32(), C.c_uint32()
+            st = fn(a.ctypes.data_as(_u8p), len(d), out.ctypes.data_as(_u8p), len(out), 1, C.byref(ol), C.byref(crc))
+            assert st == 0 and zlib.decompress(out[:ol.value].tobytes(), -15) == d and crc.value == zlib.crc32(d), (name, len(d))
+            if len(d) == 65536:
+                tot[name] += ol.value
+    assert tot["best"] < 0.93 * tot["fast"] and tot["best"] <= 0.32 * 6 * 65536, tot
