@@ -135,10 +135,11 @@ MZHIP_API int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off
 /* the same with the compression level the stream was given (mz_stream_zlib_set_prop_int64 COMPRESS_LEVEL ->
  * deflateInit2(level, ...), mz_strm_zlib.c:87,339-343).  Two classes: 0..3 = fast (one candidate per hash bucket: the
  * ratio of zlib levels 1-2), anything else (4..9 and -1 = default) = four candidates per bucket and a two-position lazy
- * rule (between zlib levels 3 and 6; 3-4x the work).  mzhip_deflate_batch == level 1. */
+ * rule (between zlib levels 3 and 6; 3-4x the work).  window_log2 = 9..15: matches reach at most 2^window_log2 - 262
+ * bytes back (zlib's MAX_DIST), so an inflater with that window decodes the stream.  mzhip_deflate_batch == level 1, 15. */
 MZHIP_API int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
-                                      const uint8_t *d_final, uint32_t n, int32_t level, uint32_t *d_out_len, uint32_t *d_crc,
+                                      const uint8_t *d_final, uint32_t n, int32_t level, int32_t window_log2, uint32_t *d_out_len, uint32_t *d_crc,
                                       int32_t *d_status, void *stream);
 
 /* LZMA1 encode (ZIP method 14 payloads, LZMA2 chunk payloads) ---------------------------- */
@@ -179,8 +180,8 @@ MZHIP_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_
 MZHIP_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
                                       uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler);
 /* ... at a compression level (see mzhip_deflate_batch_level); what mz_stream_zlib_write / _close use */
-MZHIP_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, uint8_t *out,
-                                           uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler);
+MZHIP_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level,
+                                           int32_t window_log2, uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler);
 /* mz_crypt_crc32_update on a host buffer (mz_crypt.c:35-92: chaining value in, chaining value out).  Buffers of
  * MZHIP_CRC_HOST_BELOW bytes or more are reduced on the device (K2); smaller ones -- the reference calls the symbol
  * per byte from mz_strm_pkcrypt.c:79,86 -- are folded on the host with the same generated tables.  Never aborts: if

@@ -299,11 +299,12 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
  * wave-uniform. */
 /* ways / xhead: the match finder keeps the `ways` most recent positions of every hash bucket (1 = the fast class: zlib
  * levels 1-3; MZ_DEF_WAYS_BEST = the default class: levels 4-9 and -1, mz_strm_zlib.c:87,339-343).  Way 0 is L->u.head;
- * ways 1.. are xhead[(w - 1) << MZ_DEF_HBITS | hash], extra LDS behind the wave's mz_deflate_lds (may be NULL for 1). */
+ * ways 1.. are xhead[(w - 1) << MZ_DEF_HBITS | hash], extra LDS behind the wave's mz_deflate_lds (may be NULL for 1).
+ * max_dist: the largest distance a match may use = window - 262 (zlib's MAX_DIST; 32 506 for the 32 KiB window). */
 #define MZ_DEF_WAYS_BEST 4u
 MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
                              uint32_t *tok, mz_deflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                             uint32_t ways, uint16_t *xhead, mz_deflate_result *res) {
+                             uint32_t ways, uint16_t *xhead, uint32_t max_dist, mz_deflate_result *res) {
     MZ_LANE_DECL
     int32_t status = MZHIP_OK;
     uint32_t obyte = 0; /* whole bytes already written to out */
@@ -371,7 +372,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         if (w >= ways) break;
                         const uint32_t d = (pos - (w ? P(candx)[w - 1u] : P(cand))) & 0xFFFFu;
                         /* the head table is cleared per block, so a candidate never precedes the block */
-                        if (d >= 1u && d <= 32768u && d <= pos - blk && d != dist) {
+                        if (d >= 1u && d <= max_dist && d <= pos - blk && d != dist) {
                             const uint32_t l = mz_match_len(in + pos, in + (pos - d), maxl);
                             if (l >= MZ_DEF_MINMATCH && l > mlen) {
                                 mlen = l;

@@ -275,6 +275,7 @@ struct DeflateArgs {
     const mzhip_crc_tables *tabs;
     uint32_t *tok; // token scratch: MZ_DEF_BLOCK words per resident wave
     uint32_t ways; // hash-bucket depth of the match finder: 1 (levels 1-3) or MZ_DEF_WAYS_BEST (levels 4-9, -1)
+    uint32_t max_dist; // largest match distance: window - 262
 };
 
 #define MZ_DEF_LDS_STRIDE ((sizeof(mz_deflate_lds) + 15) & ~(size_t)15)
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateA
         mz_deflate_result r;
         mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
                          a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs,
-                         MZ_UNIFORM(a.ways), xhead, &r);
+                         MZ_UNIFORM(a.ways), xhead, MZ_UNIFORM(a.max_dist), &r);
         a.out_len[e] = r.out_len;
         a.crc[e] = r.crc;
         a.status[e] = r.status;
@@ -768,14 +769,16 @@ int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t
 int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                             const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_final, uint32_t n,
                             uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream) {
-    return mzhip_deflate_batch_level(d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_final, n, 1, d_out_len, d_crc,
+    return mzhip_deflate_batch_level(d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_final, n, 1, 15, d_out_len, d_crc,
                                      d_status, stream);
 }
 
 int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                                   const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_final, uint32_t n,
-                                  int32_t level, uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream) {
+                                  int32_t level, int32_t window_log2, uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status,
+                                  void *stream) {
     if (n == 0) return 0;
+    if (window_log2 < 9 || window_log2 > 15) return MZHIP_STATUS_UNSUPPORTED;
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -800,6 +803,7 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
     /* compression classes (mz_strm_zlib.c:87 hands `level` to deflateInit2): 0-3 fast = one candidate per hash bucket,
      * everything else (4-9, and -1 = Z_DEFAULT_COMPRESSION) = MZ_DEF_WAYS_BEST candidates + a two-position lazy rule */
     a.ways = (level >= 0 && level <= 3) ? 1u : MZ_DEF_WAYS_BEST;
+    a.max_dist = (1u << window_log2) - 262u; /* zlib's MAX_DIST(s) = w_size - MIN_LOOKAHEAD */
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
     static std::once_flag big_lds;
     std::call_once(big_lds, [] { /* the default class needs 134 KiB of dynamic LDS per workgroup */
@@ -1150,11 +1154,11 @@ int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, u
 // stored block so the pieces concatenate on byte boundaries; the last piece is final iff `final`.
 int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
                             uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
-    return mzhip_deflate_host_level(in, in_len, final, 1, out, out_cap, out_len, crc, adler);
+    return mzhip_deflate_host_level(in, in_len, final, 1, 15, out, out_cap, out_len, crc, adler);
 }
 
-int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, uint8_t *out,
-                                 uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
+int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, int32_t window_log2,
+                                 uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -1196,8 +1200,8 @@ int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t fi
     int32_t *d_status = (int32_t *)(d_crc + np);
     uint32_t *d_adler = (uint32_t *)(d_status + np);
     uint8_t *d_final = (uint8_t *)(d_adler + np);
-    rc = mzhip_deflate_batch_level(base, d_in_off, d_in_len, base, d_out_off, d_out_cap, d_final, np, level, d_out_len, d_crc,
-                                   d_status, nullptr);
+    rc = mzhip_deflate_batch_level(base, d_in_off, d_in_len, base, d_out_off, d_out_cap, d_final, np, level, window_log2, d_out_len,
+                                   d_crc, d_status, nullptr);
     if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -104;
     /* zlib wrapper: Adler-32 of the same pieces, one wave each, combined below from the checksums alone */
     if (rc == 0 && adler) rc = mzhip_adler32_batch(base, d_in_off, d_in_len, np, d_adler, nullptr);

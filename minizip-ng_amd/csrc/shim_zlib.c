@@ -72,6 +72,8 @@ typedef struct mzhip_zlib_s {
     int64_t base_pos0;                /* base position at the first read = payload offset */
     const uint32_t *seg_crc;          /* GPU CRCs of the 65 535-byte segments of a primed entry */
     int32_t wrap;      /* 0 raw, 1 zlib, 2 gzip (resolved from window_bits; 3 = detect, resolved by the header) */
+    int32_t wlog;      /* log2 of the LZ77 window the caller asked for (8..15) */
+    int32_t whdr;      /* READ: the window comes from the zlib header (windowBits 0) */
     int64_t hdr_len;   /* wrapper header bytes in front of the DEFLATE payload (0 = not parsed yet) */
     int8_t payload_done; /* device verdict on the payload is in; only the trailer is outstanding */
     uint32_t out_crc, out_adler;
@@ -136,16 +138,44 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->w_adler = 1;
     z->w_total = 0;
     z->w_header_done = 0;
-    switch (z->window_bits) {
-    case -15: z->wrap = 0; break;
-    case 15: z->wrap = 1; break;
-    case 15 + 16: z->wrap = 2; break;
-    case 15 + 32: z->wrap = 3; break; /* READ only: gzip or zlib, decided by the first two bytes */
-    default: return MZH_SUPPORT_ERROR;
+    {
+        /* windowBits as inflateInit2 / deflateInit2 read it (mz_strm_zlib.c:87,97; any value the caller sets through
+         * COMPRESS_WINDOW, :348-350): -8..-15 raw, 8..15 zlib wrapper (0: READ only, window from the header), +16 gzip,
+         * +32 (READ only) gzip or zlib decided by the first two bytes.  Anything else fails the init call there
+         * (Z_STREAM_ERROR) and therefore the open here. */
+        int32_t wb = z->window_bits;
+        const int32_t rd = (mode & MZH_OPEN_MODE_WRITE) ? 0 : 1;
+        if (rd) { /* inflateReset2 (zlib 1.2.11 inflate.c): wrap from bits 4-5, window from the low four bits; 0 = from the header */
+            if (wb < 0) {
+                z->wrap = 0;
+                wb = -wb;
+            } else {
+                const int32_t wr = wb >> 4; /* 0 zlib, 1 gzip, 2 either */
+                if (wb < 48)
+                    wb &= 15;
+                z->wrap = wr + 1;
+            }
+            if (z->wrap > 3 || (wb && (wb < 8 || wb > 15)) || (z->wrap == 0 && wb == 0))
+                return MZH_OPEN_ERROR; /* Z_STREAM_ERROR from the init call, mz_strm_zlib.c:101-102 */
+            z->wlog = wb ? wb : 15;
+            z->whdr = wb == 0; /* the zlib header's own window is the limit */
+        } else { /* deflateInit2_ (zlib 1.2.11 deflate.c) */
+            if (wb < 0) {
+                z->wrap = 0;
+                wb = -wb;
+            } else if (wb > 15) {
+                z->wrap = 2;
+                wb -= 16;
+            } else {
+                z->wrap = 1;
+            }
+            if (wb < 8 || wb > 15 || (wb == 8 && z->wrap != 1))
+                return MZH_OPEN_ERROR;
+            z->wlog = wb == 8 ? 9 : wb; /* "until 256-byte window bug fixed" */
+            z->whdr = 0;
+        }
     }
     if (mode & MZH_OPEN_MODE_WRITE) {
-        if (z->wrap == 3)
-            return MZH_SUPPORT_ERROR;
         if (mzhip_device_count() <= 0) {
             z->error = MZH_STREAM_ERROR;
             return MZH_OPEN_ERROR;
@@ -269,7 +299,8 @@ static int32_t parse_wrapper_header(mzhip_zlib *z) {
         return 1;
     }
     /* zlib: CMF FLG, ((CMF << 8) | FLG) % 31 == 0, CM == 8, CINFO <= 7 */
-    if ((((uint32_t)p[0] << 8) | p[1]) % 31u != 0 || (p[0] & 0x0F) != 8 || (p[0] >> 4) > 7) {
+    if ((((uint32_t)p[0] << 8) | p[1]) % 31u != 0 || (p[0] & 0x0F) != 8 || (p[0] >> 4) > 7 ||
+        (!z->whdr && (int32_t)(p[0] >> 4) + 8 > z->wlog)) { /* "invalid window size": the stream needs a larger window than the caller allows */
         verdict(z, MZHIP_STATUS_DATA_ERROR, 2);
         return 0;
     }
@@ -466,14 +497,14 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
         return MZH_OK;
     if (z->wrap != 0 && !z->w_header_done) {
         /* the header deflate() emits when no gz_header was set: gzip = magic, CM 8, no flags, no mtime, XFL from
-         * the level (2 = best, 4 = fastest), OS 3; zlib = 0x78, level class in FLG bits 7:6, FCHECK */
+         * the level (2 = best, 4 = fastest), OS 3; zlib = CM 8 + CINFO, level class in FLG bits 7:6, FCHECK */
         uint8_t h[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, 0, 3};
         uint32_t hl = 10;
         if (z->wrap == 2) {
             h[8] = (uint8_t)(z->level == 9 ? 2 : (z->level >= 0 && z->level < 2) ? 4 : 0);
         } else {
             const int32_t lv = z->level < 0 ? 6 : z->level;
-            uint32_t w = (0x78u << 8) | ((uint32_t)(lv < 2 ? 0 : lv < 6 ? 1 : lv == 6 ? 2 : 3) << 6);
+            uint32_t w = ((0x08u | ((uint32_t)(z->wlog - 8) << 4)) << 8) | ((uint32_t)(lv < 2 ? 0 : lv < 6 ? 1 : lv == 6 ? 2 : 3) << 6); /* CINFO = log2(window) - 8 */
             w += 31u - w % 31u;
             h[0] = (uint8_t)(w >> 8);
             h[1] = (uint8_t)w;
@@ -488,8 +519,8 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
     if (!out)
         return MZH_MEM_ERROR;
     uint32_t out_len = 0, crc = 0, adler = 1;
-    int32_t st = mzhip_deflate_host_level(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, z->level, out, cap, &out_len, &crc,
-                                          z->wrap == 1 ? &adler : NULL); /* the level goes where mz_strm_zlib.c:87 hands it */
+    int32_t st = mzhip_deflate_host_level(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, z->level, z->wlog, out, cap, &out_len,
+                                          &crc, z->wrap == 1 ? &adler : NULL); /* level and window as mz_strm_zlib.c:87 hands them on */
     if (st != 0) {
         free(out);
         z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */

@@ -34,11 +34,12 @@ MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t 
 }
 
 // one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host2 does)
-MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, uint8_t *out,
-                                          uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
+MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, int32_t window_log2,
+                                          uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
     const uint32_t piece = 64u << 10;
     const uint32_t np = in_len ? (in_len + piece - 1) / piece : 1u;
     uint32_t total = 0, k = 0, ad = 1;
+    emul_deflate_window((uint32_t)window_log2);
     const uint8_t dummy = 0;
     for (uint32_t i = 0; i < np; i++) {
         const uint32_t off = in_len ? i * piece : 0u, len = in_len - off < piece ? in_len - off : piece;
@@ -56,7 +57,7 @@ MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, ui
 }
 MOCK_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
                                      uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
-    return mzhip_deflate_host_level(in, in_len, final, 1, out, out_cap, out_len, crc, adler);
+    return mzhip_deflate_host_level(in, in_len, final, 1, 15, out, out_cap, out_len, crc, adler);
 }
 MOCK_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
                                     uint32_t *out_len, uint32_t *crc) {

@@ -172,7 +172,7 @@ def test_compress_level_is_honoured(gpu, level):
 
     L = gpu.mz.lib()
     L.mzhip_deflate_batch_level.restype = C.c_int32
-    L.mzhip_deflate_batch_level.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_int32] + [C.c_void_p] * 4
+    L.mzhip_deflate_batch_level.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_int32, C.c_int32] + [C.c_void_p] * 4
     text, _ = synth.bench_corpus()
     rnd = np.random.RandomState(77)
     datas = [text[o:o + 65536] for o in rnd.randint(0, len(text) - 65536, size=400)]
@@ -183,7 +183,7 @@ def test_compress_level_is_honoured(gpu, level):
     dev = b["d_in"].device
     out_len, crc, status = (torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3))
     rc = L.mzhip_deflate_batch_level(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(), b["d_out"].data_ptr(),
-                                     b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None, n, level, out_len.data_ptr(),
+                                     b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None, n, level, 15, out_len.data_ptr(),
                                      crc.data_ptr(), status.data_ptr(), None)
     assert rc == 0
     torch.cuda.synchronize()

@@ -133,9 +133,57 @@ def test_wrapper_error_parity(libs):
 
 
 def test_unsupported_windows_are_refused(libs):
-    hip, _ = libs
-    for wb in (9, -9, 24, 0x100):
-        assert hip.stream_decode(8, b"\x03\x00", 64, window_bits=wb)["open"] == -109      # MZ_SUPPORT_ERROR
+    """open() answers every COMPRESS_WINDOW value exactly like the reference: what inflateInit2 / deflateInit2 reject
+    (Z_STREAM_ERROR -> MZ_OPEN_ERROR, mz_strm_zlib.c:101-102) is rejected, everything else opens."""
+    hip, ref = libs
+    seen = set()
+
+    def wopen(drv, wb):
+        try:
+            return drv.stream_encode(8, b"abc", level=6, window_bits=wb)[1]["open"]
+        except RuntimeError as e:                       # the driver reports a failed open of a WRITE stream this way
+            return int(str(e).rsplit(" ", 1)[1])
+
+    for wb in [w for w in range(-20, 52) if w != 0] + [0x100, -0x100]:      # 0 = "leave the default" in the test driver
+        a = hip.stream_decode(8, b"\x03\x00", 64, window_bits=wb)["open"]
+        b = ref.stream_decode(8, b"\x03\x00", 64, window_bits=wb)["open"]
+        assert a == b, ("read", wb, a, b)
+        aw, bw = wopen(hip, wb), wopen(ref, wb)
+        assert aw == bw, ("write", wb, aw, bw)
+        seen.update((a, aw))
+    assert seen == {0, -111}                                                    # MZ_OK, MZ_OPEN_ERROR
+
+
+def test_every_window_zlib_accepts(libs):
+    """COMPRESS_WINDOW takes any value (mz_strm_zlib.c:348-350): raw -8..-15, zlib 8..15 (0 on READ), gzip 24..31,
+    auto-detect 40..47.  WRITE: the stream's back-references stay inside the requested window (the REFERENCE opened
+    with the same window decodes it; the zlib header carries CINFO = window - 8).  READ: streams the reference writes at
+    that window decode identically; a zlib-wrapped stream that needs a larger window than allowed is a data error."""
+    hip, ref = libs
+    c = synth.corpus()
+    d = c[:150000]
+    for wb in (-9, -12, -15, 9, 12, 15, 25, 28, 31):
+        z, info = hip.stream_encode(8, d, level=6, window_bits=wb)
+        assert (info["open"], info["error"], info["close"], info["total_in"]) == (0, 0, 0, len(d)), wb
+        b = ref.stream_decode(8, z, len(d) + 64, window_bits=wb)              # the reference at the SAME window
+        assert (b["out"], b["error"], b["total_in"]) == (d, 0, len(z)), wb
+        if 8 <= wb <= 15:
+            assert z[0] == (0x08 | ((wb - 8) << 4)) and ((z[0] << 8) | z[1]) % 31 == 0
+        zr, _ = ref.stream_encode(8, d, level=6, window_bits=wb)
+        a = hip.stream_decode(8, zr, len(d) + 64, window_bits=wb)
+        br = ref.stream_decode(8, zr, len(d) + 64, window_bits=wb)
+        assert all(a[k] == br[k] for k in ("out", "error", "total_in", "total_out", "close")), wb
+    for wb_read, wb_made in ((32 + 15, 15), (32 + 15, 31), (47, 12), (16, 31), (32, 15), (32, 28)):
+        zr, _ = ref.stream_encode(8, d, level=6, window_bits=wb_made)
+        a = hip.stream_decode(8, zr, len(d) + 64, window_bits=wb_read)
+        br = ref.stream_decode(8, zr, len(d) + 64, window_bits=wb_read)
+        assert all(a[k] == br[k] for k in ("out", "error", "total_in", "total_out", "close")), (wb_read, wb_made)
+        assert a["out"] == d
+    z15 = _wrap(d, 15)
+    for wb in (9, 12, 44):                                                      # "invalid window size"
+        a = hip.stream_decode(8, z15, len(d) + 64, window_bits=wb)
+        br = ref.stream_decode(8, z15, len(d) + 64, window_bits=wb)
+        assert a["error"] == br["error"] == -3 and a["rets"][:2] == br["rets"][:2], (wb, a["error"], br["error"])
 
 
 def test_wrapped_write_roundtrip(libs):

@@ -64,6 +64,10 @@ def test_unsupported_windows_are_refused(libs):
     W.test_unsupported_windows_are_refused(libs)
 
 
+def test_every_window_zlib_accepts(libs):
+    W.test_every_window_zlib_accepts(libs)
+
+
 def test_wrapped_write_roundtrip(libs):
     W.test_wrapped_write_roundtrip(libs)
 
