@@ -27,8 +27,9 @@
 #include "crc32_core.h"
 #include "wave.h"
 
-#define MZ_LZMA_MAX_LCLP 3
+#define MZ_LZMA_MAX_LCLP 3 /* literal contexts held in LDS: 0x300 << 3 probabilities */
 #define MZ_LZMA_LIT_PROBS (0x300u << MZ_LZMA_MAX_LCLP)
+#define MZ_LZMA_XPROBS MZ_LZMA_LIT_PROBS /* lc + lp = 4: as many again, in a per-wave scratch in HBM */
 
 /* probability model layout inside the per-wave LDS slice (u16 indices) */
 #define LZ_IS_MATCH 0                      /* [12][16] */
@@ -116,6 +117,28 @@ typedef struct mz_lzma_result {
         MZ_WAVE_SYNC();                                                                 \
     } while (0)
 
+/* the same on the overflow part of the literal model (lc + lp = 4: the second half of the 0x300 << 4 literal
+ * probabilities does not fit the wave's LDS slice and lives in a per-wave scratch in HBM, prx[]) */
+#define LZ_BIT_X(bit, idx)                                                              \
+    do {                                                                                \
+        LZ_NORM();                                                                      \
+        uint32_t _pi = (idx) - LZ_NUM_PROBS;                                            \
+        uint32_t _p = LZ_U(prx[_pi]);                                                   \
+        uint32_t _bound = (range >> 11) * _p;                                           \
+        if (code < _bound) {                                                            \
+            range = _bound;                                                             \
+            _p += (2048u - _p) >> 5;                                                    \
+            (bit) = 0;                                                                  \
+        } else {                                                                        \
+            range -= _bound;                                                            \
+            code -= _bound;                                                             \
+            _p -= _p >> 5;                                                              \
+            (bit) = 1;                                                                  \
+        }                                                                               \
+        MZ_LANES { prx[_pi] = (uint16_t)_p; } /* uniform store, no lane-0 branch */     \
+        MZ_WAVE_SYNC();                                                                 \
+    } while (0)
+
 #define LZ_BITTREE(sym, base, nbits)                                                    \
     do {                                                                                \
         uint32_t _m = 1;                                                                \
@@ -157,6 +180,27 @@ typedef struct mz_lzma_result {
         }                                                                               \
     } while (0)
 
+/* one literal: with a match byte as context while the coder is in a "after match" state, then plain */
+#define LZ_LITERAL(BITM)                                                                \
+    do {                                                                                \
+        if (state >= 7) {                                                               \
+            uint32_t mb = match_byte;                                                   \
+            do {                                                                        \
+                uint32_t mbit = (mb >> 7) & 1u;                                         \
+                mb <<= 1;                                                               \
+                uint32_t b;                                                             \
+                BITM(b, lbase + ((1u + mbit) << 8) + sym);                              \
+                sym = (sym << 1) | b;                                                   \
+                if (mbit != b) break;                                                   \
+            } while (sym < 0x100);                                                      \
+        }                                                                               \
+        while (sym < 0x100) {                                                           \
+            uint32_t b;                                                                 \
+            BITM(b, lbase + sym);                                                       \
+            sym = (sym << 1) | b;                                                       \
+        }                                                                               \
+    } while (0)
+
 /* The packet loop, shared by K3 (LZMA1 to the end marker: lzma2 = 0, dict_start = 0) and the .xz kernel
  * (LZMA2 chunk with a known uncompressed size: lzma2 = 1, stops at opos == chunk_end).  Expects the coder,
  * model and output locals of its caller by name; leaves through `goto finish` with `status` on any failure. */
@@ -171,21 +215,10 @@ typedef struct mz_lzma_result {
             /* literal */                                                                                             \
             const uint32_t lbase = LZ_LIT + 0x300u * (((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));            \
             uint32_t sym = 1;                                                                                         \
-            if (state >= 7) {                                                                                         \
-                uint32_t mb = match_byte;                                                                             \
-                do {                                                                                                  \
-                    uint32_t mbit = (mb >> 7) & 1u;                                                                   \
-                    mb <<= 1;                                                                                         \
-                    uint32_t b;                                                                                       \
-                    LZ_BIT(b, lbase + ((1u + mbit) << 8) + sym);                                                      \
-                    sym = (sym << 1) | b;                                                                             \
-                    if (mbit != b) break;                                                                             \
-                } while (sym < 0x100);                                                                                \
-            }                                                                                                         \
-            while (sym < 0x100) {                                                                                     \
-                uint32_t b;                                                                                           \
-                LZ_BIT(b, lbase + sym);                                                                               \
-                sym = (sym << 1) | b;                                                                                 \
+            if (lbase < LZ_NUM_PROBS) {                                                                               \
+                LZ_LITERAL(LZ_BIT);                                                                                   \
+            } else { /* lc + lp = 4, upper half of the literal model */                                               \
+                LZ_LITERAL(LZ_BIT_X);                                                                                 \
             }                                                                                                         \
             if (eof) goto finish;                                                                                     \
             if (opos == out_cap) {                                                                                    \

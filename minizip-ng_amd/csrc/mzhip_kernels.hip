@@ -162,6 +162,7 @@ struct LzmaArgs {
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
     const uint64_t *tab64; // CRC-64 byte table (.xz kernel only)
+    uint16_t *xprobs;      // MZ_LZMA_XPROBS u16 per resident wave: upper half of the literal model when lc + lp = 4
 };
 
 #ifndef MZ_LZMA_VPORT_OF_8
@@ -184,10 +185,12 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
         // 8/8 469 ms for one full round of 2304 resident 1 MiB entries)
         if ((blockIdx.x & 7u) < MZ_LZMA_VPORT_OF_8)
             mz_lzma_entry_v(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
-                            a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs, &r);
+                            a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
+                            a.xprobs + (size_t)blockIdx.x * MZ_LZMA_XPROBS, &r);
         else
             mz_lzma_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
-                          a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs, &r);
+                          a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
+                          a.xprobs + (size_t)blockIdx.x * MZ_LZMA_XPROBS, &r);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -212,7 +215,8 @@ __global__ __launch_bounds__(64, 2) void k_xz_batch(LzmaArgs a) {
         if (e >= a.n) break;
         mz_lzma_result r;
         mz_xz_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
-                    a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs, &r);
+                    a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
+                    a.xprobs + (size_t)blockIdx.x * MZ_LZMA_XPROBS, &r);
         a.out_len[e] = r.out_len; // wave-uniform results: stored by all lanes
         a.in_used[e] = r.in_used;
         a.crc[e] = r.crc;
@@ -716,12 +720,19 @@ static int32_t lzma_family_batch(int xz, const void *d_in, const uint64_t *d_in_
     /* 16 KiB LDS per wave -> 10 single-wave workgroups per CU (K3); 17.6 KiB -> 8 (.xz) */
     uint32_t resident = (uint32_t)c->cu_count * (xz ? 8u : 10u);
     uint32_t grid = n < resident ? n : resident;
+    int slot = -1;
+    void *scratch = nullptr; /* 12 KiB per resident wave: the literal model's upper half for streams with lc + lp = 4 */
+    rc = scratch_acquire(c, (size_t)grid * MZ_LZMA_XPROBS * sizeof(uint16_t), s, &slot, &scratch);
+    if (rc) return rc;
+    a.xprobs = (uint16_t *)scratch;
     if (xz)
         hipLaunchKernelGGL(k_xz_batch, dim3(grid), dim3(64), 0, s, a);
     else
         hipLaunchKernelGGL(k_lzma_batch, dim3(grid), dim3(64), 0, s, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const hipError_t le = hipGetLastError();
+    rc = scratch_release(c, slot, s);
+    if (le != hipSuccess) return fail("k_lzma_batch", le);
+    return rc;
 }
 
 int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,

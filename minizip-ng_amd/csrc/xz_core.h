@@ -9,7 +9,7 @@
  * none, CRC32, CRC64 (wave-parallel, hash_core.h), SHA-256 (the wave runs the chain redundantly); other check
  * ids are skipped unverified like lzma_stream_decoder does without LZMA_TELL_UNSUPPORTED_CHECK.
  * Framing is parsed by wave-uniform code (it is a few dozen bytes per block).  Filter chains other than a
- * single LZMA2 filter, and lc + lp = 4 (model larger than the LDS slice), answer MZHIP_UNSUPPORTED.
+ * single LZMA2 filter answer MZHIP_UNSUPPORTED.  lc + lp = 4: the upper half of the literal model lives in prx[] (HBM).
  * Every framing / check / LZMA2 failure is MZHIP_DATA_ERROR (mz_stream_lzma_read maps all liblzma errors to
  * MZ_DATA_ERROR, mz_strm_lzma.c:236-237); input that ends early is MZHIP_BUF_ERROR.
  */
@@ -75,7 +75,8 @@ MZ_DEV uint64_t mz_xz_mix(uint64_t h, uint64_t v) {
 
 /* Decode one method-95 entry.  All arguments wave-uniform.  max_out < 0: no clamp. */
 MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
-                        mz_xz_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs, mz_lzma_result *res) {
+                        mz_xz_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs, uint16_t *prx,
+                        mz_lzma_result *res) {
     MZ_LANE_DECL
     uint16_t *pr = L->lz.probs;
     const uint64_t *tab64 = L->crc64_tab;
@@ -187,8 +188,8 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                         d /= 9;
                         const uint32_t nlp = d % 5, npb = d / 5;
                         if (nlc + nlp > 4) goto finish;
-                        if (nlc + nlp > MZ_LZMA_MAX_LCLP) {
-                            status = MZHIP_UNSUPPORTED; /* model does not fit the LDS slice */
+                        if (nlc + nlp > MZ_LZMA_MAX_LCLP && !prx) {
+                            status = MZHIP_UNSUPPORTED; /* the model's upper half needs the overflow scratch */
                             goto finish;
                         }
                         lc = nlc;
@@ -202,6 +203,8 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                         MZ_LANES {
                             for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64)
                                 ((uint32_t *)pr)[i] = 0x04000400u;
+                            if (prx) /* the upper half of the literal model (lc + lp = 4) */
+                                for (uint32_t i = (uint32_t)lane; i < MZ_LZMA_XPROBS / 2; i += 64) ((uint32_t *)prx)[i] = 0x04000400u;
                         }
                         MZ_WAVE_SYNC();
                         state = 0;

@@ -119,7 +119,10 @@ extern "C" int32_t emul_xz(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
     memset(L, 0xA5, sizeof(*L));
     mzhip_crc64_table_init(L->crc64_tab);
     mz_lzma_result r;
-    mz_xz_entry(in, in_len, out, out_cap, max_out, L, g_tabs.byte_tab, &g_tabs, &r);
+    uint16_t *prx = (uint16_t *)malloc(MZ_LZMA_XPROBS * sizeof(uint16_t));
+    memset(prx, 0x5A, MZ_LZMA_XPROBS * sizeof(uint16_t));
+    mz_xz_entry(in, in_len, out, out_cap, max_out, L, g_tabs.byte_tab, &g_tabs, prx, &r);
+    free(prx);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;
@@ -187,7 +190,10 @@ extern "C" int32_t emul_lzma(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     mz_lzma_lds *L = (mz_lzma_lds *)malloc(sizeof(mz_lzma_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_lzma_result r;
-    mz_lzma_entry(in, in_len, out, out_cap, max_out, L, g_tabs.byte_tab, &g_tabs, &r);
+    uint16_t *prx = (uint16_t *)malloc(MZ_LZMA_XPROBS * sizeof(uint16_t));
+    memset(prx, 0x5A, MZ_LZMA_XPROBS * sizeof(uint16_t));
+    mz_lzma_entry(in, in_len, out, out_cap, max_out, L, g_tabs.byte_tab, &g_tabs, prx, &r);
+    free(prx);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;

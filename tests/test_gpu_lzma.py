@@ -97,3 +97,25 @@ def gpu_lzma_host(gpu, z, cap, max_out):
     ol, iu, crc = C.c_uint32(), C.c_uint32(), C.c_uint32()
     st = L.mzhip_lzma_host(z, len(z), out, cap, max_out, C.byref(ol), C.byref(iu), C.byref(crc))
     return st, iu.value, out.raw[:ol.value], crc.value
+
+
+def test_lzma_every_lc_lp_pb(gpu):
+    """lc / lp / pb over the whole space lzma_alone_decoder accepts (mz_strm_lzma.c:126), lc + lp = 4 included: the
+    literal model's upper half then lives in a per-wave scratch in HBM (12 KiB) instead of the LDS slice."""
+    import lzma as pylzma
+
+    c = synth.corpus()
+    d = c[:90000] + bytes(range(256)) * 30
+    combos = [(4, 0, 2), (3, 1, 2), (0, 4, 0), (2, 2, 4), (1, 3, 1), (0, 0, 0), (3, 0, 4), (3, 0, 2)]
+    pays = []
+    for lc, lp, pb in combos:
+        raw = pylzma.compress(d, format=pylzma.FORMAT_ALONE, filters=[dict(id=pylzma.FILTER_LZMA1, preset=6, lc=lc, lp=lp, pb=pb)])
+        pays.append(bytes([5, 2, 5, 0]) + raw[:5] + raw[13:])
+    pays = pays * 40                      # more entries than one wave: the scratch is per resident wave
+    b, h_out, out_len, in_used, crc, status = run_lzma(gpu, pays, [len(d) + 8] * len(pays), [len(d)] * len(pays))
+    for i, z in enumerate(pays):
+        assert (status[i], out_len[i], in_used[i], crc[i]) == (0, len(d), len(z), zlib.crc32(d)), (i, combos[i % len(combos)])
+    assert gpu.entry_bytes(b, h_out, 0, len(d)) == d and gpu.entry_bytes(b, h_out, len(combos) + 1, len(d)) == d
+    if oracle.have_ref():
+        r = oracle.ref().stream_decode(14, pays[0], len(d) + 8, max_in=len(pays[0]), max_out=len(d))
+        assert r["out"] == d and r["error"] == 0

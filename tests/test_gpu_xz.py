@@ -63,9 +63,6 @@ def test_xz_batch_cases_and_fixture(gpu, fixtures):
     caps = [len(d) + 64 for _, d, _ in cases] + [e["usize"] + 4 for e in fx]
     b, h_out, out_len, in_used, crc, status = run_xz(gpu, pays, caps)
     for i, (name, d, x) in enumerate(cases):
-        if status[i] == -109:
-            assert _unsupported(name) and len(d) > 1, name
-            continue
         so, uo, oo = oracle.xz_decode(pays[i], caps[i])
         assert (status[i], in_used[i], out_len[i]) == (so, uo, len(oo)) == (0, len(x), len(d)), name
         assert gpu.entry_bytes(b, h_out, i, len(d)) == d, name

@@ -203,6 +203,19 @@ def test_lzma_cases(emu):
     z = _zip_lzma(c[:5000])
     st, used, out, crc = _run(emu.emul_lzma, z, 6000, C.c_int64(3000))
     assert st == 0 and out == c[:3000] and crc == zlib.crc32(c[:3000])
+    # every lc / lp / pb liblzma accepts behind lzma_alone_decoder (mz_strm_lzma.c:126), lc + lp = 4 included
+    import lzma as pylzma
+    d = c[:90000] + bytes(range(256)) * 30
+    for lc, lp, pb in ((4, 0, 2), (3, 1, 2), (0, 4, 0), (2, 2, 4), (1, 3, 1), (0, 0, 0), (3, 0, 4)):
+        raw = pylzma.compress(d, format=pylzma.FORMAT_ALONE, filters=[dict(id=pylzma.FILTER_LZMA1, preset=6, lc=lc, lp=lp, pb=pb)])
+        z = bytes([5, 2, 5, 0]) + raw[:5] + raw[13:]
+        st, used, out, crc = _run(emu.emul_lzma, z, len(d) + 64, C.c_int64(len(d)))
+        so, uo, oo = oracle.lzma_zip_decode(z, len(d) + 64, len(d))
+        assert (st, used, out) == (so, uo, oo) == (0, len(z), d) and crc == zlib.crc32(d), (lc, lp, pb)
+    bad = bytearray(_zip_lzma(c[:1000]))
+    bad[4] = 4 + 9 * 1 + 45 * 2          # lc 4, lp 1: lc + lp > 4 is an options error -> MZ_DATA_ERROR
+    st, used, out, crc = _run(emu.emul_lzma, bytes(bad), 2000, C.c_int64(-1))
+    assert st == -3 == oracle.lzma_zip_decode(bytes(bad), 2000, -1)[0]
 
 
 def test_lzma_fixture(emu, fixtures):
@@ -221,15 +234,12 @@ def test_xz_cases_and_fuzz(emu, fixtures):
 
     assert emu.emul_xz_lds_bytes() + 1024 <= 19 * 1024        # 8 single-wave workgroups per 160 KiB CU
     cases = synth.xz_cases()
-    n_unsupported = 0
+    n_lclp4 = 0
     for name, d, x in cases:
         st, used, out, crc = _run(emu.emul_xz, x + b"tail", len(d) + 64, C.c_int64(-1))
-        if st == -109:                                           # lc + lp = 4: model does not fit the LDS slice
-            assert ("lp4" in name or "lc4" in name or "lc1lp3" in name) and len(d) > 1, name
-            n_unsupported += 1
-            continue
+        n_lclp4 += ("lp4" in name or "lc4" in name or "lc1lp3" in name) and len(d) > 1
         assert (st, used, out, crc) == (0, len(x), d, zlib.crc32(d)), (name, st, used, len(x))
-    assert 4 <= n_unsupported <= 12
+    assert n_lclp4 >= 4          # lc + lp = 4 included: the upper half of the literal model lives outside the LDS slice
     for e in fixtures:
         if e["method"] == 95:
             st, used, out, crc = _run(emu.emul_xz, e["payload"], e["usize"] + 4, C.c_int64(e["usize"]))
