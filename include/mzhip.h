@@ -118,7 +118,7 @@ MZHIP_API int32_t mzhip_xz_batch(const void *d_in, const uint64_t *d_in_off, con
 MZHIP_API int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *d_off, const uint32_t *d_len, uint32_t n,
                                   uint32_t algorithm, void *d_digest, void *stream);
 
-/* K4: raw-DEFLATE encode (fixed-Huffman blocks) with fused CRC-32 of the input ------------- */
+/* K4: raw-DEFLATE encode (dynamic / fixed / stored blocks, whichever is cheapest) with fused CRC-32 of the input -- */
 
 /* Replaces, for n pieces at once, mz_stream_zlib_write/_close (mz_strm_zlib.c:203-264,280-305 -> zlib
  * deflate(), raw, level 1) + mz_crypt_crc32_update (mz_zip.c:2064).  Piece i compresses

@@ -168,6 +168,42 @@ MZ_DEV uint32_t mz_crc_dword4(uint32_t r, uint32_t d, const uint32_t *tab4) {
         }                                                                                  \
         (done) += MZ_CRC_SUPER;                                                            \
     }
+/* The same super-tiles with the byte table alone (no slicing / advance tables in LDS): K1's fused epilogue, where LDS
+ * decides the occupancy.  The advance over the other lanes' 4032 bytes is one multiplication by x^(8*4032) (kx4[]),
+ * paid once per 64 bytes of a lane instead of once per 16 as with the 1 KiB tiles. */
+#define MZ_CRC_FOLD_SUPER_BT(acc, done, buf, upto, tab, kx4)                               \
+    while ((uint64_t)(done) + MZ_CRC_SUPER <= (uint64_t)(upto)) {                          \
+        MZ_LANES {                                                                         \
+            const uint8_t *_p = (buf) + (done) + 64u * (uint32_t)lane;                     \
+            uint32_t _r = P(acc);                                                          \
+            if ((done) != 0) _r = mz_gf2_mul_kx(_r, (kx4));                                \
+            for (int _k = 0; _k < 4; _k++) {                                               \
+                uint32_t _q[4];                                                            \
+                __builtin_memcpy(_q, _p + 16 * _k, 16); /* one 16-byte load */             \
+                _r = mz_crc_dword(_r, _q[0], (tab));                                       \
+                _r = mz_crc_dword(_r, _q[1], (tab));                                       \
+                _r = mz_crc_dword(_r, _q[2], (tab));                                       \
+                _r = mz_crc_dword(_r, _q[3], (tab));                                       \
+            }                                                                              \
+            P(acc) = _r;                                                                   \
+        }                                                                                  \
+        (done) += MZ_CRC_SUPER;                                                            \
+    }
+/* finish a CRC whose complete super-tiles of buf[0 .. n) were folded by MZ_CRC_FOLD_SUPER_BT: collapse the 64 strips,
+ * then the remaining < 4 KiB with 1 KiB tiles and the byte-granular tail.  Result (uniform) in `result`. */
+#define MZ_CRC_FINISH_SUPER_BT(result, acc, tmp, done, buf, n, tab, tabs)                  \
+    do {                                                                                   \
+        uint32_t _sreg = 0xFFFFFFFFu;                                                      \
+        if ((done) != 0) {                                                                 \
+            MZ_CRC_SUPER_REDUCE(_sreg, acc, tmp, tabs);                                    \
+        }                                                                                  \
+        const uint8_t *_rest = (buf) + (done);                                             \
+        const uint32_t _nrest = (uint32_t)((n) - (done));                                  \
+        uint32_t _rdone = 0;                                                               \
+        MZ_LANES { P(acc) = (lane == 0) ? _sreg : 0u; }                                    \
+        MZ_CRC_FOLD_TILES(acc, _rdone, _rest, _nrest, tab, (tabs)->kx);                    \
+        MZ_CRC_FINISH_FROM(result, acc, tmp, _rdone, _rest, _nrest, tab, tabs, _sreg);     \
+    } while (0)
 /* collapse the super-tile registers into the raw register after byte (done) - 1 (uniform) */
 #define MZ_CRC_SUPER_REDUCE(reg, acc, tmp, tabs)                                           \
     do {                                                                                   \

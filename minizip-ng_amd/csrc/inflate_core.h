@@ -59,8 +59,12 @@ extern unsigned long long mz_stats[16];
 #endif
 #define MZ_CROOT 7 /* code-length-code table bits (== max)  */
 #ifndef MZ_SPAN_DW
-#define MZ_SPAN_DW 8 /* span-parallel decode (see mz_span_token): dwords of compressed stream per lane, 0 = off */
+#define MZ_SPAN_DW 8 /* span-parallel decode (see mz_span_token): dwords of compressed stream per lane (4 or 8), 0 = off */
 #endif
+#if MZ_SPAN_DW != 0 && MZ_SPAN_DW != 4 && MZ_SPAN_DW != 8
+#error "MZ_SPAN_DW must be 0, 4 or 8 (the span size of a window is 32 << shift bits, shift <= log2(MZ_SPAN_DW))"
+#endif
+#define MZ_SPAN_SH (MZ_SPAN_DW == 8 ? 3u : 2u)
 #define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
 #define MZ_SPAN_MAX_PASS 6u
 #ifndef MZ_POOL_BYTES
@@ -160,7 +164,7 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
 #endif
     } x;
 #if MZ_SPAN_DW
-    uint32_t win[65 * MZ_SPAN_RS]; /* span path: the window's dword d at win[(d / MZ_SPAN_DW) * MZ_SPAN_RS + d % MZ_SPAN_DW] */
+    uint32_t win[65 * MZ_SPAN_RS]; /* span path: dword d of a window of (1 << ssh)-dword spans at win[(d >> ssh) * MZ_SPAN_RS + (d & ((1 << ssh) - 1))] */
 #endif
 } mz_inflate_body_scratch;
 #if MZ_SPAN_DW
@@ -419,6 +423,22 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
         MZ_WAVE_SYNC();                                                                                        \
     } while (0)
 
+/* 64 bits of the stream at (uniform) bit position pos_: from the header window hwin (dword hw0 + lane of the stream,
+ * bytes outside the input already zero) when the three dwords lie inside it, else from memory -- same value either way */
+#define MZ_HDR_WIN_BITS(dst, pos_)                                                            \
+    do {                                                                                      \
+        const uint32_t _ab = (pos_) + 8u * in_mis, _j = (_ab >> 5) - hw0;                     \
+        if (_j + 2u < 64u) {                                                                  \
+            const uint32_t _d0 = MZ_READLANE(hwin, _j), _d1 = MZ_READLANE(hwin, _j + 1u), _d2 = MZ_READLANE(hwin, _j + 2u); \
+            const uint32_t _s = _ab & 31u;                                                    \
+            uint64_t _v = (((uint64_t)_d1 << 32) | _d0) >> _s;                                \
+            if (_s) _v |= (uint64_t)_d2 << (64u - _s);                                        \
+            (dst) = _v;                                                                       \
+        } else {                                                                              \
+            (dst) = mz_bits_at(in, in_len, (pos_));                                           \
+        }                                                                                     \
+    } while (0)
+
 /* uniform n-bit read at the block-header level */
 #define MZ_HDR_BITS(dst, n)                                                   \
     do {                                                                      \
@@ -426,7 +446,8 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
             status = MZHIP_BUF_ERROR;                                         \
             goto finish;                                                      \
         }                                                                     \
-        uint64_t _w = mz_bits_at(in, in_len, bitpos);                         \
+        uint64_t _w;                                                          \
+        MZ_HDR_WIN_BITS(_w, bitpos);                                          \
         (dst) = MZ_UNIFORM((uint32_t)_w & ((1u << (n)) - 1));                 \
         bitpos += (n);                                                        \
     } while (0)
@@ -503,9 +524,9 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
  * owns the exact error verdicts: the span path only ever commits a prefix of verified tokens.
  *
  * One token at window-relative bit `rel`: the same table walk as phase 1 of the step loop. */
-MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *win, uint32_t rel) {
+MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *win, uint32_t rel, uint32_t ssh) {
     const uint32_t d = rel >> 5;
-    const uint32_t a = (d / MZ_SPAN_DW) * MZ_SPAN_RS + (d % MZ_SPAN_DW);
+    const uint32_t a = (d >> ssh) * MZ_SPAN_RS + (d & ((1u << ssh) - 1u)); /* ssh = log2(dwords per span), wave-uniform */
     const uint32_t d0 = win[a], d1 = win[a + 1u], d2 = win[a + 2u];
     const uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
     uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
@@ -547,6 +568,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
         goto finish;
     }
     while (!last) {
+        /* the block header is read through a 256-byte window of the stream held one dword per lane (one coalesced
+         * load instead of a global round trip per 64 bits of header); positions beyond it fall back to memory */
+        const uint32_t hw0 = (bitpos + 8u * in_mis) >> 5;
+        PV(uint32_t, hwin);
+        MZ_LANES { P(hwin) = mz_load_stream_dword(in_al, in_mis, in_len, hw0 + (uint32_t)lane); }
         uint32_t hdr;
         MZ_HDR_BITS(hdr, 3);
         last = hdr & 1u;
@@ -583,7 +609,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 status = MZHIP_BUF_ERROR;
                 goto finish;
             }
-            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);
+            MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx4);
             continue;
         }
         if (btype == 3) {
@@ -642,16 +668,21 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 goto finish;
             }
             /* code lengths: serial by nature (run-length coded), wave-uniform loop
-             * consuming a 64-bit window at a time */
+             * consuming a 64-bit window at a time; the 128-entry code-length-code table sits in a register pair of
+             * halves per lane (entry i in lane i & 63, half i >> 6), so a lookup is a v_readlane, not an LDS round trip */
+            PV(uint32_t, clcreg);
+            MZ_LANES { P(clcreg) = (uint32_t)L->u.h.clc_fast[lane] | ((uint32_t)L->u.h.clc_fast[lane + 64] << 16); }
             uint32_t idx = 0, prev = 0;
             const uint32_t ntot = nlen + ndist;
             while (idx < ntot) {
-                uint64_t w = mz_bits_at(in, in_len, bitpos);
+                uint64_t w;
+                MZ_HDR_WIN_BITS(w, bitpos);
                 uint32_t wlo = MZ_UNIFORM((uint32_t)w), whi = MZ_UNIFORM((uint32_t)(w >> 32));
                 uint64_t wu = ((uint64_t)whi << 32) | wlo;
                 uint32_t used = 0;
                 while (idx < ntot && used + 14 <= 64) {
-                    uint32_t e = MZ_UNIFORM(L->u.h.clc_fast[(uint32_t)(wu >> used) & 127u]);
+                    const uint32_t ci = (uint32_t)(wu >> used) & 127u;
+                    uint32_t e = (MZ_READLANE(clcreg, ci & 63u) >> ((ci >> 6) << 4)) & 0xFFFFu;
                     uint32_t nb = e & 15u, sym = e >> 4;
                     if (nb == 0) {
                         status = (bitpos + used + 7 > total_bits) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
@@ -746,8 +777,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             for (;;) {
 #if MZ_SPAN_DW
                 {
-                    const uint32_t S = 32u * MZ_SPAN_DW;
                     const uint32_t remain = total_bits - bitpos;
+                    /* span size of this window: 256 bits, or 128 when what is left of the stream fits 64 spans of 128
+                     * (the last window of a block / a small entry: twice the lanes busy, passes half as long) */
+                    const uint32_t ssh = (MZ_SPAN_SH > 2u && remain <= 64u * 128u + 64u) ? 2u : MZ_SPAN_SH;
+                    const uint32_t S = 32u << ssh;
                     /* lanes whose every token lies inside the input (a token is at most 48 bits) */
                     uint32_t nact = (remain > 64u) ? (remain - 64u) / S : 0u;
                     if (nact > 64u) nact = 64u;
@@ -755,13 +789,13 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         uint32_t *win = MZ_L_WIN(L);
                         const uint32_t wpos = bitpos + pbase;
                         const uint32_t wb = wpos >> 5, woff = wpos & 31u;
-                        const uint32_t ndw = MZ_SPAN_DW * nact + 3u;
+                        const uint32_t ndw = (nact << ssh) + 3u;
                         MZ_LANES {
                             for (uint32_t d = (uint32_t)lane; d < ndw; d += 64u) {
                                 const uint32_t v = mz_load_stream_dword(in_al, in_mis, in_len, wb + d);
-                                const uint32_t row = d / MZ_SPAN_DW, k = d % MZ_SPAN_DW;
+                                const uint32_t row = d >> ssh, k = d & ((1u << ssh) - 1u);
                                 win[row * MZ_SPAN_RS + k] = v;
-                                if (k < 2u && row > 0u) win[(row - 1u) * MZ_SPAN_RS + MZ_SPAN_DW + k] = v;
+                                if (k < 2u && row > 0u) win[(row - 1u) * MZ_SPAN_RS + (1u << ssh) + k] = v;
                             }
                         }
                         MZ_WAVE_SYNC();
@@ -982,8 +1016,8 @@ finish:
         crc = 0;
         (void)crc_tmp;
 #else
-        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx);
-        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, out, out_pos, crc_tab, tabs);
+        MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx4);
+        MZ_CRC_FINISH_SUPER_BT(crc, crc_acc, crc_tmp, crc_done, out, out_pos, crc_tab, tabs);
 #endif
         res->crc = crc;
     }

@@ -2,10 +2,11 @@
 // include/mzhip.h).  The per-entry algorithms live in inflate_core.h / crc32_core.h; this file
 // owns launch geometry, work distribution and the device context.
 //
-// Launch shape (MI355X: 256 CUs x 4 SIMDs, 160 KiB LDS/CU, 8 XCDs):
-//   - one wavefront per ZIP entry, 4 wavefronts per workgroup, ~5.2 KiB LDS per wave
-//     (Huffman tables + a 512 B input ring -- the LZ77 window is the output buffer itself), so 7
-//     workgroups = 28 waves fit per CU by LDS; registers (72 VGPRs) allow 7 waves per SIMD;
+// Launch shape of K1 (MI355X: 256 CUs x 4 SIMDs, 160 KiB LDS/CU, 8 XCDs):
+//   - one wavefront per ZIP entry, 4 wavefronts per workgroup, 9.8 KiB LDS per wave (3.8 KiB of Huffman tables, the
+//     2.8 KiB span window, a 3.2 KiB pool in which a chunk of a window is resolved: staging bytes, pending bits,
+//     back-reference list; the LZ77 window beyond the chunk is the output buffer itself), so 4 workgroups = 16 waves
+//     fit per CU by LDS; the kernel is compiled for 4 waves per SIMD (<= 128 VGPRs);
 //   - persistent waves: the grid is sized to the chip (CUs x resident workgroups) and every wave pulls
 //     its next entry index from one device-scope counter, so short and long entries balance and
 //     a 100k-entry batch is a single launch with no host involvement.

@@ -12,7 +12,11 @@
  *   length / distance tables      appnote.txt:2107-2133
  *   decode loop                   appnote.txt:2139-2161
  * Deliberately the plain canonical-code decoder (count[]/symbol[] walk, one
- * bit at a time): slow, but with no lookup-table cleverness to get wrong.
+ * bit at a time): slow, but with no lookup-table cleverness to get wrong.  The
+ * decoder's shape -- count[] / symbol[] tables, the `code - count < first` walk,
+ * the MAXBITS / MAXLCODES / MAXDCODES / FIXLCODES names -- is that of Mark Adler's
+ * puff.c (zlib contrib/puff, the reference implementation written to specify
+ * inflate unambiguously; it is not part of /root/reference), restated here.
  *
  * Error classes follow zlib 1.2.11's (they surface through
  * mz_stream_zlib_read, mz_strm_zlib.c:159-189): every malformed construct is

@@ -421,9 +421,9 @@ def _build_variant(tag, flags):
 
 @pytest.fixture(scope="module")
 def emu_staged():
-    """Other K1 geometries in the same emulation: 192-bit spans with a smaller pool (the tuning builds), and pools so
-    small that windows are cut short or handed back to the step loop all the time."""
-    return [_build_variant("s6", ["-DMZ_SPAN_DW=6", "-DMZ_POOL_BYTES=4608u"]),
+    """Other K1 geometries in the same emulation: 128-bit spans throughout with two pieces per lane in the near pass, and
+    pools so small that windows are cut short or handed back to the step loop all the time."""
+    return [_build_variant("s4", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=4608u", "-DMZ_NEAR_SLOTS=2"]),
             _build_variant("tiny", ["-DMZ_POOL_BYTES=2048u", "-DMZ_NEAR_SLOTS=1"]),
             _build_variant("s4tiny", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=1024u"])]
 
