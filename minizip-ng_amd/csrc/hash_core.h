@@ -183,22 +183,41 @@ MZ_DEV void mz_sha512_init(uint64_t h[8], int is384) {
 MZ_DEV void mz_sha512_run(const uint8_t *p, uint64_t n, uint64_t h[8]) {
     const uint64_t blocks = (n + 17 + 127) / 128, total_words = blocks * 16;
     for (uint64_t b = 0; b < blocks; b++) {
+        /* the 16-word schedule window stays in registers: every index below is a compile-time constant (the rounds
+         * run as 5 x 16 with the inner 16 unrolled); a block that lies wholly inside the message is fetched with plain
+         * 8-byte loads, only the one or two blocks that carry the padding go through the byte-wise path */
         uint64_t w[16];
+        if ((b + 1) * 128 <= n) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = mz_sha512_word(p, n, total_words, b * 16 + (uint64_t)i);
-        uint64_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-#pragma unroll 16
-        for (int i = 0; i < 80; i++) {
-            if (i >= 16) {
-                const uint64_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-                const uint64_t s0 = MZ_ROR64(w15, 1) ^ MZ_ROR64(w15, 8) ^ (w15 >> 7);
-                const uint64_t s1 = MZ_ROR64(w2, 19) ^ MZ_ROR64(w2, 61) ^ (w2 >> 6);
-                w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            for (int i = 0; i < 16; i++) {
+                uint64_t v;
+                __builtin_memcpy(&v, p + b * 128 + 8 * (uint64_t)i, 8);
+                w[i] = __builtin_bswap64(v);
             }
-            const uint64_t t1 = hh + (MZ_ROR64(e, 14) ^ MZ_ROR64(e, 18) ^ MZ_ROR64(e, 41)) + ((e & f) ^ (~e & g)) + mz_k512[i] +
-                                w[i & 15];
-            const uint64_t t2 = (MZ_ROR64(a, 28) ^ MZ_ROR64(a, 34) ^ MZ_ROR64(a, 39)) + ((a & bb) ^ (a & c) ^ (bb & c));
-            hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+        } else {
+            MZ_NOUNROLL
+            for (int i = 0; i < 16; i++) {
+                const uint64_t v = mz_sha512_word(p, n, total_words, b * 16 + (uint64_t)i);
+#pragma unroll
+                for (int j = 0; j < 16; j++) w[j] = (j == i) ? v : w[j]; /* selects, not an indexed private array */
+            }
+        }
+        uint64_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        MZ_NOUNROLL
+        for (int r = 0; r < 5; r++) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (r > 0) {
+                    const uint64_t w15 = w[(j + 1) & 15], w2 = w[(j + 14) & 15];
+                    const uint64_t s0 = MZ_ROR64(w15, 1) ^ MZ_ROR64(w15, 8) ^ (w15 >> 7);
+                    const uint64_t s1 = MZ_ROR64(w2, 19) ^ MZ_ROR64(w2, 61) ^ (w2 >> 6);
+                    w[j] = w[j] + s0 + w[(j + 9) & 15] + s1;
+                }
+                const uint64_t t1 = hh + (MZ_ROR64(e, 14) ^ MZ_ROR64(e, 18) ^ MZ_ROR64(e, 41)) + ((e & f) ^ (~e & g)) +
+                                    mz_k512[16 * r + j] + w[j];
+                const uint64_t t2 = (MZ_ROR64(a, 28) ^ MZ_ROR64(a, 34) ^ MZ_ROR64(a, 39)) + ((a & bb) ^ (a & c) ^ (bb & c));
+                hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+            }
         }
         h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
     }

@@ -1357,9 +1357,13 @@ struct PrimedEntry {
 struct PrimeGen {
     std::vector<PrimedEntry> entries; // sorted by payload_off
     std::vector<uint32_t> seg_crc;
-    uint8_t *out = nullptr;
+    uint8_t *out = nullptr; // page-locked (hipHostMalloc): the D2H copy of the decoded bytes runs at link speed
+    bool out_pinned = false;
     uint64_t zip_len = 0, ident = 0; // archive identity: length + hash of its central directory and end records
-    ~PrimeGen() { free(out); }
+    ~PrimeGen() {
+        if (out_pinned) (void)hipHostFree(out);
+        else free(out);
+    }
 };
 struct PrimeCache {
     std::vector<std::shared_ptr<PrimeGen>> gens; // newest first, at most kMaxGens
@@ -1552,8 +1556,17 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
     }
     const size_t k = ents.size();
     if (k == 0) return 0;
-    uint8_t *h_out = (uint8_t *)malloc(total_out + 16);
+    uint8_t *h_out = nullptr;
+    bool out_pinned = hipHostMalloc((void **)&h_out, total_out + 16, hipHostMallocDefault) == hipSuccess;
+    if (!out_pinned) {
+        (void)hipGetLastError();
+        h_out = (uint8_t *)malloc(total_out + 16);
+    }
     if (!h_out) return -4;
+    auto drop_out = [&] {
+        if (out_pinned) (void)hipHostFree(h_out);
+        else free(h_out);
+    };
     std::vector<uint32_t> r_len(k), r_used(k), r_crc(k), seg_crc((size_t)nseg);
     std::vector<int32_t> r_st(k, -1);
     const int32_t world = (int32_t)std::min<size_t>(devs.size(), k);
@@ -1582,7 +1595,7 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
     for (int32_t r = 0; r < world; r++)
         if (rcs[(size_t)r]) {
             snprintf(g_err, sizeof(g_err), "%s", errs[(size_t)r].c_str());
-            free(h_out);
+            drop_out();
             return rcs[(size_t)r];
         }
     std::vector<PrimedEntry> good;
@@ -1600,6 +1613,7 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
               [](const PrimedEntry &a, const PrimedEntry &b) { return a.payload_off < b.payload_off; });
     gen->seg_crc = std::move(seg_crc);
     gen->out = h_out;
+    gen->out_pinned = out_pinned;
     gen->zip_len = zip_len;
     {
         /* identity = length + hash of everything from the first central-directory record to the end of the file */
@@ -1631,11 +1645,17 @@ static int64_t prime_file_on(const char *path, const int32_t *devices, int32_t n
     fseeko(f, 0, SEEK_END);
     const int64_t len = (int64_t)ftello(f);
     fseeko(f, 0, SEEK_SET);
-    uint8_t *buf = (uint8_t *)malloc((size_t)(len > 0 ? len : 1));
+    uint8_t *buf = nullptr; /* page-locked: the H2D copies of the payload ranges run at link speed */
+    const bool pinned = hipHostMalloc((void **)&buf, (size_t)(len > 0 ? len : 1), hipHostMallocDefault) == hipSuccess;
+    if (!pinned) {
+        (void)hipGetLastError();
+        buf = (uint8_t *)malloc((size_t)(len > 0 ? len : 1));
+    }
     int64_t rc = -115; /* MZ_READ_ERROR */
     if (buf && len > 0 && fread(buf, 1, (size_t)len, f) == (size_t)len)
         rc = multi ? mzhip_prime_mem_multi(buf, (uint64_t)len, devices, ndev) : mzhip_prime_mem(buf, (uint64_t)len);
-    free(buf);
+    if (pinned) (void)hipHostFree(buf);
+    else free(buf);
     fclose(f);
     return rc;
 }
