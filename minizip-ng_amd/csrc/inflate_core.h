@@ -42,14 +42,38 @@
 #ifndef MZHIP_INFLATE_CORE_H
 #define MZHIP_INFLATE_CORE_H
 #if defined(MZ_STATS)
-extern unsigned long long mz_stats[16];
+extern unsigned long long mz_stats[24], mz_stat_max;
 #define MZ_STAT(i, v) (mz_stats[i] += (v))
+#define MZ_STAT_LANE(v) (mz_stat_max = (v) > mz_stat_max ? (v) : mz_stat_max) /* the slowest lane ... */
+#define MZ_STAT_LANEMAX(i) (mz_stats[i] += mz_stat_max, mz_stat_max = 0)       /* ... is what the wave pays */
 #else
 #define MZ_STAT(i, v) ((void)0)
+#define MZ_STAT_LANE(v) ((void)0)
+#define MZ_STAT_LANEMAX(i) ((void)0)
 #endif
 
 #include "crc32_core.h"
 #include "wave.h"
+/* MZ_PROF (measurement builds of the device code only, profiles/ab_k1.sh): every wave adds the shader-clock cycles it
+ * spent in each section of mz_inflate_entry to mz_prof_buf[]; mzhip_prof_read() hands the sums to tests/perf_probe.py */
+#if defined(MZ_PROF) && !defined(MZHIP_HOST_EMUL)
+extern __device__ unsigned long long mz_prof_buf[32];
+#define MZ_PROF_DECL                     \
+    uint32_t prof_acc = 0; /* lane i: cycles of section i */ \
+    uint64_t prof_t0 = __builtin_readcyclecounter();
+#define MZ_PROF_MARK(i)                                                           \
+    do {                                                                          \
+        const uint32_t _pd = (uint32_t)(__builtin_readcyclecounter() - prof_t0);  \
+        prof_acc += (lane == (i)) ? _pd : 0u;                                     \
+        prof_t0 = __builtin_readcyclecounter();                                   \
+    } while (0)
+#define MZ_PROF_FLUSH                                                             \
+    if (lane < 32) atomicAdd(&mz_prof_buf[lane], (unsigned long long)prof_acc);
+#else
+#define MZ_PROF_DECL
+#define MZ_PROF_MARK(i) ((void)0)
+#define MZ_PROF_FLUSH
+#endif
 
 #ifndef MZ_LROOT
 #define MZ_LROOT 8 /* literal/length fast-table index bits */
@@ -65,7 +89,7 @@ extern unsigned long long mz_stats[16];
 #error "MZ_SPAN_DW must be 0, 4 or 8 (the span size of a window is 32 << shift bits, shift <= log2(MZ_SPAN_DW))"
 #endif
 #define MZ_SPAN_SH (MZ_SPAN_DW == 8 ? 3u : 2u)
-#define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first two, padded odd */
+#define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first three (odd) */
 #define MZ_SPAN_MAX_PASS 6u
 #ifndef MZ_POOL_BYTES
 #define MZ_POOL_BYTES 3264u /* span path: LDS pool of one window chunk = staging bytes of its output (from the front,
@@ -79,6 +103,22 @@ extern unsigned long long mz_stats[16];
 #endif
 #ifndef MZ_LDS_PAD
 #define MZ_LDS_PAD 0
+#endif
+#ifndef MZ_VIEW_MAX
+#define MZ_VIEW_MAX 0x0FFFFFFFu   /* bytes of the stream the 32-bit bit cursor can address at a time (see mz_inflate_entry) */
+#define MZ_REBASE_BITS (1u << 30) /* the view moves when the cursor is this far into it */
+#endif
+#ifndef MZ_CL_PARALLEL
+#define MZ_CL_PARALLEL 1 /* dynamic block headers: code lengths decoded 64 bits at a time (0: one symbol at a time) */
+#endif
+#ifndef MZ_FAR_SLOTS
+#define MZ_FAR_SLOTS 1 /* far pieces per lane whose global loads are in flight together (1 or 2) */
+#endif
+#ifndef MZ_NEAR_BATCHED
+#define MZ_NEAR_BATCHED 0 /* near copies whose source ends in front of the destination issue all loads first */
+#endif
+#ifndef MZ_SPAN_PRELIT
+#define MZ_SPAN_PRELIT 1 /* a walk step takes a leading literal and the token behind it (0: one token per step) */
 #endif
 #ifndef MZ_ABLATE
 #define MZ_ABLATE 0 /* measurement builds only (wrong output): 1 no match copies, 2 no far loads, 4 no CRC, 8 no store */
@@ -164,7 +204,7 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
 #endif
     } x;
 #if MZ_SPAN_DW
-    uint32_t win[65 * MZ_SPAN_RS]; /* span path: dword d of a window of (1 << ssh)-dword spans at win[(d >> ssh) * MZ_SPAN_RS + (d & ((1 << ssh) - 1))] */
+    uint32_t win[65 * MZ_SPAN_RS]; /* span path: dword d of a window of (1 << ssh)-dword spans at win[(d >> ssh) * MZ_SPAN_RS + (d & ((1 << ssh) - 1))], and the first three dwords of row r + 1 again behind row r */
 #endif
 } mz_inflate_body_scratch;
 #if MZ_SPAN_DW
@@ -480,23 +520,36 @@ MZ_DEV void mz_bitrange(uint32_t sh, uint32_t n, uint32_t *m0, uint32_t *m1) {
     *m1 = (full >> 1) >> (31u - sh);
 }
 /* n <= 32 bytes from src to dst; the two ranges do not overlap; every load is issued before the first store, so a
- * source in global memory costs one round trip */
-MZ_DEV void mz_copy32(uint8_t *dst, const uint8_t *src, uint32_t n) {
-    uint64_t v[4] = {0, 0, 0, 0};
-    uint32_t t4 = 0, t2 = 0, t1 = 0;
+ * source in global memory costs one round trip.  In two halves, so that a lane can have the loads of several pieces
+ * in flight before it stores the first. */
+typedef struct {
+    uint64_t v[4];
+    uint32_t t4, t2, t1;
+} mz_piece32;
+MZ_DEV void mz_copy32_load(mz_piece32 *r, const uint8_t *src, uint32_t n) {
+    const uint32_t n8 = n & ~7u;
+    r->v[0] = r->v[1] = r->v[2] = r->v[3] = 0;
+    r->t4 = r->t2 = r->t1 = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++)
+        if (8u * k + 8u <= n) r->v[k] = mz_ld8(src + 8u * k);
+    if (n & 4u) r->t4 = mz_ld4(src + n8);
+    if (n & 2u) r->t2 = mz_ld2(src + n8 + (n & 4u));
+    if (n & 1u) r->t1 = src[n - 1u];
+}
+MZ_DEV void mz_copy32_store(const mz_piece32 *r, uint8_t *dst, uint32_t n) {
     const uint32_t n8 = n & ~7u;
 #pragma unroll
     for (uint32_t k = 0; k < 4u; k++)
-        if (8u * k + 8u <= n) v[k] = mz_ld8(src + 8u * k);
-    if (n & 4u) t4 = mz_ld4(src + n8);
-    if (n & 2u) t2 = mz_ld2(src + n8 + (n & 4u));
-    if (n & 1u) t1 = src[n - 1u];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++)
-        if (8u * k + 8u <= n) mz_st8(dst + 8u * k, v[k]);
-    if (n & 4u) mz_st4(dst + n8, t4);
-    if (n & 2u) mz_st2(dst + n8 + (n & 4u), t2);
-    if (n & 1u) dst[n - 1u] = (uint8_t)t1;
+        if (8u * k + 8u <= n) mz_st8(dst + 8u * k, r->v[k]);
+    if (n & 4u) mz_st4(dst + n8, r->t4);
+    if (n & 2u) mz_st2(dst + n8 + (n & 4u), (uint16_t)r->t2);
+    if (n & 1u) dst[n - 1u] = (uint8_t)r->t1;
+}
+MZ_DEV void mz_copy32(uint8_t *dst, const uint8_t *src, uint32_t n) {
+    mz_piece32 r;
+    mz_copy32_load(&r, src, n);
+    mz_copy32_store(&r, dst, n);
 }
 /* the same inside the staging area, where the source may end less than n (but at least 8) bytes in front of the
  * destination: 8-byte steps in order, each one reading only what the steps before it (or earlier pieces) wrote */
@@ -523,14 +576,31 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
  * -- an invalid code on the true path, the end of the input closer than a span -- stays with the step loop, which
  * owns the exact error verdicts: the span path only ever commits a prefix of verified tokens.
  *
- * One token at window-relative bit `rel`: the same table walk as phase 1 of the step loop. */
-MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *win, uint32_t rel, uint32_t ssh) {
-    const uint32_t d = rel >> 5;
-    const uint32_t a = (d >> ssh) * MZ_SPAN_RS + (d & ((1u << ssh) - 1u)); /* ssh = log2(dwords per span), wave-uniform */
-    const uint32_t d0 = win[a], d1 = win[a + 1u], d2 = win[a + 2u];
-    const uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
+ * One step of a walk at window-relative bit `rel` (the same table walk as phase 1 of the step loop): the token that
+ * starts there, or, when that is a literal of fewer than `room` bits, the literal (*pre = its table entry, else 0) and
+ * the token behind it. */
+MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *wrow, uint32_t rel, uint32_t room, uint32_t *pre) {
+    /* wrow = the lane's row of the window, biased so that window dword d is wrow[d]: a walk stays inside its span
+     * (rel < the span's end), so everything it reads is the row's own dwords or the three copied behind them */
+    const uint32_t a = rel >> 5;
+    const uint32_t d0 = wrow[a], d1 = wrow[a + 1u], d2 = wrow[a + 2u];
+    uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
     uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
     if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
+    /* A literal that does not end the lane's walk takes the token behind it along in the same step: the slowest
+     * lanes of a pass are the literal-dense ones (26.3 -> 16.1 steps for the slowest lane of a window on text,
+     * tests/study/span_multi.c).  The 64 bits loaded above still hold the longest second token (<= 48 bits) behind the
+     * longest literal code (<= 15 bits). */
+    uint32_t p = 0;
+    if (MZ_SPAN_PRELIT && (e & (MZ_E_LEN | 0x80u)) == 0x80u && (e & 63u) < room) {
+        p = e;
+        const uint32_t n1 = e & 63u;
+        w0 = mz_funnel(w1, w0, n1);
+        w1 >>= n1;
+        e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
+        if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
+    }
+    *pre = p;
     if (!(e & MZ_E_LEN)) return e; /* literal, end of block, or an invalid code (0 bits) */
     const uint32_t nb = e & 63u, ex = mz_bfe(e, 16, 4);
     const uint32_t lenl = mz_bfe(e, 7, 9) + mz_bfe(mz_funnel(w1, w0, nb), 0, ex);
@@ -547,14 +617,37 @@ MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *win, uint
 
 
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
-MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
+MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out, uint32_t out_cap,
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
                              uint32_t use_span, mz_inflate_result *res) {
     MZ_LANE_DECL
-    const uint32_t total_bits = in_len * 8u; /* in_len < 2^28, checked below */
-    const uint32_t in_mis = (uint32_t)((uintptr_t)in & 3u);
+    /* The bit cursor is 32 bits wide, so the decoder looks at the stream through a VIEW of at most MZ_VIEW_MAX bytes
+     * ([in, in + in_len), bitpos relative to `in`) and moves the view forward (MZ_REBASE) whenever the cursor is more
+     * than MZ_REBASE_BITS into it: at the top of every block and of every window / step, i.e. long before anything
+     * could reach the far end of a view that is not the end of the stream (the longest stretch between two checks is
+     * one stored block, 64 KiB).  Streams of any length the 32-bit in_len[] of the batch can describe are served
+     * (mz_strm_zlib.c:116-193 streams any size). */
+    uint32_t in_rem = in_total;  /* bytes from `in` to the real end of the stream */
+    uint32_t in_adv = 0;         /* bytes the view has moved */
+    uint32_t in_len = in_rem < MZ_VIEW_MAX ? in_rem : MZ_VIEW_MAX;
+    uint32_t total_bits = in_len * 8u;
+    const uint32_t in_mis = (uint32_t)((uintptr_t)in & 3u); /* the view moves by multiples of 4: the misalignment stays */
     const uint8_t *in_al = in - in_mis;
     uint32_t bitpos = 0;
+#define MZ_REBASE(also)                                                \
+    if (bitpos >= MZ_REBASE_BITS) {                                    \
+        const uint32_t _adv = (bitpos >> 3) & ~3u;                     \
+        if (_adv <= in_rem) {                                          \
+            in += _adv;                                                \
+            in_al += _adv;                                             \
+            in_adv += _adv;                                            \
+            in_rem -= _adv;                                            \
+            in_len = in_rem < MZ_VIEW_MAX ? in_rem : MZ_VIEW_MAX;      \
+            total_bits = in_len * 8u;                                  \
+            bitpos -= _adv * 8u;                                       \
+            also;                                                      \
+        }                                                              \
+    }
     uint32_t out_pos = 0;
     int32_t status = MZHIP_OK;
     uint32_t last = 0;
@@ -562,12 +655,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     PV(uint32_t, crc_tmp);
     uint32_t crc_done = 0;
     MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
+    MZ_PROF_DECL
 
-    if (in_len >= (1u << 28)) { /* bit cursor is 32-bit: one entry's compressed stream must be < 256 MiB */
-        status = MZHIP_UNSUPPORTED;
-        goto finish;
-    }
     while (!last) {
+        MZ_REBASE((void)0)
         /* the block header is read through a 256-byte window of the stream held one dword per lane (one coalesced
          * load instead of a global round trip per 64 bits of header); positions beyond it fall back to memory */
         const uint32_t hw0 = (bitpos + 8u * in_mis) >> 5;
@@ -670,10 +761,91 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             /* code lengths: serial by nature (run-length coded), wave-uniform loop
              * consuming a 64-bit window at a time; the 128-entry code-length-code table sits in a register pair of
              * halves per lane (entry i in lane i & 63, half i >> 6), so a lookup is a v_readlane, not an LDS round trip */
+            MZ_PROF_MARK(0); /* block header up to the code-length code */
             PV(uint32_t, clcreg);
             MZ_LANES { P(clcreg) = (uint32_t)L->u.h.clc_fast[lane] | ((uint32_t)L->u.h.clc_fast[lane + 64] << 16); }
             uint32_t idx = 0, prev = 0;
             const uint32_t ntot = nlen + ndist;
+#if MZ_CL_PARALLEL
+            /* Front end: 64 bits of the run-length coded lengths at a time.  Lane i decodes the symbol that would start
+             * at bit i of the window (one table lookup), a scalar walk picks the lanes that really are symbol starts, a
+             * prefix sum of their repeat counts places them, and every lane stores its own lengths (zeros are already
+             * there).  ~12 symbols per step instead of one.  It only ever consumes symbols that are certainly fine --
+             * inside the header window, far from the end of the input, not running over nlen + ndist -- and leaves
+             * anything else, with the cursor in front of it, to the serial loop below, which owns the verdicts. */
+            {
+                MZ_LANES {
+                    for (uint32_t k = (uint32_t)lane; k < 80u; k += 64u) mz_st4(L->u.h.cl + 4u * k, 0u);
+                }
+                MZ_WAVE_SYNC();
+                PV(uint32_t, tl); /* bits of the symbol at this lane's offset (0: no code) */
+                PV(uint32_t, tc); /* lengths it stands for */
+                PV(uint32_t, tv); /* their value; 16 = the value before */
+                PV(uint32_t, g0);
+                PV(uint32_t, g1);
+                PV(uint32_t, cm);
+                PV(uint32_t, cs);
+                PV(uint32_t, sl);
+                PV(uint32_t, rv);
+                PV(uint32_t, vr);
+                while (idx < ntot) {
+                    const uint32_t ab = bitpos + 8u * in_mis;
+                    const uint32_t j0 = (ab >> 5) - hw0;
+                    if (j0 + 3u >= 64u || bitpos + 64u + 14u > total_bits) break;
+                    MZ_GATHER4(g0, hwin, 4u * (j0 + (((ab & 31u) + (uint32_t)lane) >> 5)));
+                    MZ_GATHER4(g1, hwin, 4u * (j0 + (((ab & 31u) + (uint32_t)lane) >> 5) + 1u));
+                    MZ_LANES {
+                        const uint32_t w = mz_funnel(P(g1), P(g0), ab + (uint32_t)lane);
+                        const uint32_t e = L->u.h.clc_fast[w & ((1u << MZ_CROOT) - 1u)];
+                        const uint32_t nb = e & 15u, sym = e >> 4;
+                        const uint32_t ext = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+                        const uint32_t xb = (w >> nb) & ((1u << ext) - 1u);
+                        P(tl) = nb ? nb + ext : 0u;
+                        P(tc) = sym < 16u ? 1u : sym == 18u ? 11u + xb : 3u + xb;
+                        P(tv) = sym < 16u ? sym : sym == 16u ? 16u : 0u;
+                    }
+                    uint64_t M = 0; /* lanes that are symbol starts and end inside the window */
+                    uint32_t cur = 0, stop = 0;
+                    while (cur < 64u) {
+                        const uint32_t l = MZ_READLANE(tl, cur);
+                        if (l == 0u) stop = 1; /* an invalid code (or garbage behind the last length): not ours */
+                        if (l == 0u || cur + l > 64u) break;
+                        M |= 1ull << cur;
+                        cur += l;
+                    }
+                    if (idx == 0u && MZ_READLANE(tv, 0) == 16u) break; /* a repeat with nothing before it */
+                    MZ_LANES { P(cm) = ((M >> lane) & 1ull) ? P(tc) : 0u; }
+                    MZ_INCL_SCAN(cs, cm);
+                    uint64_t F; /* symbols that do not end inside nlen + ndist: behind the last length, or an overrun */
+                    MZ_BALLOT(F, ((M >> lane) & 1ull) && idx + P(cs) > ntot);
+                    const uint32_t f = F ? mz_ctz64(F) : 64u;
+                    const uint64_t Pm = F ? (M & ((1ull << f) - 1ull)) : M;
+                    if (!Pm) break;
+                    uint64_t NC;
+                    MZ_BALLOT(NC, ((Pm >> lane) & 1ull) && P(tv) != 16u);
+                    MZ_LANES {
+                        const uint64_t below = NC & (((uint64_t)2 << lane) - 1ull);
+                        P(sl) = below ? 63u - mz_clz64(below) : 64u;
+                    }
+                    MZ_GATHER4(rv, tv, 4u * (P(sl) & 63u));
+                    MZ_LANES {
+                        const uint32_t v = (P(tv) != 16u) ? P(tv) : (P(sl) < 64u ? P(rv) : prev);
+                        P(vr) = v;
+                        if (((Pm >> lane) & 1ull) && v != 0u) {
+                            const uint32_t o = idx + P(cs) - P(cm);
+                            for (uint32_t k = 0; k < P(cm); k++) L->u.h.cl[o + k] = (uint8_t)v;
+                        }
+                    }
+                    const uint32_t lastl = 63u - mz_clz64(Pm);
+                    prev = MZ_READLANE(vr, lastl);
+                    idx += MZ_READLANE(cs, lastl);
+                    MZ_STAT(16, mz_popc64(Pm)); MZ_STAT(18, 1);
+                    bitpos += F ? f : cur;
+                    if (F || stop) break;
+                }
+                MZ_WAVE_SYNC();
+            }
+#endif
             while (idx < ntot) {
                 uint64_t w;
                 MZ_HDR_WIN_BITS(w, bitpos);
@@ -684,6 +856,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     const uint32_t ci = (uint32_t)(wu >> used) & 127u;
                     uint32_t e = (MZ_READLANE(clcreg, ci & 63u) >> ((ci >> 6) << 4)) & 0xFFFFu;
                     uint32_t nb = e & 15u, sym = e >> 4;
+                    MZ_STAT(17, 1);
                     if (nb == 0) {
                         status = (bitpos + used + 7 > total_bits) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
                         goto finish;
@@ -727,6 +900,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 bitpos += used;
             }
             MZ_WAVE_SYNC();
+            MZ_PROF_MARK(1); /* code lengths */
             if (MZ_UNIFORM(L->u.h.cl[256]) == 0) {
                 status = MZHIP_DATA_ERROR; /* invalid code -- missing end-of-block */
                 goto finish;
@@ -755,6 +929,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             }
         }
 
+        MZ_PROF_MARK(2); /* decode tables */
         /* ---- compressed block body: speculative 64-offset decode ----
          * Compressed bytes are staged through a 512-byte LDS ring (two 256-byte blocks, the next
          * block prefetched into a VGPR one block ahead), so the per-step window fetch is three
@@ -775,6 +950,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             uint32_t span_on = use_span; /* cleared for the rest of the block when a window cannot be committed here */
 #endif
             for (;;) {
+                MZ_REBASE(ring_valid = 0) /* the ring is indexed by the position inside the view */
 #if MZ_SPAN_DW
                 {
                     const uint32_t remain = total_bits - bitpos;
@@ -795,11 +971,12 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                                 const uint32_t v = mz_load_stream_dword(in_al, in_mis, in_len, wb + d);
                                 const uint32_t row = d >> ssh, k = d & ((1u << ssh) - 1u);
                                 win[row * MZ_SPAN_RS + k] = v;
-                                if (k < 2u && row > 0u) win[(row - 1u) * MZ_SPAN_RS + (1u << ssh) + k] = v;
+                                if (k < 3u && row > 0u) win[(row - 1u) * MZ_SPAN_RS + (1u << ssh) + k] = v;
                             }
                         }
                         MZ_WAVE_SYNC();
                         ring_valid = 0; /* the pool covers the ring's place */
+                        MZ_PROF_MARK(3); /* step loop (if any) + window load */
 #include "inflate_window.inc"
                     }
                     span_skip = 0;
@@ -1006,10 +1183,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     }
 
 finish:
+    MZ_PROF_MARK(11); /* step loop behind the last window, stored blocks */
     res->status = status;
     res->out_len = out_pos;
-    res->in_used = (bitpos + 7u) >> 3;
-    if (res->in_used > in_len) res->in_used = in_len;
+    res->in_used = in_adv + ((bitpos + 7u) >> 3);
+    if (res->in_used > in_total) res->in_used = in_total;
     {
         uint32_t crc;
 #if MZ_ABLATE & 4
@@ -1021,6 +1199,8 @@ finish:
 #endif
         res->crc = crc;
     }
+    MZ_PROF_MARK(12); /* CRC tail */
+    MZ_PROF_FLUSH
 }
 
 #endif

@@ -34,6 +34,19 @@
 #ifndef MZ_WAVES_PER_WG
 #define MZ_WAVES_PER_WG 4
 #endif
+#if defined(MZ_PROF)
+/* measurement builds (make PROF=1): cycles per section of K1, summed over all waves since the last read */
+__device__ unsigned long long mz_prof_buf[32];
+extern "C" __attribute__((visibility("default"))) int mzhip_prof_read(unsigned long long *out32, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(mz_prof_buf), sizeof(mz_prof_buf)) != hipSuccess) return -1;
+    if (reset) {
+        static const unsigned long long zero[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mz_prof_buf), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 #define MZ_CRC_TAB_BYTES 1024
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64

@@ -92,6 +92,7 @@
     } while (0)
 MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
+MZ_DEV uint32_t mz_clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); } /* v != 0 */
 MZ_DEV uint32_t mz_brev32(uint32_t v) {
     v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
     v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
@@ -164,6 +165,7 @@ __device__ __forceinline__ uint32_t mz_wave_incl_scan(uint32_t x, int lane) {
 #define MZ_WAVE_SUM(dst, name) ((dst) = (uint32_t)__builtin_amdgcn_readlane((int)mz_wave_incl_scan((name), lane), 63))
 MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__popcll(v); }
 MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
+MZ_DEV uint32_t mz_clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); } /* v != 0 */
 MZ_DEV uint32_t mz_brev32(uint32_t v) { return __brev(v); }
 
 #endif

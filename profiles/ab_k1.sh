@@ -5,11 +5,9 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "f8p3008_w16 SPAN=8 POOL=3008 WPG=2 WAVES=4"
-  "f7p3264_w16 SPAN=7 POOL=3264 WPG=2 WAVES=4"
-  "f8p3456_w16_wpg4 SPAN=8 POOL=3264 WPG=4 WAVES=4"
-  "abl_f8_walkemit SPAN=8 POOL=3008 WPG=2 WAVES=4 ABLATE=15"
-  "abl_f8_nocrc SPAN=8 POOL=3008 WPG=2 WAVES=4 ABLATE=4"
+  "j_serial_header CLPAR=0"
+  "j_base"
+  "j_base_prof PROF=1"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}
@@ -24,8 +22,8 @@ for v in "${VARIANTS[@]}"; do
     [ -f "$dir/libmzhip.so" ] || { echo "$tag: not built"; continue; }
     echo "== $tag"
     ( cd "$root"; case $tag in abl_*) ;; *) MZHIP_LIB=$dir/libmzhip.so timeout 90 python -m pytest tests/test_gpu_inflate.py -x -q 2>&1 | tail -1;; esac
-      MZHIP_LIB=$dir/libmzhip.so timeout 40 python tests/perf_probe.py 2>&1 | tail -1
-      MZHIP_LIB=$dir/libmzhip.so timeout 40 python tests/perf_probe.py 512 200000 8192 2>&1 | tail -1 )
+      MZHIP_LIB=$dir/libmzhip.so timeout 40 python tests/perf_probe.py 2>&1 | grep -v '^rep [01]\|amdgpu.ids'
+      MZHIP_LIB=$dir/libmzhip.so timeout 40 python tests/perf_probe.py 512 200000 8192 2>&1 | grep -v '^rep [01]\|amdgpu.ids' )
   fi
 done
 wait

@@ -11,7 +11,7 @@
 /* emul_inflate() runs the product configuration (span path on); emul_inflate_steps() the step loop alone */
 #include "inflate_core.h"
 #if defined(MZ_STATS)
-unsigned long long mz_stats[16];
+unsigned long long mz_stats[24], mz_stat_max;
 extern "C" unsigned long long *emul_stats() { return mz_stats; }
 #endif
 

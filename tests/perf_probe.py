@@ -33,3 +33,17 @@ for rep in range(3):
     print("rep %d: %.3f ms  %.2f GiB/s out  (%.2f GB/s in+out)  ok=%s ratio=%.3f" % (
         rep, ms, n_total * size / 2**30 / (ms / 1e3), (n_total * size + cbytes) / 1e9 / (ms / 1e3), ok,
         cbytes / (n_total * size)))
+
+# measurement builds (make PROF=1) export the per-section cycle sums of K1
+import ctypes  # noqa: E402
+
+lib = ctypes.CDLL(os.environ.get("MZHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "minizip-ng_amd", "_build", "libmzhip.so"))
+if hasattr(lib, "mzhip_prof_read"):
+    buf = (ctypes.c_ulonglong * 32)()
+    lib.mzhip_prof_read(buf, 1)
+    names = {0: "header: up to the code-length code", 1: "header: code lengths", 2: "header: decode tables", 3: "step loop + window load",
+             4: "counting passes", 5: "emitting passes", 6: "far copies", 7: "near copies", 8: "store", 9: "crc", 10: "crossings",
+             13: "choosing the chunk", 11: "block tails (step loop)", 12: "crc tail"}
+    tot = float(sum(buf)) or 1.0
+    for i in sorted(names, key=lambda k: -buf[k]):
+        print("  %-36s %5.1f %%" % (names[i], 100.0 * buf[i] / tot))

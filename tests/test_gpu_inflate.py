@@ -106,6 +106,37 @@ def test_many_entries_64k_and_8k(gpu):
             assert st == 0 and out == datas[i] and used == in_used[i] and oracle.crc32(out) == crc[i]
 
 
+def test_stream_beyond_256_mib(gpu):
+    """One entry whose compressed stream is longer than a 32-bit bit cursor can address (272 MiB; the reference streams
+    any size, mz_strm_zlib.c:116-193): 4350 stored blocks of noise, then Huffman blocks of text that start behind bit
+    2^31, next to an ordinary entry in the same batch.  Every byte compared."""
+    rnd = np.random.RandomState(3)
+    noise = rnd.randint(0, 256, size=65535, dtype=np.uint8)
+    nblk = 4350
+    hdr = np.array([0, 0xFF, 0xFF, 0x00, 0x00], dtype=np.uint8)          # BFINAL=0 BTYPE=00, LEN=65535, NLEN=0
+    blocks = np.empty((nblk, 5 + 65535), dtype=np.uint8)
+    blocks[:, :5] = hdr
+    for i in range(nblk):                                                # every block its own rotation of the noise
+        blocks[i, 5:] = np.roll(noise, i * 7)
+    text = (synth.corpus() * 30)[:6000000]
+    tail = synth.deflate_raw(text)                                       # final blocks, byte aligned behind the stored ones
+    z = blocks.tobytes() + tail
+    assert len(z) > (1 << 28) + (1 << 20)
+    want = blocks[:, 5:].tobytes() + text
+    small = synth.corpus()[:40000]
+    batch = gpu.make_batch([z, synth.deflate_raw(small)], [len(want), len(small)])
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    assert status.tolist() == [0, 0]
+    assert out_len.tolist() == [len(want), len(small)] and in_used.tolist() == [len(z), len(synth.deflate_raw(small))]
+    assert crc[0] == zlib.crc32(want) and crc[1] == zlib.crc32(small)
+    h_out = batch["d_out"].cpu().numpy()
+    assert gpu.entry_bytes(batch, h_out, 0, len(want)) == want
+    # cut inside the text blocks, behind bit 2^31: input exhausted, like the reference
+    batch = gpu.make_batch([z[:len(z) - 1000]], [len(want)])
+    out_len, in_used, crc, status = gpu.run_inflate(batch)
+    assert status[0] == -5
+
+
 def test_unaligned_offsets(gpu):
     datas = synth.slices(64, 5000, 99)
     pays = [synth.deflate_raw(d) for d in datas]

@@ -421,11 +421,13 @@ def _build_variant(tag, flags):
 
 @pytest.fixture(scope="module")
 def emu_staged():
-    """Other K1 geometries in the same emulation: 128-bit spans throughout with two pieces per lane in the near pass, and
-    pools so small that windows are cut short or handed back to the step loop all the time."""
-    return [_build_variant("s4", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=4608u", "-DMZ_NEAR_SLOTS=2"]),
-            _build_variant("tiny", ["-DMZ_POOL_BYTES=2048u", "-DMZ_NEAR_SLOTS=1"]),
-            _build_variant("s4tiny", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=1024u"])]
+    """Other K1 geometries in the same emulation: 128-bit spans throughout with two pieces per lane in the near pass, pools
+    so small that windows are cut short or handed back to the step loop all the time, and the build knobs that have a
+    non-default setting somewhere in profiles/ab_k1.sh (one token per step, two far pieces per lane, batched near loads)."""
+    return [_build_variant("s4", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=4608u", "-DMZ_NEAR_SLOTS=2", "-DMZ_SPAN_PRELIT=0"]),
+            _build_variant("tiny", ["-DMZ_POOL_BYTES=2048u", "-DMZ_NEAR_SLOTS=1", "-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"]),
+            _build_variant("s4tiny", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=1024u", "-DMZ_FAR_SLOTS=2"]),
+            _build_variant("knobs", ["-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
@@ -471,6 +473,94 @@ def test_inflate_span_and_step_paths(emu, emu_staged):
                 assert (used, out) == (uo, oo) and crc == oracle.crc32(oo), (it, kind)
         n_ok += so == 0
     assert n_ok > 150
+
+
+def test_inflate_block_header_fuzz(emu):
+    """Dynamic block headers are decoded 64 bits of code lengths at a time, with the one-symbol-at-a-time loop behind
+    it for everything doubtful.  Bit flips, byte smashes and cuts confined to the header bytes of real streams (repeat
+    codes with nothing before them, runs over nlen + ndist, unused code-length codes, over-subscribed sets, input that
+    ends inside the lengths): verdicts, bytes and consumed counts equal the oracle's."""
+    import random
+
+    c = synth.corpus()
+    rnd = random.Random(2024)
+    bases = []
+    for lvl, n in ((6, 20000), (9, 3000), (1, 60000), (6, 700), (6, 120)):
+        for _ in range(3):
+            o = rnd.randrange(0, len(c) - n)
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15)
+            bases.append(co.compress(c[o:o + n]) + co.flush())
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    bases.append(co.compress(bytes(range(256)) * 40 + c[:5000]) + co.flush())      # every literal in use: long headers
+    n_ok = n_err = 0
+    for it in range(1500):
+        z = bytearray(rnd.choice(bases))
+        span = min(len(z), 130)
+        kind = it % 4
+        if kind == 0:
+            z[rnd.randrange(span)] ^= 1 << rnd.randrange(8)
+        elif kind == 1:
+            z[rnd.randrange(span)] = rnd.randrange(256)
+        elif kind == 2:
+            del z[rnd.randrange(1, span):]
+        else:
+            for _ in range(3):
+                z[rnd.randrange(span)] ^= 1 << rnd.randrange(8)
+        z = bytes(z)
+        so, uo, oo = oracle.inflate_raw(z, 70000)
+        st, used, out, crc = _run(emu.emul_inflate, z, 70000, mis=it % 4)
+        assert st == so, (it, kind, st, so)
+        if so == 0:
+            assert (used, out) == (uo, oo) and crc == oracle.crc32(oo), it
+            n_ok += 1
+        else:
+            n_err += 1
+    assert n_ok > 20 and n_err > 300
+
+
+def test_inflate_moving_view():
+    """The decoder addresses the stream through a view that moves forward (32-bit bit cursor, streams of any length):
+    built here with a 256 KiB view that moves every 32 KiB, so that streams of a few hundred KiB cross many moves -- in
+    stored blocks, in Huffman blocks on the span path and on the step loop -- and end (or are cut) at every distance
+    from one.  Same verdicts, bytes, consumed counts and CRCs as the oracle."""
+    import random
+
+    v = _build_variant("view", ["-DMZ_VIEW_MAX=(1u<<18)", "-DMZ_REBASE_BITS=(1u<<18)"])
+    c = synth.corpus()
+    rnd = random.Random(7)
+    noise = bytes(rnd.randrange(256) for _ in range(400000))
+    mixed = bytearray()
+    while len(mixed) < 1200000:                                  # text with incompressible islands: ratio ~0.6
+        o = rnd.randrange(0, len(c) - 3000)
+        mixed += c[o:o + rnd.randrange(200, 3000)]
+        o = rnd.randrange(0, len(noise) - 2000)
+        mixed += noise[o:o + rnd.randrange(100, 2000)]
+    mixed = bytes(mixed)
+    streams = []
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    streams.append((co.compress(mixed) + co.flush(), mixed))
+    co = zlib.compressobj(0, zlib.DEFLATED, -15)                 # stored blocks only
+    streams.append((co.compress(noise) + co.flush(), noise))
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)                 # stored blocks, then text behind several moves
+    both = noise[:300000] + c[:200000]
+    streams.append((co.compress(both) + co.flush(), both))
+    for z, d in streams:
+        assert len(z) > (1 << 18) + 70000
+        for fn in (v.emul_inflate, v.emul_inflate_steps):
+            st, used, out, crc = _run(fn, z, len(d) + 8, mis=1, omis=3)
+            assert (st, used, out, crc) == (0, len(z), d, zlib.crc32(d))
+    z, d = streams[0]
+    for it in range(12):
+        cut = rnd.randrange(1 << 15, len(z))
+        zz = bytearray(z[:cut]) if it % 2 == 0 else bytearray(z)
+        if it % 2:
+            zz[cut] ^= 1 << rnd.randrange(8)
+        zz = bytes(zz)
+        so, uo, oo = oracle.inflate_raw(zz, len(d) + 8)
+        st, used, out, crc = _run(v.emul_inflate, zz, len(d) + 8, mis=it % 4)
+        assert st == so, (it, st, so)
+        if so == 0:
+            assert (used, out) == (uo, oo)
 
 
 def test_deflate_default_class_roundtrip(emu):
