@@ -13,6 +13,9 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cmd="python $root/bench.py --steps 3 --warmup 1"
 if [ $what = all ] || [ $what = bench ]; then ( cd "$root" && timeout $T $cmd > "$out/bench.log" 2> "$out/bench.err" ); tail -1 "$out/bench.log"; fi
+# the profiled passes launch the dominant kernel on the bench workload only (no legs, no CPU baseline), so that the
+# per-kernel average of --stats is the average of identical launches: 1 warm-up + 3 timed
+cmd="$cmd --no-legs --no-cpu-baseline"
 cd /tmp
 if [ $what = all ] || [ $what = stats ]; then
   timeout -k 10 $T rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- $cmd > "$out/stats.log" 2>&1
@@ -28,13 +31,14 @@ if [ $what = SQ ]; then
   # instruction mix and stall picture of the dominant kernel; a pass per counter group (never with other trace domains);
   # MZ_SQ_CMD overrides the workload (default: the short probe, one launch is enough for counters)
   sqcmd=${MZ_SQ_CMD:-python $root/tests/perf_probe.py}
+  sqk=${MZ_SQ_KERNEL:-k_inflate_batch}   # the kernel whose rows are kept
   i=0
   for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
              "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_LDS_DATA_FIFO_FULL"; do
     i=$((i+1))
     timeout -k 10 $T rocprofv3 --kernel-trace --pmc $grp -d "$out/pmc_sq$i" -o pmc --output-format csv -- $sqcmd > "$out/pmc_sq$i.log" 2>&1
-    find "$out/pmc_sq$i" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|k_inflate_batch" "$1" > "$2"' _ {} "$out/pmc_sq$i.csv" \;
+    find "$out/pmc_sq$i" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|$3" "$1" > "$2"' _ {} "$out/pmc_sq$i.csv" "$sqk" \;
   done
 fi
 ls -la "$out"

@@ -1,0 +1,10 @@
+set -u
+mkdir -p gpurun_out/final
+( timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 ) > gpurun_out/final/gputest.log 2>&1
+( python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > gpurun_out/final/smoke.log 2>&1
+bash profiles/collect.sh final all > gpurun_out/final/collect.log 2>&1
+for c in 3 4 5; do timeout 600 python bench.py --config $c > gpurun_out/final/bench_cfg$c.log 2> gpurun_out/final/bench_cfg$c.err; done
+bash profiles/collect.sh final_sq SQ > gpurun_out/final/collect_sq.log 2>&1
+MZ_SQ_KERNEL=k_lzma_batch MZ_SQ_CMD="python $PWD/bench.py --config 4 --entries 4608 --steps 1 --warmup 0 --no-cpu-baseline" bash profiles/collect.sh final_sq_k3 SQ > gpurun_out/final/collect_sq_k3.log 2>&1
+MZ_SQ_KERNEL=k_deflate_batch MZ_SQ_CMD="python $PWD/bench.py --config 5 --entries 20000 --steps 1 --warmup 0 --no-cpu-baseline" bash profiles/collect.sh final_sq_k4 SQ > gpurun_out/final/collect_sq_k4.log 2>&1
+cat gpurun_out/final/gputest.log gpurun_out/final/smoke.log; tail -2 gpurun_out/final/bench.log; for c in 3 4 5; do tail -1 gpurun_out/final/bench_cfg$c.log; done
