@@ -9,32 +9,36 @@
  *   - Huffman tables are built by the whole wave (histogram -> canonical first
  *     codes -> ranked symbols -> LDS lookup tables whose 32-bit entries are
  *     ready-made tokens / operand descriptors), see MZ_BUILD_HUFF.
- *   - Two decode front ends produce the same 32-bit tokens:
- *       SPAN PATH (mz_span_token, the default for all but the tail of a stream): every lane walks its own
- *       256-bit span of the compressed stream token by token; a walk started at an arbitrary bit meets the
- *       true token sequence after ~8 tokens, so chaining the walks (each lane restarts where its left
- *       neighbour crossed into its span) converges to the true parse in ~3.7 passes; one more walk emits
- *       the tokens in stream order.  Every lane does useful work.
- *       STEP LOOP (the last span of a stream, and every error verdict): lane l decodes the complete token
+ *   - Two decode front ends:
+ *       SPAN PATH (inflate_window.inc, the default for all but the tail of a stream): every lane walks its own
+ *       256-bit span of the compressed stream (mz_span_token: a leading literal + the token behind it per step); a
+ *       walk started at an arbitrary bit meets the true token sequence after ~8 tokens, so chaining the walks (each
+ *       lane restarts where its left neighbour crossed into its span) converges to the true parse in ~3 passes.
+ *       Verified lanes are committed in chunks INSIDE LDS: literals to a staging byte, back-references to a list,
+ *       far sources fetched from the output buffer, near ones copied LDS to LDS in dependency order, then one
+ *       coalesced 16-byte store per lane.  Nothing goes through HBM twice.
+ *       STEP LOOP (the last span of a stream, hand-backs, and every error verdict): lane l decodes the complete token
  *       that would start at bit cursor+l, for all 64 bit offsets at once; which candidates are real is
  *       decided without a serial walk: f(l) = l + bits(l) is squared with cross-lane gathers and lane i
- *       composes f^i(0).  One step retires about 64 bits of input (4.6 tokens on text).
- *   - Tokens are handed to the flush (inflate_flush.inc) 64 at a time, one per lane: wave prefix sum
- *     of the sizes, literals scatter in one store, matches (LZ77 back-references) are copied eight at a
- *     time, 8 lanes each, as long as every source of a group ends before the group's first destination
- *     byte; overlapping (dist < len) runs and in-group dependencies take an in-order cooperative copy.
- *     MZ_STAGED_FLUSH assembles the batch in LDS instead and stores it once (opt-in build).
+ *       composes f^i(0).  One step retires about 64 bits of input (4.6 tokens on text).  Its tokens are handed to
+ *       the flush (inflate_flush.inc) 64 at a time, one per lane: wave prefix sum of the sizes, literals scatter in
+ *       one store, matches are copied eight at a time, 8 lanes each, as long as every source of a group ends before
+ *       the group's first destination byte; overlapping (dist < len) runs and in-group dependencies take an
+ *       in-order cooperative copy.
  *   - The sliding window IS the output buffer: back-references read bytes this
  *     wave wrote earlier (a wave's vector-memory operations execute in order),
- *     so no 32 KiB LDS window is needed; compressed input is staged through a
+ *     so no 32 KiB LDS window is needed; the step loop stages compressed input through a
  *     512-byte LDS ring with a register-held prefetch.
- *   - CRC-32 is folded from the freshly written output one 1 KiB tile at a
- *     time (crc32_core.h), so the output is never re-read from HBM.
+ *   - CRC-32 is folded from the freshly written output (still in L2) in 4 KiB super-tiles, 64 bytes per lane
+ *     (crc32_core.h), so the output is never re-read from HBM.
  *   - The per-lane decode is kept to 32-bit funnel shifts (v_alignbit), bit-field extracts and table
- *     entries that need no arithmetic, and the tables are sized for residency: an 8-bit literal/length
- *     root plus second-level tables (4.7 KiB of LDS per wave) and the 2.8 KiB span window let five
- *     workgroups = 20 waves share a CU (the step loop alone: eight workgroups, VALU-issue-bound).
- *   - MZ_STATS (host emulation only) counts flushes / matches / dependent copies.
+ *     entries that need no arithmetic, and LDS is sized for residency: 9.8 KiB per wave (3.8 KiB of tables with an
+ *     8-bit literal/length root, the 2.8 KiB span window, a 3.2 KiB commit pool) = 16 waves per CU, matching the
+ *     128-VGPR budget of 4 waves per SIMD.
+ *   - Dynamic block headers: the code lengths are decoded 64 bits at a time (MZ_CL_PARALLEL).
+ *   - The 32-bit bit cursor looks at the stream through a view that moves forward (MZ_REBASE): any stream length.
+ *   - MZ_STATS (host emulation only) counts windows / passes / SIMT steps / pieces; MZ_PROF (device measurement
+ *     builds) sums the cycles a wave spends per section; MZ_ABLATE removes stages (wrong output, timing only).
  *
  * Error classes mirror zlib's as the reference surfaces them
  * (mz_strm_zlib.c:159-189): malformed data -> -3, input exhausted -> -5.
@@ -570,8 +574,8 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
  *   pass 1    lane i walks from the first bit of span i until it crosses into span i + 1 (lane 0 starts at the true
  *             cursor);
  *   pass 2..  lane i restarts from where lane i - 1 crossed; when no start moves any more the walks are the true parse;
- *   emit      one more walk writes the tokens (same format as the step loop's) to a per-wave scratch in stream order,
- *             and the shared flush consumes them 64 at a time.
+ *   emit      the lanes of a chunk walk once more and write bytes / back-reference pieces into the LDS pool
+ *             (inflate_window.inc has the whole window logic).
  * Every lane does useful work in the final walks, where the step loop keeps ~5 of 64 candidates.  Anything unusual
  * -- an invalid code on the true path, the end of the input closer than a span -- stays with the step loop, which
  * owns the exact error verdicts: the span path only ever commits a prefix of verified tokens.
