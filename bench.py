@@ -390,7 +390,24 @@ def main():
         pays, crcs = make_unique_lzma(datas, world)
     else:
         offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
     U = len(pays)
+    if strong and world > 1:
+        # one table for all ranks: the slice generator stops early on a slow host (--gen-seconds), so agree on the
+        # number of unique streams every rank really has (same seeds: the first U are the same everywhere)
+        u = torch.tensor([U], dtype=torch.int64, device=dev)
+        dist.all_reduce(u, op=dist.ReduceOp.MIN)
+        U = int(u.item())
+        pays, crcs = pays[:U], crcs[:U]
+        if offs is not None:
+            offs = offs[:U]
     rnd = np.random.RandomState(99 if strong else 99 + rank)
     pick_all = rnd.randint(0, U, size=n_table)
     plen = np.array([len(p) for p in pays], dtype=np.int64)
@@ -405,14 +422,6 @@ def main():
     pick = pick_all[lo:hi]
     n = len(pick)
     max_shard = int(np.diff(bounds).max()) if bounds is not None else n
-
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group("nccl", device_id=dev)
 
     L = mz.lib()
     want_crc_np = crcs[pick]
