@@ -29,7 +29,9 @@
 #include "crc32_core.h"
 #include "wave.h"
 
+#ifndef MZ_DEF_HBITS
 #define MZ_DEF_HBITS 12
+#endif
 #define MZ_DEF_MINMATCH 4u
 #define MZ_DEF_MAXMATCH 258u
 #define MZ_DEF_BLOCK 65536u /* input positions per DEFLATE block = token scratch entries per wave */

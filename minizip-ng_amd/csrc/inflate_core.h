@@ -611,7 +611,11 @@ MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *wrow, uin
     const uint32_t nb2 = nb + ex;
     const uint32_t dl = mz_funnel(w1, w0, nb2);
     uint32_t dd = L->dist_fast[dl & ((1u << MZ_DROOT) - 1u)];
-    if (dd == 0u) dd = mz_long_code(dl, MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
+    MZ_STAT(19, 1);
+    if (dd == 0u) {
+        MZ_STAT(20, 1);
+        dd = mz_long_code(dl, MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
+    }
     if ((int32_t)dd <= 0) return 0u; /* unused / 30 / 31 distance code */
     const uint32_t dn = dd & 15u, dex = mz_bfe(dd, 4, 4);
     const uint32_t dist = mz_bfe(dd, 8, 15) + mz_bfe(dl, dn, dex);

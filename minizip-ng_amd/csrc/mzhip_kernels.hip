@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -1373,9 +1374,23 @@ struct PrimeGen {
     uint8_t *out = nullptr; // page-locked (hipHostMalloc): the D2H copy of the decoded bytes runs at link speed
     bool out_pinned = false;
     uint64_t zip_len = 0, ident = 0; // archive identity: length + hash of its central directory and end records
+    // STORE entries: no codec stream sees them (the reference's raw stream hands the bytes to mz_crypt_crc32_update,
+    // mz_zip.c:2047-2049), so the CRC symbol recognises a chunk by content: the payloads are kept, cut into the reader's
+    // 65 535-byte chunks with their device-computed CRCs, indexed by a fingerprint of each chunk
+    struct StoreSeg {
+        uint64_t off; // into store[]
+        uint32_t len, crc;
+    };
+    std::vector<StoreSeg> store_segs;
+    std::unordered_multimap<uint64_t, uint32_t> store_idx; // fingerprint -> segment
+    uint8_t *store = nullptr;
+    bool store_pinned = false;
+    uint64_t store_entries = 0;
     ~PrimeGen() {
         if (out_pinned) (void)hipHostFree(out);
         else free(out);
+        if (store_pinned) (void)hipHostFree(store);
+        else free(store);
     }
 };
 struct PrimeCache {
@@ -1384,12 +1399,25 @@ struct PrimeCache {
 };
 PrimeCache g_prime;
 std::mutex g_prime_mu;
+std::atomic<int> g_store_gens{0}; // generations that hold STORE chunks: the CRC symbol's fast "nothing to look up"
 constexpr uint32_t kSeg = 65535u;
 constexpr size_t kMaxGens = 8;
 
 uint64_t fnv1a64(const uint8_t *p, uint64_t n, uint64_t h = 0xCBF29CE484222325ull) {
     for (uint64_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001B3ull;
     return h;
+}
+// fingerprint of a chunk of at least 32 bytes: its length, first and last 16 bytes (a hint only: a hit is confirmed
+// byte by byte)
+uint64_t store_key(const uint8_t *p, uint32_t n) {
+    uint64_t h = fnv1a64((const uint8_t *)&n, 4);
+    h = fnv1a64(p, 16, h);
+    return fnv1a64(p + n - 16, 16, h);
+}
+void count_store_gens_locked() {
+    int k = 0;
+    for (const auto &g : g_prime.gens) k += g->store_segs.empty() ? 0 : 1;
+    g_store_gens.store(k);
 }
 } // namespace
 
@@ -1398,6 +1426,7 @@ extern "C" {
 void mzhip_prime_clear(void) {
     std::lock_guard<std::mutex> lk(g_prime_mu);
     g_prime = PrimeCache(); // generations pinned by open streams live until those streams let go
+    g_store_gens.store(0);
 }
 
 } // extern "C"
@@ -1502,6 +1531,62 @@ int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const st
     }
     return 0;
 }
+// STORE entries of a primed archive: their payloads are copied into the generation, cut into the reader's chunks
+// (kSeg bytes from the start of each entry), and every chunk's CRC-32 is computed on the current device, one launch
+// per <= 1 GiB of payload.
+int32_t prime_store(const uint8_t *zip, const std::vector<std::pair<int64_t, int64_t>> &stores, PrimeGen *gen) {
+    uint64_t total = 0;
+    for (const auto &e : stores) total += ((uint64_t)e.second + 15) & ~15ull;
+    if (!total) return 0;
+    gen->store_pinned = hipHostMalloc((void **)&gen->store, total + 16, hipHostMallocDefault) == hipSuccess;
+    if (!gen->store_pinned) {
+        (void)hipGetLastError();
+        gen->store = (uint8_t *)malloc(total + 16);
+    }
+    if (!gen->store) return -4;
+    uint64_t pos = 0;
+    for (const auto &e : stores) {
+        memcpy(gen->store + pos, zip + e.first, (size_t)e.second);
+        for (int64_t o = 0; o < e.second; o += kSeg)
+            gen->store_segs.push_back({pos + (uint64_t)o, (uint32_t)(e.second - o < kSeg ? e.second - o : kSeg), 0u});
+        pos += ((uint64_t)e.second + 15) & ~15ull;
+    }
+    const size_t ns = gen->store_segs.size();
+    constexpr uint64_t kGroup = 1ull << 30;
+    for (size_t s0 = 0; s0 < ns;) {
+        size_t s1 = s0;
+        const uint64_t base = gen->store_segs[s0].off;
+        while (s1 < ns && gen->store_segs[s1].off + gen->store_segs[s1].len - base <= kGroup) s1++;
+        const uint32_t gn = (uint32_t)(s1 - s0);
+        const uint64_t bytes = gen->store_segs[s1 - 1].off + gen->store_segs[s1 - 1].len - base;
+        std::vector<uint64_t> off(gn);
+        std::vector<uint32_t> len(gn), crc(gn);
+        for (uint32_t i = 0; i < gn; i++) {
+            off[i] = gen->store_segs[s0 + i].off - base;
+            len[i] = gen->store_segs[s0 + i].len;
+        }
+        Scratch d_buf, d_meta;
+        HIP_TRY(hipMalloc(&d_buf.p, bytes + 16));
+        HIP_TRY(hipMalloc(&d_meta.p, (size_t)gn * 16 + 64));
+        uint64_t *d_off = (uint64_t *)d_meta.p;
+        uint32_t *d_len = (uint32_t *)(d_off + gn), *d_crc = d_len + gn;
+        HIP_TRY(hipMemcpy(d_buf.p, gen->store + base, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_off, off.data(), (size_t)gn * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_len, len.data(), (size_t)gn * 4, hipMemcpyHostToDevice));
+        const int32_t rc = mzhip_crc32_batch(d_buf.p, d_off, d_len, gn, nullptr, d_crc, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(crc.data(), d_crc, (size_t)gn * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < gn; i++) gen->store_segs[s0 + i].crc = crc[i];
+        s0 = s1;
+    }
+    for (size_t i = 0; i < ns; i++) {
+        const PrimeGen::StoreSeg &sg = gen->store_segs[i];
+        if (sg.len >= 32u) gen->store_idx.emplace(store_key(gen->store + sg.off, sg.len), (uint32_t)i);
+    }
+    gen->store_entries = stores.size();
+    return 0;
+}
 } // namespace
 
 extern "C" {
@@ -1545,11 +1630,14 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
     std::vector<int64_t> max_out, wtab;
     uint64_t total_out = 0;
     int64_t nseg = 0;
+    std::vector<std::pair<int64_t, int64_t>> stores; /* STORE entries: payload offset, size */
     for (int64_t i = 0; i < n; i++) {
         const int64_t *t = &table[(size_t)i * 8];
-        if ((t[0] != 8 && t[0] != 14 && t[0] != 95) || (t[1] & 1) || t[7] < 0 || t[3] < 0 || t[4] < 0 ||
-            t[3] >= (1ll << 28) || t[4] >= (1ll << 31) || (uint64_t)t[7] > zip_len || (uint64_t)t[3] > zip_len - (uint64_t)t[7])
+        if ((t[1] & 1) || t[7] < 0 || t[3] < 0 || t[4] < 0 || t[3] >= (1ll << 31) || t[4] >= (1ll << 31) ||
+            (uint64_t)t[7] > zip_len || (uint64_t)t[3] > zip_len - (uint64_t)t[7])
             continue;
+        if (t[0] == 0 && t[3] == t[4] && t[4] >= (int64_t)MZHIP_CRC_HOST_BELOW) stores.emplace_back(t[7], t[4]);
+        if (t[0] != 8 && t[0] != 14 && t[0] != 95) continue;
         PrimedEntry e;
         memset(&e, 0, sizeof(e));
         e.method = (int32_t)t[0];
@@ -1568,7 +1656,7 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
         nseg += (t[4] + kSeg - 1) / kSeg;
     }
     const size_t k = ents.size();
-    if (k == 0) return 0;
+    if (k == 0 && stores.empty()) return 0;
     uint8_t *h_out = nullptr;
     bool out_pinned = hipHostMalloc((void **)&h_out, total_out + 16, hipHostMallocDefault) == hipSuccess;
     if (!out_pinned) {
@@ -1582,7 +1670,7 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
     };
     std::vector<uint32_t> r_len(k), r_used(k), r_crc(k), seg_crc((size_t)nseg);
     std::vector<int32_t> r_st(k, -1);
-    const int32_t world = (int32_t)std::min<size_t>(devs.size(), k);
+    const int32_t world = (int32_t)std::min<size_t>(devs.size(), std::max<size_t>(k, 1));
     std::vector<int64_t> bounds((size_t)world + 1);
     mzhip_shard_bounds(wtab.data(), (int64_t)k, world, bounds.data());
     std::vector<int32_t> rcs((size_t)world, 0);
@@ -1633,7 +1721,11 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
         const uint64_t cd0 = (uint64_t)table[6];
         gen->ident = fnv1a64(zip + cd0, zip_len - cd0);
     }
-    const int64_t n_good = (int64_t)gen->entries.size();
+    if (!stores.empty()) {
+        const int32_t src = prime_store(zip, stores, gen.get()); /* on the calling thread's device */
+        if (src) return src;
+    }
+    const int64_t n_good = (int64_t)gen->entries.size() + (int64_t)gen->store_entries;
     std::lock_guard<std::mutex> lk(g_prime_mu);
     auto &gens = g_prime.gens;
     for (size_t i = 0; i < gens.size();) { /* a re-prime of the same archive replaces its generation */
@@ -1642,6 +1734,7 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
     }
     gens.insert(gens.begin(), std::move(gen));
     if (gens.size() > kMaxGens) gens.resize(kMaxGens);
+    count_store_gens_locked();
     return n_good;
 }
 
@@ -1681,10 +1774,36 @@ void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses) {
     std::lock_guard<std::mutex> lk(g_prime_mu);
     if (entries) {
         *entries = 0;
-        for (const auto &g : g_prime.gens) *entries += g->entries.size();
+        for (const auto &g : g_prime.gens) *entries += g->entries.size() + g->store_entries;
     }
     if (hits) *hits = g_prime.hits;
     if (misses) *misses = g_prime.misses;
+}
+
+// Used by mz_crypt_crc32_update: are these `size` bytes a chunk of a primed STORE entry?  The fingerprint finds the
+// candidates, memcmp against the kept payload decides (so a file that changed between the prime and the read is
+// never answered with the old CRC).  1 = yes, *crc = the chunk's CRC-32 as the device computed it.
+__attribute__((visibility("hidden"))) int32_t mzhip_prime_store_crc(const uint8_t *buf, int32_t size, uint32_t *crc) {
+    if (g_store_gens.load(std::memory_order_relaxed) == 0 || size < 32 || (uint32_t)size > kSeg) return 0;
+    std::vector<std::shared_ptr<PrimeGen>> gens;
+    {
+        std::lock_guard<std::mutex> lk(g_prime_mu);
+        gens = g_prime.gens; /* the generations are immutable once published: search them without the lock */
+    }
+    const uint64_t key = store_key(buf, (uint32_t)size);
+    for (const std::shared_ptr<PrimeGen> &g : gens) {
+        auto range = g->store_idx.equal_range(key);
+        for (auto it = range.first; it != range.second; ++it) {
+            const PrimeGen::StoreSeg &sg = g->store_segs[it->second];
+            if (sg.len == (uint32_t)size && memcmp(buf, g->store + sg.off, (size_t)size) == 0) {
+                *crc = sg.crc;
+                std::lock_guard<std::mutex> lk(g_prime_mu);
+                g_prime.hits++;
+                return 1;
+            }
+        }
+    }
+    return 0;
 }
 
 // Used by the READ shims: is the entry whose payload starts at `payload_off` primed?  The stream presents the payload

@@ -10,6 +10,9 @@ int32_t mzhip_prime_lookup3(int32_t method, int64_t payload_off, const uint8_t *
                             const uint8_t **data, int64_t *usize, int64_t *csize, uint32_t *crc, const uint32_t **seg_crc,
                             void **pin);
 void mzhip_prime_unpin(void *pin);
+/* are these bytes one 65 535-byte reader chunk of a primed STORE entry?  1 = yes (*crc = its device-computed CRC-32;
+ * equality was checked byte for byte against the primed payload) */
+int32_t mzhip_prime_store_crc(const uint8_t *buf, int32_t size, uint32_t *crc);
 /* MZHIP_AUTOPRIME: prime the archive behind a codec stream's base on first use (shim_autoprime.c); no-op otherwise */
 struct mzhip_stream_s;
 void mzhip_autoprime(struct mzhip_stream_s *codec_base);

@@ -7,7 +7,8 @@
  * The bytes are reduced on the device (k_crc32_batch, wave-parallel tile
  * folding); there is no table-driven CPU loop in this file.  When the buffer is
  * one that a primed stream just served (see mzhip_prime_*), the device already
- * computed its CRC and only the GF(2) chaining arithmetic happens here.
+ * computed its CRC and only the GF(2) chaining arithmetic happens here; the same for a chunk of a primed STORE entry,
+ * recognised by content (fingerprint + memcmp against the primed payload).
  */
 #include <string.h>
 
@@ -30,5 +31,12 @@ uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int32_t size)
             return mzhip_crc32_combine(value, mzhip_last_served.crc, (uint64_t)size);
     }
     mzhip_last_served.valid = 0;
+    if (size >= (int32_t)MZHIP_CRC_HOST_BELOW) {
+        /* a chunk of a primed STORE entry (the raw stream handed it over untouched, mz_zip.c:2047-2049): the device
+         * computed its CRC when the archive was primed; byte-for-byte equality with the primed payload is checked */
+        uint32_t c;
+        if (mzhip_prime_store_crc(buf, size, &c))
+            return mzhip_crc32_combine(value, c, (uint64_t)size);
+    }
     return mzhip_crc32_host(value, buf, (size_t)size);
 }

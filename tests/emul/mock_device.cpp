@@ -115,6 +115,7 @@ extern "C" int32_t mzhip_prime_lookup3(int32_t, int64_t, const uint8_t *, int32_
     return 0;
 }
 extern "C" void mzhip_prime_unpin(void *) {}
+extern "C" int32_t mzhip_prime_store_crc(const uint8_t *, int32_t, uint32_t *) { return 0; }
 extern "C" int32_t mzhip_take_crc_fault(void) { return 0; }
 extern "C" int32_t mzhip_wprime_track(int32_t, int64_t *, int64_t, const uint8_t *, int32_t, uint32_t *, int32_t *have_crc) {
     *have_crc = 0;

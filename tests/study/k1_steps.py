@@ -42,6 +42,7 @@ def main():
     print("windows %d (%.0f output bytes each), passes per window %.2f, chunks per window %.2f" % (win, s[10] / win, passes / win, chunks / win))
     print("walk steps per window: %.1f in emitting passes + %.1f in counting passes = %.1f" % (s[7] / win, s[5] / win, (s[7] + s[5]) / win))
     print("block headers: %d code-length symbols through the 64-bit front end in %d steps, %d through the serial loop" % (s[16], s[18], s[17]))
+    print("span walks: %d length codes decoded, %.2f %% of them with a distance code longer than the root table" % (s[19], 100.0 * s[20] / max(1, s[19])))
     print("pieces per window %.0f, of them near %.0f, near rounds %.1f" % (s[12] / win, s[13] / win, s[14] / win))
 
 

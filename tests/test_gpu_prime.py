@@ -205,3 +205,60 @@ def test_prime_multi_device_slices_and_generations():
         L.mzhip_prime_clear()
         _, crc2, _, st2 = hip.zip_read_all(paths[1], cds[1][:20], nthreads=1, own_crc=False)
         assert (st2 == 0).all() and (crc2 == refs[1][0][:20]).all()
+
+
+def test_prime_serves_store_entries():
+    """STORE entries never meet a codec stream: the reference's raw stream hands their bytes straight to
+    mz_crypt_crc32_update, 65 535 at a time (mz_zip.c:2047-2049, mz_zip_rw.c:55).  A primed archive keeps those chunks
+    with device-computed CRCs and the CRC symbol recognises them by content (fingerprint, then memcmp): the
+    unmodified reader loop runs without a device round trip per chunk, entries still verify, and bytes that changed
+    after the prime are NOT answered from the cache (the reader reports the CRC error like the reference)."""
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    L = mz.lib()
+    L.mzhip_prime_file.restype = C.c_int64
+    L.mzhip_prime_file.argtypes = [C.c_char_p]
+    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    rnd = np.random.RandomState(8)
+    blob = rnd.randint(0, 256, size=6 << 20, dtype=np.uint8)
+    n = 300
+    lens = rnd.randint(0, 400000, size=n).astype(np.int32)
+    lens[:6] = (0, 1, 4095, 4096, 65535, 65536)                    # around the host-path threshold and one chunk
+    offs = rnd.randint(0, len(blob) - 400000, size=n).astype(np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "s.zip")
+        ref.zip_write(path, blob, offs, lens, method=0, level=0)
+        table = ref.zip_index(path)
+        assert (table[:, 0] == 0).all()
+        cd = table[:, 6].copy()
+        t_ref, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False)
+        assert (st_r == 0).all()
+        L.mzhip_prime_clear()
+        t_cold, crc_c, _, st_c = hip.zip_read_all(path, cd, nthreads=1, own_crc=False)   # one device call per chunk
+        assert (st_c == 0).all() and (crc_c == crc_r).all()
+        cached = L.mzhip_prime_file(path.encode())
+        assert cached == int((lens >= 4096).sum())
+        ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        h0 = hits.value
+        t_hip, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=1, own_crc=False)
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        assert (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all()
+        big = lens[lens >= 4096].astype(np.int64)
+        # every chunk of 4096 bytes or more was answered from the prime (the tails below the threshold are host-side)
+        want_hits = int(((big // 65535) + ((big % 65535) >= 4096)).sum())
+        assert hits.value - h0 == want_hits
+        print("STORE, 1 thread: reference %.3f s, drop-in per-chunk device calls %.3f s, primed %.3f s" % (t_ref, t_cold, t_hip))
+        assert t_hip < t_cold
+        # the file changes after the prime: same chunk fingerprints (first / last 16 bytes untouched), different bytes
+        raw = bytearray(open(path, "rb").read())
+        k = int(np.argmax(lens))
+        raw[int(table[k, 7]) + 30000] ^= 0x40
+        open(path, "wb").write(raw)
+        _, _, _, st_b = hip.zip_read_all(path, cd, nthreads=1, own_crc=False)
+        _, _, _, st_rb = ref.zip_read_all(path, cd, nthreads=1, own_crc=False)
+        assert st_b[k] != 0 and st_b[k] == st_rb[k] and (np.delete(st_b, k) == 0).all()
+        L.mzhip_prime_clear()
