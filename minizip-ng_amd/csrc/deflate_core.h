@@ -29,6 +29,21 @@
 #include "crc32_core.h"
 #include "wave.h"
 
+/* MZ_PROF (measurement builds): cycles per section of K4 go to mz_prof_buf[16..] (see inflate_core.h) */
+#if defined(MZ_PROF) && !defined(MZHIP_HOST_EMUL)
+#define MZ_DPROF_DECL uint32_t prof_acc = 0; uint64_t prof_t0 = __builtin_readcyclecounter();
+#define MZ_DPROF_MARK(i)                                                          \
+    do {                                                                          \
+        const uint32_t _pd = (uint32_t)(__builtin_readcyclecounter() - prof_t0);  \
+        prof_acc += (lane == (i)) ? _pd : 0u;                                     \
+        prof_t0 = __builtin_readcyclecounter();                                   \
+    } while (0)
+#define MZ_DPROF_FLUSH if (lane >= 16 && lane < 32) atomicAdd(&mz_prof_buf[lane], (unsigned long long)prof_acc);
+#else
+#define MZ_DPROF_DECL
+#define MZ_DPROF_MARK(i) ((void)0)
+#define MZ_DPROF_FLUSH
+#endif
 #ifndef MZ_DEF_HBITS
 #define MZ_DEF_HBITS 12
 #endif
@@ -316,6 +331,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     PV(uint32_t, crc_tmp);
     uint32_t crc_done = 0;
     MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
+    MZ_DPROF_DECL
 
     for (uint32_t blk = 0; blk < in_len || blk == 0u; blk += MZ_DEF_BLOCK) {
         const uint32_t blk_end = (in_len - blk < MZ_DEF_BLOCK) ? in_len : blk + MZ_DEF_BLOCK;
@@ -335,6 +351,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             const uint32_t pos = blk + (uint32_t)lane;
             P(vnx) = (pos + 4u <= blk_end) ? mz_load_u32(in + pos) : 0u;
         }
+        MZ_DPROF_MARK(16); /* block set-up: tables cleared */
         for (uint32_t p = blk; p < blk_end; p += 64u) {
             const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u; /* valid positions in this step */
             PV(uint32_t, hh);
@@ -362,6 +379,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
             }
             MZ_WAVE_SYNC();
+            MZ_DPROF_MARK(17); /* hash, candidates, bucket update */
             PV(uint32_t, pk); /* [8:0] match length (0 = literal), [24:9] distance | literal byte */
             PV(uint32_t, lit);
             PV(uint32_t, g1); /* 4 * successor lane; bit 12 set: terminal */
@@ -386,6 +404,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 P(pk) = mlen | ((mlen ? dist : 0u) << 9);
                 P(lit) = (uint32_t)in[pos < blk_end ? pos : blk];
             }
+            MZ_DPROF_MARK(18); /* match measurement */
             /* lazy evaluation (what zlib does from level 4 up): a match yields to a longer one starting at the
              * next position -- this position then goes out as a literal */
             PV(uint32_t, pkn);
@@ -428,6 +447,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
 #undef MZ_DEF_ROUND
             uint64_t live;
             MZ_BALLOT(live, !(P(cpos) & 0x1000u));
+            MZ_DPROF_MARK(19); /* lazy rule + greedy selection */
             const uint32_t ntok = mz_popc64(live); /* tokens sit in lanes 0..ntok-1 */
             PV(uint32_t, tpk);
             MZ_GATHER4(tpk, pk, P(cpos));
@@ -454,7 +474,9 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
             }
             ntokens += ntok;
+            MZ_DPROF_MARK(20); /* tokens out, histograms */
             MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, (p + nv), crc_tab, tabs->kx);
+            MZ_DPROF_MARK(21); /* CRC of the input */
         }
         MZ_LANES { L->freq[256] = 1u; } /* end of block */
         MZ_WAVE_SYNC();
@@ -602,6 +624,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 MZ_WAVE_SYNC();
             }
         }
+        MZ_DPROF_MARK(22); /* codes, block costs, header */
         /* ================= pass 2: the tokens' bits ================= */
         for (uint32_t t0 = 0; t0 < ntokens; t0 += 64u) {
             const uint32_t nt = (ntokens - t0 < 64u) ? (ntokens - t0) : 64u;
@@ -682,6 +705,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     }
 
 finish:
+    MZ_DPROF_MARK(23); /* pass 2: the tokens' bits */
     res->status = status;
     res->out_len = obyte;
     {
@@ -690,6 +714,7 @@ finish:
         MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, in, in_len, crc_tab, tabs);
         res->crc = crc;
     }
+    MZ_DPROF_FLUSH
 }
 
 #endif

@@ -112,6 +112,10 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_VIEW_MAX 0x0FFFFFFFu   /* bytes of the stream the 32-bit bit cursor can address at a time (see mz_inflate_entry) */
 #define MZ_REBASE_BITS (1u << 30) /* the view moves when the cursor is this far into it */
 #endif
+#ifndef MZ_SUBSPAN_EMIT
+#define MZ_SUBSPAN_EMIT 1 /* a pass that only emits splits every span of the chunk over three lanes (0: one lane per span) */
+#endif
+#define MZ_SPAN_LANES (MZ_SUBSPAN_EMIT ? 63u : 64u) /* spans per window: 63 = three chunks of 21, each emitted by 63 lanes */
 #ifndef MZ_CL_PARALLEL
 #define MZ_CL_PARALLEL 1 /* dynamic block headers: code lengths decoded 64 bits at a time (0: one symbol at a time) */
 #endif
@@ -968,7 +972,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                     const uint32_t S = 32u << ssh;
                     /* lanes whose every token lies inside the input (a token is at most 48 bits) */
                     uint32_t nact = (remain > 64u) ? (remain - 64u) / S : 0u;
-                    if (nact > 64u) nact = 64u;
+                    if (nact > MZ_SPAN_LANES) nact = MZ_SPAN_LANES;
                     if (span_on && qn == 0u && !span_skip && nact >= 2u) {
                         uint32_t *win = MZ_L_WIN(L);
                         const uint32_t wpos = bitpos + pbase;

@@ -5,9 +5,9 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "j_serial_header CLPAR=0"
-  "j_base"
-  "j_base_prof PROF=1"
+  "k_nosub SUBEMIT=0"
+  "k_sub"
+  "k_sub_prof PROF=1"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}

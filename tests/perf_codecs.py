@@ -174,3 +174,13 @@ if which in ("crc", "all"):
     ok = all(int(crc[i]) == zlib.crc32(h[i * size:(i + 1) * size].tobytes()) for i in range(3))
     print("CRC-32 batch: %d x %d B: %.1f ms  %.1f GiB/s  (%.2f TB/s)  ok=%s" % (n_total, size, ms, n_total * size / 2**30 / (ms / 1e3),
                                                                          n_total * size / 1e12 / (ms / 1e3), ok), flush=True)
+
+# measurement builds (make PROF=1): per-section cycle sums of K4
+if which in ("deflate", "both", "all") and hasattr(L, "mzhip_prof_read"):
+    buf = (C.c_ulonglong * 32)()
+    L.mzhip_prof_read(buf, 1)
+    names = {16: "block set-up", 17: "hash, candidates, bucket update", 18: "match measurement", 19: "lazy rule + greedy selection",
+             20: "tokens out, histograms", 21: "CRC of the input", 22: "codes, block costs, header", 23: "pass 2 (bits out)"}
+    tot = float(sum(buf[i] for i in names)) or 1.0
+    for i in sorted(names, key=lambda k: -buf[k]):
+        print("  %-36s %5.1f %%" % (names[i], 100.0 * buf[i] / tot))
