@@ -5,9 +5,12 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "k_nosub SUBEMIT=0"
-  "k_sub"
-  "k_sub_prof PROF=1"
+  "l_base"
+  "l_slots2 SLOTS=2"
+  "l_fs2 FSLOTS=2"
+  "l_emin20 EMIN=20"
+  "l_emin8 EMIN=8"
+  "l_pool3200_wpg2 POOL=3200 WPG=2"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}

@@ -40,6 +40,7 @@ def main():
     win, passes, chunks = s[8], s[9], s[15]
     print("%s, 200 x 64 KiB at level 6; flags %s" % (desc, " ".join(flags) or "(default)"))
     print("windows %d (%.0f output bytes each), passes per window %.2f, chunks per window %.2f" % (win, s[10] / win, passes / win, chunks / win))
+    print("chunks emitted on a pass the other lanes still count on (one lane per span): %.2f per window" % (s[21] / win))
     print("walk steps per window: %.1f in emitting passes + %.1f in counting passes = %.1f" % (s[7] / win, s[5] / win, (s[7] + s[5]) / win))
     print("block headers: %d code-length symbols through the 64-bit front end in %d steps, %d through the serial loop" % (s[16], s[18], s[17]))
     print("span walks: %d length codes decoded, %.2f %% of them with a distance code longer than the root table" % (s[19], 100.0 * s[20] / max(1, s[19])))
