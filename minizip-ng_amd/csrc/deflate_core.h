@@ -351,25 +351,60 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             const uint32_t pos = blk + (uint32_t)lane;
             P(vnx) = (pos + 4u <= blk_end) ? mz_load_u32(in + pos) : 0u;
         }
+        /* The step is software-pipelined: while step s measures its matches, step s + 1 has already looked up its
+         * candidates (the bucket update of step s is done by then) and its first sixteen bytes -- its own and the newest
+         * candidate's -- are on their way, so the measurement of a typical match (shorter than 16 bytes) never waits for
+         * memory.  *_n = what the look-up of the next step found. */
+        PV(uint32_t, hh_n);
+        PV(uint32_t, cand_n);
+        PV(uint32_t, own_n); /* the step's own four bytes (the literal is their low byte) */
+        PV2(uint32_t, candx_n, MZ_DEF_WAYS_BEST - 1u);
+        PV(uint32_t, pre_n); /* 1: pa_n / pb_n hold the first 16 bytes at the position and at the newest candidate */
+        PV2(uint32_t, pa_n, 4);
+        PV2(uint32_t, pb_n, 4);
+#define MZ_DEF_LOOKUP(pn)                                                                                              \
+        MZ_LANES {                                                                                                     \
+            const uint32_t pos = (pn) + (uint32_t)lane;                                                                \
+            const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;                                                    \
+            const uint32_t v = P(vnx);                                                                                 \
+            P(vnx) = (pos + 68u <= blk_end) ? mz_load_u32(in + pos + 64u) : 0u;                                        \
+            const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);                                               \
+            P(own_n) = v;                                                                                              \
+            P(hh_n) = have4 ? h : 0xFFFFFFFFu;                                                                         \
+            P(cand_n) = have4 ? (uint32_t)L->u.head[h] : 0u;                                                           \
+            for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++)                                                            \
+                P(candx_n)[w - 1u] = (have4 && w < ways) ? (uint32_t)xhead[((w - 1u) << MZ_DEF_HBITS) | h] : 0u;       \
+            const uint32_t d = (pos - P(cand_n)) & 0xFFFFu;                                                            \
+            uint32_t ok = (have4 && pos + 16u <= blk_end && d >= 1u && d <= max_dist && d <= pos - blk) ? 1u : 0u;     \
+            P(pre_n) = ok;                                                                                             \
+            if (ok) {                                                                                                  \
+                for (uint32_t k = 0; k < 4u; k++) {                                                                    \
+                    P(pa_n)[k] = mz_load_u32(in + pos + 4u * k);                                                       \
+                    P(pb_n)[k] = mz_load_u32(in + (pos - d) + 4u * k);                                                 \
+                }                                                                                                      \
+            }                                                                                                          \
+        }
+        MZ_DEF_LOOKUP(blk)
         MZ_DPROF_MARK(16); /* block set-up: tables cleared */
         for (uint32_t p = blk; p < blk_end; p += 64u) {
             const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u; /* valid positions in this step */
             PV(uint32_t, hh);
             PV(uint32_t, cand);
+            PV(uint32_t, own);
             PV2(uint32_t, candx, MZ_DEF_WAYS_BEST - 1u); /* the older positions of the bucket (ways > 1) */
+            PV(uint32_t, pre);
+            PV2(uint32_t, pa, 4);
+            PV2(uint32_t, pb, 4);
             MZ_LANES {
-                const uint32_t pos = p + (uint32_t)lane;
-                const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
-                const uint32_t v = P(vnx);
-                P(vnx) = (pos + 68u <= blk_end) ? mz_load_u32(in + pos + 64u) : 0u;
-                const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
-                P(hh) = have4 ? h : 0xFFFFFFFFu;
-                P(cand) = have4 ? (uint32_t)L->u.head[h] : 0u;
-                for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++)
-                    P(candx)[w - 1u] = (have4 && w < ways) ? (uint32_t)xhead[((w - 1u) << MZ_DEF_HBITS) | h] : 0u;
-            }
-            MZ_WAVE_SYNC();
-            MZ_LANES {
+                P(hh) = P(hh_n);
+                P(cand) = P(cand_n);
+                P(own) = P(own_n);
+                P(pre) = P(pre_n);
+                for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++) P(candx)[w - 1u] = P(candx_n)[w - 1u];
+                for (uint32_t k = 0; k < 4u; k++) {
+                    P(pa)[k] = P(pa_n)[k];
+                    P(pb)[k] = P(pb_n)[k];
+                }
                 if (P(hh) != 0xFFFFFFFFu) {
                     /* the bucket shifts by one: lanes that share a bucket write the same older entries, one of them
                      * wins way 0 */
@@ -379,7 +414,10 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 }
             }
             MZ_WAVE_SYNC();
-            MZ_DPROF_MARK(17); /* hash, candidates, bucket update */
+            if (p + 64u < blk_end) {
+                MZ_DEF_LOOKUP(p + 64u)
+            }
+            MZ_DPROF_MARK(17); /* bucket update, look-up of the next step */
             PV(uint32_t, pk); /* [8:0] match length (0 = literal), [24:9] distance | literal byte */
             PV(uint32_t, lit);
             PV(uint32_t, g1); /* 4 * successor lane; bit 12 set: terminal */
@@ -393,7 +431,20 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         const uint32_t d = (pos - (w ? P(candx)[w - 1u] : P(cand))) & 0xFFFFu;
                         /* the head table is cleared per block, so a candidate never precedes the block */
                         if (d >= 1u && d <= max_dist && d <= pos - blk && d != dist) {
-                            const uint32_t l = mz_match_len(in + pos, in + (pos - d), maxl);
+                            uint32_t l;
+                            if (w == 0u && P(pre)) { /* the first 16 bytes are here already */
+                                const uint32_t x0 = P(pa)[0] ^ P(pb)[0], x1 = P(pa)[1] ^ P(pb)[1], x2 = P(pa)[2] ^ P(pb)[2],
+                                               x3 = P(pa)[3] ^ P(pb)[3];
+                                if ((x0 | x1 | x2 | x3) == 0u) {
+                                    l = 16u + mz_match_len(in + pos + 16u, in + (pos - d) + 16u, maxl - 16u);
+                                } else {
+                                    const uint32_t x = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3;
+                                    const uint32_t k = x0 ? 0u : x1 ? 4u : x2 ? 8u : 12u;
+                                    l = k + ((31u - mz_clz32(x & (0u - x))) >> 3);
+                                }
+                            } else {
+                                l = mz_match_len(in + pos, in + (pos - d), maxl);
+                            }
                             if (l >= MZ_DEF_MINMATCH && l > mlen) {
                                 mlen = l;
                                 dist = d;
@@ -402,7 +453,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                     }
                 }
                 P(pk) = mlen | ((mlen ? dist : 0u) << 9);
-                P(lit) = (uint32_t)in[pos < blk_end ? pos : blk];
+                P(lit) = (P(hh) != 0xFFFFFFFFu) ? (P(own) & 0xFFu) : (uint32_t)in[pos < blk_end ? pos : blk];
             }
             MZ_DPROF_MARK(18); /* match measurement */
             /* lazy evaluation (what zlib does from level 4 up): a match yields to a longer one starting at the
@@ -478,6 +529,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, (p + nv), crc_tab, tabs->kx);
             MZ_DPROF_MARK(21); /* CRC of the input */
         }
+#undef MZ_DEF_LOOKUP
         MZ_LANES { L->freq[256] = 1u; } /* end of block */
         MZ_WAVE_SYNC();
         uint32_t extra_total;
