@@ -112,6 +112,18 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_VIEW_MAX 0x0FFFFFFFu   /* bytes of the stream the 32-bit bit cursor can address at a time (see mz_inflate_entry) */
 #define MZ_REBASE_BITS (1u << 30) /* the view moves when the cursor is this far into it */
 #endif
+#ifndef MZ_FUSED_EMIT
+#define MZ_FUSED_EMIT (!MZ_SUBSPAN_EMIT) /* 1: a chunk of >= MZ_EMIT_MIN_LANES verified lanes is emitted on a pass the other lanes still
+                                         count on (one lane per span); 0: every emit waits for convergence and uses three lanes per span.
+                                         Same step count either way (tests/study/k1_steps.py); 0 is less code and fewer registers */
+#endif
+#if !MZ_SUBSPAN_EMIT && !MZ_FUSED_EMIT
+#error "MZ_SUBSPAN_EMIT = 0 needs MZ_FUSED_EMIT = 1: nothing else would emit"
+#endif
+#ifndef MZ_NEAR_FRONTIER
+#define MZ_NEAR_FRONTIER 0 /* near copies: 0 = a pending bit per byte (24 rounds per text window), 1 = "source ends below the first
+                              unfinished destination" (one comparison per round, but 56 rounds: measured in tests/study/k1_steps.py) */
+#endif
 #ifndef MZ_SUBSPAN_EMIT
 #define MZ_SUBSPAN_EMIT 1 /* a pass that only emits splits every span of the chunk over three lanes (0: one lane per span) */
 #endif

@@ -5,12 +5,9 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "l_base"
-  "l_slots2 SLOTS=2"
-  "l_fs2 FSLOTS=2"
-  "l_emin20 EMIN=20"
-  "l_emin8 EMIN=8"
-  "l_pool3200_wpg2 POOL=3200 WPG=2"
+  "m_base"
+  "m_nofused FUSED=0"
+  "m_frontier FRONTIER=1"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}

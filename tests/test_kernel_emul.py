@@ -427,7 +427,9 @@ def emu_staged():
     return [_build_variant("s4", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=4608u", "-DMZ_NEAR_SLOTS=2", "-DMZ_SPAN_PRELIT=0"]),
             _build_variant("tiny", ["-DMZ_POOL_BYTES=2048u", "-DMZ_NEAR_SLOTS=1", "-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"]),
             _build_variant("s4tiny", ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=1024u", "-DMZ_FAR_SLOTS=2"]),
-            _build_variant("knobs", ["-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"])]
+            _build_variant("knobs", ["-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1", "-DMZ_SUBSPAN_EMIT=0"]),
+            _build_variant("fused", ["-DMZ_FUSED_EMIT=1", "-DMZ_EMIT_MIN_LANES=8u"]),
+            _build_variant("frontier", ["-DMZ_NEAR_FRONTIER=1", "-DMZ_CL_PARALLEL=0"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
