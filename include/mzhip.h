@@ -63,6 +63,7 @@ MZHIP_API const char *mzhip_version(void);
  * Results per entry: d_out_len (== PROP_TOTAL_OUT), d_in_used (== PROP_TOTAL_IN,
  * exact compressed bytes consumed, mz_zip.c:2090,2116), d_crc (CRC-32 of the
  * output, what mz_zip.c:2122 compares with the central directory), d_status.
+ * Any stream length the 32-bit d_in_len[] can describe (the reference streams any size).
  * Asynchronous on `stream`. */
 MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,
@@ -91,7 +92,7 @@ MZHIP_API int32_t mzhip_adler32_batch(const void *d_buf, const uint64_t *d_off, 
  * d_crc are clamped to it like mz_strm_lzma.c:214-215.  d_in_used counts the 9 header
  * bytes (ZIP accounting, mz_strm_lzma.c:124,198).  Status: 0, -3 data error, -5 input
  * ended early (mz_stream_lzma_read reports both as MZ_DATA_ERROR), -200 out_cap hit,
- * -109 for lc+lp > 3 (model does not fit the per-wave LDS slice). */
+ * lc + lp up to 4, as liblzma (the upper half of an lc + lp = 4 literal model lives in a per-wave HBM scratch). */
 MZHIP_API int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                                    const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out,
                                    uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,
@@ -103,7 +104,7 @@ MZHIP_API int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, c
  * (mz_strm_lzma.c:127-128,147-241) + mz_crypt_crc32_update (mz_zip.c:2049).  Entry i's input is one .xz stream
  * (stream header, blocks of LZMA2 chunks, index, footer); block checks none / CRC32 / CRC64 / SHA-256 are verified
  * on the device.  Same argument and status conventions as mzhip_lzma_batch; d_in_used = bytes through the stream
- * footer.  -109: filter chain other than a single LZMA2 filter, or lc + lp = 4. */
+ * footer.  -109: filter chain other than a single LZMA2 filter. */
 MZHIP_API int32_t mzhip_xz_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                                  const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out,
                                  uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,
