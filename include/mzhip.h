@@ -104,7 +104,8 @@ MZHIP_API int32_t mzhip_lzma_batch(const void *d_in, const uint64_t *d_in_off, c
  * (mz_strm_lzma.c:127-128,147-241) + mz_crypt_crc32_update (mz_zip.c:2049).  Entry i's input is one .xz stream
  * (stream header, blocks of LZMA2 chunks, index, footer); block checks none / CRC32 / CRC64 / SHA-256 are verified
  * on the device.  Same argument and status conventions as mzhip_lzma_batch; d_in_used = bytes through the stream
- * footer.  -109: filter chain other than a single LZMA2 filter. */
+ * footer.  Filter chains as liblzma 5.2.5 accepts them: LZMA2 last, up to three of Delta / BCJ (x86, PowerPC, IA-64, ARM,
+ * ARM-Thumb, SPARC) in front; any other chain is a data error (-3) like LZMA_OPTIONS_ERROR behind mz_stream_lzma_read. */
 MZHIP_API int32_t mzhip_xz_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                                  const uint64_t *d_out_off, const uint32_t *d_out_cap, const int64_t *d_max_out,
                                  uint32_t n, uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc,

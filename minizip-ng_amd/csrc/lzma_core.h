@@ -46,6 +46,12 @@
 #define LZ_LIT (LZ_REP_LEN + 514)
 #define LZ_NUM_PROBS (LZ_LIT + MZ_LZMA_LIT_PROBS)
 
+/* how far the fused CRC may fold: everything written -- except while an .xz block with Delta / BCJ filters is being
+ * decoded, whose bytes are not final before the filters are undone (xz_core.h redefines this) */
+#ifndef LZ_CRC_LIMIT
+#define LZ_CRC_LIMIT(o) (o)
+#endif
+
 typedef struct mz_lzma_lds {
     uint16_t probs[(LZ_NUM_PROBS + 1) & ~1u];
 } mz_lzma_lds;
@@ -230,7 +236,7 @@ typedef struct mz_lzma_result {
             prev_byte = sym & 0xFFu;                                                                                  \
             opos++;                                                                                                   \
             state = state < 4 ? 0 : (state < 10 ? state - 3 : state - 6);                                             \
-            if ((opos & (MZ_CRC_TILE - 1)) == 0) MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);  \
+            if ((opos & (MZ_CRC_TILE - 1)) == 0) MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx);  \
             continue;                                                                                                 \
         }                                                                                                             \
         uint32_t len;                                                                                                 \
@@ -256,7 +262,7 @@ typedef struct mz_lzma_result {
                     match_byte = LZ_U(out[opos - rep0 - 1]);                                                          \
                     state = state < 7 ? 9 : 11;                                                                       \
                     if ((opos & (MZ_CRC_TILE - 1)) == 0)                                                              \
-                        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);                           \
+                        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx);                           \
                     continue;                                                                                         \
                 }                                                                                                     \
             } else {                                                                                                  \
@@ -351,7 +357,7 @@ typedef struct mz_lzma_result {
             }                                                                                                         \
             prev_byte = LZ_U(out[opos - 1]);                                                                          \
             match_byte = LZ_U(out[opos - dist]);                                                                      \
-            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);                                       \
+            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx);                                       \
         }                                                                                                             \
     }
 

@@ -8,8 +8,12 @@
  * packet loop is the one K3 uses (lzma_core.h, LZ_PACKET_LOOP with lzma2 = 1).  Checks verified on the device:
  * none, CRC32, CRC64 (wave-parallel, hash_core.h), SHA-256 (the wave runs the chain redundantly); other check
  * ids are skipped unverified like lzma_stream_decoder does without LZMA_TELL_UNSUPPORTED_CHECK.
- * Framing is parsed by wave-uniform code (it is a few dozen bytes per block).  Filter chains other than a
- * single LZMA2 filter answer MZHIP_UNSUPPORTED.  lc + lp = 4: the upper half of the literal model lives in prx[] (HBM).
+ * Framing is parsed by wave-uniform code (it is a few dozen bytes per block).  Filter chains: LZMA2 last, behind it
+ * up to three of Delta and the BCJ filters x86 / PowerPC / IA-64 / ARM / ARM-Thumb / SPARC, what liblzma 5.2.5's
+ * lzma_stream_decoder accepts (filter_common.c); a block's bytes are unfiltered in place when the block is complete,
+ * 8 KiB at a time through the LDS of the probability model (dead between blocks), by wave-uniform byte code -- a BCJ
+ * scan is a serial state machine, and filtered entries are rare.  lc + lp = 4: the upper half of the literal model
+ * lives in prx[] (HBM).
  * Every framing / check / LZMA2 failure is MZHIP_DATA_ERROR (mz_stream_lzma_read maps all liblzma errors to
  * MZ_DATA_ERROR, mz_strm_lzma.c:236-237); input that ends early is MZHIP_BUF_ERROR.
  */
@@ -68,11 +72,174 @@ typedef struct mz_xz_lds {
         (dst) = _v;                                                                      \
     } while (0)
 
+/* ---- Delta / BCJ, decoding direction (liblzma 5.2.5 delta_decoder.c, simple/{x86,powerpc,ia64,arm,armthumb,sparc}.c;
+ * oracle/xz_dec.c restates them and is pinned against liblzma).  Streaming form: b[0 .. n) = bytes not yet final, now =
+ * their position in the block (+ the filter's start offset); returns how many leading bytes are final now, the rest
+ * is presented again with more data behind it.  All values wave-uniform (every lane runs the same bytes). ---- */
+#define XZ_FB(i) MZ_UNIFORM(b[(i)])
+#define XZ_FS(i, v) do { b[(i)] = (uint8_t)(v); } while (0)
+typedef struct mz_xz_filter {
+    uint32_t id, arg;             /* 3 = Delta (arg = distance), 4..9 = BCJ (arg = start offset) */
+    uint32_t prev_mask, prev_pos; /* x86 */
+    uint32_t hpos;                /* Delta: ring position */
+} mz_xz_filter;
+MZ_DEV uint32_t mz_xz_msb86(uint32_t c) { return (c == 0u || c == 0xFFu) ? 1u : 0u; }
+MZ_DEV uint32_t mz_xz_unfilter(mz_xz_filter *f, uint8_t *b, uint32_t n, uint32_t now, uint8_t *hist) {
+    if (f->id == 3u) { /* out[i] = in[i] + out[i - distance]; 256-byte ring like liblzma's */
+        uint32_t hp = f->hpos;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t v = (XZ_FB(i) + MZ_UNIFORM(hist[(f->arg + hp) & 0xFFu])) & 0xFFu;
+            XZ_FS(i, v);
+            hist[hp & 0xFFu] = (uint8_t)v;
+            hp--;
+        }
+        f->hpos = hp;
+        return n;
+    }
+    if (f->id == 4u) {
+        uint32_t prev_mask = f->prev_mask, prev_pos = f->prev_pos;
+        if (n < 5u) return 0u;
+        if (now - prev_pos > 5u) prev_pos = now - 5u;
+        const uint32_t limit = n - 5u;
+        uint32_t i = 0;
+        while (i <= limit) {
+            uint32_t c = XZ_FB(i);
+            if (c != 0xE8u && c != 0xE9u) {
+                i++;
+                continue;
+            }
+            const uint32_t off = now + i - prev_pos;
+            prev_pos = now + i;
+            if (off > 5u) {
+                prev_mask = 0;
+            } else {
+                for (uint32_t k = 0; k < off; k++) prev_mask = (prev_mask & 0x77u) << 1;
+            }
+            c = XZ_FB(i + 4u);
+            const uint32_t pm = prev_mask >> 1;
+            /* MASK_TO_ALLOWED_STATUS = {1,1,1,0,1,0,0,0}, MASK_TO_BIT_NUMBER = {0,1,2,2,3,3,3,3} */
+            if (mz_xz_msb86(c) && ((0x17u >> (pm & 7u)) & 1u) && pm < 0x10u) {
+                uint32_t src = (c << 24) | (XZ_FB(i + 3u) << 16) | (XZ_FB(i + 2u) << 8) | XZ_FB(i + 1u), dest;
+                for (;;) {
+                    dest = src - (now + i + 5u);
+                    if (prev_mask == 0u) break;
+                    const uint32_t k = (0xFFA4u >> (2u * (pm & 7u))) & 3u; /* (pm < 8 here: a set 0x10 has been shifted up at least once) */
+                    c = (dest >> (24u - k * 8u)) & 0xFFu;
+                    if (!mz_xz_msb86(c)) break;
+                    src = dest ^ ((1u << (32u - k * 8u)) - 1u);
+                }
+                XZ_FS(i + 4u, ~(((dest >> 24) & 1u) - 1u));
+                XZ_FS(i + 3u, dest >> 16);
+                XZ_FS(i + 2u, dest >> 8);
+                XZ_FS(i + 1u, dest);
+                i += 5u;
+                prev_mask = 0;
+            } else {
+                i++;
+                prev_mask |= 1u;
+                if (mz_xz_msb86(c)) prev_mask |= 0x10u;
+            }
+        }
+        f->prev_mask = prev_mask;
+        f->prev_pos = prev_pos;
+        return i;
+    }
+    if (f->id == 6u) { /* IA-64: 128-bit bundles, three 41-bit slots, branch slots by template */
+        uint32_t i = 0;
+        for (; i + 16u <= n; i += 16u) {
+            const uint32_t tmpl = XZ_FB(i) & 0x1Fu;
+            /* BRANCH_TABLE: templates 16,17 -> 4; 18,19 -> 6; 22,23 -> 7; 24,25 -> 4; 28,29 -> 4; else 0 */
+            const uint32_t mask = (tmpl == 16u || tmpl == 17u || tmpl == 24u || tmpl == 25u || tmpl == 28u || tmpl == 29u) ? 4u
+                                  : (tmpl == 18u || tmpl == 19u) ? 6u : (tmpl == 22u || tmpl == 23u) ? 7u : 0u;
+            uint32_t bit_pos = 5u;
+            for (uint32_t slot = 0; slot < 3u; slot++, bit_pos += 41u) {
+                if (((mask >> slot) & 1u) == 0u) continue;
+                const uint32_t byte_pos = bit_pos >> 3, bit_res = bit_pos & 7u;
+                uint64_t ins = 0;
+                for (uint32_t j = 0; j < 6u; j++) ins += (uint64_t)XZ_FB(i + j + byte_pos) << (8u * j);
+                uint64_t norm = ins >> bit_res;
+                if (((norm >> 37) & 0xFu) == 0x5u && ((norm >> 9) & 0x7u) == 0u) {
+                    uint32_t src = (uint32_t)((norm >> 13) & 0xFFFFFu);
+                    src |= (uint32_t)((norm >> 36) & 1u) << 20;
+                    src <<= 4;
+                    uint32_t dest = src - (now + i);
+                    dest >>= 4;
+                    norm &= ~((uint64_t)0x8FFFFF << 13);
+                    norm |= (uint64_t)(dest & 0xFFFFFu) << 13;
+                    norm |= (uint64_t)(dest & 0x100000u) << (36 - 20);
+                    ins &= ((uint64_t)1 << bit_res) - 1u;
+                    ins |= norm << bit_res;
+                    for (uint32_t j = 0; j < 6u; j++) XZ_FS(i + j + byte_pos, ins >> (8u * j));
+                }
+            }
+        }
+        return i;
+    }
+    if (f->id == 8u) { /* ARM-Thumb: BL pairs on 2-byte boundaries */
+        uint32_t i = 0;
+        for (; i + 4u <= n; i += 2u) {
+            const uint32_t b1 = XZ_FB(i + 1u), b3 = XZ_FB(i + 3u);
+            if ((b1 & 0xF8u) == 0xF0u && (b3 & 0xF8u) == 0xF8u) {
+                uint32_t src = ((b1 & 7u) << 19) | (XZ_FB(i) << 11) | ((b3 & 7u) << 8) | XZ_FB(i + 2u);
+                src <<= 1;
+                uint32_t dest = src - (now + i + 4u);
+                dest >>= 1;
+                XZ_FS(i + 1u, 0xF0u | ((dest >> 19) & 7u));
+                XZ_FS(i, dest >> 11);
+                XZ_FS(i + 3u, 0xF8u | ((dest >> 8) & 7u));
+                XZ_FS(i + 2u, dest);
+                i += 2u;
+            }
+        }
+        return i;
+    }
+    { /* PowerPC (5), ARM (7), SPARC (9): one 32-bit instruction at a time */
+        uint32_t i = 0;
+        for (; i + 4u <= n; i += 4u) {
+            const uint32_t b0 = XZ_FB(i), b1 = XZ_FB(i + 1u), b2 = XZ_FB(i + 2u), b3 = XZ_FB(i + 3u);
+            if (f->id == 5u) {
+                if ((b0 >> 2) == 0x12u && (b3 & 3u) == 1u) {
+                    const uint32_t src = ((b0 & 3u) << 24) | (b1 << 16) | (b2 << 8) | (b3 & ~3u);
+                    const uint32_t dest = src - (now + i);
+                    XZ_FS(i, 0x48u | ((dest >> 24) & 3u));
+                    XZ_FS(i + 1u, dest >> 16);
+                    XZ_FS(i + 2u, dest >> 8);
+                    XZ_FS(i + 3u, (b3 & 3u) | (dest & 0xFCu));
+                }
+            } else if (f->id == 7u) {
+                if (b3 == 0xEBu) {
+                    uint32_t src = ((b2 << 16) | (b1 << 8) | b0) << 2;
+                    const uint32_t dest = (src - (now + i + 8u)) >> 2;
+                    XZ_FS(i + 2u, dest >> 16);
+                    XZ_FS(i + 1u, dest >> 8);
+                    XZ_FS(i, dest);
+                }
+            } else {
+                if ((b0 == 0x40u && (b1 & 0xC0u) == 0x00u) || (b0 == 0x7Fu && (b1 & 0xC0u) == 0xC0u)) {
+                    uint32_t src = ((b0 << 24) | (b1 << 16) | (b2 << 8) | b3) << 2;
+                    uint32_t dest = (src - (now + i)) >> 2;
+                    dest = (((0u - ((dest >> 22) & 1u)) << 22) & 0x3FFFFFFFu) | (dest & 0x3FFFFFu) | 0x40000000u;
+                    XZ_FS(i, dest >> 24);
+                    XZ_FS(i + 1u, dest >> 16);
+                    XZ_FS(i + 2u, dest >> 8);
+                    XZ_FS(i + 3u, dest);
+                }
+            }
+        }
+        return i;
+    }
+}
+#undef XZ_FB
+#undef XZ_FS
+#define MZ_XZ_FCHUNK 8192u /* bytes of a block unfiltered per round (+ up to 15 carried over) */
+
 MZ_DEV uint64_t mz_xz_mix(uint64_t h, uint64_t v) {
     h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
     return h * 0xFF51AFD7ED558CCDull;
 }
 
+#undef LZ_CRC_LIMIT
+#define LZ_CRC_LIMIT(o) ((o) < crc_hold ? (o) : crc_hold) /* a filtered block's bytes are not final until it ends */
 /* Decode one method-95 entry.  All arguments wave-uniform.  max_out < 0: no clamp. */
 MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                         mz_xz_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs, uint16_t *prx,
@@ -95,6 +262,7 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
     PV(uint32_t, crc_acc);
     PV(uint32_t, crc_tmp);
     uint32_t crc_done = 0;
+    uint32_t crc_hold = 0xFFFFFFFFu; /* the fused CRC folds no further than this (start of a filtered block in progress) */
     MZ_LANES {
         P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u;
         P(win) = 0;
@@ -137,22 +305,59 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                 if (want_csize == 0) goto finish;
             }
             if (bflags & 0x80u) XZ_VLI(want_usize, p, hend, MZHIP_DATA_ERROR);
-            {
+            /* filter flags (3.1.5, 5.3): LZMA2 last; in front of it Delta and BCJ filters (filter_common.c: only
+             * LZMA2 may be last, only these may stand before it).  Anything else is LZMA_OPTIONS_ERROR = a data error. */
+            mz_xz_filter pre0, pre1, pre2, fnew; /* (three named slots, not an array: a dynamic index would put them in scratch) */
+            uint32_t npre = 0;
+            pre0.id = pre1.id = pre2.id = 0;
+            pre0.arg = pre1.arg = pre2.arg = 0;
+            pre0.prev_mask = pre1.prev_mask = pre2.prev_mask = 0;
+            pre0.prev_pos = pre1.prev_pos = pre2.prev_pos = 0;
+            pre0.hpos = pre1.hpos = pre2.hpos = 0;
+#define XZ_PUSH_FILTER()                  \
+    do {                                  \
+        if (npre == 0u) pre0 = fnew;      \
+        else if (npre == 1u) pre1 = fnew; \
+        else pre2 = fnew;                 \
+        npre++;                           \
+    } while (0)
+            const uint32_t nfilt = (bflags & 3u) + 1u;
+            for (uint32_t fi = 0; fi < nfilt; fi++) {
                 uint64_t id, psize;
                 XZ_VLI(id, p, hend, MZHIP_DATA_ERROR);
                 XZ_VLI(psize, p, hend, MZHIP_DATA_ERROR);
                 if (psize > hend - p) goto finish;
-                if (id != 0x21 || (bflags & 3u) != 0) {
-                    status = MZHIP_UNSUPPORTED; /* delta / BCJ chains */
+                if (fi + 1u == nfilt) {
+                    if (id != 0x21 || psize != 1) goto finish;
+                    const uint32_t db = XZ_BYTE(p);
+                    p++;
+                    if (db > 40) goto finish;
+                    dict = db == 40 ? 0xFFFFFFFFull : (uint64_t)(2u | (db & 1u)) << (db / 2u + 11u);
+                    if (dict < 4096) dict = 4096;
+                    dict = (dict + 15) & ~(uint64_t)15;
+                } else if (id == 0x03) {
+                    if (psize != 1) goto finish;
+                    fnew.id = 3u;
+                    fnew.arg = XZ_BYTE(p) + 1u;
+                    fnew.prev_mask = fnew.prev_pos = fnew.hpos = 0;
+                    XZ_PUSH_FILTER();
+                    p++;
+                } else if (id >= 0x04 && id <= 0x09) {
+                    uint32_t so = 0;
+                    if (psize == 4) so = XZ_LE32(p);
+                    else if (psize != 0) goto finish;
+                    const uint32_t al = id == 4 ? 1u : id == 6 ? 16u : id == 8 ? 2u : 4u;
+                    if (so & (al - 1u)) goto finish; /* misaligned start offset */
+                    fnew.id = (uint32_t)id;
+                    fnew.arg = so;
+                    fnew.prev_mask = 0;
+                    fnew.prev_pos = 0xFFFFFFFBu; /* (uint32_t)-5 */
+                    fnew.hpos = 0;
+                    XZ_PUSH_FILTER();
+                    p += (uint32_t)psize;
+                } else {
                     goto finish;
                 }
-                if (psize != 1) goto finish;
-                const uint32_t db = XZ_BYTE(p);
-                p++;
-                if (db > 40) goto finish;
-                dict = db == 40 ? 0xFFFFFFFFull : (uint64_t)(2u | (db & 1u)) << (db / 2u + 11u);
-                if (dict < 4096) dict = 4096;
-                dict = (dict + 15) & ~(uint64_t)15;
             }
             for (; p < hend; p++)
                 if (XZ_BYTE(p) != 0) goto finish; /* header padding */
@@ -160,6 +365,7 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
 
             /* ---- LZMA2 chunks ---- */
             const uint32_t data_pos = pos, block_out = opos;
+            if (npre) crc_hold = block_out;
             uint32_t need_props = 1, need_dict_reset = 1;
             for (;;) {
                 XZ_NEED(1);
@@ -258,7 +464,7 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
                     MZ_WAVE_SYNC();
                     opos += n;
                     pos += n;
-                    MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, opos, crc_tab, tabs->kx);
+                    MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx);
                     if (full) {
                         status = MZHIP_OUT_FULL;
                         goto finish;
@@ -273,6 +479,50 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
             const uint32_t csize_blk = pos - data_pos, usize_blk = opos - block_out;
             if ((want_csize != ~0ull && want_csize != csize_blk) || (want_usize != ~0ull && want_usize != usize_blk))
                 goto finish;
+            if (npre) {
+                /* undo the filters, last applied first, 8 KiB of the block at a time: the bytes go through the LDS of the
+                 * probability model (every block re-initialises it with its first chunk), where wave-uniform code runs
+                 * the filter; bytes the filter cannot decide yet (< 16) are carried into the next round */
+                uint8_t *fb = (uint8_t *)pr;         /* MZ_XZ_FCHUNK + 16 bytes of staging ... */
+                uint8_t *hist = fb + MZ_XZ_FCHUNK + 16u; /* ... and Delta's 256-byte ring behind it */
+                for (uint32_t fi = 3u; fi-- > 0u;) {
+                    if (fi >= npre) continue;
+                    mz_xz_filter flt = fi == 0u ? pre0 : fi == 1u ? pre1 : pre2;
+                    uint32_t done = 0, carry = 0; /* bytes final so far; bytes sitting in fb[0 .. carry) */
+                    if (flt.id == 3u) {
+                        MZ_LANES {
+                            for (uint32_t i = (uint32_t)lane; i < 256u; i += 64u) hist[i] = 0;
+                        }
+                        MZ_WAVE_SYNC();
+                    }
+                    while (done + carry < usize_blk) {
+                        uint32_t take = usize_blk - done - carry;
+                        if (take > MZ_XZ_FCHUNK) take = MZ_XZ_FCHUNK;
+                        const uint8_t *src = out + block_out + done + carry;
+                        MZ_LANES {
+                            for (uint32_t i = (uint32_t)lane; i < take; i += 64u) fb[carry + i] = src[i];
+                        }
+                        MZ_WAVE_SYNC();
+                        const uint32_t have = carry + take;
+                        const uint32_t fin = mz_xz_unfilter(&flt, fb, have, flt.id == 3u ? 0u : flt.arg + done, hist);
+                        MZ_WAVE_SYNC();
+                        uint8_t *dst = out + block_out + done;
+                        MZ_LANES {
+                            for (uint32_t i = (uint32_t)lane; i < fin; i += 64u) dst[i] = fb[i];
+                        }
+                        MZ_WAVE_SYNC();
+                        carry = have - fin;
+                        MZ_LANES { /* (carry < 16: one lane each) */
+                            if ((uint32_t)lane < carry) fb[lane] = fb[fin + (uint32_t)lane];
+                        }
+                        MZ_WAVE_SYNC();
+                        done += fin;
+                        if (fin == 0u && take == 0u) break;
+                    }
+                    /* what is left in the carry never had enough bytes behind it: it stays as it is */
+                }
+                crc_hold = 0xFFFFFFFFu;
+            }
             while ((pos - data_pos) & 3u) {
                 XZ_NEED(1);
                 if (XZ_BYTE(pos) != 0) goto finish;
@@ -365,5 +615,7 @@ finish:
         res->crc = crc;
     }
 }
+#undef LZ_CRC_LIMIT
+#define LZ_CRC_LIMIT(o) (o)
 
 #endif

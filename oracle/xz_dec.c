@@ -10,8 +10,13 @@
  * other check IDs are skipped unverified, as lzma_stream_decoder does without LZMA_TELL_UNSUPPORTED_CHECK.
  * flags = 0 means: exactly one stream, no stream padding, no concatenation.
  *
- * Filter chain: a single LZMA2 filter (what mz_stream_lzma_open writes, mz_strm_lzma.c:86-89,106).  Delta / BCJ
- * filters are outside SURVEY 8's scope and answer ORC_UNSUPPORTED here and MZHIP_STATUS_UNSUPPORTED on the device.
+ * Filter chain: LZMA2 last (what mz_stream_lzma_open writes alone, mz_strm_lzma.c:86-89,106), behind it up to three
+ * of the filters liblzma 5.2.5 knows -- Delta (0x03) and the BCJ filters x86 (0x04), PowerPC (0x05), IA-64 (0x06), ARM
+ * (0x07), ARM-Thumb (0x08), SPARC (0x09) -- as lzma_stream_decoder(flags 0) accepts them behind mz_strm_lzma.c:127-128.
+ * The filters are third-party code that is not under /root/reference (liblzma 5.2.5: src/liblzma/delta/delta_decoder.c,
+ * src/liblzma/simple/{x86,powerpc,ia64,arm,armthumb,sparc}.c, the chain rules of common/filter_common.c); restated here
+ * from the format (".xz File Format" 1.0.4, 5.3) and pinned against liblzma itself in tests/test_oracle.py (Python's
+ * lzma module is that library).  Anything else in the chain is LZMA_OPTIONS_ERROR there, a data error here.
  */
 #include "lzma_model.h"
 
@@ -219,6 +224,139 @@ static int32_t lzma2_block(lz_t *z, cur_t *c) {
     }
 }
 
+/* ---- the filters in front of LZMA2, decoding direction, over one whole block (a filter only looks at the bytes and at
+ * their position in the block, so one call over the block equals liblzma's buffered calls) ---- */
+static void unfilter_delta(uint8_t *b, size_t n, unsigned dist) {
+    for (size_t i = dist; i < n; i++) b[i] = (uint8_t)(b[i] + b[i - dist]);
+}
+static int msbyte86(uint8_t b) { return b == 0 || b == 0xFF; }
+static void unfilter_x86(uint8_t *b, size_t n, uint32_t now) {
+    static const uint8_t allowed[8] = {1, 1, 1, 0, 1, 0, 0, 0}, bitnum[8] = {0, 1, 2, 2, 3, 3, 3, 3};
+    uint32_t prev_mask = 0, prev_pos = (uint32_t)-5;
+    if (n < 5) return;
+    if (now - prev_pos > 5) prev_pos = now - 5;
+    const size_t limit = n - 5;
+    size_t i = 0;
+    while (i <= limit) {
+        uint8_t c = b[i];
+        if (c != 0xE8 && c != 0xE9) {
+            i++;
+            continue;
+        }
+        const uint32_t off = now + (uint32_t)i - prev_pos;
+        prev_pos = now + (uint32_t)i;
+        if (off > 5) {
+            prev_mask = 0;
+        } else {
+            for (uint32_t k = 0; k < off; k++) {
+                prev_mask &= 0x77;
+                prev_mask <<= 1;
+            }
+        }
+        c = b[i + 4];
+        if (msbyte86(c) && allowed[(prev_mask >> 1) & 7] && (prev_mask >> 1) < 0x10) {
+            uint32_t src = ((uint32_t)c << 24) | ((uint32_t)b[i + 3] << 16) | ((uint32_t)b[i + 2] << 8) | b[i + 1], dest;
+            for (;;) {
+                dest = src - (now + (uint32_t)i + 5);
+                if (prev_mask == 0) break;
+                const uint32_t k = bitnum[prev_mask >> 1];
+                c = (uint8_t)(dest >> (24 - k * 8));
+                if (!msbyte86(c)) break;
+                src = dest ^ ((1u << (32 - k * 8)) - 1);
+            }
+            b[i + 4] = (uint8_t)~(((dest >> 24) & 1) - 1);
+            b[i + 3] = (uint8_t)(dest >> 16);
+            b[i + 2] = (uint8_t)(dest >> 8);
+            b[i + 1] = (uint8_t)dest;
+            i += 5;
+            prev_mask = 0;
+        } else {
+            i++;
+            prev_mask |= 1;
+            if (msbyte86(c)) prev_mask |= 0x10;
+        }
+    }
+}
+static void unfilter_powerpc(uint8_t *b, size_t n, uint32_t now) {
+    for (size_t i = 0; i + 4 <= n; i += 4)
+        if ((b[i] >> 2) == 0x12 && (b[i + 3] & 3) == 1) {
+            const uint32_t src = ((uint32_t)(b[i] & 3) << 24) | ((uint32_t)b[i + 1] << 16) | ((uint32_t)b[i + 2] << 8) | (b[i + 3] & ~3u);
+            const uint32_t dest = src - (now + (uint32_t)i);
+            b[i] = (uint8_t)(0x48 | ((dest >> 24) & 3));
+            b[i + 1] = (uint8_t)(dest >> 16);
+            b[i + 2] = (uint8_t)(dest >> 8);
+            b[i + 3] = (uint8_t)((b[i + 3] & 3) | (dest & ~3u));
+        }
+}
+static void unfilter_ia64(uint8_t *b, size_t n, uint32_t now) {
+    static const uint8_t branch[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 6, 6, 0, 0, 7, 7, 4, 4, 0, 0, 4, 4, 0, 0};
+    for (size_t i = 0; i + 16 <= n; i += 16) {
+        const uint32_t mask = branch[b[i] & 0x1F];
+        uint32_t bit_pos = 5;
+        for (unsigned slot = 0; slot < 3; slot++, bit_pos += 41) {
+            if (((mask >> slot) & 1) == 0) continue;
+            const size_t byte_pos = bit_pos >> 3;
+            const uint32_t bit_res = bit_pos & 7;
+            uint64_t ins = 0;
+            for (unsigned j = 0; j < 6; j++) ins += (uint64_t)b[i + j + byte_pos] << (8 * j);
+            uint64_t norm = ins >> bit_res;
+            if (((norm >> 37) & 0xF) == 0x5 && ((norm >> 9) & 0x7) == 0) {
+                uint32_t src = (uint32_t)((norm >> 13) & 0xFFFFF);
+                src |= (uint32_t)((norm >> 36) & 1) << 20;
+                src <<= 4;
+                uint32_t dest = src - (now + (uint32_t)i);
+                dest >>= 4;
+                norm &= ~((uint64_t)0x8FFFFF << 13);
+                norm |= (uint64_t)(dest & 0xFFFFF) << 13;
+                norm |= (uint64_t)(dest & 0x100000) << (36 - 20);
+                ins &= ((uint64_t)1 << bit_res) - 1;
+                ins |= norm << bit_res;
+                for (unsigned j = 0; j < 6; j++) b[i + j + byte_pos] = (uint8_t)(ins >> (8 * j));
+            }
+        }
+    }
+}
+static void unfilter_arm(uint8_t *b, size_t n, uint32_t now) {
+    for (size_t i = 0; i + 4 <= n; i += 4)
+        if (b[i + 3] == 0xEB) {
+            uint32_t src = ((uint32_t)b[i + 2] << 16) | ((uint32_t)b[i + 1] << 8) | b[i];
+            src <<= 2;
+            uint32_t dest = src - (now + (uint32_t)i + 8);
+            dest >>= 2;
+            b[i + 2] = (uint8_t)(dest >> 16);
+            b[i + 1] = (uint8_t)(dest >> 8);
+            b[i] = (uint8_t)dest;
+        }
+}
+static void unfilter_armthumb(uint8_t *b, size_t n, uint32_t now) {
+    for (size_t i = 0; i + 4 <= n; i += 2)
+        if ((b[i + 1] & 0xF8) == 0xF0 && (b[i + 3] & 0xF8) == 0xF8) {
+            uint32_t src = ((uint32_t)(b[i + 1] & 7) << 19) | ((uint32_t)b[i] << 11) | ((uint32_t)(b[i + 3] & 7) << 8) | b[i + 2];
+            src <<= 1;
+            uint32_t dest = src - (now + (uint32_t)i + 4);
+            dest >>= 1;
+            b[i + 1] = (uint8_t)(0xF0 | ((dest >> 19) & 7));
+            b[i] = (uint8_t)(dest >> 11);
+            b[i + 3] = (uint8_t)(0xF8 | ((dest >> 8) & 7));
+            b[i + 2] = (uint8_t)dest;
+            i += 2;
+        }
+}
+static void unfilter_sparc(uint8_t *b, size_t n, uint32_t now) {
+    for (size_t i = 0; i + 4 <= n; i += 4)
+        if ((b[i] == 0x40 && (b[i + 1] & 0xC0) == 0x00) || (b[i] == 0x7F && (b[i + 1] & 0xC0) == 0xC0)) {
+            uint32_t src = ((uint32_t)b[i] << 24) | ((uint32_t)b[i + 1] << 16) | ((uint32_t)b[i + 2] << 8) | b[i + 3];
+            src <<= 2;
+            uint32_t dest = src - (now + (uint32_t)i);
+            dest >>= 2;
+            dest = (((0 - ((dest >> 22) & 1)) << 22) & 0x3FFFFFFF) | (dest & 0x3FFFFF) | 0x40000000;
+            b[i] = (uint8_t)(dest >> 24);
+            b[i + 1] = (uint8_t)(dest >> 16);
+            b[i + 2] = (uint8_t)(dest >> 8);
+            b[i + 3] = (uint8_t)dest;
+        }
+}
+
 int32_t orc_xz_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, int64_t max_out, size_t *in_used,
                       size_t *out_len) {
     static const uint8_t magic[6] = {0xFD, '7', 'z', 'X', 'Z', 0x00};
@@ -276,7 +414,10 @@ int32_t orc_xz_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
             p += used;
         }
         uint64_t dict = 0;
-        for (unsigned f = 0; f <= (bflags & 3u); f++) {
+        unsigned pre_id[3], npre = 0; /* the filters in front of LZMA2, in header order */
+        uint32_t pre_arg[3];          /* delta: distance; BCJ: start offset */
+        const unsigned nfilt = (bflags & 3u) + 1u;
+        for (unsigned f = 0; f < nfilt; f++) {
             uint64_t id, psize;
             if (vli(in + p, hend - p, &used, &id) != 0)
                 goto done;
@@ -284,13 +425,29 @@ int32_t orc_xz_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
             if (vli(in + p, hend - p, &used, &psize) != 0 || psize > hend - p - used)
                 goto done;
             p += used;
-            if (id != 0x21 || (bflags & 3u) != 0) {
-                ret = ORC_UNSUPPORTED; /* delta / BCJ chains: outside this backend's scope */
-                goto done;
+            if (f + 1 == nfilt) { /* the last filter must be LZMA2 (filter_common.c: last_ok) */
+                if (id != 0x21 || psize != 1 || in[p] > 40)
+                    goto done; /* LZMA_OPTIONS_ERROR */
+                dict = in[p] == 40 ? 0xFFFFFFFFull : (uint64_t)(2u | (in[p] & 1u)) << (in[p] / 2 + 11);
+            } else if (id == 0x03) { /* Delta: one byte, distance - 1 */
+                if (psize != 1)
+                    goto done;
+                pre_id[npre] = 3;
+                pre_arg[npre++] = (uint32_t)in[p] + 1u;
+            } else if (id >= 0x04 && id <= 0x09) { /* BCJ: no properties, or a 32-bit start offset */
+                static const uint8_t align[6] = {1, 4, 16, 4, 2, 4};
+                uint32_t so = 0;
+                if (psize == 4)
+                    so = le32(in + p);
+                else if (psize != 0)
+                    goto done;
+                if (so & (align[id - 4] - 1u))
+                    goto done; /* LZMA_OPTIONS_ERROR: misaligned start offset */
+                pre_id[npre] = (unsigned)id;
+                pre_arg[npre++] = so;
+            } else {
+                goto done; /* unknown filter, or LZMA2 where it cannot stand: LZMA_OPTIONS_ERROR */
             }
-            if (psize != 1 || in[p] > 40)
-                goto done; /* LZMA_OPTIONS_ERROR */
-            dict = in[p] == 40 ? 0xFFFFFFFFull : (uint64_t)(2u | (in[p] & 1u)) << (in[p] / 2 + 11);
             p += (size_t)psize;
         }
         for (; p < hend; p++)
@@ -312,6 +469,19 @@ int32_t orc_xz_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
         const uint64_t csize = c.pos - data_pos, usize = z->opos - out_pos0;
         if ((want_csize != UINT64_MAX && want_csize != csize) || (want_usize != UINT64_MAX && want_usize != usize))
             goto done;
+        for (unsigned f = npre; f-- > 0;) { /* undo the filters, last applied first */
+            uint8_t *b = out + out_pos0;
+            const size_t n = (size_t)usize;
+            switch (pre_id[f]) {
+            case 3: unfilter_delta(b, n, pre_arg[f]); break;
+            case 4: unfilter_x86(b, n, pre_arg[f]); break;
+            case 5: unfilter_powerpc(b, n, pre_arg[f]); break;
+            case 6: unfilter_ia64(b, n, pre_arg[f]); break;
+            case 7: unfilter_arm(b, n, pre_arg[f]); break;
+            case 8: unfilter_armthumb(b, n, pre_arg[f]); break;
+            default: unfilter_sparc(b, n, pre_arg[f]); break;
+            }
+        }
         while ((c.pos - data_pos) & 3) {
             if (!need(&c, 1)) {
                 ret = ORC_BUF_ERROR;

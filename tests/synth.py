@@ -212,6 +212,113 @@ def xz_cases():
     cases.append(("multi-block", b"".join(parts), xz_join([lzma.compress(p, format=lzma.FORMAT_XZ) for p in parts])))
     cases.append(("multi-block-sha", b"".join(parts),
                   xz_join([lzma.compress(p, format=lzma.FORMAT_XZ, check=lzma.CHECK_SHA256) for p in parts])))
+    cases += xz_filter_cases()
+    return cases
+
+
+def _branch_soup(rnd, n, kind):
+    """n bytes of noise in which the branch patterns the BCJ filter `kind` converts are frequent"""
+    b = bytearray(rnd.randrange(256) for _ in range(n))
+    i = 0
+    while i + 16 < n:
+        r = rnd.random()
+        if kind == "x86" and r < 0.3:
+            b[i] = rnd.choice((0xE8, 0xE9))
+            b[i + 4] = rnd.choice((0x00, 0xFF, 0x00, 0xFF, rnd.randrange(256)))
+            if rnd.random() < 0.3:
+                b[i + 1] = rnd.choice((0xE8, 0xE9))       # calls on top of each other: the prev_mask paths
+            i += rnd.randrange(1, 9)
+        elif kind == "arm" and r < 0.3:
+            b[(i & ~3) + 3] = 0xEB
+            i += 4
+        elif kind == "armthumb" and r < 0.4:
+            j = i & ~1
+            b[j + 1] = 0xF0 | rnd.randrange(8)
+            b[j + 3] = 0xF8 | rnd.randrange(8)
+            i += rnd.choice((2, 2, 4, 6))                  # overlapping candidates: the skip-after-a-pair rule
+        elif kind == "powerpc" and r < 0.3:
+            j = i & ~3
+            b[j] = 0x48 | rnd.randrange(4)
+            b[j + 3] = (b[j + 3] & ~3) | 1
+            i += 4
+        elif kind == "sparc" and r < 0.3:
+            j = i & ~3
+            if rnd.random() < 0.5:
+                b[j], b[j + 1] = 0x40, b[j + 1] & 0x3F
+            else:
+                b[j], b[j + 1] = 0x7F, b[j + 1] | 0xC0
+            i += 4
+        elif kind == "ia64" and r < 0.5:
+            j = i & ~15
+            b[j] = (b[j] & 0xE0) | rnd.choice((16, 17, 18, 19, 22, 23, 24, 25, 28, 29))
+            for k in range(1, 16):
+                if rnd.random() < 0.5:
+                    b[j + k] = rnd.choice((0x00, 0x50, 0xA0, 0x0A, 0x28, 0x14, 0x05))
+            i += 16
+        else:
+            i += rnd.randrange(1, 7)
+    return bytes(b)
+
+
+def xz_bad_chain_cases():
+    """(name, xz_stream): block headers whose filter chain liblzma refuses (LZMA_OPTIONS_ERROR): a misaligned BCJ start
+    offset, an unknown filter id, LZMA2 in front of another filter, Delta last.  Made from valid streams by editing the
+    filter flags and re-sealing the header's CRC32."""
+    import lzma
+
+    lz2 = {"id": lzma.FILTER_LZMA2, "preset": 1}
+    d = corpus()[:3000]
+
+    def reseal(x, edit):
+        x = bytearray(x)
+        hsize = (x[12] + 1) * 4
+        edit(x, 12)
+        x[12 + hsize - 4:12 + hsize] = zlib.crc32(bytes(x[12:12 + hsize - 4])).to_bytes(4, "little")
+        return bytes(x)
+
+    out = []
+    x = lzma.compress(d, format=lzma.FORMAT_XZ, filters=[{"id": lzma.FILTER_ARM, "start_offset": 4096}, lz2])
+    out.append(("arm start offset 4098", reseal(x, lambda b, h: b.__setitem__(h + 4, 2))))      # id 07, size 04, offset bytes
+    x = lzma.compress(d, format=lzma.FORMAT_XZ, filters=[{"id": lzma.FILTER_X86}, lz2])
+    out.append(("unknown filter 0x0A", reseal(x, lambda b, h: b.__setitem__(h + 2, 0x0A))))
+    out.append(("lzma2 in front", reseal(x, lambda b, h: b.__setitem__(slice(h + 2, h + 7), bytes([0x21, 0x01, b[h + 6], 0x04, 0x00])))))
+    x = lzma.compress(d, format=lzma.FORMAT_XZ, filters=[{"id": lzma.FILTER_DELTA, "dist": 1}, lz2])
+    out.append(("delta last", reseal(x, lambda b, h: b.__setitem__(slice(h + 5, h + 8), bytes([0x03, 0x01, 0x00])))))
+    return out
+
+
+def xz_filter_cases():
+    """(name, data, xz_stream): .xz blocks whose filter chain has Delta / BCJ filters in front of LZMA2 -- every filter
+    liblzma 5.2.5 knows, with and without a start offset, sizes around the filters' unit and look-ahead, more than one
+    8 KiB round of the device's unfilter, and chains of two and three filters -- written by liblzma itself."""
+    import lzma
+    import random
+
+    rnd = random.Random(77)
+    bcj = (("x86", lzma.FILTER_X86, 1), ("powerpc", lzma.FILTER_POWERPC, 4), ("ia64", lzma.FILTER_IA64, 16),
+           ("arm", lzma.FILTER_ARM, 4), ("armthumb", lzma.FILTER_ARMTHUMB, 2), ("sparc", lzma.FILTER_SPARC, 4))
+    lz2 = {"id": lzma.FILTER_LZMA2, "preset": 1}
+    cases = []
+    for kind, fid, align in bcj:
+        for k, n in enumerate((0, 3, 4, 5, 15, 16, 17, 5000, 70000)):
+            f = {"id": fid}
+            if k % 2:
+                f["start_offset"] = align * rnd.randrange(1, 1 << 20)
+            d = _branch_soup(rnd, n, kind)
+            cases.append(("filter/%s/%d" % (kind, n), d, lzma.compress(d, format=lzma.FORMAT_XZ, filters=[f, lz2])))
+        d = bytes(rnd.getrandbits(8) for _ in range(40000)) + _branch_soup(rnd, 60000, kind)
+        cases.append(("filter/%s/100k-crc64" % kind, d, lzma.compress(d, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC64,
+                                                                     filters=[{"id": fid, "start_offset": align * 777}, lz2])))
+    for dist in (1, 2, 3, 4, 7, 63, 64, 65, 255, 256):
+        n = rnd.choice((0, 1, dist, dist + 1, 3000, 50000))
+        d = bytes((rnd.randrange(256) if rnd.random() < 0.1 else (i * 3) & 255) for i in range(n))
+        cases.append(("filter/delta%d/%d" % (dist, n), d,
+                      lzma.compress(d, format=lzma.FORMAT_XZ, filters=[{"id": lzma.FILTER_DELTA, "dist": dist}, lz2])))
+    d = _branch_soup(rnd, 40000, "x86")
+    cases.append(("filter/x86+delta4", d, lzma.compress(d, format=lzma.FORMAT_XZ, check=lzma.CHECK_SHA256, filters=[
+        {"id": lzma.FILTER_X86}, {"id": lzma.FILTER_DELTA, "dist": 4}, lz2])))
+    cases.append(("filter/delta1+delta2+arm", d, lzma.compress(d, format=lzma.FORMAT_XZ, filters=[
+        {"id": lzma.FILTER_DELTA, "dist": 1}, {"id": lzma.FILTER_DELTA, "dist": 2}, {"id": lzma.FILTER_ARM}, lz2])))
     return cases
 
 

@@ -72,6 +72,16 @@ def test_xz_batch_cases_and_fixture(gpu, fixtures):
         assert (status[i], in_used[i], out_len[i], crc[i]) == (0, e["csize"], e["usize"], e["crc"])
         assert in_used[i] == e["ref"]["total_in"] and out_len[i] == e["ref"]["total_out"]
     assert len(fx) >= 1
+    assert sum(n.startswith("filter/") for n, _, _ in cases) >= 70     # Delta / BCJ chains in front of LZMA2 included
+
+
+def test_xz_filter_chains_liblzma_refuses(gpu):
+    """A misaligned BCJ start offset, an unknown filter, LZMA2 in front, Delta last: LZMA_OPTIONS_ERROR in liblzma,
+    MZ_DATA_ERROR through mz_stream_lzma_read (mz_strm_lzma.c:236-237), -3 here."""
+    bad = synth.xz_bad_chain_cases()
+    b, h_out, out_len, in_used, crc, status = run_xz(gpu, [x for _, x in bad], [10000] * len(bad))
+    for i, (name, x) in enumerate(bad):
+        assert status[i] == -3 and oracle.xz_decode(x, 10000)[0] == -3, name
 
 
 def test_xz_clamp_and_out_cap(gpu):

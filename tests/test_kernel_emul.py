@@ -249,6 +249,9 @@ def test_xz_cases_and_fuzz(emu, fixtures):
     assert st == 0 and out == d[:3000] and crc == zlib.crc32(d[:3000])
     st, used, out, crc = _run(emu.emul_xz, x, len(d) - 1, C.c_int64(-1))
     assert st == -200
+    assert sum(n.startswith("filter/") for n, _, _ in cases) >= 70     # Delta / BCJ chains in front of LZMA2 included
+    for name, x in synth.xz_bad_chain_cases():                         # chains liblzma refuses: data errors
+        assert _run(emu.emul_xz, x, 10000, C.c_int64(-1))[0] == -3, name
     rnd = random.Random(9)
     bases = [x for n, d, x in cases if 0 < len(d) <= 100000 and "lp4" not in n and "lc4" not in n and "lc1lp3" not in n]
     for it in range(1500):

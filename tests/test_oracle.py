@@ -164,6 +164,18 @@ def test_xz_decode_cases_vs_python_lzma():
         assert lzma.decompress(x) == d, name
 
 
+def test_xz_filter_chain_rules_vs_liblzma():
+    """The chains liblzma refuses (Python's lzma module is liblzma: LZMA_OPTIONS_ERROR) are data errors here, as
+    mz_stream_lzma_read reports every liblzma failure (mz_strm_lzma.c:236-237)."""
+    for name, x in synth.xz_bad_chain_cases():
+        with pytest.raises(lzma.LZMAError):
+            lzma.decompress(x)
+        assert oracle.xz_decode(x, 10000)[0] == -3, name
+        if oracle.have_ref():
+            r = oracle.ref().stream_decode(95, x, 10000)
+            assert r["rets"][-1] == -3, name
+
+
 @needs_ref
 def test_xz_parity_with_reference():
     """Valid streams: bytes and TOTAL_IN equal to mz_stream_lzma_read(method 95).  3000 corrupted / truncated
