@@ -390,20 +390,45 @@ def main():
         pays, crcs = make_unique_lzma(datas, world)
     else:
         offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world)
+    # MZHIP_BENCH_SHARE_GPU=1 (tests/test_gpu_bench_ranks.py, a box with ONE GPU): every rank uses device 0 and the
+    # collectives go through gloo on host copies -- the N > 1 logic (sharding, gather, reductions) on real kernels
+    # where RCCL cannot run (it refuses two ranks on one device).  Never set by the driver: the product path is RCCL.
+    share = world > 1 and os.environ.get("MZHIP_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_reduce(t, op):
+        if share:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def all_gather_into(dst, src):
+        if share:
+            h = torch.empty(dst.shape, dtype=dst.dtype)
+            dist.all_gather_into_tensor(h, src.cpu())
+            dst.copy_(h)
+        else:
+            dist.all_gather_into_tensor(dst, src)
 
     U = len(pays)
     if strong and world > 1:
         # one table for all ranks: the slice generator stops early on a slow host (--gen-seconds), so agree on the
         # number of unique streams every rank really has (same seeds: the first U are the same everywhere)
         u = torch.tensor([U], dtype=torch.int64, device=dev)
-        dist.all_reduce(u, op=dist.ReduceOp.MIN)
+        all_reduce(u, dist.ReduceOp.MIN)
         U = int(u.item())
         pays, crcs = pays[:U], crcs[:U]
         if offs is not None:
@@ -490,7 +515,7 @@ def main():
         stats["match"] = ok.sum()
         if world > 1:
             mine[:2 * n] = torch.stack((crc, status)).reshape(-1)
-            dist.all_gather_into_tensor(gathered, mine)
+            all_gather_into(gathered, mine)
 
     for _ in range(args.warmup):
         step()
@@ -528,9 +553,9 @@ def main():
     algo_all = float(algo_bytes)
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         s = torch.tensor([float(match), float(n), float(algo_bytes), float(bytes_ok)], dtype=torch.float64, device=dev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        all_reduce(s, dist.ReduceOp.SUM)
         elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
         match, total_entries, algo_all = int(s[0].item()), int(s[1].item()), float(s[2].item())
         bytes_ok = int(s[3].item()) == world
