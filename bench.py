@@ -69,12 +69,13 @@ CONFIGS = {
 
 
 def measured_traffic(cfg, n, size):
-    """HBM bytes per launch from the committed PMC passes (profiles/r2/hbm_traffic.json), only when they were taken on
+    """HBM bytes per launch from the committed PMC passes (profiles/r2/hbm_traffic*.json), only when they were taken on
     this very workload; counters cannot be collected from inside a timed run."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2", "hbm_traffic.json")) as f:
+        name = "hbm_traffic.json" if cfg == 2 else "hbm_traffic_cfg%d.json" % cfg
+        with open(os.path.join(ROOT, "profiles", "r2", name)) as f:
             t = json.load(f)
-        if cfg == 2 and n == 100000 and size == 65536:
+        if n == t.get("entries", 100000) and size == t.get("entry_bytes", 65536):
             return t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass

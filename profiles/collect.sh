@@ -11,7 +11,9 @@ root=$PWD
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-cmd="python $root/bench.py --steps 3 --warmup 1"
+cfgflag=${MZ_COLLECT_CONFIG:+--config $MZ_COLLECT_CONFIG}   # default: the headline config
+kern=${MZ_COLLECT_KERNEL:-k_inflate_batch}                  # the kernel whose counter rows are kept
+cmd="python $root/bench.py $cfgflag --steps 3 --warmup 1"
 if [ $what = all ] || [ $what = bench ]; then ( cd "$root" && timeout $T $cmd > "$out/bench.log" 2> "$out/bench.err" ); tail -1 "$out/bench.log"; fi
 # the profiled passes launch the dominant kernel on the bench workload only (no legs, no CPU baseline), so that the
 # per-kernel average of --stats is the average of identical launches: 1 warm-up + 3 timed
@@ -25,7 +27,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   if [ $what != all ] && [ $what != $c ]; then continue; fi
   lc=$(echo $c | tr 'A-Z' 'a-z')
   timeout -k 10 $T rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$lc" -o pmc --output-format csv -- $cmd > "$out/pmc_$lc.log" 2>&1
-  find "$out/pmc_$lc" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|k_inflate_batch" "$1" > "$2"' _ {} "$out/pmc_$lc.csv" \;
+  find "$out/pmc_$lc" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|$3" "$1" > "$2"' _ {} "$out/pmc_$lc.csv" "$kern" \;
 done
 if [ $what = SQ ]; then
   # instruction mix and stall picture of the dominant kernel; a pass per counter group (never with other trace domains);
