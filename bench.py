@@ -504,19 +504,23 @@ def main():
         return r_len, None, r_crc, r_st
 
     def step(i_timed=None):
+        """one pass of the hot path over the rank's shard (+ the CRC gather when N > 1).  The per-entry comparison with
+        the central directory's CRCs is the CHECK of the step, not part of the path: it runs on the warm-up steps and on
+        the last timed one (a handful of tiny elementwise launches that would otherwise weigh on a 3 ms step at N = 8)."""
         if i_timed is not None:
             ev[i_timed][0].record()
         out_len, in_used, crc, status = launch()
         if i_timed is not None:
             ev[i_timed][1].record()
-        if cfg["codec"] == "deflate":
-            ok = (crc == want_crc) & (status == 0) & (out_len > 0)
-        else:
-            ok = (crc == want_crc) & (status == 0) & (out_len == size) & (in_used == d_in_len)
-        stats["match"] = ok.sum()
         if world > 1:
             mine[:2 * n] = torch.stack((crc, status)).reshape(-1)
             all_gather_into(gathered, mine)
+        if i_timed is None or i_timed == args.steps - 1:
+            if cfg["codec"] == "deflate":
+                ok = (crc == want_crc) & (status == 0) & (out_len > 0)
+            else:
+                ok = (crc == want_crc) & (status == 0) & (out_len == size) & (in_used == d_in_len)
+            stats["match"] = ok.sum()
 
     for _ in range(args.warmup):
         step()
