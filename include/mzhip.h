@@ -158,6 +158,13 @@ MZHIP_API int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in
                                           uint32_t max_in_len, void *d_out, const uint64_t *d_out_off,
                                           const uint32_t *d_out_cap, const uint8_t *d_mode, uint32_t n,
                                           uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream);
+/* ... with the preset the reference hands to lzma_lzma_preset (mz_strm_lzma.c:81; COMPRESS_LEVEL, -1 = the default 6):
+ * presets 0-3 try one hash candidate per position (what the call above does), 4-9 and the default try four and apply
+ * a two-position lazy rule -- smaller output, a slower parse */
+MZHIP_API int32_t mzhip_lzma_encode_batch_preset(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
+                                                 uint32_t max_in_len, void *d_out, const uint64_t *d_out_off,
+                                                 const uint32_t *d_out_cap, const uint8_t *d_mode, uint32_t n, int32_t preset,
+                                                 uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream);
 
 /* Host-buffer conveniences (H2D + kernel + D2H, synchronous); these are what the
  * vtbl shim uses for one-entry-at-a-time callers. */
@@ -173,6 +180,11 @@ MZHIP_API int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uin
                                          uint32_t *out_len, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
                                        uint32_t *out_len, uint32_t *crc);
+/* ... at a preset (see mzhip_lzma_encode_batch_preset); what mz_stream_lzma_write / _close use */
+MZHIP_API int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out,
+                                                uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
+MZHIP_API int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out,
+                                              uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
 /* one segment of a stream: 64 KiB pieces, the last one final iff `final`; *crc = CRC-32 of `in` */
 MZHIP_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
                                      uint32_t out_cap, uint32_t *out_len, uint32_t *crc);

@@ -23,6 +23,7 @@ BATCH_SYMBOLS = [
     "mzhip_zip_index_mem", "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_clear", "mzhip_prime_stats",
     "mzhip_prime_write", "mzhip_prime_write_clear", "mzhip_prime_write_stats", "mzhip_prime_file_multi",
     "mzhip_prime_mem_multi", "mzhip_shard_bounds", "mzhip_deflate_batch_level", "mzhip_deflate_host_level",
+    "mzhip_lzma_encode_batch", "mzhip_lzma_encode_batch_preset", "mzhip_lzma_encode_host_preset", "mzhip_xz_encode_host_preset",
 ]
 
 _u64p, _u32p, _i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)

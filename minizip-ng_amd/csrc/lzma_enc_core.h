@@ -35,21 +35,41 @@ typedef struct mz_lz_tok_lds {
 
 /* LZ77 parse of in[blk, blk_end) (blk_end - blk <= MZ_DEF_BLOCK) of the stream in[0..); matches may start up to 32 KiB
  * before blk.  Returns the
- * number of tokens written to tok[]: [8:0] match length (0 = literal), [24:9] distance | literal byte. */
-MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end, uint32_t *tok, mz_lz_tok_lds *L) {
+ * number of tokens written to tok[]: [8:0] match length (0 = literal), [24:9] distance | literal byte.
+ * ways / xhead: as in K4 (deflate_core.h) -- the `ways` most recent positions of every hash bucket are tried and the
+ * longest match wins; 1 = the fast class (presets 0-3), MZ_DEF_WAYS_BEST = presets 4-9 and the default
+ * (mz_strm_lzma.c:81 hands the level to lzma_lzma_preset).  xhead: (ways - 1) more tables behind the wave's LDS. */
+MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end, uint32_t *tok, mz_lz_tok_lds *L,
+                               uint32_t ways, uint16_t *xhead) {
     MZ_LANE_DECL
     MZ_LANES {
         for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->head)[i] = 0u;
+        for (uint32_t i = (uint32_t)lane; i < (ways - 1u) * ((1u << MZ_DEF_HBITS) / 2u); i += 64u) ((uint32_t *)xhead)[i] = 0u;
     }
     MZ_WAVE_SYNC();
     /* the stream's previous 32 KiB are legal match sources (the dictionary is 64 KiB): enter them into the hash table
      * first, without producing tokens, so that a block does not start with an empty history */
     const uint32_t hist = blk > 32768u ? blk - 32768u : 0u;
     for (uint32_t p = hist; p < blk; p += 64u) {
+        PV(uint32_t, hh0);
+        PV(uint32_t, c0);
+        PV2(uint32_t, cx0, MZ_DEF_WAYS_BEST - 1u);
         MZ_LANES {
             const uint32_t pos = p + (uint32_t)lane;
-            if (pos < blk && pos + 4u <= blk_end)
-                L->head[(mz_load_u32(in + pos) * 2654435761u) >> (32 - MZ_DEF_HBITS)] = (uint16_t)pos;
+            const uint32_t ok = (pos < blk && pos + 4u <= blk_end) ? 1u : 0u;
+            const uint32_t h = ok ? (mz_load_u32(in + pos) * 2654435761u) >> (32 - MZ_DEF_HBITS) : 0u;
+            P(hh0) = ok ? h : 0xFFFFFFFFu;
+            P(c0) = (ok && ways > 1u) ? (uint32_t)L->head[h] : 0u;
+            for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++)
+                P(cx0)[w - 1u] = (ok && w < ways) ? (uint32_t)xhead[((w - 1u) << MZ_DEF_HBITS) | h] : 0u;
+        }
+        MZ_WAVE_SYNC();
+        MZ_LANES {
+            if (P(hh0) != 0xFFFFFFFFu) {
+                for (uint32_t w = MZ_DEF_WAYS_BEST - 1u; w >= 1u; w--)
+                    if (w < ways) xhead[((w - 1u) << MZ_DEF_HBITS) | P(hh0)] = (uint16_t)(w == 1u ? P(c0) : P(cx0)[w - 2u]);
+                L->head[P(hh0)] = (uint16_t)(p + (uint32_t)lane);
+            }
         }
         MZ_WAVE_SYNC();
     }
@@ -63,6 +83,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
         const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u;
         PV(uint32_t, hh);
         PV(uint32_t, cand);
+        PV2(uint32_t, candx, MZ_DEF_WAYS_BEST - 1u);
         MZ_LANES {
             const uint32_t pos = p + (uint32_t)lane;
             const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
@@ -71,10 +92,16 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
             const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
             P(hh) = have4 ? h : 0xFFFFFFFFu;
             P(cand) = have4 ? (uint32_t)L->head[h] : 0u;
+            for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++)
+                P(candx)[w - 1u] = (have4 && w < ways) ? (uint32_t)xhead[((w - 1u) << MZ_DEF_HBITS) | h] : 0u;
         }
         MZ_WAVE_SYNC();
         MZ_LANES {
-            if (P(hh) != 0xFFFFFFFFu) L->head[P(hh)] = (uint16_t)(p + (uint32_t)lane);
+            if (P(hh) != 0xFFFFFFFFu) {
+                for (uint32_t w = MZ_DEF_WAYS_BEST - 1u; w >= 1u; w--)
+                    if (w < ways) xhead[((w - 1u) << MZ_DEF_HBITS) | P(hh)] = (uint16_t)(w == 1u ? P(cand) : P(candx)[w - 2u]);
+                L->head[P(hh)] = (uint16_t)(p + (uint32_t)lane);
+            }
         }
         MZ_WAVE_SYNC();
         PV(uint32_t, pk);
@@ -83,15 +110,17 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
         MZ_LANES {
             const uint32_t pos = p + (uint32_t)lane;
             uint32_t mlen = 0, dist = 0;
-            if ((uint32_t)lane < nv) {
-                const uint32_t d = (pos - P(cand)) & 0xFFFFu;
-                if (P(hh) != 0xFFFFFFFFu && d >= 1u && d <= 32768u && d <= pos - hist) {
-                    const uint8_t *a = in + pos, *b = in + (pos - d);
-                    const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
-                    const uint32_t l = mz_match_len(a, b, maxl);
-                    if (l >= MZ_DEF_MINMATCH) {
-                        mlen = l;
-                        dist = d;
+            if ((uint32_t)lane < nv && P(hh) != 0xFFFFFFFFu) {
+                const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
+                for (uint32_t w = 0; w < MZ_DEF_WAYS_BEST; w++) { /* most recent first: a tie keeps the shorter distance */
+                    if (w >= ways) break;
+                    const uint32_t d = (pos - (w ? P(candx)[w - 1u] : P(cand))) & 0xFFFFu;
+                    if (d >= 1u && d <= 32768u && d <= pos - hist && d != dist) {
+                        const uint32_t l = mz_match_len(in + pos, in + (pos - d), maxl);
+                        if (l >= MZ_DEF_MINMATCH && l > mlen) {
+                            mlen = l;
+                            dist = d;
+                        }
                     }
                 }
             }
@@ -99,10 +128,13 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
             P(lit) = (uint32_t)in[pos < blk_end ? pos : blk];
         }
         PV(uint32_t, pkn);
+        PV(uint32_t, pkn2);
         MZ_GATHER4(pkn, pk, 4u * ((uint32_t)lane + 1u));
+        MZ_GATHER4(pkn2, pk, 4u * ((uint32_t)lane + 2u));
         MZ_LANES {
             uint32_t mlen = P(pk) & 511u;
             if (mlen && (uint32_t)lane + 1u < nv && (P(pkn) & 511u) > mlen) mlen = 0u; /* lazy rule */
+            if (ways > 1u && mlen && (uint32_t)lane + 2u < nv && (P(pkn2) & 511u) > mlen + 1u) mlen = 0u; /* two ahead */
             P(pk) = mlen ? P(pk) : (P(lit) << 9);
             const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
             P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);

@@ -341,6 +341,7 @@ struct LzmaEncArgs {
     const uint8_t *mode; // may be null (all 0): 0 = ZIP method-14 payload, 1 = raw LZMA2 chunk payload
     uint32_t n;
     uint32_t maxb; // 64 KiB blocks reserved per entry in tok / ntok
+    uint32_t ways; // hash candidates per position in the LZ77 parse (1 or MZ_DEF_WAYS_BEST), by preset
     uint32_t *tok;
     uint32_t *ntok;
     uint32_t *out_len;
@@ -352,9 +353,11 @@ struct LzmaEncArgs {
 
 // LZMA encode, pass 1: the LZ77 parse, one wave per 64 KiB block of any entry (work item = entry * maxb + block).
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(LzmaEncArgs a) {
-    __shared__ __attribute__((aligned(16))) mz_lz_tok_lds lds[MZ_WAVES_PER_WG];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; /* one head table per wave, then (ways - 1) more each */
     MZ_LANE_DECL
-    mz_lz_tok_lds *L = &lds[threadIdx.x >> 6];
+    const uint32_t wave = threadIdx.x >> 6;
+    mz_lz_tok_lds *L = (mz_lz_tok_lds *)smem + wave;
+    uint16_t *xhead = a.ways > 1u ? (uint16_t *)(smem + MZ_WAVES_PER_WG * sizeof(mz_lz_tok_lds) + wave * MZ_DEF_XHEAD_BYTES) : (uint16_t *)nullptr;
     const uint32_t items = a.n * a.maxb;
     for (;;) {
         uint32_t w;
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(Lzma
         if (lo < len) {
             const uint64_t io = a.in_off[e];
             const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
-            nt = mz_lz_tokenize(in, lo, (len - lo < MZ_DEF_BLOCK) ? len : lo + MZ_DEF_BLOCK, a.tok + (size_t)w * MZ_DEF_BLOCK, L);
+            nt = mz_lz_tokenize(in, lo, (len - lo < MZ_DEF_BLOCK) ? len : lo + MZ_DEF_BLOCK, a.tok + (size_t)w * MZ_DEF_BLOCK, L,
+                                MZ_UNIFORM(a.ways), xhead);
         }
         a.ntok[w] = nt; // uniform store
     }
@@ -854,6 +858,16 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
 int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, uint32_t max_in_len,
                                 void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_mode,
                                 uint32_t n, uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    return mzhip_lzma_encode_batch_preset(d_in, d_in_off, d_in_len, max_in_len, d_out, d_out_off, d_out_cap, d_mode, n, 1,
+                                          d_out_len, d_crc, d_status, stream);
+}
+
+/* preset (mz_strm_lzma.c:81 hands COMPRESS_LEVEL to lzma_lzma_preset): 0-3 -> one hash candidate per position, 4-9 and
+ * the default (-1 = 6) -> MZ_DEF_WAYS_BEST candidates + the two-position lazy rule, as K4's classes */
+int32_t mzhip_lzma_encode_batch_preset(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, uint32_t max_in_len,
+                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, const uint8_t *d_mode,
+                                       uint32_t n, int32_t preset, uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status,
+                                       void *stream) {
     if (n == 0) return 0;
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
@@ -869,6 +883,7 @@ int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, cons
     a.mode = d_mode;
     a.n = n;
     a.maxb = max_in_len ? (max_in_len + MZ_DEF_BLOCK - 1) / MZ_DEF_BLOCK : 1u;
+    a.ways = (preset >= 0 && preset <= 3) ? 1u : MZ_DEF_WAYS_BEST;
     a.out_len = d_out_len;
     a.crc = d_crc;
     a.status = d_status;
@@ -891,8 +906,12 @@ int32_t mzhip_lzma_encode_batch(const void *d_in, const uint64_t *d_in_off, cons
     }
     {
         uint32_t wgs = (uint32_t)((items + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG);
-        uint32_t resident = (uint32_t)c->cu_count * 4u; /* 33 KiB LDS per workgroup */
-        hipLaunchKernelGGL(k_lz_tokenize_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), 0, s, a);
+        const size_t lds = MZ_WAVES_PER_WG * (sizeof(mz_lz_tok_lds) + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
+        uint32_t resident = (uint32_t)c->cu_count * (a.ways > 1u ? 1u : 4u); /* 32 KiB (128 KiB) of LDS per workgroup */
+        if (a.ways > 1u)
+            (void)hipFuncSetAttribute((const void *)k_lz_tokenize_batch, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(MZ_WAVES_PER_WG * (sizeof(mz_lz_tok_lds) + MZ_DEF_XHEAD_BYTES)));
+        hipLaunchKernelGGL(k_lz_tokenize_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
     }
     {
         uint32_t resident = (uint32_t)c->cu_count * 9u; /* 17 KiB LDS per single-wave workgroup */
@@ -1030,6 +1049,11 @@ int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t
 // One ZIP method-14 payload from a host buffer.
 int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                                uint32_t *crc) {
+    return mzhip_lzma_encode_host_preset(in, in_len, 1, out, out_cap, out_len, crc);
+}
+
+int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out, uint32_t out_cap,
+                                      uint32_t *out_len, uint32_t *crc) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -1052,8 +1076,8 @@ int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out,
     HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
     if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
     Meta *dm = (Meta *)base;
-    rc = mzhip_lzma_encode_batch(base, &dm->in_off, &dm->in_len, in_len, base, &dm->out_off, &dm->out_cap, nullptr, 1,
-                                 &dm->out_len, &dm->crc, &dm->status, nullptr);
+    rc = mzhip_lzma_encode_batch_preset(base, &dm->in_off, &dm->in_len, in_len, base, &dm->out_off, &dm->out_cap, nullptr, 1,
+                                        preset, &dm->out_len, &dm->crc, &dm->status, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
@@ -1069,6 +1093,11 @@ int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out,
 // batch; framing bytes (a few per chunk) are laid out here, their CRC-32s come from the device as well.
 int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                              uint32_t *crc) {
+    return mzhip_xz_encode_host_preset(in, in_len, 1, out, out_cap, out_len, crc);
+}
+
+int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out, uint32_t out_cap,
+                                    uint32_t *out_len, uint32_t *crc) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -1104,7 +1133,7 @@ int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                  *d_crc = d_out_len + np;
         int32_t *d_status = (int32_t *)(d_crc + np);
         uint8_t *d_mode = (uint8_t *)(d_status + np);
-        rc = mzhip_lzma_encode_batch(base, d_in_off, d_in_len, piece, base, d_out_off, d_out_cap, d_mode, np, d_out_len,
+        rc = mzhip_lzma_encode_batch_preset(base, d_in_off, d_in_len, piece, base, d_out_off, d_out_cap, d_mode, np, preset, d_out_len,
                                      d_crc, d_status, nullptr);
         if (rc) return rc;
         HIP_TRY(hipDeviceSynchronize());

@@ -399,8 +399,8 @@ static int32_t finish_write(mzhip_lzma *z) {
     if (!out)
         return MZH_MEM_ERROR;
     uint32_t out_len = 0, crc = 0;
-    int32_t st = (z->method == MZH_COMPRESS_METHOD_XZ ? mzhip_xz_encode_host : mzhip_lzma_encode_host)(
-        z->wbuf ? z->wbuf : (const uint8_t *)"", (uint32_t)z->wlen, out, cap, &out_len, &crc);
+    int32_t st = (z->method == MZH_COMPRESS_METHOD_XZ ? mzhip_xz_encode_host_preset : mzhip_lzma_encode_host_preset)(
+        z->wbuf ? z->wbuf : (const uint8_t *)"", (uint32_t)z->wlen, (int32_t)z->preset, out, cap, &out_len, &crc);
     if (st != 0) {
         free(out);
         return MZH_DATA_ERROR; /* device failure: never substitute a CPU result */

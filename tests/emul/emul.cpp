@@ -135,18 +135,29 @@ extern "C" uint32_t emul_xz_lds_bytes(void) { return (uint32_t)sizeof(mz_xz_lds)
 #include "lzma_enc_core.h"
 
 /* mode 0: ZIP method-14 payload; mode 1: raw LZMA2 chunk payload */
+extern "C" int32_t emul_lzma_encode_ways(const uint8_t *in, uint32_t in_len, uint32_t mode, uint32_t ways, uint8_t *out,
+                                         uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
 extern "C" int32_t emul_lzma_encode(const uint8_t *in, uint32_t in_len, uint32_t mode, uint8_t *out, uint32_t out_cap,
                                     uint32_t *out_len, uint32_t *crc) {
+    return emul_lzma_encode_ways(in, in_len, mode, 1u, out, out_cap, out_len, crc);
+}
+/* ways: 1 = presets 0-3, MZ_DEF_WAYS_BEST = presets 4-9 and the default */
+extern "C" int32_t emul_lzma_encode_ways(const uint8_t *in, uint32_t in_len, uint32_t mode, uint32_t ways, uint8_t *out,
+                                         uint32_t out_cap, uint32_t *out_len, uint32_t *crc) {
     ready();
     const uint32_t nblocks = (in_len + MZ_DEF_BLOCK - 1) / MZ_DEF_BLOCK;
     uint32_t *tok = (uint32_t *)malloc((size_t)(nblocks ? nblocks : 1) * MZ_DEF_BLOCK * sizeof(uint32_t));
     uint32_t *ntok = (uint32_t *)calloc(nblocks ? nblocks : 1, sizeof(uint32_t));
     mz_lz_tok_lds *T = (mz_lz_tok_lds *)malloc(sizeof(mz_lz_tok_lds));
+    const size_t xbytes = (MZ_DEF_WAYS_BEST - 1u) * (sizeof(uint16_t) << MZ_DEF_HBITS);
+    uint16_t *xhead = (uint16_t *)malloc(xbytes);
     for (uint32_t b = 0; b < nblocks; b++) {
         memset(T, 0xA5, sizeof(*T));
+        memset(xhead, 0xA5, xbytes);
         const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
-        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T);
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0);
     }
+    free(xhead);
     mz_lzma_lds *L = (mz_lzma_lds *)malloc(sizeof(mz_lzma_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_lzma_enc_result r;

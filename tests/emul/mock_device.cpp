@@ -90,6 +90,15 @@ MOCK_API int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint
 MOCK_API int32_t mzhip_xz_encode_host(const uint8_t *, uint32_t, uint8_t *, uint32_t, uint32_t *, uint32_t *) {
     return MZHIP_STATUS_UNSUPPORTED; /* the .xz container is laid out by host code inside mzhip_kernels.hip */
 }
+MOCK_API int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out, uint32_t out_cap,
+                                               uint32_t *out_len, uint32_t *crc) {
+    const uint8_t dummy = 0;
+    return emul_lzma_encode_ways(in ? in : &dummy, in_len, 0u, (preset >= 0 && preset <= 3) ? 1u : MZ_DEF_WAYS_BEST, out, out_cap, out_len,
+                                 crc);
+}
+MOCK_API int32_t mzhip_xz_encode_host_preset(const uint8_t *, uint32_t, int32_t, uint8_t *, uint32_t, uint32_t *, uint32_t *) {
+    return MZHIP_STATUS_UNSUPPORTED;
+}
 
 MOCK_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
     uint32_t v = value;

@@ -91,6 +91,35 @@ def test_host_entry_points(gpu):
                 assert oracle.xz_decode(z + b"tail", len(d) + 64) == (0, len(z), d)
 
 
+def test_preset_selects_the_parse_class(gpu):
+    """COMPRESS_LEVEL reaches the encoder as liblzma's preset (mz_strm_lzma.c:81): presets 0-3 = the one-candidate parse,
+    4-9 and the default four candidates + lazy rule -- every stream decodes with liblzma, the default class is smaller."""
+    L = gpu.mz.lib()
+    for f in (L.mzhip_lzma_encode_host_preset, L.mzhip_xz_encode_host_preset):
+        f.restype = C.c_int32
+        f.argtypes = [C.c_char_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    c = synth.corpus()
+    sizes = {}
+    for preset in (0, 3, 4, 6, 9, -1):
+        tot = 0
+        for d in (c[:65536], c[100000:300000], b"", b"abc" * 5000):
+            for fn, kind in ((L.mzhip_lzma_encode_host_preset, 14), (L.mzhip_xz_encode_host_preset, 95)):
+                cap = len(d) + len(d) // 8 + 4096
+                out = np.zeros(cap, dtype=np.uint8)
+                ol, crc = C.c_uint32(), C.c_uint32()
+                assert fn(d, len(d), preset, out.ctypes.data, cap, C.byref(ol), C.byref(crc)) == 0
+                z = out[:ol.value].tobytes()
+                assert crc.value == zlib.crc32(d)
+                if kind == 14:
+                    assert lzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=lzma.FORMAT_ALONE) == d
+                else:
+                    assert lzma.decompress(z, format=lzma.FORMAT_XZ) == d
+                tot += len(z)
+        sizes[preset] = tot
+    assert sizes[0] == sizes[3] and sizes[4] == sizes[6] == sizes[9] == sizes[-1]
+    assert sizes[6] < 0.95 * sizes[3]
+
+
 @pytest.fixture(scope="module")
 def libs(gpu):
     if not os.path.exists(DROP) or not oracle.have_ref():

@@ -347,6 +347,21 @@ def test_lzma_encode_roundtrip(emu):
         st2, used2, out2, crc2 = _run(emu.emul_lzma, z, len(d) + 64, C.c_int64(-1))      # and back through K3's core
         assert (st2, used2, out2, crc2) == (0, len(z), d, crc)
     assert len(_lzma_encode(emu, c[:65536])[1]) < 0.4 * 65536
+    # the default class (presets 4-9 and -1: four hash candidates + two-position lazy rule): valid streams, and smaller
+    emu.emul_lzma_encode_ways.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    fast = best = 0
+    for d in cases:
+        a = np.frombuffer(d, dtype=np.uint8) if d else np.zeros(1, np.uint8)
+        out = np.zeros(len(d) + len(d) // 8 + 1024, np.uint8)
+        ol, crc = C.c_uint32(), C.c_uint32()
+        st = emu.emul_lzma_encode_ways(C.cast(a.ctypes.data, _u8p), len(d), 0, 4, C.cast(out.ctypes.data, _u8p), len(out), C.byref(ol), C.byref(crc))
+        z = out[:ol.value].tobytes()
+        assert st == 0 and crc.value == zlib.crc32(d), len(d)
+        assert pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == d
+        assert oracle.lzma_zip_decode(z, len(d) + 64, -1) == (0, len(z), d)
+        fast += len(_lzma_encode(emu, d)[1])
+        best += len(z)
+    assert best < 0.97 * fast
     # LZMA2 chunk payloads -> one .xz stream (single block, CRC32 check, every chunk resets dict + state + props)
     for d in (c[:150000], rnd.bytes(60000) + c[:1000], b"x"):
         body = b""
