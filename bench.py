@@ -8,24 +8,34 @@ config 3: DEFLATE level-6 1 000 000 x 8 KiB entries, same kernel (the small-entr
 config 4: LZMA (ZIP method 14, preset 6, EOS marker) 10 000 x 1 MiB entries, range decode + fused CRC-32 (k_lzma_batch)
 config 5: DEFLATE compress (level 1) of 100 000 x 64 KiB buffers + CRC-32 of the input (k_deflate_batch)
 
-step    : ONE pass of the hot path over the whole batch = one batch launch over every entry of this rank's shard, the
-          per-entry CRC / status comparison against the central-directory values and (N > 1) the RCCL gather of the
-          per-entry {crc, status} words -- the only collective on the path.  Inputs and outputs are resident in HBM.
+step    : ONE pass of the hot path over the whole batch = one batch launch over every entry of this rank's shard (the
+          CRC-32 of every entry is computed inside that launch, every step) and (N > 1) the RCCL gather of the per-entry
+          {crc, status} words -- the only collective on the path.  The comparison of those words with the central
+          directory's values is the CHECK of a step, not part of the path: it runs on every warm-up step and on the last
+          timed step.  Inputs and outputs are resident in HBM.
+launch  : `python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) re-executes itself under
+          `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); when the box has fewer than N
+          GPUs it prints {"error": ...} and exits non-zero.  world == --gpus is asserted in every case.
 scaling : strong by default, as north_star states it: ONE entry table (100 000 entries for config 2) is cut into N
           contiguous slices balanced by compressed + uncompressed bytes (archive.shard_bounds), rank r decodes slice r.
           --scaling weak gives every rank its own full-size table.
 data    : synthetic, SURVEY 8(d): entries are slices of C = appnote.txt || appnote.iz.txt || alice29.txt of the reference
           tree (oracle/_ref/corpus.bin, built by oracle/make_corpus.py; CPython's pydoc prose when it did not travel);
-          config 4 uses the seeded order-2 word-Markov expansion of C.  Level-6 compression costs ~2.4 ms per entry on
-          one core, so a bounded number of UNIQUE slices is compressed (all host cores, <= --gen-seconds) with exactly
-          the reference writer's parameters (mz_strm_zlib.c:87: raw, 32 KiB window, memLevel 8 -- the cpu_baseline leg
-          checks that the reference writer emits the same bytes) and tiled to the full entry count; every entry still
-          has its own copy of its compressed bytes and its own output region in HBM.
+          config 4 uses the seeded order-2 word-Markov expansion of C.  Every entry of config 2 is its OWN stream
+          (100 000 unique slices, ~240 core-seconds of level-6 compression spread over all host cores; config 3: 131 072
+          unique, config 4: 256 unique 1 MiB streams), compressed with exactly the reference writer's parameters
+          (mz_strm_zlib.c:87: raw, 32 KiB window, memLevel 8 -- the cpu_baseline leg checks that the reference writer
+          emits the same bytes).  Only when the host is too slow (--gen-seconds runs out) the streams made so far are
+          tiled to the entry count, and `data` says how many were tiled; every entry has its own copy of its compressed
+          bytes and its own output region in HBM either way.
 
 Besides the contract fields the JSON line carries
   roofline     : the dominant kernel against the 8 TB/s HBM roofline; achieved = algorithmic bytes (compressed bytes
                  read once + decompressed bytes written once) / mean launch duration, measured with HIP
-                 events on the launch stream inside the timed region (max over ranks);
+                 events on the launch stream inside the timed region (max over ranks).  `traffic` is NOT measured by this
+                 run (counters cannot be collected from inside a timed run): it is the FETCH_SIZE + WRITE_SIZE of the
+                 committed rocprofv3 --pmc passes named in `traffic_source`, and null when those were taken on another
+                 workload shape;
   cpu_baseline : the UNMODIFIED reference path (oracle/_ref) on the host cores of the same box, on a bounded sample of
                  the same workload.  Rank 0, N = 1 only;
   legs         : (config 2, N = 1) SURVEY 8(d) i-iii: kernel only / H2D of the compressed bytes + kernel + D2H of
@@ -53,33 +63,37 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 CONFIGS = {
-    2: dict(entries=100000, size=65536, codec="inflate", kernel="k_inflate_batch", unique=8192,
+    2: dict(entries=100000, size=65536, codec="inflate", kernel="k_inflate_batch", unique=100000,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 100k x 64KiB DEFLATE entries",
             workload="BASELINE.json configs[1]: DEFLATE level-6 %d x %d B entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
-    3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=16384,
+    3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=131072,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 1M x 8KiB DEFLATE entries",
             workload="BASELINE.json configs[2]: DEFLATE level-6 %d x %d B small entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
-    4: dict(entries=10000, size=1 << 20, codec="lzma", kernel="k_lzma_batch", unique=16,
+    4: dict(entries=10000, size=1 << 20, codec="lzma", kernel="k_lzma_batch", unique=256,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 10k x 1MiB LZMA entries",
             workload="BASELINE.json configs[3]: LZMA (method 14, preset 6) %d x %d B entries, range decode + fused CRC32 (mzhip_lzma_batch), device-resident"),
-    5: dict(entries=100000, size=65536, codec="deflate", kernel="k_deflate_batch", unique=8192,
+    5: dict(entries=100000, size=65536, codec="deflate", kernel="k_deflate_batch", unique=100000,
             metric="compressed-input GiB/s (whole node) + round-trip match rate, 100k x 64KiB DEFLATE level-1 compress",
             workload="BASELINE.json configs[4]: DEFLATE compress level 1 of %d x %d B buffers + CRC32 of the input (mzhip_deflate_batch), device-resident"),
 }
 
 
 def measured_traffic(cfg, n, size):
-    """HBM bytes per launch from the committed PMC passes (profiles/r2/hbm_traffic*.json), only when they were taken on
-    this very workload; counters cannot be collected from inside a timed run."""
-    try:
-        name = "hbm_traffic.json" if cfg == 2 else "hbm_traffic_cfg%d.json" % cfg
-        with open(os.path.join(ROOT, "profiles", "r2", name)) as f:
-            t = json.load(f)
-        if n == t.get("entries", 100000) and size == t.get("entry_bytes", 65536):
-            return t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """(HBM bytes per launch, where the number comes from): the committed PMC passes (profiles/r*/hbm_traffic*.json, newest
+    round first), only when they were taken on this very workload shape; counters cannot be collected from inside a timed
+    run, so this is a STATIC number and `traffic_source` says so."""
+    name = "hbm_traffic.json" if cfg == 2 else "hbm_traffic_cfg%d.json" % cfg
+    for rnd in ("r3", "r2"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
+                t = json.load(f)
+            if n == t.get("entries", 100000) and size == t.get("entry_bytes", 65536):
+                return (t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"],
+                        "static: profiles/%s/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit %s), not measured by this run"
+                        % (rnd, name, t.get("commit", "unknown")))
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
 
 
 def corpus():
@@ -105,13 +119,22 @@ def _pool_init(c, level):
 
 
 def make_unique_deflate(c, n_unique, size, seed, gen_seconds, world):
+    """n_unique level-6 streams of distinct slices of the corpus, on every host core this rank may use.  Stops early
+    (at least 256 streams) only when gen_seconds runs out: the caller then tiles and says so."""
     rnd = random.Random(seed)
-    offs = [(rnd.randrange(len(c) - size), size) for _ in range(n_unique)]
-    procs = max(1, min((os.cpu_count() or 1) // max(world, 1), 64))  # ranks share the host cores
+    seen, offs = set(), []
+    span = len(c) - size
+    while len(offs) < n_unique:  # distinct offsets while the corpus has them
+        o = rnd.randrange(span)
+        if o in seen and len(seen) < span:
+            continue
+        seen.add(o)
+        offs.append((o, size))
+    procs = max(1, (os.cpu_count() or 1) // max(world, 1))  # ranks share the host cores
     t0 = time.time()
     out = []
     with mp.Pool(procs, initializer=_pool_init, initargs=(c, 6)) as pool:
-        for r in pool.imap(_compress_one, offs, chunksize=8):
+        for r in pool.imap(_compress_one, offs, chunksize=64):
             out.append(r)
             if time.time() - t0 > gen_seconds and len(out) >= 256:
                 pool.terminate()
@@ -128,6 +151,20 @@ def _lzma_one(d):
     raw = lzma.compress(d, format=lzma.FORMAT_ALONE, filters=[dict(id=lzma.FILTER_LZMA1, preset=6)])
     assert raw[5:13] == b"\xff" * 8  # .lzma alone = props(5) + size(8, unknown) + stream + end marker
     return bytes([5, 2, 5, 0]) + raw[:5] + raw[13:], zlib.crc32(d)
+
+
+def _markov_one(args):
+    from tests import synth
+
+    size, seed = args
+    return synth.markov_entries(1, size, seed, _C)[0]
+
+
+def make_markov(c, n_unique, size, seed, world):
+    """n_unique order-2 word-Markov expansions of the corpus, one seed each (pure Python: ~0.3 s per MiB, so on all cores)"""
+    procs = max(1, min((os.cpu_count() or 1) // max(world, 1), n_unique))
+    with mp.Pool(procs, initializer=_pool_init, initargs=(c, 6)) as pool:
+        return pool.map(_markov_one, [(size, seed * 100003 + i) for i in range(n_unique)])
 
 
 def make_unique_lzma(datas, world):
@@ -349,6 +386,42 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
     return out
 
 
+def fail(msg):
+    """one JSON line and a non-zero exit: a run that cannot be the run that was asked for must not print a metric"""
+    print(json.dumps({"error": msg}), flush=True)
+    sys.exit(2)
+
+
+def _visible_gpus():
+    """GPUs this process could use, without creating a HIP context in the launcher process"""
+    import subprocess
+
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher: run N ranks of this script under torch.distributed.run (what the
+    driver's own command line does), one per GPU; exit non-zero with an {"error"} line when the box cannot."""
+    import socket
+    import subprocess
+
+    have = _visible_gpus()
+    if have < n and os.environ.get("MZHIP_BENCH_SHARE_GPU") != "1":
+        fail("--gpus %d but only %d GPU(s) are visible on this node; not measuring fewer GPUs than asked for" % (n, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,6 +437,10 @@ def main():
     ap.add_argument("--no-legs", action="store_true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    if args.gpus < 1:
+        fail("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))  # no launcher around us: become one (one rank per GPU)
 
     import torch
 
@@ -374,9 +451,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if world != args.gpus:  # (a launcher with another world size, or --gpus 1 under a launcher)
+        fail("WORLD_SIZE (%d) != --gpus (%d): start one rank per GPU" % (world, args.gpus))
     mz.require_gpu()  # no CPU fallback: fail loudly if the HIP path is unavailable
+    share_gpu = os.environ.get("MZHIP_BENCH_SHARE_GPU") == "1"
+    if not share_gpu and torch.cuda.device_count() < world:
+        fail("--gpus %d but this rank sees %d device(s)" % (world, torch.cuda.device_count()))
     size = args.entry_size or cfg["size"]
     n_table = args.entries or cfg["entries"]
     n_unique = args.unique or cfg["unique"]
@@ -387,14 +467,14 @@ def main():
     seed = 1234 if strong else 1234 + rank
     offs = datas = None
     if cfg["codec"] == "lzma":
-        datas = synth.markov_entries(n_unique, size, seed, c)
+        datas = make_markov(c, n_unique, size, seed, world)
         pays, crcs = make_unique_lzma(datas, world)
     else:
         offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world)
     # MZHIP_BENCH_SHARE_GPU=1 (tests/test_gpu_bench_ranks.py, a box with ONE GPU): every rank uses device 0 and the
     # collectives go through gloo on host copies -- the N > 1 logic (sharding, gather, reductions) on real kernels
     # where RCCL cannot run (it refuses two ranks on one device).  Never set by the driver: the product path is RCCL.
-    share = world > 1 and os.environ.get("MZHIP_BENCH_SHARE_GPU") == "1"
+    share = world > 1 and share_gpu
     if share:
         local = 0
     torch.cuda.set_device(local)
@@ -435,7 +515,11 @@ def main():
         if offs is not None:
             offs = offs[:U]
     rnd = np.random.RandomState(99 if strong else 99 + rank)
-    pick_all = rnd.randint(0, U, size=n_table)
+    if U >= n_table:
+        pick_all = np.arange(n_table)  # every entry is its own stream
+    else:
+        pick_all = rnd.randint(0, U, size=n_table)  # the generator ran out of time (or --unique asked for fewer): tiled
+    tiled = n_table - len(np.unique(pick_all))
     plen = np.array([len(p) for p in pays], dtype=np.int64)
     lo, hi = 0, n_table
     bounds = None
@@ -556,7 +640,14 @@ def main():
 
     total_entries = n
     algo_all = float(algo_bytes)
+    rank_ms = [kernel_ms]
+    rank_entries = [n]
     if world > 1:
+        pr = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+        pr[2 * rank], pr[2 * rank + 1] = kernel_ms, float(n)
+        all_reduce(pr, dist.ReduceOp.SUM)
+        rank_ms = [round(float(x), 3) for x in pr[0::2].tolist()]
+        rank_entries = [int(x) for x in pr[1::2].tolist()]
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         all_reduce(t, dist.ReduceOp.MAX)
         s = torch.tensor([float(match), float(n), float(algo_bytes), float(bytes_ok)], dtype=torch.float64, device=dev)
@@ -566,16 +657,18 @@ def main():
         bytes_ok = int(s[3].item()) == world
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic(args.config, n, size)
         value = total_entries * size * args.steps / elapsed / 2**30
         achieved = algo_all / world / (kernel_ms / 1e3) / 1e9  # per GPU: the slowest rank's launch over an average shard
         line = {
             "metric": cfg["metric"], "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic: %d x %d B %s of %s (%s, ratio %.3f); %d unique tiled to %d entries%s, each entry with its own "
+            "data": "synthetic: %d x %d B %s of %s (%s, ratio %.3f); %d unique streams%s%s, each entry with its own "
                     "bytes in HBM" % (n_table, size, "order-2 word-Markov expansions" if datas is not None else "slices", cdesc,
                                       {"inflate": "zlib level 6 raw", "lzma": "LZMA preset 6 + end marker",
-                                       "deflate": "compressed here at level 1"}[cfg["codec"]], ratio, U, n_table,
+                                       "deflate": "compressed here at level 1"}[cfg["codec"]], ratio, n_table - tiled,
+                                      (", %d entries are tiled repeats" % tiled) if tiled else ", none tiled",
                                       "" if strong else " per GPU"),
             "crc32_match_rate": match / total_entries, "bytes_spot_check": bool(bytes_ok),
             "config": {"workload": cfg["workload"] % (n_table, size), "config": args.config,
@@ -584,14 +677,22 @@ def main():
                                     if strong else "independent table per rank, ") +
                                    "RCCL all_gather of per-entry {crc,status} only" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": measured_traffic(args.config, n, size),
-                         "kernel": cfg["kernel"], "kernel_ms": round(kernel_ms, 3),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": cfg["kernel"], "kernel_ms": round(kernel_ms, 3), "kernel_ms_per_rank": rank_ms,
                          "algorithmic_bytes_per_launch": int(algo_all / world), "per_gpu": True},
         }
         if cfg["codec"] == "inflate":
             geo = (C.c_uint32(), C.c_uint32(), C.c_uint32())
             L.mzhip_inflate_launch_geometry(n, *(C.byref(g) for g in geo))
-            line["config"]["launch"] = {"workgroups": geo[0].value, "waves_per_wg": geo[1].value, "lds_bytes_per_wg": geo[2].value}
+            resident = geo[0].value * geo[1].value
+            # one wave decodes one entry and the waves of a launch are persistent: a shard of E equal entries takes
+            # ceil(E / resident waves) rounds, so a shard that is not a multiple of the resident waves pays for a last,
+            # partly empty round (at N = 8, 12 500 entries over 4096 waves = 3.05 -> 4 rounds)
+            rounds = [e / max(resident, 1) for e in rank_entries]
+            line["config"]["launch"] = {"workgroups": geo[0].value, "waves_per_wg": geo[1].value, "lds_bytes_per_wg": geo[2].value,
+                                        "resident_waves": resident, "entries_per_rank": rank_entries,
+                                        "rounds_per_rank": [round(r, 3) for r in rounds],
+                                        "predicted_quantisation_efficiency": round(min(r / max(1.0, float(np.ceil(r))) for r in rounds), 3)}
         sample_zip = None
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1

@@ -26,16 +26,23 @@ def bench_corpus():
     return corpus(), "CPython's pydoc prose (oracle/_ref/corpus.bin absent)"
 
 
+_CHAIN = {}
+
+
 def markov_entries(n_unique, size, seed=3, text=None, jump=0.45):
     """Seeded order-2 word-Markov expansion of the corpus (mandatory for config 4: the corpus is only
     ~470 KB, so 1 MiB entries tiled from slices would repeat inside LZMA's dictionary).  `jump` = probability of leaving
     the chain at a word: 0.45 gives liblzma preset 6 a ratio of ~0.25 on the SURVEY corpus (0.15 without jumps)."""
     rnd = random.Random(seed)
-    words = (text if text is not None else corpus()).split()
-    nxt = {}
-    for a, b, c in zip(words, words[1:], words[2:]):
-        nxt.setdefault((a, b), []).append(c)
-    keys = list(nxt)
+    src = text if text is not None else corpus()
+    ck = (len(src), zlib.crc32(src))
+    if _CHAIN.get("key") != ck:  # the chain of one corpus is built once per process (bench.py's workers make one entry per call)
+        words = src.split()
+        nxt = {}
+        for a, b, c in zip(words, words[1:], words[2:]):
+            nxt.setdefault((a, b), []).append(c)
+        _CHAIN.update(key=ck, nxt=nxt, keys=list(nxt))
+    nxt, keys = _CHAIN["nxt"], _CHAIN["keys"]
     out = []
     for _ in range(n_unique):
         a, b = keys[rnd.randrange(len(keys))]

@@ -48,3 +48,33 @@ def test_weak_scaling_line():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["config"]["entries_total"] == 3000 and line["config"]["entries_rank0"] == 1500
     assert line["crc32_match_rate"] == 1.0
+
+
+def test_plain_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (WORLD_SIZE unset, the way the driver starts --gpus 1) must
+    start two ranks itself, not measure one GPU and call it two."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MZHIP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--entries", "3001", "--unique", "256"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["entries_total"] == 3001
+    assert len(line["roofline"]["kernel_ms_per_rank"]) == 2 and all(x > 0 for x in line["roofline"]["kernel_ms_per_rank"])
+    assert sum(line["config"]["launch"]["entries_per_rank"]) == 3001
+    assert line["crc32_match_rate"] == 1.0
+
+
+def test_more_gpus_than_the_box_has_is_an_error_not_a_smaller_run():
+    import torch
+
+    n = torch.cuda.device_count() + 7
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MZHIP_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "error" in json.loads(lines[0]) and "value" not in json.loads(lines[0])
