@@ -86,6 +86,12 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_DROOT 8 /* distance fast-table index bits        */
 #endif
 #define MZ_CROOT 7 /* code-length-code table bits (== max)  */
+#ifndef MZ_WINDOW_CHASE
+#define MZ_WINDOW_CHASE 1 /* span path, round 3 (inflate_chase.inc): every lane decodes its span ONCE and records its steps in
+                             a per-wave HBM scratch, then keeps walking into the next span until it stands on a token start the
+                             next lane also recorded ("chase"); bytes are made from the records.  0: the round-2 window
+                             (inflate_window.inc: passes re-decode until the starts stop moving) */
+#endif
 #ifndef MZ_SPAN_DW
 #define MZ_SPAN_DW 8 /* span-parallel decode (see mz_span_token): dwords of compressed stream per lane (4 or 8), 0 = off */
 #endif
@@ -95,6 +101,25 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_SPAN_SH (MZ_SPAN_DW == 8 ? 3u : 2u)
 #define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first three (odd) */
 #define MZ_SPAN_MAX_PASS 6u
+/* ---- chase window (MZ_WINDOW_CHASE): spans of up to MZ_CHASE_SMAX bits, one per lane; the stream reaches a lane through
+ * its own ring of MZ_CRING_DW dwords in LDS (+ 2 that mirror the first two, so dword a, a + 1, a + 2 are one address),
+ * topped up 4 dwords at a time every second step from a prefetch register; a step record is two dwords
+ * (token, leading literal: exactly what mz_span_token returns), two records per 16-byte store, row-major
+ * [pair of steps][lane] so that the wave's stores of one pair are 1 KiB contiguous. */
+#define MZ_CHASE_SMAX 3072u /* bits per span at most: ~170 steps on text, under the record cap below */
+#define MZ_REC_CAP1 256u    /* steps a lane may record on its own span ... */
+#define MZ_REC_CAP2 96u     /* ... and while chasing into the next one(s) */
+#define MZ_REC_BYTES ((MZ_REC_CAP1 + MZ_REC_CAP2) / 2u * 1024u + 64u * MZ_REC_CAP1 + 1024u) /* HBM scratch per wave: records + a byte per own step */
+#define MZ_CRING_DW 12u
+#define MZ_CRING_RS 15u /* row stride: 12 + 2 mirrored, odd */
+#define MZ_EMIT_GROUP 4u /* records one lane turns into bytes per emit round */
+#ifndef MZ_POOL_BYTES
+#if MZ_WINDOW_CHASE
+#define MZ_POOL_BYTES 2288u /* what the rings leave of the 9984 bytes a wave may have at 16 waves per CU */
+#else
+#define MZ_POOL_BYTES 3264u
+#endif
+#endif
 #ifndef MZ_POOL_BYTES
 #define MZ_POOL_BYTES 3264u /* span path: LDS pool of one window chunk = staging bytes of its output (from the front,
                                at most 4 KiB), a pending bit per byte, its back-reference list, 4 bytes each (from the back) */
@@ -223,7 +248,10 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
         uint32_t pool[MZ_POOL_BYTES / 4]; /* span path (never live together with the step loop's ring) */
 #endif
     } x;
-#if MZ_SPAN_DW
+#if MZ_SPAN_DW && MZ_WINDOW_CHASE
+    uint32_t win[64 * MZ_CRING_RS]; /* chase window: one ring row per lane while the lanes walk; the chain's per-lane tables
+                                       (steps, entry points, group counts) while the records become bytes */
+#elif MZ_SPAN_DW
     uint32_t win[65 * MZ_SPAN_RS]; /* span path: dword d of a window of (1 << ssh)-dword spans at win[(d >> ssh) * MZ_SPAN_RS + (d & ((1 << ssh) - 1))], and the first three dwords of row r + 1 again behind row r */
 #endif
 } mz_inflate_body_scratch;
@@ -599,11 +627,9 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
  * One step of a walk at window-relative bit `rel` (the same table walk as phase 1 of the step loop): the token that
  * starts there, or, when that is a literal of fewer than `room` bits, the literal (*pre = its table entry, else 0) and
  * the token behind it. */
-MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *wrow, uint32_t rel, uint32_t room, uint32_t *pre) {
-    /* wrow = the lane's row of the window, biased so that window dword d is wrow[d]: a walk stays inside its span
-     * (rel < the span's end), so everything it reads is the row's own dwords or the three copied behind them */
-    const uint32_t a = rel >> 5;
-    const uint32_t d0 = wrow[a], d1 = wrow[a + 1u], d2 = wrow[a + 2u];
+MZ_DEV uint32_t mz_span_token3(const mz_inflate_lds *L, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t rel, uint32_t room,
+                               uint32_t *pre) {
+    /* d0, d1, d2 = the stream dword that holds bit `rel` (only rel & 31 is looked at) and the two behind it */
     uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
     uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
     if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
@@ -637,13 +663,33 @@ MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *wrow, uin
     const uint32_t dist = mz_bfe(dd, 8, 15) + mz_bfe(dl, dn, dex);
     return (nb2 + dn + dex) | (lenl << 7) | (dist << 16);
 }
+MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *wrow, uint32_t rel, uint32_t room, uint32_t *pre) {
+    /* wrow = the lane's row of the window, biased so that window dword d is wrow[d]: a walk stays inside its span
+     * (rel < the span's end), so everything it reads is the row's own dwords or the three copied behind them */
+    const uint32_t a = rel >> 5;
+    return mz_span_token3(L, wrow[a], wrow[a + 1u], wrow[a + 2u], rel, room, pre);
+}
+/* dwords d .. d + 3 of the aligned stream (see mz_load_stream_dword), bytes outside the input read as zero */
+typedef struct { uint32_t v[4]; } mz_dw4;
+MZ_DEV mz_dw4 mz_load_stream_dw4(const uint8_t *in_al, uint32_t in_mis, uint32_t in_len, uint32_t d) {
+    mz_dw4 r;
+    const uint64_t lo = (uint64_t)d * 4u, end = (uint64_t)in_mis + in_len;
+    if (lo >= in_mis && lo + 16u <= end) {
+        __builtin_memcpy(&r, in_al + lo, 16); /* one global_load_dwordx4 (4-byte aligned) */
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) r.v[k] = mz_load_stream_dword(in_al, in_mis, in_len, d + k);
+    }
+    return r;
+}
 #endif
 
 
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out, uint32_t out_cap,
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                             uint32_t use_span, mz_inflate_result *res) {
+                             uint32_t use_span, uint8_t *rec /* MZ_REC_BYTES of HBM scratch of this wave (chase window) */,
+                             mz_inflate_result *res) {
     MZ_LANE_DECL
     /* The bit cursor is 32 bits wide, so the decoder looks at the stream through a VIEW of at most MZ_VIEW_MAX bytes
      * ([in, in + in_len), bitpos relative to `in`) and moves the view forward (MZ_REBASE) whenever the cursor is more
@@ -971,11 +1017,22 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
 
 #if MZ_SPAN_DW
             uint32_t span_skip = 0;     /* the step loop takes the next step (it owns the exact verdicts) */
-            uint32_t span_on = use_span; /* cleared for the rest of the block when a window cannot be committed here */
+            uint32_t span_on = (use_span && (!MZ_WINDOW_CHASE || rec)) ? 1u : 0u; /* cleared for the rest of the block when a window cannot be committed here */
 #endif
             for (;;) {
                 MZ_REBASE(ring_valid = 0) /* the ring is indexed by the position inside the view */
-#if MZ_SPAN_DW
+#if MZ_SPAN_DW && MZ_WINDOW_CHASE
+                {
+                    const uint32_t remain = total_bits - bitpos;
+                    /* at least two spans of 128 bits in front of the last 64 bits of the input (the longest token is 48) */
+                    if (span_on && qn == 0u && !span_skip && remain >= 64u + 2u * 128u) {
+                        ring_valid = 0; /* the pool covers the step loop's ring */
+                        MZ_PROF_MARK(3); /* step loop (if any) */
+#include "inflate_chase.inc"
+                    }
+                    span_skip = 0;
+                }
+#elif MZ_SPAN_DW
                 {
                     const uint32_t remain = total_bits - bitpos;
                     /* span size of this window: 256 bits, or 128 when what is left of the stream fits 64 spans of 128

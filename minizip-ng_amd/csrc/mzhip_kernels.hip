@@ -69,6 +69,7 @@ struct InflateArgs {
     int32_t *status;
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
+    uint8_t *rec; // MZ_REC_BYTES of step-record scratch per wave of the grid (chase window), or null
 };
 
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_batch(InflateArgs a) {
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
     MZ_LANE_DECL
     const int wave = threadIdx.x >> 6;
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
+    uint8_t *const rec = a.rec ? a.rec + ((size_t)blockIdx.x * MZ_WAVES_PER_WG + (size_t)wave) * MZ_REC_BYTES : nullptr;
     for (;;) {
         uint32_t e;
         MZ_WAVE_FETCH_ADD(e, a.counter);
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
         const uint64_t io = a.in_off[e], oo = a.out_off[e];
         const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
-        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, 1u, &r);
+        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, 1u, rec, &r);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -655,8 +657,22 @@ int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     a.tabs = c->d_tabs;
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE;
     const uint32_t grid = grid_for(c, n);
+    a.rec = nullptr;
+    int slot = -1;
+#if MZ_SPAN_DW && MZ_WINDOW_CHASE
+    { /* the step records of the chase window: MZ_REC_BYTES per wave of the launch (176 KiB x 4096 resident waves at most) */
+        void *scratch = nullptr;
+        rc = scratch_acquire(c, (size_t)grid * MZ_WAVES_PER_WG * MZ_REC_BYTES + 1024, s, &slot, &scratch);
+        if (rc) return rc;
+        a.rec = (uint8_t *)scratch;
+    }
+#endif
     hipLaunchKernelGGL(k_inflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
     const hipError_t le = hipGetLastError();
+    if (slot >= 0) {
+        const int32_t rr = scratch_release(c, slot, s);
+        if (rr && le == hipSuccess) return rr;
+    }
     if (le != hipSuccess) return fail("k_inflate_batch", le);
     return 0;
 }

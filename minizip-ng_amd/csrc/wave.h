@@ -38,6 +38,7 @@
 #define MZ_WRITELANE(name, idx, val) (name[(idx)] = (val)) /* one wave-uniform value into lane idx */
 #define MZ_UNIFORM(x) (x)
 #define MZ_WAVE_SYNC() ((void)0)
+#define MZ_CHASE_FENCE() ((void)0)
 #define MZ_BALLOT(dst, cond)                         \
     do {                                             \
         uint64_t _bal_acc = 0;                       \
@@ -119,6 +120,13 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
     do {                                                      \
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); \
         __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+/* global memory written by some lanes of this wave is about to be read through other lanes' addresses (K1's step
+ * records): the stores have left the CU and the vector L1 does not answer with what it held before them */
+#define MZ_CHASE_FENCE()                                       \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    \
     } while (0)
 #define MZ_BALLOT(dst, cond) ((dst) = __ballot(cond))
 /* One device-scope fetch-add per WAVE, result broadcast to every lane.  The wave barriers pin the

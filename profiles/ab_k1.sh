@@ -5,9 +5,10 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "m_base"
-  "m_nofused FUSED=0"
-  "m_frontier FRONTIER=1"
+  "chase"
+  "chase_prof PROF=1"
+  "r2 CHASE=0"
+  "r2_prof CHASE=0 PROF=1"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}

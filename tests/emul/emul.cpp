@@ -31,7 +31,10 @@ extern "C" int32_t emul_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out
     mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_inflate_result r;
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, &r);
+    uint8_t *rec = (uint8_t *)malloc(MZ_REC_BYTES + 1024); /* the wave's HBM record scratch (chase window) */
+    memset(rec, 0x5A, MZ_REC_BYTES + 1024);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, &r);
+    free(rec);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;
@@ -46,7 +49,7 @@ extern "C" int32_t emul_inflate_steps(const uint8_t *in, uint32_t in_len, uint8_
     mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_inflate_result r;
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 0u, &r);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 0u, (uint8_t *)0, &r);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;

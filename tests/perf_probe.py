@@ -42,8 +42,9 @@ if hasattr(lib, "mzhip_prof_read"):
     buf = (ctypes.c_ulonglong * 32)()
     lib.mzhip_prof_read(buf, 1)
     names = {0: "header: up to the code-length code", 1: "header: code lengths", 2: "header: decode tables", 3: "step loop + window load",
-             4: "counting passes", 5: "emitting passes", 6: "far copies", 7: "near copies", 8: "store", 9: "crc", 10: "crossings",
-             13: "choosing the chunk", 11: "block tails (step loop)", 12: "crc tail"}
+             4: "counting passes | chase: pass 1", 5: "emitting passes | chase: pass 2", 6: "far copies", 7: "near copies", 8: "store",
+             9: "crc", 10: "crossings | chase: the chain", 13: "choosing the chunk | chase: emit rounds", 11: "block tails (step loop)",
+             12: "crc tail"}
     tot = float(sum(buf)) or 1.0
     for i in sorted(names, key=lambda k: -buf[k]):
         print("  %-36s %5.1f %%" % (names[i], 100.0 * buf[i] / tot))
