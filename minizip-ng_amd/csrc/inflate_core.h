@@ -112,7 +112,9 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_REC_BYTES ((MZ_REC_CAP1 + MZ_REC_CAP2) / 2u * 1024u + 64u * MZ_REC_CAP1 + 1024u) /* HBM scratch per wave: records + a byte per own step */
 #define MZ_CRING_DW 12u
 #define MZ_CRING_RS 15u /* row stride: 12 + 2 mirrored, odd */
-#define MZ_EMIT_GROUP 4u /* records one lane turns into bytes per emit round */
+#ifndef MZ_EMIT_GROUP
+#define MZ_EMIT_GROUP 8u /* records one lane turns into bytes per emit round (a multiple of 2: records are stored in pairs) */
+#endif
 #ifndef MZ_POOL_BYTES
 #if MZ_WINDOW_CHASE
 #define MZ_POOL_BYTES 2288u /* what the rings leave of the 9984 bytes a wave may have at 16 waves per CU */
@@ -1024,7 +1026,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
 #if MZ_SPAN_DW && MZ_WINDOW_CHASE
                 {
                     const uint32_t remain = total_bits - bitpos;
-                    /* at least two spans of 128 bits in front of the last 64 bits of the input (the longest token is 48) */
+                    /* worth a window: two spans of 128 bits and some */
                     if (span_on && qn == 0u && !span_skip && remain >= 64u + 2u * 128u) {
                         ring_valid = 0; /* the pool covers the step loop's ring */
                         MZ_PROF_MARK(3); /* step loop (if any) */

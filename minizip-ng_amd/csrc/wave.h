@@ -122,11 +122,14 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
         __builtin_amdgcn_wave_barrier();                      \
     } while (0)
 /* global memory written by some lanes of this wave is about to be read through other lanes' addresses (K1's step
- * records): the stores have left the CU and the vector L1 does not answer with what it held before them */
-#define MZ_CHASE_FENCE()                                       \
-    do {                                                      \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    \
+ * records).  Workgroup scope: the wave's stores have been issued and waited for, and the compiler keeps the order; no
+ * cache maintenance is needed, because every lane of a wave sits behind the same vector L1 (gfx950, not in
+ * threadgroup-split mode).  The agent-scope pair that stood here first (buffer_wbl2 + buffer_inv) wrote back and
+ * invalidated caches three times per window: 7.77 ms instead of 4.75 ms on the 64 KiB probe (profiles/r3/ab_fence.log). */
+#define MZ_CHASE_FENCE()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
     } while (0)
 #define MZ_BALLOT(dst, cond) ((dst) = __ballot(cond))
 /* One device-scope fetch-add per WAVE, result broadcast to every lane.  The wave barriers pin the

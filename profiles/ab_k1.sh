@@ -7,8 +7,8 @@ set -u
 VARIANTS=(
   "chase"
   "chase_prof PROF=1"
-  "r2 CHASE=0"
-  "r2_prof CHASE=0 PROF=1"
+  "g4_prof PROF=1 EXTRA=-DMZ_EMIT_GROUP=4u"
+  "x2_prof PROF=1 EXTRA=-DMZ_CHASE_X=2"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}
