@@ -5,10 +5,12 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "chase"
-  "chase_prof PROF=1"
-  "g4_prof PROF=1 EXTRA=-DMZ_EMIT_GROUP=4u"
-  "x2_prof PROF=1 EXTRA=-DMZ_CHASE_X=2"
+  "nt EXTRA=-DMZ_CHASE_X=32"
+  "nt_f2 FSLOTS=2 EXTRA=-DMZ_CHASE_X=32"
+  "nt_nb NBATCH=1 EXTRA=-DMZ_CHASE_X=32"
+  "nt_s2 SLOTS=2 EXTRA=-DMZ_CHASE_X=32"
+  "nt_f2_nb FSLOTS=2 NBATCH=1 EXTRA=-DMZ_CHASE_X=32"
+  "nt_f2_nb_prof PROF=1 FSLOTS=2 NBATCH=1 EXTRA=-DMZ_CHASE_X=32"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}

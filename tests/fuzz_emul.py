@@ -1,12 +1,13 @@
 """CPU-side probe (not a pytest): a long differential run of K1 in the 64-lane host emulation against the oracle -- valid streams of
 every zlib level / strategy / window / memLevel, with mid-stream flushes, and bit flips, byte smashes and cuts of them, at
-four input / output misalignments and tight capacities.  Usage: python tests/fuzz_emul.py [seed=1] [N=2500]"""
+four input / output misalignments and tight capacities.  Usage: python tests/fuzz_emul.py [seed=1] [N=2500] [-D flags of the build ...]
+(e.g. -DMZ_REC_CAP1=16u -DMZ_REC_CAP2=8u -DMZ_CHASE_SMAX=512u: the chase window with every cap in reach)"""
 import sys, random, zlib, ctypes as C
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from tests import test_kernel_emul as t, synth
 import oracle
-L=t._build_variant("fuzz%d" % (int(sys.argv[1]) if len(sys.argv) > 1 else 1), [])
+L=t._build_variant("fuzz%d" % (int(sys.argv[1]) if len(sys.argv) > 1 else 1), sys.argv[3:])
 c=synth.corpus()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 2500

@@ -47,4 +47,4 @@ if hasattr(lib, "mzhip_prof_read"):
              12: "crc tail"}
     tot = float(sum(buf)) or 1.0
     for i in sorted(names, key=lambda k: -buf[k]):
-        print("  %-36s %5.1f %%" % (names[i], 100.0 * buf[i] / tot))
+        print("  %-36s %5.1f %%  %9.1f Mcycles" % (names[i], 100.0 * buf[i] / tot, buf[i] / 1e6))
