@@ -948,6 +948,17 @@ struct Scratch {
         if (p) (void)hipFree(p);
     }
 };
+// The synchronous host-buffer entry points (one entry at a time: what the vtbl shims call) run on the calling thread's
+// own stream: copies and launches are ordered on hipStreamPerThread and only that stream is waited for, so two host
+// threads never serialise on the null stream or on a device-wide synchronisation.
+#define MZ_HOST_STREAM hipStreamPerThread
+static inline hipError_t mz_h2d(void *dst, const void *src, size_t n) {
+    return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, MZ_HOST_STREAM); // (pageable source: staged before the call returns)
+}
+static inline hipError_t mz_d2h(void *dst, const void *src, size_t n) {
+    const hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, MZ_HOST_STREAM);
+    return e != hipSuccess ? e : hipStreamSynchronize(MZ_HOST_STREAM);
+}
 // Staging of the synchronous host-buffer calls: a buffer of the scratch cache instead of a hipMalloc / hipFree pair
 // per call (hipFree alone is a device-wide synchronisation); released when the call returns, after its own sync.
 struct Staging {
@@ -956,10 +967,10 @@ struct Staging {
     void *p = nullptr;
     int32_t get(DeviceCtx *ctx, size_t bytes) {
         c = ctx;
-        return scratch_acquire(ctx, bytes, nullptr, &slot, &p);
+        return scratch_acquire(ctx, bytes, MZ_HOST_STREAM, &slot, &p);
     }
     ~Staging() {
-        if (slot >= 0) (void)scratch_release(c, slot, nullptr);
+        if (slot >= 0) (void)scratch_release(c, slot, MZ_HOST_STREAM);
     }
 };
 } // namespace
@@ -987,21 +998,21 @@ int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, ui
     m.out_off = 64 + in_pad;
     m.in_len = in_len;
     m.out_cap = out_cap;
-    HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
-    if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
+    HIP_TRY(mz_h2d(base, &m, sizeof(m)));
+    if (in_len) HIP_TRY(mz_h2d(base + 64, in, in_len));
     Meta *dm = (Meta *)base;
     rc = mzhip_inflate_batch(base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, 1, &dm->out_len,
-                             &dm->in_used, &dm->crc, &dm->status, nullptr);
+                             &dm->in_used, &dm->crc, &dm->status, MZ_HOST_STREAM);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(MZ_HOST_STREAM));
     if (adler) { /* zlib wrapper: Adler-32 of the decoded bytes, reduced on the device as well */
-        HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
-        rc = mzhip_adler32_batch(base, &dm->out_off, &dm->out_len, 1, &dm->adler, nullptr);
+        HIP_TRY(mz_d2h(&m, base, sizeof(m)));
+        rc = mzhip_adler32_batch(base, &dm->out_off, &dm->out_len, 1, &dm->adler, MZ_HOST_STREAM);
         if (rc) return rc;
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(MZ_HOST_STREAM));
     }
-    HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
-    if (m.out_len && out) HIP_TRY(hipMemcpy(out, base + m.out_off, m.out_len, hipMemcpyDeviceToHost));
+    HIP_TRY(mz_d2h(&m, base, sizeof(m)));
+    if (m.out_len && out) HIP_TRY(mz_d2h(out, base + m.out_off, m.out_len));
     if (out_len) *out_len = m.out_len;
     if (in_used) *in_used = m.in_used;
     if (crc) *crc = m.crc;
@@ -1037,15 +1048,15 @@ static int32_t lzma_family_host(int xz, const uint8_t *in, uint32_t in_len, uint
     m.max_out = max_out;
     m.in_len = in_len;
     m.out_cap = out_cap;
-    HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
-    if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
+    HIP_TRY(mz_h2d(base, &m, sizeof(m)));
+    if (in_len) HIP_TRY(mz_h2d(base + 64, in, in_len));
     Meta *dm = (Meta *)base;
     rc = lzma_family_batch(xz, base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, &dm->max_out, 1,
-                           &dm->out_len, &dm->in_used, &dm->crc, &dm->status, nullptr);
+                           &dm->out_len, &dm->in_used, &dm->crc, &dm->status, MZ_HOST_STREAM);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
-    if (m.out_len && out) HIP_TRY(hipMemcpy(out, base + m.out_off, m.out_len, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(MZ_HOST_STREAM));
+    HIP_TRY(mz_d2h(&m, base, sizeof(m)));
+    if (m.out_len && out) HIP_TRY(mz_d2h(out, base + m.out_off, m.out_len));
     if (out_len) *out_len = m.out_len;
     if (in_used) *in_used = m.in_used;
     if (crc) *crc = m.crc;
@@ -1089,16 +1100,16 @@ int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_
     m.out_off = 64 + in_pad;
     m.in_len = in_len;
     m.out_cap = cap;
-    HIP_TRY(hipMemcpy(base, &m, sizeof(m), hipMemcpyHostToDevice));
-    if (in_len) HIP_TRY(hipMemcpy(base + 64, in, in_len, hipMemcpyHostToDevice));
+    HIP_TRY(mz_h2d(base, &m, sizeof(m)));
+    if (in_len) HIP_TRY(mz_h2d(base + 64, in, in_len));
     Meta *dm = (Meta *)base;
     rc = mzhip_lzma_encode_batch_preset(base, &dm->in_off, &dm->in_len, in_len, base, &dm->out_off, &dm->out_cap, nullptr, 1,
-                                        preset, &dm->out_len, &dm->crc, &dm->status, nullptr);
+                                        preset, &dm->out_len, &dm->crc, &dm->status, MZ_HOST_STREAM);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(&m, base, sizeof(m), hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(MZ_HOST_STREAM));
+    HIP_TRY(mz_d2h(&m, base, sizeof(m)));
     if (m.status == 0 && m.out_len > out_cap) m.status = MZHIP_STATUS_OUT_FULL;
-    if (m.status == 0 && m.out_len) HIP_TRY(hipMemcpy(out, base + m.out_off, m.out_len, hipMemcpyDeviceToHost));
+    if (m.status == 0 && m.out_len) HIP_TRY(mz_d2h(out, base + m.out_off, m.out_len));
     if (out_len) *out_len = m.out_len;
     if (crc) *crc = m.crc;
     return m.status;
@@ -1142,18 +1153,18 @@ int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t 
     }
     uint32_t total_crc = 0;
     if (np) {
-        HIP_TRY(hipMemcpy(base, hm.data(), meta, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(base + meta_pad, in, in_len, hipMemcpyHostToDevice));
+        HIP_TRY(mz_h2d(base, hm.data(), meta));
+        HIP_TRY(mz_h2d(base + meta_pad, in, in_len));
         uint64_t *d_in_off = (uint64_t *)base, *d_out_off = d_in_off + np;
         uint32_t *d_in_len = (uint32_t *)(d_out_off + np), *d_out_cap = d_in_len + np, *d_out_len = d_out_cap + np,
                  *d_crc = d_out_len + np;
         int32_t *d_status = (int32_t *)(d_crc + np);
         uint8_t *d_mode = (uint8_t *)(d_status + np);
         rc = mzhip_lzma_encode_batch_preset(base, d_in_off, d_in_len, piece, base, d_out_off, d_out_cap, d_mode, np, preset, d_out_len,
-                                     d_crc, d_status, nullptr);
+                                     d_crc, d_status, MZ_HOST_STREAM);
         if (rc) return rc;
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(hm.data(), base, meta, hipMemcpyDeviceToHost));
+        HIP_TRY(hipStreamSynchronize(MZ_HOST_STREAM));
+        HIP_TRY(mz_d2h(hm.data(), base, meta));
     }
     // ---- container (The .xz File Format 1.0.4): stream header, one block, index, footer
     uint32_t pos = 0;
@@ -1187,7 +1198,7 @@ int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t 
             uint8_t ch[6] = {(uint8_t)(0xE0 | ((us - 1) >> 16)), (uint8_t)((us - 1) >> 8), (uint8_t)(us - 1),
                              (uint8_t)((cs - 1) >> 8), (uint8_t)(cs - 1), MZ_LZE_PROPS};
             if (!put(ch, 6) || cs > out_cap - pos) return MZHIP_STATUS_OUT_FULL;
-            HIP_TRY(hipMemcpy(out + pos, base + h_out_off[i], cs, hipMemcpyDeviceToHost));
+            HIP_TRY(mz_d2h(out + pos, base + h_out_off[i], cs));
             pos += cs;
         }
     }
@@ -1259,8 +1270,8 @@ int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t fi
         h_out_cap[i] = pcap;
         h_final[i] = (uint8_t)((i + 1 == np && final) ? 1 : 0);
     }
-    hipError_t he = hipMemcpy(base, hm, meta, hipMemcpyHostToDevice);
-    if (he == hipSuccess && in_len) he = hipMemcpy(base + meta_pad, in, in_len, hipMemcpyHostToDevice);
+    hipError_t he = mz_h2d(base, hm, meta);
+    if (he == hipSuccess && in_len) he = mz_h2d(base + meta_pad, in, in_len);
     if (he != hipSuccess) {
         free(hm);
         return fail("hipMemcpy (deflate input)", he);
@@ -1272,17 +1283,17 @@ int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t fi
     uint32_t *d_adler = (uint32_t *)(d_status + np);
     uint8_t *d_final = (uint8_t *)(d_adler + np);
     rc = mzhip_deflate_batch_level(base, d_in_off, d_in_len, base, d_out_off, d_out_cap, d_final, np, level, window_log2, d_out_len,
-                                   d_crc, d_status, nullptr);
-    if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = -104;
+                                   d_crc, d_status, MZ_HOST_STREAM);
+    if (rc == 0 && hipStreamSynchronize(MZ_HOST_STREAM) != hipSuccess) rc = -104;
     /* zlib wrapper: Adler-32 of the same pieces, one wave each, combined below from the checksums alone */
-    if (rc == 0 && adler) rc = mzhip_adler32_batch(base, d_in_off, d_in_len, np, d_adler, nullptr);
-    if (rc == 0 && adler && hipDeviceSynchronize() != hipSuccess) rc = -104;
-    if (rc == 0 && hipMemcpy(hm, base, meta, hipMemcpyDeviceToHost) != hipSuccess) rc = -104;
+    if (rc == 0 && adler) rc = mzhip_adler32_batch(base, d_in_off, d_in_len, np, d_adler, MZ_HOST_STREAM);
+    if (rc == 0 && adler && hipStreamSynchronize(MZ_HOST_STREAM) != hipSuccess) rc = -104;
+    if (rc == 0 && mz_d2h(hm, base, meta) != hipSuccess) rc = -104;
     uint32_t total = 0, k = 0, ad = 1;
     for (uint32_t i = 0; rc == 0 && i < np; i++) {
         if (h_status[i] != 0) rc = h_status[i];
         else if (h_out_len[i] > out_cap - total) rc = MZHIP_STATUS_OUT_FULL;
-        else if (hipMemcpy(out + total, base + h_out_off[i], h_out_len[i], hipMemcpyDeviceToHost) != hipSuccess) rc = -104;
+        else if (mz_d2h(out + total, base + h_out_off[i], h_out_len[i]) != hipSuccess) rc = -104;
         else {
             total += h_out_len[i];
             k = (i == 0) ? h_crc[0] : mzhip_crc32_combine_host(k, h_crc[i], h_in_len[i]); /* checksums only */
@@ -1364,14 +1375,13 @@ uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
             size_t left = size - (size_t)i * seg;
             h_len[i] = (uint32_t)(left < seg ? left : seg);
         }
-        ok = hipMemcpy(base, h_off, meta, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMemcpy(base + meta_pad, buf, size, hipMemcpyHostToDevice) == hipSuccess;
+        ok = mz_h2d(base, h_off, meta) == hipSuccess &&
+             mz_h2d(base + meta_pad, buf, size) == hipSuccess;
         uint64_t *d_off = (uint64_t *)base;
         uint32_t *d_len = (uint32_t *)(d_off + nseg);
         uint32_t *d_crc = d_len + nseg;
-        ok = ok && mzhip_crc32_batch(base, d_off, d_len, nseg, nullptr, d_crc, nullptr) == 0;
-        ok = ok && hipDeviceSynchronize() == hipSuccess;
-        ok = ok && hipMemcpy(h_crc, d_crc, nseg * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && mzhip_crc32_batch(base, d_off, d_len, nseg, nullptr, d_crc, MZ_HOST_STREAM) == 0;
+        ok = ok && mz_d2h(h_crc, d_crc, nseg * sizeof(uint32_t)) == hipSuccess;
         if (ok)
             for (uint32_t i = 0; i < nseg; i++) v = mzhip_crc32_combine_host(v, h_crc[i], h_len[i]);
     }
@@ -1477,102 +1487,178 @@ void mzhip_prime_clear(void) {
 } // extern "C"
 
 namespace {
-// One slice of the primed entries, decoded on the CURRENT device of the calling thread: H2D of the byte range of the
-// archive that holds the slice's payloads, one launch per codec, D2H of the outputs into the shared host buffer.
-// ents[lo..hi) are in archive order; results land in the shared per-entry arrays at the same indices.
+// One slice of the primed entries, decoded on the CURRENT device of the calling thread, as a PIPELINE: the slice is
+// cut into chunks of about kPrimeChunk decoded bytes, and chunk i's H2D copy (the byte range of the archive that holds
+// its payloads), its launches (one per codec + the segment CRCs) and its D2H copies (results and every decoded byte)
+// are queued on stream i % 3, so that H2D(i + 1), kernel(i) and D2H(i - 1) run at the same time and the PCIe link is
+// busy in both directions while the kernels run (round 2: blocking copies and a device-wide synchronisation around one
+// launch per codec -- 31 GB/s over the link).  Only the stream that is about to be reused is waited
+// for, never the device.  ents[lo..hi) are in archive order; results land in the shared per-entry arrays.
+constexpr uint64_t kPrimeChunk = 48ull << 20;
+constexpr int kPrimeLanes = 3;
+struct PrimeLane {
+    hipStream_t s = nullptr;
+    Scratch d_zip, d_out, d_meta;
+    size_t zip_cap = 0, out_cap = 0, meta_cap = 0;
+    uint8_t *h_meta = nullptr; // page-locked staging: launch arrays up, results down
+    size_t h_cap = 0;
+    // the chunk in flight on this lane
+    bool busy = false;
+    size_t lo = 0, hi = 0;
+    uint32_t k = 0, ns = 0;
+    int64_t seg0 = 0;
+    std::vector<uint32_t> order;
+    size_t res_off = 0; // where the result arrays start inside h_meta
+    ~PrimeLane() {
+        if (s) (void)hipStreamDestroy(s);
+        if (h_meta) (void)hipHostFree(h_meta);
+    }
+};
+int32_t prime_lane_reserve(void **p, size_t *cap, size_t need) {
+    if (need <= *cap) return 0;
+    if (*p) HIP_TRY(hipFree(*p)); // (the lane's stream has been waited for: nothing uses the buffer)
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = (need + (need >> 2) + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+    HIP_TRY(hipMalloc(p, want));
+    *cap = want;
+    return 0;
+}
+// results of the chunk that ran on lane L: wait for its stream (only this one), scatter the per-entry words
+int32_t prime_lane_collect(PrimeLane &L, uint32_t *r_len, uint32_t *r_used, uint32_t *r_crc, int32_t *r_st,
+                           std::vector<uint32_t> &seg_crc_all) {
+    if (!L.busy) return 0;
+    HIP_TRY(hipStreamSynchronize(L.s));
+    const uint32_t k = L.k;
+    const uint32_t *h_len = (const uint32_t *)(L.h_meta + L.res_off), *h_used = h_len + k, *h_crc = h_used + k;
+    const int32_t *h_st = (const int32_t *)(h_crc + k);
+    const uint32_t *h_seg = (const uint32_t *)(h_st + k);
+    for (uint32_t i = 0; i < k; i++) {
+        const size_t g = L.lo + L.order[i];
+        r_len[g] = h_len[i];
+        r_used[g] = h_used[i];
+        r_crc[g] = h_crc[i];
+        r_st[g] = h_st[i];
+    }
+    if (L.ns) memcpy(seg_crc_all.data() + L.seg0, h_seg, (size_t)L.ns * 4);
+    L.busy = false;
+    return 0;
+}
 int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const std::vector<int64_t> &max_out_all, size_t lo,
                     size_t hi, uint8_t *h_out, uint32_t *r_len, uint32_t *r_used, uint32_t *r_crc, int32_t *r_st,
                     std::vector<uint32_t> &seg_crc_all) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
-    const uint32_t k = (uint32_t)(hi - lo);
-    if (k == 0) return 0;
-    uint64_t zlo = UINT64_MAX, zhi = 0;
-    for (size_t i = lo; i < hi; i++) {
-        zlo = std::min(zlo, (uint64_t)ents[i].payload_off);
-        zhi = std::max(zhi, (uint64_t)(ents[i].payload_off + ents[i].csize));
-    }
-    const int64_t out_base = ents[lo].out_off;
-    const uint64_t out_bytes = (uint64_t)(ents[hi - 1].out_off - out_base) + (((uint64_t)ents[hi - 1].usize + 15) & ~15ull);
-    /* group the launch arrays by method (8, 14, 95): one batch launch per codec */
-    std::vector<uint32_t> order(k);
-    for (uint32_t i = 0; i < k; i++) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ents[lo + a].method < ents[lo + b].method; });
-    std::vector<uint64_t> in_off(k), out_off(k), seg_off;
-    std::vector<uint32_t> in_len(k), out_cap(k), seg_len;
-    std::vector<int64_t> max_out(k), seg_first(k);
-    for (uint32_t i = 0; i < k; i++) {
-        const PrimedEntry &e = ents[lo + order[i]];
-        in_off[i] = (uint64_t)e.payload_off - zlo;
-        in_len[i] = (uint32_t)e.csize;
-        out_off[i] = (uint64_t)(e.out_off - out_base);
-        out_cap[i] = (uint32_t)e.usize;
-        max_out[i] = max_out_all[lo + order[i]];
-    }
-    // segments for the chunked CRC updates, in archive order (seg0 was assigned by the caller)
-    for (size_t i = lo; i < hi; i++)
-        for (int64_t o = 0; o < ents[i].usize; o += kSeg) {
-            seg_off.push_back((uint64_t)(ents[i].out_off - out_base) + (uint64_t)o);
-            seg_len.push_back((uint32_t)(ents[i].usize - o < kSeg ? ents[i].usize - o : kSeg));
+    if (hi <= lo) return 0;
+    PrimeLane lanes[kPrimeLanes];
+    for (auto &L : lanes) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+    int turn = 0;
+    for (size_t c0 = lo; c0 < hi;) {
+        /* the next chunk: entries [c0, c1), about kPrimeChunk decoded bytes (one entry at least) */
+        size_t c1 = c0;
+        uint64_t acc = 0;
+        while (c1 < hi && (c1 == c0 || acc + (uint64_t)ents[c1].usize + (uint64_t)ents[c1].csize <= kPrimeChunk)) {
+            acc += (uint64_t)ents[c1].usize + (uint64_t)ents[c1].csize;
+            c1++;
         }
-    const uint32_t ns = (uint32_t)seg_off.size();
-    const size_t meta = (size_t)k * (8 + 8 + 8 + 4 + 4 + 4 + 4 + 4 + 4) + (size_t)ns * (8 + 4 + 4) + 256;
-    Scratch d_zip, d_out, d_meta;
-    HIP_TRY(hipMalloc(&d_zip.p, zhi - zlo + 16));
-    HIP_TRY(hipMalloc(&d_out.p, out_bytes + 16));
-    HIP_TRY(hipMalloc(&d_meta.p, meta));
-    HIP_TRY(hipMemcpy(d_zip.p, zip + zlo, zhi - zlo, hipMemcpyHostToDevice));
-    uint8_t *m = (uint8_t *)d_meta.p;
-    uint64_t *d_in_off = (uint64_t *)m, *d_out_off = d_in_off + k, *d_seg_off = d_out_off + k;
-    int64_t *d_max_out = (int64_t *)(d_seg_off + ns);
-    uint32_t *d_in_len = (uint32_t *)(d_max_out + k), *d_out_cap = d_in_len + k, *d_out_len = d_out_cap + k,
-             *d_in_used = d_out_len + k, *d_crc = d_in_used + k;
-    int32_t *d_status = (int32_t *)(d_crc + k);
-    uint32_t *d_seg_len = (uint32_t *)(d_status + k), *d_seg_crc = d_seg_len + ns;
-    HIP_TRY(hipMemcpy(d_in_off, in_off.data(), k * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_out_off, out_off.data(), k * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_in_len, in_len.data(), k * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_out_cap, out_cap.data(), k * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_max_out, max_out.data(), k * 8, hipMemcpyHostToDevice));
-    if (ns) {
-        HIP_TRY(hipMemcpy(d_seg_off, seg_off.data(), ns * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_seg_len, seg_len.data(), ns * 4, hipMemcpyHostToDevice));
-    }
-    for (uint32_t g0 = 0; g0 < k;) {
-        uint32_t g1 = g0;
-        const int32_t method = ents[lo + order[g0]].method;
-        while (g1 < k && ents[lo + order[g1]].method == method) g1++;
-        const uint32_t gn = g1 - g0;
-        if (method == 8)
-            rc = mzhip_inflate_batch(d_zip.p, d_in_off + g0, d_in_len + g0, d_out.p, d_out_off + g0, d_out_cap + g0, gn,
-                                     d_out_len + g0, d_in_used + g0, d_crc + g0, d_status + g0, nullptr);
-        else
-            rc = lzma_family_batch(method == 95, d_zip.p, d_in_off + g0, d_in_len + g0, d_out.p, d_out_off + g0,
-                                   d_out_cap + g0, d_max_out + g0, gn, d_out_len + g0, d_in_used + g0, d_crc + g0,
-                                   d_status + g0, nullptr);
+        PrimeLane &L = lanes[turn];
+        turn = (turn + 1) % kPrimeLanes;
+        rc = prime_lane_collect(L, r_len, r_used, r_crc, r_st, seg_crc_all); /* the chunk this lane ran three chunks ago */
         if (rc) return rc;
-        g0 = g1;
-    }
-    if (ns) {
-        rc = mzhip_crc32_batch(d_out.p, d_seg_off, d_seg_len, ns, nullptr, d_seg_crc, nullptr);
+        const uint32_t k = (uint32_t)(c1 - c0);
+        uint64_t zlo = UINT64_MAX, zhi = 0;
+        for (size_t i = c0; i < c1; i++) {
+            zlo = std::min(zlo, (uint64_t)ents[i].payload_off);
+            zhi = std::max(zhi, (uint64_t)(ents[i].payload_off + ents[i].csize));
+        }
+        const int64_t out_base = ents[c0].out_off;
+        const uint64_t out_bytes = (uint64_t)(ents[c1 - 1].out_off - out_base) + (((uint64_t)ents[c1 - 1].usize + 15) & ~15ull);
+        uint32_t ns = 0;
+        for (size_t i = c0; i < c1; i++) ns += (uint32_t)((ents[i].usize + kSeg - 1) / kSeg);
+        /* launch arrays (grouped by method: one batch launch per codec) and result arrays, one page-locked block:
+         *   up:   in_off[k] out_off[k] seg_off[ns] max_out[k] (8 bytes each)  in_len[k] out_cap[k] seg_len[ns] (4 bytes each)
+         *   down: out_len[k] in_used[k] crc[k] status[k] seg_crc[ns] */
+        const size_t up = (size_t)k * 24 + (size_t)ns * 8 + (size_t)k * 8 + (size_t)ns * 4;
+        const size_t down = (size_t)k * 16 + (size_t)ns * 4;
+        const size_t up_al = (up + 255) & ~(size_t)255;
+        if (up_al + down > L.h_cap) {
+            if (L.h_meta) HIP_TRY(hipHostFree(L.h_meta));
+            L.h_meta = nullptr;
+            L.h_cap = 0;
+            const size_t want = ((up_al + down) * 2 + 4095) & ~(size_t)4095;
+            HIP_TRY(hipHostMalloc((void **)&L.h_meta, want, hipHostMallocDefault));
+            L.h_cap = want;
+        }
+        rc = prime_lane_reserve(&L.d_zip.p, &L.zip_cap, (size_t)(zhi - zlo) + 16);
+        if (!rc) rc = prime_lane_reserve(&L.d_out.p, &L.out_cap, (size_t)out_bytes + 16);
+        if (!rc) rc = prime_lane_reserve(&L.d_meta.p, &L.meta_cap, up_al + down + 256);
         if (rc) return rc;
+        L.order.resize(k);
+        for (uint32_t i = 0; i < k; i++) L.order[i] = i;
+        std::stable_sort(L.order.begin(), L.order.end(), [&](uint32_t a, uint32_t b) { return ents[c0 + a].method < ents[c0 + b].method; });
+        uint64_t *h_in_off = (uint64_t *)L.h_meta, *h_out_off = h_in_off + k, *h_seg_off = h_out_off + k;
+        int64_t *h_max_out = (int64_t *)(h_seg_off + ns);
+        uint32_t *h_in_len = (uint32_t *)(h_max_out + k), *h_out_cap = h_in_len + k, *h_seg_len = h_out_cap + k;
+        for (uint32_t i = 0; i < k; i++) {
+            const PrimedEntry &e = ents[c0 + L.order[i]];
+            h_in_off[i] = (uint64_t)e.payload_off - zlo;
+            h_in_len[i] = (uint32_t)e.csize;
+            h_out_off[i] = (uint64_t)(e.out_off - out_base);
+            h_out_cap[i] = (uint32_t)e.usize;
+            h_max_out[i] = max_out_all[c0 + L.order[i]];
+        }
+        { // segments for the chunked CRC updates, in archive order (seg0 was assigned by the caller)
+            uint32_t j = 0;
+            for (size_t i = c0; i < c1; i++)
+                for (int64_t o = 0; o < ents[i].usize; o += kSeg) {
+                    h_seg_off[j] = (uint64_t)(ents[i].out_off - out_base) + (uint64_t)o;
+                    h_seg_len[j] = (uint32_t)(ents[i].usize - o < kSeg ? ents[i].usize - o : kSeg);
+                    j++;
+                }
+        }
+        uint8_t *m = (uint8_t *)L.d_meta.p;
+        uint64_t *d_in_off = (uint64_t *)m, *d_out_off = d_in_off + k, *d_seg_off = d_out_off + k;
+        int64_t *d_max_out = (int64_t *)(d_seg_off + ns);
+        uint32_t *d_in_len = (uint32_t *)(d_max_out + k), *d_out_cap = d_in_len + k, *d_seg_len = d_out_cap + k;
+        uint32_t *d_out_len = (uint32_t *)(m + up_al), *d_in_used = d_out_len + k, *d_crc = d_in_used + k;
+        int32_t *d_status = (int32_t *)(d_crc + k);
+        uint32_t *d_seg_crc = (uint32_t *)(d_status + k);
+        HIP_TRY(hipMemcpyAsync(L.d_zip.p, zip + zlo, zhi - zlo, hipMemcpyHostToDevice, L.s));
+        HIP_TRY(hipMemcpyAsync(m, L.h_meta, up, hipMemcpyHostToDevice, L.s));
+        for (uint32_t g0 = 0; g0 < k;) {
+            uint32_t g1 = g0;
+            const int32_t method = ents[c0 + L.order[g0]].method;
+            while (g1 < k && ents[c0 + L.order[g1]].method == method) g1++;
+            const uint32_t gn = g1 - g0;
+            if (method == 8)
+                rc = mzhip_inflate_batch(L.d_zip.p, d_in_off + g0, d_in_len + g0, L.d_out.p, d_out_off + g0, d_out_cap + g0, gn,
+                                         d_out_len + g0, d_in_used + g0, d_crc + g0, d_status + g0, L.s);
+            else
+                rc = lzma_family_batch(method == 95, L.d_zip.p, d_in_off + g0, d_in_len + g0, L.d_out.p, d_out_off + g0,
+                                       d_out_cap + g0, d_max_out + g0, gn, d_out_len + g0, d_in_used + g0, d_crc + g0,
+                                       d_status + g0, L.s);
+            if (rc) return rc;
+            g0 = g1;
+        }
+        if (ns) {
+            rc = mzhip_crc32_batch(L.d_out.p, d_seg_off, d_seg_len, ns, nullptr, d_seg_crc, L.s);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(L.h_meta + up_al, m + up_al, down, hipMemcpyDeviceToHost, L.s));
+        HIP_TRY(hipMemcpyAsync(h_out + out_base, L.d_out.p, out_bytes, hipMemcpyDeviceToHost, L.s));
+        L.busy = true;
+        L.lo = c0;
+        L.hi = c1;
+        L.k = k;
+        L.ns = ns;
+        L.seg0 = ents[c0].seg0;
+        L.res_off = up_al;
+        c0 = c1;
     }
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<uint32_t> h_len(k), h_used(k), h_crc(k);
-    std::vector<int32_t> h_st(k);
-    HIP_TRY(hipMemcpy(h_len.data(), d_out_len, k * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_used.data(), d_in_used, k * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_crc.data(), d_crc, k * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_st.data(), d_status, k * 4, hipMemcpyDeviceToHost));
-    if (ns) HIP_TRY(hipMemcpy(seg_crc_all.data() + ents[lo].seg0, d_seg_crc, ns * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_out + out_base, d_out.p, out_bytes, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < k; i++) {
-        const size_t g = lo + order[i];
-        r_len[g] = h_len[i];
-        r_used[g] = h_used[i];
-        r_crc[g] = h_crc[i];
-        r_st[g] = h_st[i];
+    for (int i = 0; i < kPrimeLanes; i++) { /* in the order they were started */
+        rc = prime_lane_collect(lanes[(turn + i) % kPrimeLanes], r_len, r_used, r_crc, r_st, seg_crc_all);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -1620,7 +1706,7 @@ int32_t prime_store(const uint8_t *zip, const std::vector<std::pair<int64_t, int
         HIP_TRY(hipMemcpy(d_len, len.data(), (size_t)gn * 4, hipMemcpyHostToDevice));
         const int32_t rc = mzhip_crc32_batch(d_buf.p, d_off, d_len, gn, nullptr, d_crc, nullptr);
         if (rc) return rc;
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(nullptr)); /* the launches above are on the null stream */
         HIP_TRY(hipMemcpy(crc.data(), d_crc, (size_t)gn * 4, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < gn; i++) gen->store_segs[s0 + i].crc = crc[i];
         s0 = s1;
@@ -2074,7 +2160,7 @@ int64_t mzhip_prime_write(int32_t method, const uint8_t *blob, const uint64_t *o
         if (rc) return rc;
         rc = mzhip_crc32_batch(d_data.p, d_seg_off, d_seg_len, ns, nullptr, d_seg_crc, nullptr);
         if (rc) return rc;
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(nullptr)); /* the launches above are on the null stream */
         std::vector<uint32_t> h_len(nu), h_crc(nu), h_seg(ns);
         std::vector<int32_t> h_st(nu);
         HIP_TRY(hipMemcpy(h_len.data(), d_out_len, (size_t)nu * 4, hipMemcpyDeviceToHost));

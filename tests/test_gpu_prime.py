@@ -262,3 +262,57 @@ def test_prime_serves_store_entries():
         _, _, _, st_rb = ref.zip_read_all(path, cd, nthreads=1, own_crc=False)
         assert st_b[k] != 0 and st_b[k] == st_rb[k] and (np.delete(st_b, k) == 0).all()
         L.mzhip_prime_clear()
+
+
+def test_pipelined_prime_many_chunks_and_reader_threads():
+    """The prime is a pipeline now (chunks of ~48 MiB of decoded bytes on three streams, H2D / launches / D2H overlapped):
+    an archive of several chunks, mixed sizes and methods, must come out exactly as the one-thread reference reads it;
+    and four (then sixteen) reader threads, one mz_zip_reader each, over the primed archive verify every entry
+    (integration/extract_threads.c) -- the shims are used from many host threads at once."""
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    D = C.CDLL(DROP)
+    if not hasattr(D, "mzdrop_extract_all"):
+        pytest.skip("libmzhipdrop.so predates extract_threads.c")
+    D.mzdrop_extract_all.restype = C.c_double
+    D.mzdrop_extract_all.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L = mz.lib()
+    L.mzhip_prime_file.restype = C.c_int64
+    L.mzhip_prime_file.argtypes = [C.c_char_p]
+    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(16)
+    n = 3000
+    lens = np.full(n, 65536, dtype=np.int32)
+    lens[::7] = rnd.randint(0, 400000, size=len(lens[::7]))
+    lens[5] = 0
+    offs = rnd.randint(0, len(c) - 400000, size=n).astype(np.int64)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "big.zip")
+        ref.zip_write(path, c, offs, lens, method=8, level=1)           # ~250 MB decoded: five or six chunks
+        table = ref.zip_index(path)
+        cd = table[:, 6].copy()
+        out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+        o_ref = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        _, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=4, own_crc=False, out=o_ref, out_off=out_off)
+        assert (st_r == 0).all()
+        L.mzhip_prime_clear()
+        cached = L.mzhip_prime_file(path.encode())
+        assert cached >= n - 2
+        _, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=4, own_crc=False, out=o_hip, out_off=out_off)
+        assert (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all() and (o_hip == o_ref).all()
+        ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        assert miss.value == 0 and hits.value >= cached - 2
+        for T in (4, 16):
+            L.mzhip_prime_clear()
+            ne, nb, tp, fe = C.c_int64(0), C.c_int64(0), C.c_double(0), C.c_int32(0)
+            sec = D.mzdrop_extract_all(path.encode(), T, 1, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
+            assert sec > 0 and fe.value == 0 and ne.value == n and nb.value == int(lens.sum()), (T, sec, fe.value, ne.value)
+            print("%d reader threads: %.3f s (prime %.3f s) = %.2f GiB/s" % (T, sec, tp.value, nb.value / 2**30 / sec))
+        L.mzhip_prime_clear()
