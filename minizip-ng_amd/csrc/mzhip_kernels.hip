@@ -483,6 +483,15 @@ int32_t ctx_for_current(DeviceCtx **out) {
 // profiles/r1/side_measurements.log), so buffers are plain hipMalloc memory cached here.  A buffer is handed out again
 // when the next launch is on the stream that used it last (stream order protects it) or when the event recorded behind
 // its last use has completed; otherwise another buffer is allocated, so concurrent streams never share scratch.
+// Identity of a stream for the "same stream => stream order protects the buffer" shortcut of the two caches below.
+// hipStreamPerThread is ONE handle value that names a different stream in every host thread: two threads must not
+// take each other for the same stream (they did for a day: a second thread's launch reused the work-queue head and the
+// record scratch of a kernel that was still running -- CRC errors in the two-thread drop-in test).
+hipStream_t stream_key(hipStream_t s) {
+    static thread_local char tls_marker;
+    return s == hipStreamPerThread ? (hipStream_t)(void *)&tls_marker : s;
+}
+
 int32_t scratch_acquire(DeviceCtx *c, size_t bytes, hipStream_t s, int *slot, void **p) {
     std::lock_guard<std::mutex> lk(g_mu);
     constexpr int kSlots = (int)(sizeof(c->scratch) / sizeof(c->scratch[0]));
@@ -495,7 +504,7 @@ int32_t scratch_acquire(DeviceCtx *c, size_t bytes, hipStream_t s, int *slot, vo
         }
         if (e.held) continue;
         const bool done = !e.used || hipEventQuery(e.ev) == hipSuccess;
-        if (e.cap >= bytes && (done || e.last == s)) {
+        if (e.cap >= bytes && (done || e.last == stream_key(s))) {
             if (best < 0 || e.cap < c->scratch[best].cap) best = i;
         } else if (done && (victim < 0 || e.cap < c->scratch[victim].cap)) {
             victim = i; // idle and too small
@@ -536,7 +545,7 @@ int32_t scratch_release(DeviceCtx *c, int slot, hipStream_t s) {
     DeviceCtx::ScratchEnt &e = c->scratch[slot];
     e.held = false;
     e.used = true;
-    e.last = s;
+    e.last = stream_key(s);
     HIP_TRY(hipEventRecord(e.ev, s));
     return 0;
 }
@@ -553,15 +562,16 @@ struct CounterLease {
     int32_t get(DeviceCtx *ctx, hipStream_t st) {
         c = ctx;
         s = st;
+        hipEvent_t wait_for = nullptr;
         {
             std::lock_guard<std::mutex> lk(g_mu);
             for (uint32_t k = 0; k < MZ_NUM_COUNTERS && idx < 0; k++) {
                 const uint32_t i = (c->next_counter + k) % MZ_NUM_COUNTERS;
                 DeviceCtx::CounterSlot &e = c->cslots[i];
                 if (e.held) continue;
-                if (!e.used || e.last == s || hipEventQuery(e.ev) == hipSuccess) idx = (int)i;
+                if (!e.used || e.last == stream_key(s) || hipEventQuery(e.ev) == hipSuccess) idx = (int)i;
             }
-            if (idx < 0) { /* every counter is busy on another stream: wait for one that is not being set up right now */
+            if (idx < 0) { /* every counter is busy on another stream: take one that is not being set up right now and wait for its launch */
                 for (uint32_t k = 0; k < MZ_NUM_COUNTERS && idx < 0; k++) {
                     const uint32_t i = (c->next_counter + k) % MZ_NUM_COUNTERS;
                     if (!c->cslots[i].held) idx = (int)i;
@@ -570,11 +580,12 @@ struct CounterLease {
                     snprintf(g_err, sizeof(g_err), "more than %d launches being set up at once", MZ_NUM_COUNTERS);
                     return -104;
                 }
-                HIP_TRY(hipEventSynchronize(c->cslots[idx].ev));
+                wait_for = c->cslots[idx].ev;
             }
-            c->cslots[idx].held = true;
+            c->cslots[idx].held = true; /* ours from here on: the wait below happens outside the lock */
             c->next_counter = (uint32_t)idx + 1u;
         }
+        if (wait_for) HIP_TRY(hipEventSynchronize(wait_for));
         p = c->d_counters + 2 * idx; /* two words per slot: the LZMA encoder's two kernels each have a head */
         HIP_TRY(hipMemsetAsync(p, 0, 2 * sizeof(uint32_t), s));
         return 0;
@@ -586,7 +597,7 @@ struct CounterLease {
         if (!e.ev && hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) e.ev = nullptr;
         if (e.ev) (void)hipEventRecord(e.ev, s);
         e.used = e.ev != nullptr;
-        e.last = s;
+        e.last = stream_key(s);
         e.held = false;
     }
 };
@@ -606,8 +617,11 @@ const char *mzhip_last_error(void) { return g_err; }
 const char *mzhip_version(void) { return "mzhip 0.1 (gfx950)"; }
 
 int32_t mzhip_device_count(void) {
+    static std::atomic<int> known{0}; /* every open() of a codec stream asks: one runtime call per process is enough */
+    if (known.load(std::memory_order_relaxed) > 0) return known.load(std::memory_order_relaxed);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipSuccess && n > 0) known.store(n);
     if (e != hipSuccess) {
         fail("hipGetDeviceCount", e);
         return -1;
@@ -1412,6 +1426,77 @@ __attribute__((visibility("hidden"))) int32_t mzhip_take_crc_fault(void) {
 // per entry, and per 65 535-byte segment (the reader's buffer size, mz_zip_rw.c:55) for the chunked updates.
 
 namespace {
+// Page-locked host memory is expensive to make (the pages are faulted in and pinned: ~100 ms per GiB) and a process that
+// primes one archive after another needs the same two blocks again and again (the file image, the decoded bytes), so
+// freed blocks are kept -- four at most, 4 GiB in all -- and handed out again when they are large enough.
+struct PinnedPool {
+    std::mutex mu;
+    struct Blk {
+        void *p = nullptr;
+        size_t cap = 0;
+    } blk[4];
+    void *get(size_t need, size_t *cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (int i = 0; i < 4; i++)
+                if (blk[i].p && blk[i].cap >= need && (best < 0 || blk[i].cap < blk[best].cap)) best = i;
+            if (best >= 0 && blk[best].cap <= 2 * need + ((size_t)64 << 20)) {
+                void *p = blk[best].p;
+                *cap = blk[best].cap;
+                blk[best] = Blk();
+                return p;
+            }
+        }
+        void *p = nullptr;
+        const size_t want = (need + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        *cap = want;
+        return p;
+    }
+    void put(void *p, size_t cap) {
+        if (!p) return;
+        void *drop = p;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t total = cap;
+            int empty = -1, smallest = -1;
+            for (int i = 0; i < 4; i++) {
+                if (!blk[i].p) {
+                    if (empty < 0) empty = i;
+                    continue;
+                }
+                total += blk[i].cap;
+                if (smallest < 0 || blk[i].cap < blk[smallest].cap) smallest = i;
+            }
+            if (total <= ((size_t)4 << 30)) {
+                if (empty >= 0) {
+                    blk[empty].p = p;
+                    blk[empty].cap = cap;
+                    drop = nullptr;
+                } else if (blk[smallest].cap < cap) {
+                    drop = blk[smallest].p;
+                    blk[smallest].p = p;
+                    blk[smallest].cap = cap;
+                }
+            }
+        }
+        if (drop) (void)hipHostFree(drop);
+    }
+};
+PinnedPool g_pinned;
+double prime_now() {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+bool prime_trace() {
+    static const bool on = getenv("MZHIP_PRIME_TRACE") != nullptr;
+    return on;
+}
 struct PrimedEntry {
     int64_t payload_off, csize, usize, out_off;
     uint32_t crc;
@@ -1426,8 +1511,9 @@ struct PrimedEntry {
 struct PrimeGen {
     std::vector<PrimedEntry> entries; // sorted by payload_off
     std::vector<uint32_t> seg_crc;
-    uint8_t *out = nullptr; // page-locked (hipHostMalloc): the D2H copy of the decoded bytes runs at link speed
+    uint8_t *out = nullptr; // page-locked (hipHostMalloc, from g_pinned): the D2H copy of the decoded bytes runs at link speed
     bool out_pinned = false;
+    size_t out_cap = 0;
     uint64_t zip_len = 0, ident = 0; // archive identity: length + hash of its central directory and end records
     // STORE entries: no codec stream sees them (the reference's raw stream hands the bytes to mz_crypt_crc32_update,
     // mz_zip.c:2047-2049), so the CRC symbol recognises a chunk by content: the payloads are kept, cut into the reader's
@@ -1442,7 +1528,7 @@ struct PrimeGen {
     bool store_pinned = false;
     uint64_t store_entries = 0;
     ~PrimeGen() {
-        if (out_pinned) (void)hipHostFree(out);
+        if (out_pinned) g_pinned.put(out, out_cap);
         else free(out);
         if (store_pinned) (void)hipHostFree(store);
         else free(store);
@@ -1454,6 +1540,7 @@ struct PrimeCache {
 };
 PrimeCache g_prime;
 std::mutex g_prime_mu;
+std::atomic<int> g_any_gens{0};   // generations present at all: the streams' "is there anything to look up" (mzhip_prime_any)
 std::atomic<int> g_store_gens{0}; // generations that hold STORE chunks: the CRC symbol's fast "nothing to look up"
 constexpr uint32_t kSeg = 65535u;
 constexpr size_t kMaxGens = 8;
@@ -1473,6 +1560,7 @@ void count_store_gens_locked() {
     int k = 0;
     for (const auto &g : g_prime.gens) k += g->store_segs.empty() ? 0 : 1;
     g_store_gens.store(k);
+    g_any_gens.store((int)g_prime.gens.size());
 }
 } // namespace
 
@@ -1482,6 +1570,7 @@ void mzhip_prime_clear(void) {
     std::lock_guard<std::mutex> lk(g_prime_mu);
     g_prime = PrimeCache(); // generations pinned by open streams live until those streams let go
     g_store_gens.store(0);
+    g_any_gens.store(0);
 }
 
 } // extern "C"
@@ -1788,15 +1877,15 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
     }
     const size_t k = ents.size();
     if (k == 0 && stores.empty()) return 0;
-    uint8_t *h_out = nullptr;
-    bool out_pinned = hipHostMalloc((void **)&h_out, total_out + 16, hipHostMallocDefault) == hipSuccess;
-    if (!out_pinned) {
-        (void)hipGetLastError();
-        h_out = (uint8_t *)malloc(total_out + 16);
-    }
+    const double t_idx = prime_now();
+    size_t h_cap = 0;
+    uint8_t *h_out = (uint8_t *)g_pinned.get(total_out + 16, &h_cap);
+    bool out_pinned = h_out != nullptr;
+    if (!out_pinned) h_out = (uint8_t *)malloc(total_out + 16);
     if (!h_out) return -4;
+    const double t_alloc = prime_now();
     auto drop_out = [&] {
-        if (out_pinned) (void)hipHostFree(h_out);
+        if (out_pinned) g_pinned.put(h_out, h_cap);
         else free(h_out);
     };
     std::vector<uint32_t> r_len(k), r_used(k), r_crc(k), seg_crc((size_t)nseg);
@@ -1846,6 +1935,10 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
     gen->seg_crc = std::move(seg_crc);
     gen->out = h_out;
     gen->out_pinned = out_pinned;
+    gen->out_cap = h_cap;
+    if (prime_trace())
+        fprintf(stderr, "[mzhip prime] %zu entries, %.1f MiB decoded: pinned output %.1f ms, decode pipeline %.1f ms\n", k,
+                (double)total_out / 1048576.0, (t_alloc - t_idx) * 1e3, (prime_now() - t_alloc) * 1e3);
     gen->zip_len = zip_len;
     {
         /* identity = length + hash of everything from the first central-directory record to the end of the file */
@@ -1882,16 +1975,20 @@ static int64_t prime_file_on(const char *path, const int32_t *devices, int32_t n
     fseeko(f, 0, SEEK_END);
     const int64_t len = (int64_t)ftello(f);
     fseeko(f, 0, SEEK_SET);
-    uint8_t *buf = nullptr; /* page-locked: the H2D copies of the payload ranges run at link speed */
-    const bool pinned = hipHostMalloc((void **)&buf, (size_t)(len > 0 ? len : 1), hipHostMallocDefault) == hipSuccess;
-    if (!pinned) {
-        (void)hipGetLastError();
-        buf = (uint8_t *)malloc((size_t)(len > 0 ? len : 1));
-    }
+    const double t0 = prime_now();
+    size_t cap = 0;
+    uint8_t *buf = (uint8_t *)g_pinned.get((size_t)(len > 0 ? len : 1), &cap); /* page-locked: the H2D copies of the payload ranges run at link speed */
+    const bool pinned = buf != nullptr;
+    if (!pinned) buf = (uint8_t *)malloc((size_t)(len > 0 ? len : 1));
+    const double t1 = prime_now();
     int64_t rc = -115; /* MZ_READ_ERROR */
-    if (buf && len > 0 && fread(buf, 1, (size_t)len, f) == (size_t)len)
-        rc = multi ? mzhip_prime_mem_multi(buf, (uint64_t)len, devices, ndev) : mzhip_prime_mem(buf, (uint64_t)len);
-    if (pinned) (void)hipHostFree(buf);
+    const bool got = buf && len > 0 && fread(buf, 1, (size_t)len, f) == (size_t)len;
+    const double t2 = prime_now();
+    if (got) rc = multi ? mzhip_prime_mem_multi(buf, (uint64_t)len, devices, ndev) : mzhip_prime_mem(buf, (uint64_t)len);
+    if (prime_trace())
+        fprintf(stderr, "[mzhip prime] %s: %.1f MiB image: pinned buffer %.1f ms, read %.1f ms, prime %.1f ms\n", path,
+                (double)len / 1048576.0, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (prime_now() - t2) * 1e3);
+    if (pinned) g_pinned.put(buf, cap);
     else free(buf);
     fclose(f);
     return rc;
@@ -1936,6 +2033,8 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_store_crc(const uint8_
     }
     return 0;
 }
+
+__attribute__((visibility("hidden"))) int32_t mzhip_prime_any(void) { return g_any_gens.load(std::memory_order_relaxed) != 0; }
 
 // Used by the READ shims: is the entry whose payload starts at `payload_off` primed?  The stream presents the payload
 // bytes it has pulled so far (`head`, at least min(csize, 16) of them) and, when the zip layer set one, its
@@ -2229,7 +2328,8 @@ int64_t mzhip_prime_write(int32_t method, const uint8_t *blob, const uint64_t *o
 // `pos` of that buffer continue with them?  Returns 1 on a match; *have_crc says whether the chunk is one of the
 // buffer's 65 535-byte segments, whose CRC-32 the device already computed.
 __attribute__((visibility("hidden"))) int32_t mzhip_wprime_track(int32_t method, int64_t *id, int64_t pos, const uint8_t *buf,
-                                                                 int32_t size, uint32_t *chunk_crc, int32_t *have_crc) {
+                                                                 int32_t size, uint32_t *chunk_crc, int32_t *have_crc,
+                                                                 const uint8_t **src) {
     const int slot = wprime_slot(method);
     *have_crc = 0;
     if (slot < 0 || size <= 0) return 0;
@@ -2261,6 +2361,7 @@ __attribute__((visibility("hidden"))) int32_t mzhip_wprime_track(int32_t method,
     if (pos % kSeg == 0 && ((uint32_t)size == kSeg || pos + size == (int64_t)e->len)) {
         *chunk_crc = w.seg_crc[(size_t)(e->seg0 + pos / kSeg)];
         *have_crc = 1;
+        *src = e->src + pos; /* the primed bytes these were compared with: what the CRC symbol compares again */
     }
     return 1;
 }

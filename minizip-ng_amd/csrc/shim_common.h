@@ -18,7 +18,8 @@ struct mzhip_stream_s;
 void mzhip_autoprime(struct mzhip_stream_s *codec_base);
 /* write-side prime (mzhip_prime_write): follow the bytes a WRITE stream is handed against the primed buffers */
 int32_t mzhip_wprime_track(int32_t method, int64_t *id, int64_t pos, const uint8_t *buf, int32_t size, uint32_t *chunk_crc,
-                           int32_t *have_crc);
+                           int32_t *have_crc, const uint8_t **src);
+int32_t mzhip_prime_any(void); /* is any archive primed at all? */
 int32_t mzhip_wprime_result(int32_t method, int64_t id, int64_t pos, const uint8_t **src, const uint8_t **out,
                             uint32_t *out_len);
 /* the device failure a mz_crypt_crc32_update of this thread could not report (the symbol has no error channel); 0 = none */
@@ -37,21 +38,19 @@ typedef struct mzhip_served_s {
     int32_t size;
     uint32_t crc;
     int32_t valid;
-    uint8_t first[8], last[8]; /* the buffer's first and last bytes at the time it was served (size >= 8: else both = first `size`) */
+    const void *src; /* the primed bytes that were served (or that a written buffer was found equal to): compared again, byte
+                        for byte, when the checksum is asked for -- a caller that changed the buffer in between gets the CRC of
+                        what the buffer holds now.  Valid while the hint is: the stream that set it pins the primed generation
+                        and every shim call, close and delete included, drops the hint first */
 } mzhip_served;
 extern __thread mzhip_served mzhip_last_served;
 /* record / drop the hint; every shim read, write and open drops it first, so it only ever describes the bytes the
  * immediately preceding codec call produced */
-static inline void mzhip_served_set(const void *buf, int32_t size, uint32_t crc) {
-    const uint8_t *p = (const uint8_t *)buf;
-    const int32_t k = size < 8 ? size : 8;
+static inline void mzhip_served_set(const void *buf, int32_t size, uint32_t crc, const void *src) {
     mzhip_last_served.buf = buf;
     mzhip_last_served.size = size;
     mzhip_last_served.crc = crc;
-    for (int32_t i = 0; i < 8; i++) {
-        mzhip_last_served.first[i] = i < k ? p[i] : 0;
-        mzhip_last_served.last[i] = i < k ? p[size - k + i] : 0;
-    }
+    mzhip_last_served.src = src;
     mzhip_last_served.valid = 1;
 }
 static inline void mzhip_served_drop(void) { mzhip_last_served.valid = 0; }

@@ -22,12 +22,11 @@ uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int32_t size)
     if (size <= 0 || !buf)
         return value;
     if (mzhip_last_served.valid && mzhip_last_served.buf == (const void *)buf && mzhip_last_served.size == size) {
-        /* these exact bytes were just served from the prime cache; their CRC was computed on the device.  The
-         * record is dropped by every other codec call; the end bytes are compared as well, so a buffer that was
-         * refilled in between cannot be answered with a stale value */
-        const int32_t k = size < 8 ? size : 8;
+        /* this buffer was just served from the prime cache (or written and found equal to a primed buffer); the CRC of
+         * those bytes was computed on the device.  The record is dropped by every other codec call, and the bytes are
+         * compared with the primed ones once more, so a buffer that changed in between is never answered from the cache */
         mzhip_last_served.valid = 0;
-        if (memcmp(buf, mzhip_last_served.first, (size_t)k) == 0 && memcmp(buf + size - k, mzhip_last_served.last, (size_t)k) == 0)
+        if (memcmp(buf, mzhip_last_served.src, (size_t)size) == 0)
             return mzhip_crc32_combine(value, mzhip_last_served.crc, (uint64_t)size);
     }
     mzhip_last_served.valid = 0;

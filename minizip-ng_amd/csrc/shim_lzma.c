@@ -78,7 +78,7 @@ static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
 static int32_t grow_in(mzhip_lzma *z, int64_t need) {
     if (need <= z->in_cap)
         return MZH_OK;
-    int64_t ncap = z->in_cap ? z->in_cap * 2 : 65536;
+    int64_t ncap = z->in_cap ? z->in_cap * 2 : (need <= 1024 ? 1024 : 65536);
     while (ncap < need)
         ncap *= 2;
     uint8_t *p = (uint8_t *)realloc(z->in, (size_t)ncap);
@@ -162,6 +162,11 @@ int32_t mz_stream_lzma_is_open(void *stream) {
 
 static int32_t pull_chunk(mzhip_lzma *z) {
     int32_t want = MZH_STAGING_BYTES;
+    /* the first pull of a stream that may be served from a primed archive asks for no more than the bytes the lookup
+     * compares (the size of a pull is not observable: the zip layer positions the base stream itself, mz_zip.c:1713);
+     * a primed 64 KiB entry costs a 256-byte copy instead of 32 KiB, and the pages behind it are never touched */
+    if (z->in_len == 0 && !z->tried_cache && mzhip_prime_any())
+        want = 256;
     if (z->max_total_in > 0) {
         int64_t left = z->max_total_in - z->in_len;
         if (left < want)
@@ -277,7 +282,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: its device-computed CRC answers the mz_crypt_crc32_update that follows */
-            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT]);
+            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served);
         }
         z->out_served += n;
         z->total_out += n;
@@ -343,12 +348,13 @@ int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
     if (!z->wp_off) {
         uint32_t crc = 0;
         int32_t have_crc = 0;
+        const uint8_t *wsrc = NULL;
         if ((z->wp_id >= 0 || z->total_in == 0) &&
-            mzhip_wprime_track(z->method, &z->wp_id, z->wp_pos, (const uint8_t *)buf, size, &crc, &have_crc) == 1) {
+            mzhip_wprime_track(z->method, &z->wp_id, z->wp_pos, (const uint8_t *)buf, size, &crc, &have_crc, &wsrc) == 1) {
             z->wp_pos += size;
             z->total_in += size;
             if (have_crc) { /* answers the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) */
-                mzhip_served_set(buf, size, crc);
+                mzhip_served_set(buf, size, crc, wsrc);
             }
             return size;
         }
@@ -432,6 +438,7 @@ int32_t mz_stream_lzma_seek(void *stream, int64_t offset, int32_t origin) {
 }
 
 int32_t mz_stream_lzma_close(void *stream) {
+    mzhip_served_drop(); /* (the hint points into a primed generation this stream pins) */
     mzhip_lzma *z = (mzhip_lzma *)stream;
     if ((z->mode & MZH_OPEN_MODE_WRITE) && z->initialized == 1 && finish_write(z) != MZH_OK)
         z->error = 11; /* LZMA_PROG_ERROR: reported as MZ_CLOSE_ERROR below */
@@ -516,6 +523,7 @@ void *mz_stream_lzma_create(void) {
 }
 
 void mz_stream_lzma_delete(void **stream) {
+    mzhip_served_drop();
     mzhip_lzma *z;
     if (!stream)
         return;

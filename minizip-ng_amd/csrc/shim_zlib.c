@@ -199,6 +199,11 @@ int32_t mz_stream_zlib_is_open(void *stream) {
 /* pull one staging chunk; returns bytes read (0 = base exhausted) or <0 */
 static int32_t pull_chunk(mzhip_zlib *z) {
     int32_t want = MZH_STAGING_BYTES;
+    /* the first pull of a stream that may be served from a primed archive asks for no more than the bytes the lookup
+     * compares (the size of a pull is not observable: the zip layer positions the base stream itself, mz_zip.c:1713);
+     * a primed 64 KiB entry costs a 256-byte copy instead of 32 KiB, and the pages behind it are never touched */
+    if (z->in_len == 0 && !z->tried_cache && mzhip_prime_any())
+        want = 256;
     if (z->max_total_in > 0) {
         int64_t left = z->max_total_in - z->in_len;
         if (left < want)
@@ -209,7 +214,7 @@ static int32_t pull_chunk(mzhip_zlib *z) {
         return 0;
     }
     if (z->in_len + want > z->in_cap) {
-        int64_t ncap = z->in_cap ? z->in_cap * 2 : 65536;
+        int64_t ncap = z->in_cap ? z->in_cap * 2 : (want <= 256 ? 1024 : 65536);
         while (ncap < z->in_len + want)
             ncap *= 2;
         uint8_t *p = (uint8_t *)realloc(z->in, (size_t)ncap);
@@ -450,7 +455,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: remember its device-computed CRC for the mz_crypt_crc32_update that follows */
-            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT]);
+            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served);
         }
         z->out_served += n;
         z->total_out += n;
@@ -603,12 +608,13 @@ int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
         /* mzhip_prime_write: is this entry, so far, one of the buffers that were compressed ahead of time? */
         uint32_t crc = 0;
         int32_t have_crc = 0;
+        const uint8_t *wsrc = NULL;
         if ((z->wp_id >= 0 || z->total_in == 0) &&
-            mzhip_wprime_track(8, &z->wp_id, z->wp_pos, (const uint8_t *)buf, size, &crc, &have_crc) == 1) {
+            mzhip_wprime_track(8, &z->wp_id, z->wp_pos, (const uint8_t *)buf, size, &crc, &have_crc, &wsrc) == 1) {
             z->wp_pos += size;
             z->total_in += size;
             if (have_crc) { /* the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) is answered from the cache */
-                mzhip_served_set(buf, size, crc);
+                mzhip_served_set(buf, size, crc, wsrc);
             }
             return size;
         }
@@ -636,6 +642,7 @@ int32_t mz_stream_zlib_seek(void *stream, int64_t offset, int32_t origin) {
 }
 
 int32_t mz_stream_zlib_close(void *stream) {
+    mzhip_served_drop(); /* (the hint points into a primed generation this stream pins) */
     mzhip_zlib *z = (mzhip_zlib *)stream;
     if (z->mode & MZH_OPEN_MODE_WRITE) {
         const uint8_t *src = NULL, *out = NULL;
@@ -722,6 +729,7 @@ void *mz_stream_zlib_create(void) {
 }
 
 void mz_stream_zlib_delete(void **stream) {
+    mzhip_served_drop();
     mzhip_zlib *z;
     if (!stream)
         return;

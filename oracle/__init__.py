@@ -195,8 +195,10 @@ class MzDriver:
             raise RuntimeError("drv_zip_index failed: %d" % n)
         return t[:n].copy()
 
-    def zip_read_all(self, path, cd_pos, nthreads=1, chunk=65535, own_crc=True, out=None, out_off=None):
-        """-> (seconds, crc[n] u32, ulen[n] i64, status[n] i32)"""
+    def zip_read_all(self, path, cd_pos, nthreads=1, chunk=65535, own_crc=True, out=None, out_off=None, mapped=False):
+        """-> (seconds, crc[n] u32, ulen[n] i64, status[n] i32).  mapped: every reader sits on mz_stream_mem over one shared
+        read-only mapping of the archive instead of mz_zip_reader_open_file (whose split stream re-opens the file twice
+        per entry: the difference between 3 and 30 GiB/s with 256 threads on one path)"""
         cd = np.ascontiguousarray(cd_pos, dtype=np.int64)
         n = len(cd)
         crc = np.zeros(n, dtype=np.uint32)
@@ -208,7 +210,7 @@ class MzDriver:
             out_off = np.ascontiguousarray(out_off, dtype=np.int64)
             oo = out_off.ctypes.data_as(C.POINTER(C.c_int64))
         sec = self.L.drv_zip_read_all(path.encode(), cd.ctypes.data_as(C.POINTER(C.c_int64)), n, nthreads, chunk,
-                                      1 if own_crc else 0, crc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                      (1 if own_crc else 0) | (2 if mapped else 0), crc.ctypes.data_as(C.POINTER(C.c_uint32)),
                                       ulen.ctypes.data_as(C.POINTER(C.c_int64)),
                                       st.ctypes.data_as(C.POINTER(C.c_int32)), po, oo)
         return float(sec), crc, ulen, st

@@ -18,12 +18,16 @@
  * call the two libraries with identical arguments and compare every return
  * value, property and output byte.
  */
+#include <fcntl.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "mz.h"
 #include "mz_crypt.h"
@@ -252,6 +256,8 @@ typedef struct {
     int32_t chunk;
     int32_t own_crc; /* also run drv-side crc over the bytes (parity mode); timing mode leaves it to mz_zip */
     int64_t bytes;
+    const uint8_t *img; /* "mapped" mode (own_crc bit 1): the reader sits on mz_stream_mem over one shared read-only mapping */
+    int64_t img_len;    /* instead of mz_zip_reader_open_file, whose split stream re-opens the file twice per entry */
 } job_t;
 
 /* one thread = one independent reader handle on the same file (distinct
@@ -263,13 +269,27 @@ static void *job_run(void *arg) {
     job_t *j = (job_t *)arg;
     void *r = mz_zip_reader_create();
     void *zip = NULL;
+    void *mem = NULL;
     uint8_t *buf = (uint8_t *)malloc((size_t)j->chunk);
-    if (!r || !buf || mz_zip_reader_open_file(r, j->path) != MZ_OK) {
+    int32_t oerr = MZ_OPEN_ERROR;
+    if (r && buf && j->img) {
+        mem = mz_stream_mem_create();
+        if (mem) {
+            mz_stream_mem_set_buffer(mem, (void *)j->img, (int32_t)j->img_len);
+            if (mz_stream_open(mem, NULL, MZ_OPEN_MODE_READ) == MZ_OK)
+                oerr = mz_zip_reader_open(r, mem);
+        }
+    } else if (r && buf) {
+        oerr = mz_zip_reader_open_file(r, j->path);
+    }
+    if (oerr != MZ_OK) {
         for (int64_t i = 0; i < j->count; i++)
             j->status[j->first + i] = MZ_OPEN_ERROR;
         free(buf);
         if (r)
             mz_zip_reader_delete(&r);
+        if (mem)
+            mz_stream_mem_delete(&mem);
         return NULL;
     }
     mz_zip_reader_get_zip_handle(r, &zip);
@@ -288,7 +308,7 @@ static void *job_run(void *arg) {
                 }
                 if (rd == 0)
                     break;
-                if (j->own_crc)
+                if (j->own_crc & 1)
                     crc = mz_crypt_crc32_update(crc, buf, rd);
                 if (j->out)
                     memcpy(j->out + j->out_off[i] + total, buf, (size_t)rd);
@@ -298,7 +318,7 @@ static void *job_run(void *arg) {
             if (err == MZ_OK)
                 err = cerr;
         }
-        if (!j->own_crc && err == MZ_OK) {
+        if (!(j->own_crc & 1) && err == MZ_OK) {
             /* mz_zip verified entry_crc32 == stored crc (mz_zip.c:2122) */
             mz_zip_file *fi = NULL;
             if (mz_zip_goto_entry(zip, j->cd_pos[i]) == MZ_OK && mz_zip_entry_get_info(zip, &fi) == MZ_OK)
@@ -311,6 +331,8 @@ static void *job_run(void *arg) {
     }
     mz_zip_reader_close(r);
     mz_zip_reader_delete(&r);
+    if (mem)
+        mz_stream_mem_delete(&mem);
     free(buf);
     return NULL;
 }
@@ -328,7 +350,22 @@ DRV_EXPORT double drv_zip_read_all(const char *path, const int64_t *cd_pos, int6
     job_t *jobs = (job_t *)calloc((size_t)nthreads, sizeof(job_t));
     struct timespec t0, t1;
     int64_t per = n / nthreads, extra = n % nthreads, first = 0;
+    const uint8_t *img = NULL;
+    int64_t img_len = 0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (own_crc & 2) { /* mapped mode: one read-only mapping of the archive for every reader */
+        int fd = open(path, O_RDONLY);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && sb.st_size > 0 && sb.st_size <= INT32_MAX) {
+            void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m != MAP_FAILED) {
+                img = (const uint8_t *)m;
+                img_len = (int64_t)sb.st_size;
+            }
+        }
+        if (fd >= 0)
+            close(fd);
+    }
     for (int32_t t = 0; t < nthreads; t++) {
         job_t *j = &jobs[t];
         j->path = path;
@@ -343,6 +380,8 @@ DRV_EXPORT double drv_zip_read_all(const char *path, const int64_t *cd_pos, int6
         j->out_off = out_off;
         j->chunk = chunk;
         j->own_crc = own_crc;
+        j->img = img;
+        j->img_len = img_len;
         if (nthreads == 1)
             job_run(j);
         else
@@ -351,6 +390,8 @@ DRV_EXPORT double drv_zip_read_all(const char *path, const int64_t *cd_pos, int6
     if (nthreads > 1)
         for (int32_t t = 0; t < nthreads; t++)
             pthread_join(th[t], NULL);
+    if (img)
+        munmap((void *)img, (size_t)img_len);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     free(th);
     free(jobs);

@@ -126,8 +126,15 @@ extern "C" int32_t mzhip_prime_lookup3(int32_t, int64_t, const uint8_t *, int32_
 extern "C" void mzhip_prime_unpin(void *) {}
 extern "C" int32_t mzhip_prime_store_crc(const uint8_t *, int32_t, uint32_t *) { return 0; }
 extern "C" int32_t mzhip_take_crc_fault(void) { return 0; }
-extern "C" int32_t mzhip_wprime_track(int32_t, int64_t *, int64_t, const uint8_t *, int32_t, uint32_t *, int32_t *have_crc) {
+extern "C" int32_t mzhip_wprime_track(int32_t, int64_t *, int64_t, const uint8_t *, int32_t, uint32_t *, int32_t *have_crc,
+                                      const uint8_t **) {
     *have_crc = 0;
     return 0;
+}
+// "is any archive primed?": MZMOCK_PRIME_ANY=1 says yes (every lookup still misses), so that the streams' short first
+// pull and the ordinary decode behind it run on the CPU as well
+extern "C" int32_t mzhip_prime_any(void) {
+    static const int on = getenv("MZMOCK_PRIME_ANY") != nullptr;
+    return on;
 }
 extern "C" int32_t mzhip_wprime_result(int32_t, int64_t, int64_t, const uint8_t **, const uint8_t **, uint32_t *) { return 0; }

@@ -96,3 +96,16 @@ def test_cli_gz_ungz_on_mock(libs, cli_src, tmp_path, monkeypatch):
         pytest.skip("CLI binaries need the reference sources at build time")
     monkeypatch.setattr(K, "HIP_GZ", MOCK_GZ)
     K.test_cli_gz_ungz(cli_src, tmp_path)
+
+
+def test_streams_with_a_prime_cache_present(libs):
+    """With an archive primed somewhere in the process, a READ stream's first pull asks for only the 256 bytes the prime
+    lookup compares (shim_zlib.c / shim_lzma.c pull_chunk); when the lookup misses, the ordinary decode goes on from
+    there.  MZMOCK_PRIME_ANY=1 makes the mock say "something is primed" while every lookup misses: the stream, archive
+    and CLI bodies above must pass unchanged (a fresh process: the mock reads the variable once)."""
+    import sys
+
+    env = dict(os.environ, MZMOCK_PRIME_ANY="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k",
+                        "not prime_cache_present"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
