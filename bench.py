@@ -96,6 +96,28 @@ def measured_traffic(cfg, n, size):
     return None, None
 
 
+def usable_cores():
+    """host cores this process may really use: the affinity mask, cut by the container's CPU quota (cgroup cpu.max).
+    A box that shows 256 CPUs under a 16-CPU quota runs 256 threads slower than 16 (they burn the quota and are all
+    throttled for the rest of the period: measured, profiles/r3/threads_quota.log)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def corpus():
     from tests import synth
 
@@ -130,7 +152,7 @@ def make_unique_deflate(c, n_unique, size, seed, gen_seconds, world):
             continue
         seen.add(o)
         offs.append((o, size))
-    procs = max(1, (os.cpu_count() or 1) // max(world, 1))  # ranks share the host cores
+    procs = max(1, usable_cores() // max(world, 1))  # ranks share the host cores
     t0 = time.time()
     out = []
     with mp.Pool(procs, initializer=_pool_init, initargs=(c, 6)) as pool:
@@ -162,13 +184,13 @@ def _markov_one(args):
 
 def make_markov(c, n_unique, size, seed, world):
     """n_unique order-2 word-Markov expansions of the corpus, one seed each (pure Python: ~0.3 s per MiB, so on all cores)"""
-    procs = max(1, min((os.cpu_count() or 1) // max(world, 1), n_unique))
+    procs = max(1, min(usable_cores() // max(world, 1), n_unique))
     with mp.Pool(procs, initializer=_pool_init, initargs=(c, 6)) as pool:
         return pool.map(_markov_one, [(size, seed * 100003 + i) for i in range(n_unique)])
 
 
 def make_unique_lzma(datas, world):
-    procs = max(1, min((os.cpu_count() or 1) // max(world, 1), len(datas)))
+    procs = max(1, min(usable_cores() // max(world, 1), len(datas)))
     with mp.Pool(procs) as pool:
         out = pool.map(_lzma_one, datas)
     return [p for p, _ in out], np.array([k for _, k in out], dtype=np.uint32)
@@ -385,7 +407,7 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
             D.mzdrop_extract_all.restype = C.c_double
             D.mzdrop_extract_all.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                              C.POINTER(C.c_double), C.POINTER(C.c_int32)]
-            cores = os.cpu_count() or 1
+            cores = max(1, usable_cores() * 3 // 4)  # the HIP runtime's own threads count against the same CPU quota
             for key, T in (("vtbl_end_to_end", 1), ("vtbl_end_to_end_T", cores)):
                 best, desc = None, ""
                 for _ in range(3):
@@ -394,9 +416,10 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
                     sec = D.mzdrop_extract_all(sample_zip.encode(), T, 1, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
                     if sec > 0 and fe.value == 0 and ne.value > 0 and (best is None or sec < best):
                         best = sec
-                        desc = ("%d entries / %.0f MiB: mzhip_prime_file (index + pipelined H2D, launches, D2H of every byte: %.0f ms) "
-                                "+ %d reader thread(s), one mz_zip_reader each, mz_zip_entry_read in 65 535-byte calls + CRC "
-                                "verification (mz_zip.c:2116-2128) on libmzhipdrop.so; best of 3"
+                        desc = ("%d entries / %.0f MiB: one read-only mapping of the archive, mzhip_prime_mem over it (index + pipelined "
+                                "H2D, launches, D2H of every byte: %.0f ms) + %d reader thread(s), one mz_zip_reader each on mz_stream_mem "
+                                "over the mapping, mz_zip_entry_read in 65 535-byte calls + CRC verification (mz_zip.c:2116-2128) on "
+                                "libmzhipdrop.so; best of 3"
                                 % (ne.value, nb.value / 2**20, tp.value * 1e3, T))
                         nbytes = nb.value
                 L.mzhip_prime_clear()
@@ -443,6 +466,12 @@ def self_launch(n):
 
 
 def main():
+    # the reference's header parser turns every DOS date into a time_t with mktime() (mz_zip.c: mz_zip_dosdate_to_time_t),
+    # and glibc's mktime stats /etc/localtime under a process-wide lock when TZ is unset: 16 reader threads then spend 95 %
+    # of their time queueing there (profiles/r3/threads_tz.log: 125 ms -> 27 ms).  Both the reference baseline and the
+    # drop-in legs run with a fixed zone; it changes no byte of what they read.
+    os.environ.setdefault("TZ", "UTC")
+    time.tzset()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -715,7 +744,7 @@ def main():
                                         "predicted_quantisation_efficiency": round(min(r / max(1.0, float(np.ceil(r))) for r in rounds), 3)}
         sample_zip = None
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            cores = usable_cores()  # threads the CPU baseline really gets (affinity and cgroup quota, not the CPU count)
             if cfg["codec"] == "inflate":
                 sample_zip = os.path.join(tempfile.mkdtemp(prefix="mzhip_bench_"), "sample.zip")
                 cb = cpu_baseline_inflate(c, offs, size, pays, crcs, cores, keep_path=sample_zip)

@@ -5,8 +5,8 @@
  * mapping of the file, mz_zip_rw.c:160-260), walks its share of
  * the entries (mz_zip_goto_entry) and reads each one through mz_zip_entry_read_open / _read / _close in the reader's
  * 65 535-byte buffer (mz_zip_rw.c:55), so that mz_zip.c:2116-2128 verifies every entry's CRC-32 against the central
- * directory.  The only line that is not the reference's: mzhip_prime_file() in front (or MZHIP_AUTOPRIME in the
- * environment), after which the codec streams and mz_crypt_crc32_update behind those calls answer from the batch
+ * directory.  The only line that is not the reference's: mzhip_prime_mem() over the same mapping in front (or
+ * mzhip_prime_file() / MZHIP_AUTOPRIME in the environment), after which the codec streams and mz_crypt_crc32_update behind those calls answer from the batch
  * decode -- pipelined H2D / kernels / D2H on the device while nothing but memcpy is left for the threads.
  * Linked into integration/_build/libmzhipdrop.so (reference zip layer unmodified + HIP codecs); bench.py's
  * `legs.vtbl_end_to_end_T` and tests/test_gpu_prime.py call it.  The entry table comes from the product's own bulk
@@ -112,11 +112,6 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
                                                                   int32_t *first_err) {
     const double t0 = xt_now();
     double tp = 0.0;
-    if (prime) {
-        const int64_t pr = mzhip_prime_file(path);
-        if (pr < 0) return (double)pr;
-        tp = xt_now() - t0;
-    }
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return (double)MZ_OPEN_ERROR;
     struct stat sb;
@@ -127,6 +122,15 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
     const uint8_t *img = (const uint8_t *)mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0); /* (faulted in here, once: 256 threads taking page faults on one mapping queue up behind its lock) */
     close(fd);
     if (img == MAP_FAILED) return (double)MZ_MEM_ERROR;
+    if (prime) { /* the same mapping feeds the batch decode and, afterwards, every reader thread: the file is read once */
+        const double a = xt_now();
+        const int64_t pr = mzhip_prime_mem(img, (uint64_t)sb.st_size);
+        if (pr < 0) {
+            munmap((void *)img, (size_t)sb.st_size);
+            return (double)pr;
+        }
+        tp = xt_now() - a;
+    }
     int64_t n = mzhip_zip_index_mem(img, (uint64_t)sb.st_size, NULL, 0);
     int64_t *table = n > 0 ? (int64_t *)malloc((size_t)n * 8 * sizeof(int64_t)) : NULL;
     if (table) n = mzhip_zip_index_mem(img, (uint64_t)sb.st_size, table, n);
@@ -135,6 +139,7 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
         free(table);
         return (double)(n < 0 ? n : MZ_FORMAT_ERROR);
     }
+    const double t_idx = xt_now();
     if (nthreads < 1) nthreads = 1;
     if (nthreads > n) nthreads = (int32_t)n;
     pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
@@ -162,6 +167,8 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
         if (err == MZ_OK) err = jobs[t].err;
         tg += jobs[t].t_goto; to += jobs[t].t_open; tr += jobs[t].t_read; tc += jobs[t].t_close;
     }
+    if (getenv("MZDROP_TRACE"))
+        fprintf(stderr, "[mzdrop] prime %.1f ms, map + index %.1f ms, threads %.1f ms\n", tp * 1e3, (t_idx - t0 - tp) * 1e3, (xt_now() - t_idx) * 1e3);
     if (getenv("MZDROP_TRACE"))
         fprintf(stderr, "[mzdrop] %d threads: per thread goto %.1f ms, read_open %.1f ms, read %.1f ms, close %.1f ms\n", nthreads,
                 tg / nthreads * 1e3, to / nthreads * 1e3, tr / nthreads * 1e3, tc / nthreads * 1e3);

@@ -1603,6 +1603,11 @@ struct PrimeLane {
         if (h_meta) (void)hipHostFree(h_meta);
     }
 };
+struct PrimeLaneSet {
+    PrimeLane lanes[kPrimeLanes];
+};
+std::mutex g_lane_mu;
+PrimeLaneSet *g_lane_sets[kMaxDevices]; // never destroyed at exit: the runtime may be gone before static destructors run
 int32_t prime_lane_reserve(void **p, size_t *cap, size_t need) {
     if (need <= *cap) return 0;
     if (*p) HIP_TRY(hipFree(*p)); // (the lane's stream has been waited for: nothing uses the buffer)
@@ -1640,8 +1645,35 @@ int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const st
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
     if (hi <= lo) return 0;
-    PrimeLane lanes[kPrimeLanes];
-    for (auto &L : lanes) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+    /* streams, device buffers and page-locked staging of the three lanes are kept between calls (one set per device
+     * is parked; a second prime on the same device at the same time makes its own): hipMalloc / hipFree / hipHostMalloc
+     * of ~200 MB per call cost more than the pipeline itself on a 1 GiB archive (44 ms -> see profiles/r3) */
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::unique_ptr<PrimeLaneSet> set;
+    {
+        std::lock_guard<std::mutex> lk(g_lane_mu);
+        if (dev >= 0 && dev < kMaxDevices && g_lane_sets[dev]) {
+            set.reset(g_lane_sets[dev]);
+            g_lane_sets[dev] = nullptr;
+        }
+    }
+    if (!set) {
+        set.reset(new PrimeLaneSet());
+        for (auto &L : set->lanes) HIP_TRY(hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking));
+    }
+    struct Park { /* back to the shelf on every way out (the lanes are idle by then: collect() waited for each stream, or
+                     the set is dropped when a call failed in the middle) */
+        std::unique_ptr<PrimeLaneSet> &set;
+        int dev;
+        bool ok = false;
+        ~Park() {
+            if (!ok || !set) return;
+            std::lock_guard<std::mutex> lk(g_lane_mu);
+            if (dev >= 0 && dev < kMaxDevices && !g_lane_sets[dev]) g_lane_sets[dev] = set.release();
+        }
+    } park{set, dev};
+    PrimeLane *lanes = set->lanes;
     int turn = 0;
     for (size_t c0 = lo; c0 < hi;) {
         /* the next chunk: entries [c0, c1), about kPrimeChunk decoded bytes (one entry at least) */
@@ -1749,6 +1781,7 @@ int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const st
         rc = prime_lane_collect(lanes[(turn + i) % kPrimeLanes], r_len, r_used, r_crc, r_st, seg_crc_all);
         if (rc) return rc;
     }
+    park.ok = true;
     return 0;
 }
 // STORE entries of a primed archive: their payloads are copied into the generation, cut into the reader's chunks

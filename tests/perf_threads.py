@@ -19,7 +19,7 @@ mz = importlib.import_module("minizip-ng_amd"); L = mz.lib()
 D = C.CDLL(os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so"))
 D.mzdrop_extract_all.restype = C.c_double
 D.mzdrop_extract_all.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
-for T in (1, 4, 32, os.cpu_count()):
+for T in (1, 8, 16):
     best = None
     for _ in range(3):
         L.mzhip_prime_clear()
