@@ -27,7 +27,9 @@
 #include "crc32_core.h"
 #include "wave.h"
 
-#define MZ_LZMA_MAX_LCLP 3 /* literal contexts held in LDS: 0x300 << 3 probabilities */
+#ifndef MZ_LZMA_MAX_LCLP
+#define MZ_LZMA_MAX_LCLP 3 /* literal contexts held in LDS: 0x300 << 3 probabilities (measurement builds: 0, profiles/ab_k3.sh) */
+#endif
 #define MZ_LZMA_LIT_PROBS (0x300u << MZ_LZMA_MAX_LCLP)
 #define MZ_LZMA_XPROBS MZ_LZMA_LIT_PROBS /* lc + lp = 4: as many again, in a per-wave scratch in HBM */
 

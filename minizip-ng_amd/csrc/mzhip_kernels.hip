@@ -187,7 +187,11 @@ struct LzmaArgs {
 #endif
 
 // K3: one wave per workgroup, the wave's whole probability model (15.6 KiB) in LDS -> 10 waves per CU.
+#ifdef MZ_LZMA_WAVES /* measurement builds (profiles/ab_k3.sh): waves per SIMD the register allocation is held to */
+__global__ __launch_bounds__(64, MZ_LZMA_WAVES) void k_lzma_batch(LzmaArgs a) {
+#else
 __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
+#endif
     __shared__ __attribute__((aligned(16))) mz_lzma_lds lds;
     __shared__ uint32_t crc_tab[256];
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
@@ -768,6 +772,9 @@ static int32_t lzma_family_batch(int xz, const void *d_in, const uint64_t *d_in_
     a.tab64 = c->d_tab64;
     /* 16 KiB LDS per wave -> 10 single-wave workgroups per CU (K3); 17.6 KiB -> 8 (.xz) */
     uint32_t resident = (uint32_t)c->cu_count * (xz ? 8u : 10u);
+#ifdef MZ_LZMA_RESIDENT /* measurement builds: single-wave workgroups per CU that really fit (LDS and registers) */
+    if (!xz) resident = (uint32_t)c->cu_count * MZ_LZMA_RESIDENT;
+#endif
     uint32_t grid = n < resident ? n : resident;
     int slot = -1;
     void *scratch = nullptr; /* 12 KiB per resident wave: the literal model's upper half for streams with lc + lp = 4 */

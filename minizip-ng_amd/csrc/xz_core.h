@@ -233,6 +233,65 @@ MZ_DEV uint32_t mz_xz_unfilter(mz_xz_filter *f, uint8_t *b, uint32_t n, uint32_t
 #undef XZ_FS
 #define MZ_XZ_FCHUNK 8192u /* bytes of a block unfiltered per round (+ up to 15 carried over) */
 
+/* Undo the filter chain of one finished block in place (out[0 .. n) = the block's bytes, still filtered), last applied
+ * first, 8 KiB at a time: the bytes go through `fb` (the LDS of the probability model: every block re-initialises it with
+ * its first chunk), where wave-uniform code runs the filter; bytes the filter cannot decide yet (< 16) are carried into
+ * the next round.  Filtered entries are rare (minizip never writes them) and a BCJ scan is a serial state machine: this is
+ * about being correct, so it is a call, not inline code -- inlined into mz_xz_entry it cost the hot decode loop 24 VGPRs
+ * (161 -> 185) and 36 more parked SGPRs. */
+#if defined(MZHIP_HOST_EMUL)
+static void
+#else
+__device__ __noinline__ void
+#endif
+mz_xz_unfilter_block(uint8_t *blk, uint32_t usize_blk, uint32_t npre, uint32_t fids, uint32_t farg0, uint32_t farg1, uint32_t farg2,
+                     uint8_t *fb) {
+    MZ_LANE_DECL
+    uint8_t *hist = fb + MZ_XZ_FCHUNK + 16u; /* MZ_XZ_FCHUNK + 16 bytes of staging, Delta's 256-byte ring behind it */
+    for (uint32_t fi = 3u; fi-- > 0u;) {
+        if (fi >= npre) continue;
+        mz_xz_filter flt;
+        flt.id = (fids >> (8u * fi)) & 0xFFu;
+        flt.arg = fi == 0u ? farg0 : fi == 1u ? farg1 : farg2;
+        flt.prev_mask = 0;
+        flt.prev_pos = 0xFFFFFFFBu; /* (uint32_t)-5: x86 */
+        flt.hpos = 0;
+        uint32_t done = 0, carry = 0; /* bytes final so far; bytes sitting in fb[0 .. carry) */
+        if (flt.id == 3u) {
+            MZ_LANES {
+                for (uint32_t i = (uint32_t)lane; i < 256u; i += 64u) hist[i] = 0;
+            }
+            MZ_WAVE_SYNC();
+        }
+        while (done + carry < usize_blk) {
+            uint32_t take = usize_blk - done - carry;
+            if (take > MZ_XZ_FCHUNK) take = MZ_XZ_FCHUNK;
+            const uint8_t *src = blk + done + carry;
+            MZ_LANES {
+                for (uint32_t i = (uint32_t)lane; i < take; i += 64u) fb[carry + i] = src[i];
+            }
+            MZ_WAVE_SYNC();
+            const uint32_t have = carry + take;
+            const uint32_t fin = mz_xz_unfilter(&flt, fb, have, flt.id == 3u ? 0u : flt.arg + done, hist);
+            MZ_WAVE_SYNC();
+            uint8_t *dst = blk + done;
+            MZ_LANES {
+                for (uint32_t i = (uint32_t)lane; i < fin; i += 64u) dst[i] = fb[i];
+            }
+            MZ_WAVE_SYNC();
+            carry = have - fin;
+            MZ_LANES { /* (carry < 16: one lane each) */
+                if ((uint32_t)lane < carry) fb[lane] = fb[fin + (uint32_t)lane];
+            }
+            MZ_WAVE_SYNC();
+            done += fin;
+            if (fin == 0u && take == 0u) break;
+        }
+        /* what is left in the carry never had enough bytes behind it: it stays as it is */
+    }
+}
+
+
 MZ_DEV uint64_t mz_xz_mix(uint64_t h, uint64_t v) {
     h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
     return h * 0xFF51AFD7ED558CCDull;
@@ -307,19 +366,18 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
             if (bflags & 0x80u) XZ_VLI(want_usize, p, hend, MZHIP_DATA_ERROR);
             /* filter flags (3.1.5, 5.3): LZMA2 last; in front of it Delta and BCJ filters (filter_common.c: only
              * LZMA2 may be last, only these may stand before it).  Anything else is LZMA_OPTIONS_ERROR = a data error. */
-            mz_xz_filter pre0, pre1, pre2, fnew; /* (three named slots, not an array: a dynamic index would put them in scratch) */
-            uint32_t npre = 0;
-            pre0.id = pre1.id = pre2.id = 0;
-            pre0.arg = pre1.arg = pre2.arg = 0;
-            pre0.prev_mask = pre1.prev_mask = pre2.prev_mask = 0;
-            pre0.prev_pos = pre1.prev_pos = pre2.prev_pos = 0;
-            pre0.hpos = pre1.hpos = pre2.hpos = 0;
-#define XZ_PUSH_FILTER()                  \
-    do {                                  \
-        if (npre == 0u) pre0 = fnew;      \
-        else if (npre == 1u) pre1 = fnew; \
-        else pre2 = fnew;                 \
-        npre++;                           \
+            /* what the header says of them is an id and one argument each; the filters' running state starts from
+             * constants when the block is unfiltered (mz_xz_unfilter_block) -- four wave-uniform words live across the block's
+             * decode loop instead of the fifteen of three filter structs */
+            uint32_t fids = 0, farg0 = 0, farg1 = 0, farg2 = 0, npre = 0; /* id of filter k in bits 8k .. 8k + 7 */
+            mz_xz_filter fnew;
+#define XZ_PUSH_FILTER()                         \
+    do {                                         \
+        fids |= fnew.id << (8u * npre);          \
+        if (npre == 0u) farg0 = fnew.arg;        \
+        else if (npre == 1u) farg1 = fnew.arg;   \
+        else farg2 = fnew.arg;                   \
+        npre++;                                  \
     } while (0)
             const uint32_t nfilt = (bflags & 3u) + 1u;
             for (uint32_t fi = 0; fi < nfilt; fi++) {
@@ -480,47 +538,7 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
             if ((want_csize != ~0ull && want_csize != csize_blk) || (want_usize != ~0ull && want_usize != usize_blk))
                 goto finish;
             if (npre) {
-                /* undo the filters, last applied first, 8 KiB of the block at a time: the bytes go through the LDS of the
-                 * probability model (every block re-initialises it with its first chunk), where wave-uniform code runs
-                 * the filter; bytes the filter cannot decide yet (< 16) are carried into the next round */
-                uint8_t *fb = (uint8_t *)pr;         /* MZ_XZ_FCHUNK + 16 bytes of staging ... */
-                uint8_t *hist = fb + MZ_XZ_FCHUNK + 16u; /* ... and Delta's 256-byte ring behind it */
-                for (uint32_t fi = 3u; fi-- > 0u;) {
-                    if (fi >= npre) continue;
-                    mz_xz_filter flt = fi == 0u ? pre0 : fi == 1u ? pre1 : pre2;
-                    uint32_t done = 0, carry = 0; /* bytes final so far; bytes sitting in fb[0 .. carry) */
-                    if (flt.id == 3u) {
-                        MZ_LANES {
-                            for (uint32_t i = (uint32_t)lane; i < 256u; i += 64u) hist[i] = 0;
-                        }
-                        MZ_WAVE_SYNC();
-                    }
-                    while (done + carry < usize_blk) {
-                        uint32_t take = usize_blk - done - carry;
-                        if (take > MZ_XZ_FCHUNK) take = MZ_XZ_FCHUNK;
-                        const uint8_t *src = out + block_out + done + carry;
-                        MZ_LANES {
-                            for (uint32_t i = (uint32_t)lane; i < take; i += 64u) fb[carry + i] = src[i];
-                        }
-                        MZ_WAVE_SYNC();
-                        const uint32_t have = carry + take;
-                        const uint32_t fin = mz_xz_unfilter(&flt, fb, have, flt.id == 3u ? 0u : flt.arg + done, hist);
-                        MZ_WAVE_SYNC();
-                        uint8_t *dst = out + block_out + done;
-                        MZ_LANES {
-                            for (uint32_t i = (uint32_t)lane; i < fin; i += 64u) dst[i] = fb[i];
-                        }
-                        MZ_WAVE_SYNC();
-                        carry = have - fin;
-                        MZ_LANES { /* (carry < 16: one lane each) */
-                            if ((uint32_t)lane < carry) fb[lane] = fb[fin + (uint32_t)lane];
-                        }
-                        MZ_WAVE_SYNC();
-                        done += fin;
-                        if (fin == 0u && take == 0u) break;
-                    }
-                    /* what is left in the carry never had enough bytes behind it: it stays as it is */
-                }
+                mz_xz_unfilter_block(out + block_out, usize_blk, npre, fids, farg0, farg1, farg2, (uint8_t *)pr);
                 crc_hold = 0xFFFFFFFFu;
             }
             while ((pos - data_pos) & 3u) {
@@ -596,6 +614,10 @@ MZ_DEV void mz_xz_entry(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
 finish:
     {
         uint32_t olen = opos;
+        /* an exit inside a block whose filters are not undone yet (output full, a data error, short input): the bytes
+         * from the start of that block on are still in the filtered domain -- liblzma streams its filter chain and would
+         * never have shown them -- so the result ends where the block began (crc_hold) */
+        if (crc_hold != 0xFFFFFFFFu && olen > crc_hold) olen = crc_hold;
         if (max_out >= 0 && (int64_t)olen > max_out) olen = (uint32_t)max_out; /* mz_strm_lzma.c:214-215 */
         if (status == MZHIP_DATA_ERROR && eof && rc_short) {
             /* the coder ran off a chunk that the input does not hold completely: input ended early */

@@ -44,7 +44,17 @@ if which in ("lzma", "both", "all"):
     for u in range(n_unique):
         blob = b" ".join(words[i] for i in rnd.randint(0, len(words), size=240000))
         datas.append(blob[:size])
-    pays = [_zip_lzma(d) for d in datas]
+    import os
+    lc = int(os.environ.get("LZMA_LC", "3"))  # profiles/ab_k3.sh: lc = 0 streams fit a literal model of 0x300 probabilities
+    if lc == 3:
+        pays = [_zip_lzma(d) for d in datas]
+    else:
+        import lzma as _lz
+
+        def _zl(d):
+            raw = _lz.compress(d, format=_lz.FORMAT_ALONE, filters=[dict(id=_lz.FILTER_LZMA1, preset=6, lc=lc, lp=0, pb=2)])
+            return bytes([5, 2, 5, 0]) + raw[:5] + raw[13:]
+        pays = [_zl(d) for d in datas]
     idx = np.arange(n_total) % n_unique
     b = gpu_util.make_batch([pays[i] for i in idx], [size] * n_total)
     out_len, in_used, crc, status = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(4))
