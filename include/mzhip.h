@@ -65,6 +65,30 @@ MZHIP_API const char *mzhip_version(void);
  * output, what mz_zip.c:2122 compares with the central directory), d_status.
  * Any stream length the 32-bit d_in_len[] can describe (the reference streams any size).
  * Asynchronous on `stream`. */
+/* Decode that can be taken up again: the reference streams an entry of any size through a 32 767-byte buffer
+ * (mz_strm_zlib.c:51,116-193); the batch kernel decodes a stream into one buffer.  Between the two: a stream is decoded
+ * WINDOW BY WINDOW.  A state names a token boundary of the stream -- the bit position of the header of the block it lies
+ * in (the block's Huffman tables are rebuilt from there) and of the next token -- and how many bytes of history sit in
+ * front of the output.  When the output buffer is full (MZHIP_STATUS_OUT_FULL: the next token does not fit) or the input
+ * ends (MZHIP_STATUS_BUF_ERROR) the kernel reports such a state; the caller keeps the last 32 KiB of what it was given
+ * as history, drops the input in front of the block header (and rebases the two bit positions) and calls again. */
+typedef struct mzhip_inflate_state {
+    uint32_t hdr_bit; /* bit position of the current block's header, from the first input byte of the call */
+    uint32_t bit;     /* bit position of the next token (== hdr_bit: at the start of the block) */
+    uint32_t out_pos; /* in: bytes of history at the front of the output buffer (<= 32768); out: bytes valid in it */
+    uint32_t flags;   /* bit 0 in: take the stream up at (hdr_bit, bit); out: the state is usable */
+} mzhip_inflate_state;
+/* mzhip_inflate_batch with one state in / one state out per entry (device pointers, either may be NULL) */
+MZHIP_API int32_t mzhip_inflate_resume_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                                             const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,
+                                             uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status,
+                                             const mzhip_inflate_state *d_resume, mzhip_inflate_state *d_stop, void *stream);
+/* one window of one stream through host buffers: buf[0 .. state_in->out_pos) = history, new bytes behind it, buf_cap
+ * bytes in all; *out_len = bytes valid in buf, *crc = CRC-32 of the NEW bytes.  Returns the device verdict. */
+MZHIP_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                            const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
+                                            uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+
 MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,
                                       uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status,

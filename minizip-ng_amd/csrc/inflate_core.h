@@ -297,6 +297,18 @@ typedef struct mz_inflate_result {
     uint32_t crc;
 } mz_inflate_result;
 
+/* Where a decode may be taken up again (streams decoded window by window, mzhip_inflate_resume_host): a token boundary
+ * of the stream, the block it lies in, and how much of the output buffer is history.  The tables of a Huffman block are
+ * rebuilt from its header, so a position inside a block is (bit position of the block's header, bit position of the next
+ * token); at the start of a block the two are equal.  Bit positions count from the first byte the call is given.
+ * mzhip.h declares the same four words as mzhip_inflate_state. */
+typedef struct mz_inflate_state {
+    uint32_t hdr_bit;  /* the current block's header */
+    uint32_t bit;      /* the next token (== hdr_bit: the block has not been entered) */
+    uint32_t out_pos;  /* in: bytes of history in front of the output (<= 32768, 0 at the start of a stream); out: bytes valid in the buffer */
+    uint32_t flags;    /* bit 0: take the stream up at (hdr_bit, bit) instead of at bit 0 */
+} mz_inflate_state;
+
 /* 32 bits of (hi:lo) starting at bit (s & 31): v_alignbit_b32 */
 MZ_DEV uint32_t mz_funnel(uint32_t hi, uint32_t lo, uint32_t s) {
 #if defined(MZHIP_HOST_EMUL)
@@ -697,6 +709,8 @@ MZ_DEV mz_dw4 mz_load_stream_dw4(const uint8_t *in_al, uint32_t in_mis, uint32_t
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out, uint32_t out_cap,
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
                              uint32_t use_span, uint8_t *rec /* MZ_REC_BYTES of HBM scratch of this wave (chase window) */,
+                             const mz_inflate_state *rs /* take the stream up here (or null) */,
+                             mz_inflate_state *st /* where it can be taken up again when the output is full / the input ends (or null) */,
                              mz_inflate_result *res) {
     MZ_LANE_DECL
     /* The bit cursor is 32 bits wide, so the decoder looks at the stream through a VIEW of at most MZ_VIEW_MAX bytes
@@ -712,6 +726,14 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
     const uint32_t in_mis = (uint32_t)((uintptr_t)in & 3u); /* the view moves by multiples of 4: the misalignment stays */
     const uint8_t *in_al = in - in_mis;
     uint32_t bitpos = 0;
+    /* resumable decode: hdr_bit = the header of the block being decoded, qbit = where the step loop's token queue starts
+     * (tokens behind it are decoded but not written yet), in_header = the cursor is inside a block header */
+    uint32_t hdr_bit = 0, qbit = 0, in_header = 0, unwritten = 0, resume_at = 0xFFFFFFFFu;
+    const uint32_t resumable = st ? 1u : 0u;
+    if (rs && (MZ_UNIFORM(rs->flags) & 1u)) {
+        bitpos = MZ_UNIFORM(rs->hdr_bit);
+        resume_at = MZ_UNIFORM(rs->bit);
+    }
 #define MZ_REBASE(also)                                                \
     if (bitpos >= MZ_REBASE_BITS) {                                    \
         const uint32_t _adv = (bitpos >> 3) & ~3u;                     \
@@ -726,7 +748,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
             also;                                                      \
         }                                                              \
     }
-    uint32_t out_pos = 0;
+    uint32_t out_pos = rs ? MZ_UNIFORM(rs->out_pos) : 0u; /* bytes [0, out_pos) of out[] are history (back-references may reach them) */
 #if MZ_SPAN_DW && MZ_WINDOW_CHASE
     uint32_t chase_smax = MZ_CHASE_SMAX; /* bits per span at most (inflate_chase.inc halves it when a window runs into a record cap) */
 #endif
@@ -734,12 +756,15 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
     uint32_t last = 0;
     PV(uint32_t, crc_acc);
     PV(uint32_t, crc_tmp);
+    const uint32_t crc_base = out_pos; /* the CRC is of the bytes this call produces: the folding counts from here */
     uint32_t crc_done = 0;
     MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
     MZ_PROF_DECL
 
     while (!last) {
         MZ_REBASE((void)0)
+        hdr_bit = bitpos;
+        in_header = 1;
         /* the block header is read through a 256-byte window of the stream held one dword per lane (one coalesced
          * load instead of a global round trip per 64 bits of header); positions beyond it fall back to memory */
         const uint32_t hw0 = (bitpos + 8u * in_mis) >> 5;
@@ -767,6 +792,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
             }
             uint32_t avail = in_len - byte;
             uint32_t n = len < avail ? len : avail;
+            if (resumable && n < len) { /* taken up again at the block's header when the rest of the block has arrived */
+                status = MZHIP_BUF_ERROR;
+                goto finish;
+            }
             if (n > out_cap - out_pos) {
                 status = MZHIP_OUT_FULL;
                 goto finish;
@@ -781,7 +810,9 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                 status = MZHIP_BUF_ERROR;
                 goto finish;
             }
-            MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx4);
+            MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out + crc_base, out_pos - crc_base, crc_tab, tabs->kx4);
+            in_header = 0;
+            hdr_bit = bitpos;
             continue;
         }
         if (btype == 3) {
@@ -1011,6 +1042,11 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
         }
 
         MZ_PROF_MARK(2); /* decode tables */
+        in_header = 0;
+        if (resume_at != 0xFFFFFFFFu) { /* taken up inside this block: the tables are back, on to the next token */
+            if (resume_at > bitpos) bitpos = resume_at;
+            resume_at = 0xFFFFFFFFu;
+        }
         /* ---- compressed block body: speculative 64-offset decode ----
          * Compressed bytes are staged through a 512-byte LDS ring (two 256-byte blocks, the next
          * block prefetched into a VGPR one block ahead), so the per-step window fetch is three
@@ -1088,6 +1124,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                     ring_valid = 1;
                     MZ_WAVE_SYNC();
                 }
+                if (qn == 0u) qbit = bitpos; /* the token queue starts here: a flush that does not fit is taken up again from here */
                 const uint32_t pbit = bitpos + pbase;
                 if ((pbit >> 11) + 1u >= ring_hi) {
                     /* the cursor entered the newest block: retire the oldest, start the next fetch */
@@ -1276,6 +1313,17 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
 
 finish:
     MZ_PROF_MARK(11); /* step loop behind the last window, stored blocks */
+    if (st) {
+        /* a position from which (with this output, and more room or more input) the decode goes on exactly: the header of
+         * the block when the cursor is inside it, else the start of the step loop's unwritten tokens, else the cursor */
+        const uint32_t rb = in_header ? hdr_bit : (unwritten ? qbit : bitpos);
+        MZ_LANES { /* uniform stores */
+            st->hdr_bit = hdr_bit;
+            st->bit = rb;
+            st->out_pos = out_pos;
+            st->flags = (in_adv == 0u) ? 1u : 0u; /* (positions are only meaningful while the view has not moved: the caller keeps calls < 128 MiB) */
+        }
+    }
     res->status = status;
     res->out_len = out_pos;
     res->in_used = in_adv + ((bitpos + 7u) >> 3);
@@ -1286,8 +1334,8 @@ finish:
         crc = 0;
         (void)crc_tmp;
 #else
-        MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out, out_pos, crc_tab, tabs->kx4);
-        MZ_CRC_FINISH_SUPER_BT(crc, crc_acc, crc_tmp, crc_done, out, out_pos, crc_tab, tabs);
+        MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out + crc_base, out_pos - crc_base, crc_tab, tabs->kx4);
+        MZ_CRC_FINISH_SUPER_BT(crc, crc_acc, crc_tmp, crc_done, out + crc_base, out_pos - crc_base, crc_tab, tabs);
 #endif
         res->crc = crc;
     }

@@ -70,6 +70,8 @@ struct InflateArgs {
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
     uint8_t *rec; // MZ_REC_BYTES of step-record scratch per wave of the grid (chase window), or null
+    const mz_inflate_state *resume; // per entry: take the stream up at this state (window-by-window decode), or null
+    mz_inflate_state *stop;         // per entry: where it can be taken up again, or null
 };
 
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_batch(InflateArgs a) {
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
         const uint64_t io = a.in_off[e], oo = a.out_off[e];
         const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
-        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, 1u, rec, &r);
+        mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, 1u, rec,
+                         a.resume ? a.resume + e : nullptr, a.stop ? a.stop + e : nullptr, &r);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -651,6 +654,14 @@ void mzhip_inflate_launch_geometry(uint32_t n, uint32_t *grid, uint32_t *waves_p
 int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
                             const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n, uint32_t *d_out_len,
                             uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, void *stream) {
+    return mzhip_inflate_resume_batch(d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, n, d_out_len, d_in_used, d_crc,
+                                      d_status, nullptr, nullptr, stream);
+}
+
+int32_t mzhip_inflate_resume_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
+                                   const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n, uint32_t *d_out_len,
+                                   uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status, const mzhip_inflate_state *d_resume,
+                                   mzhip_inflate_state *d_stop, void *stream) {
     if (n == 0) return 0;
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
@@ -676,6 +687,8 @@ int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const ui
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_LDS_STRIDE;
     const uint32_t grid = grid_for(c, n);
     a.rec = nullptr;
+    a.resume = (const mz_inflate_state *)d_resume;
+    a.stop = (mz_inflate_state *)d_stop;
     int slot = -1;
 #if MZ_SPAN_DW && MZ_WINDOW_CHASE
     { /* the step records of the chase window: MZ_REC_BYTES per wave of the launch (176 KiB x 4096 resident waves at most) */
@@ -995,6 +1008,55 @@ struct Staging {
     }
 };
 } // namespace
+
+// One window of a stream that is decoded window by window (the READ shim's bounded-memory path): buf[0 .. state_in->out_pos)
+// is the history the caller kept (the last 32 KiB it was given, nothing at the start of the stream), the new bytes land
+// behind it, at most buf_cap bytes in all.  Returns the device verdict: MZHIP_OK (stream end), MZHIP_OUT_FULL (call again
+// with state_out and the tail of buf as history), MZHIP_BUF_ERROR (call again with more input from state_out's block
+// header on), or a data error.  *out_len = bytes valid in buf (history included), *crc = CRC-32 of the new bytes only.
+int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                  const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                  uint32_t *in_used, uint32_t *crc) {
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    const uint32_t hist = state_in ? state_in->out_pos : 0u;
+    if (hist > buf_cap) return -102; /* MZ_PARAM_ERROR */
+    // layout: [meta 128 B][in (16-aligned)][buf]
+    const size_t in_pad = ((size_t)in_len + 15) & ~(size_t)15;
+    const size_t total = 128 + in_pad + buf_cap + 16;
+    Staging sc;
+    rc = sc.get(c, total);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)sc.p;
+    struct Meta {
+        uint64_t in_off, out_off;
+        uint32_t in_len, out_cap, out_len, in_used, crc;
+        int32_t status;
+        mz_inflate_state rs, st;
+    } m;
+    memset(&m, 0, sizeof(m));
+    m.in_off = 128;
+    m.out_off = 128 + in_pad;
+    m.in_len = in_len;
+    m.out_cap = buf_cap;
+    if (state_in) memcpy(&m.rs, state_in, sizeof(m.rs));
+    HIP_TRY(mz_h2d(base, &m, sizeof(m)));
+    if (in_len) HIP_TRY(mz_h2d(base + 128, in, in_len));
+    if (hist) HIP_TRY(mz_h2d(base + m.out_off, buf, hist));
+    Meta *dm = (Meta *)base;
+    rc = mzhip_inflate_resume_batch(base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, 1, &dm->out_len,
+                                    &dm->in_used, &dm->crc, &dm->status, (const mzhip_inflate_state *)&dm->rs,
+                                    (mzhip_inflate_state *)&dm->st, MZ_HOST_STREAM);
+    if (rc) return rc;
+    HIP_TRY(mz_d2h(&m, base, sizeof(m)));
+    if (m.out_len > hist) HIP_TRY(mz_d2h(buf + hist, base + m.out_off + hist, m.out_len - hist));
+    if (out_len) *out_len = m.out_len;
+    if (in_used) *in_used = m.in_used;
+    if (crc) *crc = m.crc;
+    if (state_out) memcpy(state_out, &m.st, sizeof(m.st));
+    return m.status;
+}
 
 int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                             uint32_t *in_used, uint32_t *crc, uint32_t *adler) {

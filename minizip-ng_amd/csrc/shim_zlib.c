@@ -36,6 +36,7 @@
  * a bad header or trailer is Z_DATA_ERROR (-3), a preset dictionary request is Z_NEED_DICT (2), input that
  * ends inside the header or trailer is Z_BUF_ERROR (-5).  Other window sizes answer MZ_SUPPORT_ERROR.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -77,6 +78,12 @@ typedef struct mzhip_zlib_s {
     int64_t hdr_len;   /* wrapper header bytes in front of the DEFLATE payload (0 = not parsed yet) */
     int8_t payload_done; /* device verdict on the payload is in; only the trailer is outstanding */
     uint32_t out_crc, out_adler;
+    /* read side, entries too large for one device buffer (MZH_STREAM_WINDOW): decoded window by window.  out[] then holds
+     * [history | the window's bytes]; the compressed bytes in front of the current block's header have been dropped */
+    int8_t streaming;       /* window mode is on */
+    int8_t stream_end;      /* the device has seen the end of the stream */
+    mzhip_inflate_state sst; /* where the decode goes on (bit positions from in[0]) */
+    int64_t in_dropped;     /* compressed bytes dropped from the front of in[] */
     /* write side */
     uint8_t *wbuf;
     int64_t wlen, wcap;
@@ -126,6 +133,8 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->wp_pos = 0;
     z->wp_off = 0;
     z->decoded = 0;
+    z->streaming = z->stream_end = 0;
+    z->in_dropped = 0;
     z->dev_status = 0;
     z->dev_in_used = 0;
     z->next_attempt = 0;
@@ -205,7 +214,7 @@ static int32_t pull_chunk(mzhip_zlib *z) {
     if (z->in_len == 0 && !z->tried_cache && mzhip_prime_any())
         want = 256;
     if (z->max_total_in > 0) {
-        int64_t left = z->max_total_in - z->in_len;
+        int64_t left = z->max_total_in - (z->in_dropped + z->in_len); /* (window mode drops input it is done with) */
         if (left < want)
             want = (int32_t)(left < 0 ? 0 : left);
     }
@@ -321,6 +330,123 @@ static int32_t parse_wrapper_header(mzhip_zlib *z) {
 }
 
 /* run the device over everything pulled so far; 0 = verdict reached, 1 = wants more input */
+/* Entries whose decoded size exceeds one window are decoded window by window (mz_strm_zlib.c:116-193 streams any size
+ * through 32 767 bytes; here the unit is what is worth a launch).  Memory is O(window + one DEFLATE block of input). */
+#ifndef MZH_STREAM_WINDOW
+#define MZH_STREAM_WINDOW (64 << 20)
+#endif
+#ifndef MZH_STREAM_GULP
+#define MZH_STREAM_GULP (16 << 20) /* compressed bytes pulled ahead of a window's launch */
+#endif
+
+static int32_t stream_drop_input(mzhip_zlib *z) {
+    /* everything in front of the current block's header is done with (dword granular: the device addresses dwords) */
+    const int64_t drop = (int64_t)((z->sst.hdr_bit >> 3) & ~3u);
+    if (drop > 0) {
+        memmove(z->in, z->in + drop, (size_t)(z->in_len - drop));
+        z->in_len -= drop;
+        z->in_dropped += drop;
+        z->sst.hdr_bit -= (uint32_t)drop * 8u;
+        z->sst.bit -= (uint32_t)drop * 8u;
+    }
+    return 0;
+}
+
+/* window mode: make more decoded bytes available behind out_served.  Returns 0 (bytes, the stream end or a verdict are
+ * there) or a negative MZ error. */
+static int32_t stream_next(mzhip_zlib *z) {
+    /* little left to serve: slide.  What stays is what has not been served yet and, in any case, the last 32 KiB that
+     * were produced (the history back-references may reach); the rest of the buffer is room for the next window */
+    if (z->out_len - z->out_served < 65536) {
+        int64_t from = z->out_len > 32768 ? z->out_len - 32768 : 0;
+        if (from > z->out_served)
+            from = z->out_served;
+        if (from > 0) {
+            memmove(z->out, z->out + from, (size_t)(z->out_len - from));
+            z->out_len -= from;
+            z->out_served -= from;
+        }
+    }
+    for (;;) {
+        /* compressed bytes for about a window: pull ahead (each pull <= 32767 bytes like the reference's) */
+        while (!z->base_eof && z->in_len < MZH_STREAM_GULP) {
+            const int32_t rd = pull_chunk(z);
+            if (rd < 0) {
+                if (z->in_len == 0)
+                    return rd;
+                z->base_err = rd;
+                z->base_eof = 1;
+            }
+        }
+        z->sst.out_pos = (uint32_t)z->out_len;
+        z->sst.flags = 1;
+        mzhip_inflate_state nst;
+        uint32_t out_len = 0, in_used = 0, crc = 0;
+        int32_t st = mzhip_inflate_resume_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
+                                               &in_used, &crc);
+        if (st == MZHIP_STATUS_BUF_ERROR && z->base_eof && (nst.flags & 1u)) {
+            /* the stream really ends short.  What this call decoded stays; then once more from where it stopped, without
+             * the "all or nothing" rule of a resumable decode, so that what the reference would still have produced (the
+             * available part of a stored block) is produced -- when the window has room for it */
+            z->out_len = nst.out_pos;
+            z->sst = nst;
+            stream_drop_input(z);
+            if (z->out_cap - z->out_len < 70000 && z->out_len > z->out_served)
+                return 0; /* serve first; the next call slides the window and comes back here */
+            z->sst.out_pos = (uint32_t)z->out_len;
+            z->sst.flags = 1;
+            st = mzhip_inflate_resume_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, NULL, &out_len,
+                                           &in_used, &crc);
+            if (st == MZHIP_STATUS_OK || st == MZHIP_STATUS_BUF_ERROR || st == MZHIP_STATUS_DATA_ERROR)
+                z->out_len = out_len;
+            else
+                st = MZH_STREAM_ERROR; /* (a full window cannot be: there was room for a block) */
+            z->stream_end = 1;
+            return verdict(z, st, st == MZHIP_STATUS_BUF_ERROR ? z->in_dropped + z->in_len /* inflate() has taken all there was */
+                                                               : z->in_dropped + in_used);
+        }
+        if (st == MZHIP_STATUS_OK || st == MZHIP_STATUS_DATA_ERROR) {
+            z->out_len = out_len;
+            z->stream_end = 1;
+            return verdict(z, st, z->in_dropped + in_used);
+        }
+        if (st != MZHIP_STATUS_OUT_FULL && st != MZHIP_STATUS_BUF_ERROR) {
+            z->stream_end = 1;
+            return verdict(z, MZH_STREAM_ERROR, z->in_dropped + in_used); /* device / runtime failure */
+        }
+        if (!(nst.flags & 1u)) {
+            z->stream_end = 1;
+            return verdict(z, MZH_STREAM_ERROR, z->in_dropped);
+        }
+        const int64_t had = z->out_len;
+        z->out_len = nst.out_pos;
+        z->sst = nst;
+        stream_drop_input(z);
+        if (st == MZHIP_STATUS_OUT_FULL) {
+            if (z->out_len > z->out_served)
+                return 0; /* a window (or what was left of one) is there */
+            if (z->out_len == had) { /* no room for even one token group: cannot happen with a 64 MiB window */
+                z->stream_end = 1;
+                return verdict(z, MZH_STREAM_ERROR, z->in_dropped);
+            }
+            continue;
+        }
+        /* input ended inside the window and the base stream has more: go on with it (what was decoded so far stays) */
+        if (z->in_len >= MZH_STREAM_GULP) { /* a single block larger than the gulp: let the input buffer grow */
+            int tries = 0;
+            while (!z->base_eof && tries++ < 512) {
+                const int32_t rd = pull_chunk(z);
+                if (rd < 0) {
+                    z->base_err = rd;
+                    z->base_eof = 1;
+                }
+            }
+        }
+        if (z->out_len > z->out_served && z->out_len - z->out_served >= 65536)
+            return 0; /* enough to serve while more input is fetched */
+    }
+}
+
 static int32_t attempt_decode(mzhip_zlib *z) {
     if (z->wrap != 0 && z->hdr_len == 0) {
         const int32_t h = parse_wrapper_header(z);
@@ -342,10 +468,25 @@ static int32_t attempt_decode(mzhip_zlib *z) {
         int32_t st = mzhip_inflate_host2(z->in + z->hdr_len, (uint32_t)(z->in_len - z->hdr_len), z->out,
                                          (uint32_t)z->out_cap, &out_len, &in_used, &z->out_crc,
                                          z->wrap == 1 ? &z->out_adler : NULL);
+        if (st == MZHIP_STATUS_OUT_FULL && z->wrap == 0 && z->out_cap >= MZH_STREAM_WINDOW) {
+            /* more than a window of output: from here on the entry is decoded window by window.  The first window once
+             * more, this time asking where it stops */
+            z->streaming = 1;
+            z->in_dropped = 0;
+            memset(&z->sst, 0, sizeof(z->sst));
+            z->out_len = z->out_served = 0;
+            const int32_t sr = stream_next(z);
+            if (sr < 0)
+                return sr;
+            z->decoded = 1; /* (bytes are there; the verdict comes with the last window) */
+            return 0;
+        }
         if (st == MZHIP_STATUS_OUT_FULL) {
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
             int64_t ncap = z->out_cap * 4;
+            if (z->wrap == 0 && ncap > MZH_STREAM_WINDOW)
+                ncap = MZH_STREAM_WINDOW;
             if (ncap > 0x7FFFFFFF)
                 ncap = 0x7FFFFFFF;
             free(z->out);
@@ -362,6 +503,8 @@ static int32_t attempt_decode(mzhip_zlib *z) {
         z->out_len = out_len;
         if (st != MZHIP_STATUS_OK && st != MZHIP_STATUS_BUF_ERROR && st != MZHIP_STATUS_DATA_ERROR)
             return verdict(z, MZH_STREAM_ERROR, z->hdr_len + in_used); /* device/runtime failure: no CPU substitute */
+        if (st == MZHIP_STATUS_BUF_ERROR)
+            return verdict(z, st, z->in_len); /* input exhausted: inflate() has consumed every byte it was given (total_in) */
         if (st != MZHIP_STATUS_OK || z->wrap == 0)
             return verdict(z, st, z->hdr_len + in_used);
         z->dev_in_used = z->hdr_len + in_used;
@@ -441,6 +584,38 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         }
     }
 
+    if (z->streaming) {
+        /* window mode: the call is served across windows -- what the current one still holds, then the next one(s),
+         * until `size` bytes are there or the stream is over (inflate() fills the caller's buffer the same way) */
+        int32_t got = 0;
+        for (;;) {
+            const int64_t av = z->out_len - z->out_served;
+            const int32_t k = (int32_t)(av < size - got ? av : size - got);
+            if (k > 0) {
+                memcpy((uint8_t *)buf + got, z->out + z->out_served, (size_t)k);
+                z->out_served += k;
+                z->total_out += k;
+                got += k;
+            }
+            if (got == size || z->stream_end)
+                break;
+            const int32_t sr = stream_next(z);
+            if (sr < 0) {
+                z->error = sr;
+                return sr;
+            }
+        }
+        if (got < size && z->dev_status != 0) {
+            /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189) */
+            z->error = (z->base_err != 0 && z->dev_status == MZHIP_STATUS_BUF_ERROR) ? z->base_err : z->dev_status;
+            z->total_in = z->dev_in_used;
+            return z->error;
+        }
+        /* TOTAL_IN is exact once the stream end has been served; before that it is a lower bound (the blocks that are
+         * done with; with the end in sight, all but the last byte -- the rule of the one-buffer path below) */
+        z->total_in = !z->stream_end ? z->in_dropped : (z->out_served == z->out_len ? z->dev_in_used : z->dev_in_used - 1);
+        return got;
+    }
     int64_t avail = z->out_len - z->out_served;
     if (z->dev_status != 0 && avail < size) {
         /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189) */

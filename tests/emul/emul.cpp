@@ -33,7 +33,30 @@ extern "C" int32_t emul_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out
     mz_inflate_result r;
     uint8_t *rec = (uint8_t *)malloc(MZ_REC_BYTES + 1024); /* the wave's HBM record scratch (chase window) */
     memset(rec, 0x5A, MZ_REC_BYTES + 1024);
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, &r);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, (const mz_inflate_state *)0, (mz_inflate_state *)0, &r);
+    free(rec);
+    free(L);
+    *out_len = r.out_len;
+    *in_used = r.in_used;
+    *crc = r.crc;
+    return r.status;
+}
+
+/* resumable decode (mzhip_inflate_resume_host's device side): out[0 .. st_in->out_pos) is history */
+extern "C" int32_t emul_inflate_resume(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, const uint32_t *st_in,
+                                       uint32_t *st_out, uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    ready();
+    mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
+    memset(L, 0xA5, sizeof(*L));
+    uint8_t *rec = (uint8_t *)malloc(MZ_REC_BYTES + 1024);
+    memset(rec, 0x5A, MZ_REC_BYTES + 1024);
+    mz_inflate_state a, b;
+    memset(&a, 0, sizeof(a));
+    if (st_in) memcpy(&a, st_in, sizeof(a));
+    memset(&b, 0, sizeof(b));
+    mz_inflate_result r;
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, &a, st_out ? &b : (mz_inflate_state *)0, &r);
+    if (st_out) memcpy(st_out, &b, sizeof(b));
     free(rec);
     free(L);
     *out_len = r.out_len;
@@ -49,7 +72,7 @@ extern "C" int32_t emul_inflate_steps(const uint8_t *in, uint32_t in_len, uint8_
     mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_inflate_result r;
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 0u, (uint8_t *)0, &r);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 0u, (uint8_t *)0, (const mz_inflate_state *)0, (mz_inflate_state *)0, &r);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;

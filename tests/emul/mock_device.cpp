@@ -28,6 +28,18 @@ MOCK_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t
     if (adler) *adler = emul_adler32(out, ol);
     return st;
 }
+MOCK_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                           const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                           uint32_t *in_used, uint32_t *crc) {
+    uint32_t ol = 0, iu = 0, k = 0;
+    const uint8_t dummy = 0;
+    const int32_t st = emul_inflate_resume(in ? in : &dummy, in_len, buf, buf_cap, (const uint32_t *)state_in, (uint32_t *)state_out, &ol,
+                                           &iu, &k);
+    if (out_len) *out_len = ol;
+    if (in_used) *in_used = iu;
+    if (crc) *crc = k;
+    return st;
+}
 MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                                     uint32_t *in_used, uint32_t *crc) {
     return mzhip_inflate_host2(in, in_len, out, out_cap, out_len, in_used, crc, nullptr);

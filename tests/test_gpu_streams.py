@@ -89,3 +89,49 @@ def test_encoders_on_concurrent_streams(gpu):
                     assert lzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=lzma.FORMAT_ALONE) == datas[i], (t, kind, i)
                 checked += 1
     assert checked > 300
+
+
+def test_entry_larger_than_any_window_bounded_memory(tmp_path):
+    """A ZIP64 entry of 3 GiB (the reference streams any size through 32 767 bytes, mz_strm_zlib.c:51,116-193): the
+    drop-in decodes it window by window on the device (64 MiB windows, 32 KiB of history, resumable kernel) -- same sizes,
+    CRC verdicts and status as the all-reference reader, in a process whose peak RSS stays far below the entry."""
+    import json
+    import subprocess
+    import sys
+    import zipfile
+    import zlib
+
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing")
+    path = str(tmp_path / "big.zip")
+    total = 3 * (1 << 30) + 12345
+    piece = (b"sparse " * 1024 + bytes(120000)) * 8                      # ~1 MiB, compresses 300:1
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as zf:
+        with zf.open("huge.bin", "w", force_zip64=True) as f:
+            left = total
+            while left > 0:
+                k = min(left, len(piece))
+                f.write(piece[:k])
+                left -= k
+        zf.writestr("small.txt", synth.corpus()[:70000])
+    ref = oracle.ref()
+    table = ref.zip_index(path)
+    assert len(table) == 2 and int(table[0, 4]) == total
+    cd = table[:, 6].copy()
+    _, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False)
+    assert (st_r == 0).all() and int(ulen_r[0]) == total
+    prog = (
+        "import sys, json, resource\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np, oracle\n"
+        "hip = oracle.MzDriver(%r)\n"
+        "cd = np.array(%r, dtype=np.int64)\n"
+        "sec, crc, ulen, st = hip.zip_read_all(%r, cd, nthreads=1, own_crc=False)\n"
+        "print(json.dumps(dict(sec=sec, crc=[int(x) for x in crc], ulen=[int(x) for x in ulen], st=[int(x) for x in st],\n"
+        "                      rss_kib=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)))\n" % (ROOT, DROP, [int(x) for x in cd], path))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert got["st"] == [0, 0] and got["ulen"] == [int(x) for x in ulen_r] and got["crc"] == [int(x) for x in crc_r]
+    print("3 GiB entry through the drop-in: %.1f s, peak RSS %.0f MiB" % (got["sec"], got["rss_kib"] / 1024))
+    assert got["rss_kib"] < 1536 * 1024                                   # far below the 3 GiB of the entry (64 MiB window + runtime)

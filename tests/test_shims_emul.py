@@ -109,3 +109,34 @@ def test_streams_with_a_prime_cache_present(libs):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k",
                         "not prime_cache_present"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_window_mode_streams():
+    """Entries larger than one decode window are decoded window by window (shim_zlib.c stream_next: the last 32 KiB carried
+    as history, the compressed bytes in front of the current block dropped, the decode taken up at a token boundary the
+    kernel reports).  Built here with a 192 KiB window and 48 KiB input gulps so that streams of a few hundred KiB cross
+    many windows: same read() return values, bytes, TOTAL_IN / TOTAL_OUT, close() and error() as the reference, for whole,
+    truncated and corrupted streams, Huffman and stored blocks, reads smaller and larger than a window."""
+    import random
+
+    from tests import synth
+
+    if not os.path.isdir("/root/reference") or not oracle.have_ref():
+        pytest.skip("needs the reference sources at build time")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul"), "B=_build_small",
+                    'SHIM_DEFS=-DMZH_STREAM_WINDOW="(192<<10)" -DMZH_STREAM_GULP="(48<<10)"'], check=True, capture_output=True)
+    hip = oracle.MzDriver(os.path.join(ROOT, "tests", "emul", "_build_small", "libmockdrop.so"))
+    ref = oracle.ref()
+    text, _ = synth.bench_corpus()
+    rnd = random.Random(9)
+    cases = [text[:450000], bytes(1200000), bytes(rnd.getrandbits(8) for _ in range(300000)), text[1000:150000] + bytes(250000) + text[:90000]]
+    for i, d in enumerate(cases):
+        for lvl in (6, 0):
+            z = synth.deflate_raw(d, lvl)
+            for chunk in (65535, 1000, 300000):
+                assert ref.stream_decode(8, z, len(d) + 10, chunk=chunk) == hip.stream_decode(8, z, len(d) + 10, chunk=chunk), (i, lvl, chunk)
+            for cut in (len(z) // 2, len(z) - 3):
+                assert ref.stream_decode(8, z[:cut], len(d) + 10) == hip.stream_decode(8, z[:cut], len(d) + 10), (i, lvl, "cut", cut)
+            zz = bytearray(z)
+            zz[len(zz) * 2 // 3] ^= 0x10
+            assert ref.stream_decode(8, bytes(zz), len(d) + 10) == hip.stream_decode(8, bytes(zz), len(d) + 10), (i, lvl, "flip")
