@@ -57,6 +57,14 @@
 typedef struct mz_lzma_lds {
     uint16_t probs[(LZ_NUM_PROBS + 1) & ~1u];
 } mz_lzma_lds;
+#ifndef MZ_LZMA_SLOTS
+#define MZ_LZMA_SLOTS 4u /* literal contexts the slot build keeps in LDS (see LZ_LITERAL_SITE_SLOT) */
+#endif
+#define LZ_NUM_PROBS_S (LZ_LIT + 0x300u * MZ_LZMA_SLOTS)
+#define MZ_LZMA_SPROBS (0x300u << 4) /* the slot build's whole literal model in HBM, per resident wave */
+typedef struct mz_lzma_lds_s {
+    uint16_t probs[(LZ_NUM_PROBS_S + 1) & ~1u];
+} mz_lzma_lds_s;
 
 typedef struct mz_lzma_result {
     int32_t status;
@@ -209,6 +217,68 @@ typedef struct mz_lzma_result {
         }                                                                               \
     } while (0)
 
+/* Where a literal's 0x300 probabilities are.  Full model (K3's fall-back kernel, the .xz kernel): context c at
+ * LZ_LIT + 0x300 * c in LDS, the upper half of an lc + lp = 4 model in the HBM scratch. */
+#define LZ_LITERAL_SITE_FULL(sym)                                                                                     \
+    do {                                                                                                              \
+        const uint32_t lbase = LZ_LIT + 0x300u * (((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));                \
+        if (lbase < LZ_NUM_PROBS) {                                                                                   \
+            LZ_LITERAL(LZ_BIT);                                                                                       \
+        } else { /* lc + lp = 4, upper half of the literal model */                                                   \
+            LZ_LITERAL(LZ_BIT_X);                                                                                     \
+        }                                                                                                             \
+    } while (0)
+/* Slot build (K3's main kernel): LDS holds MZ_LZMA_SLOTS literal contexts, the whole literal model lives in the wave's
+ * HBM scratch prx[] (0x300 << 4 probabilities) and a context is swapped in when it is needed (1.5 KiB out, 1.5 KiB in,
+ * all lanes).  Text touches three or four contexts (the top lc bits of the previous byte: letters, punctuation, capitals),
+ * so it never swaps after the first bytes, and the wave's LDS slice is 9.6 KiB instead of 16.6: 16 streams per CU
+ * instead of 10 -- K3 is one serial chain per wave, more waves are the only throughput there is (profiles/r3/
+ * ab_k3_residency.log).  A stream that keeps swapping (binary data: all eight contexts live) is given back with
+ * MZHIP_RETRY after a bounded number of swaps and decoded by the full-model kernel. */
+#define MZHIP_RETRY (-300)
+#define LZ_LITERAL_SITE_SLOT(sym)                                                                                     \
+    do {                                                                                                              \
+        const uint32_t cx_ = MZ_UNIFORM(((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));                          \
+        uint32_t sl_ = 0;                                                                                             \
+        uint32_t hit_ = 0;                                                                                            \
+        _Pragma("unroll") for (uint32_t k_ = 0; k_ < MZ_LZMA_SLOTS; k_++) {                                           \
+            if (stag[k_] == cx_) {                                                                                    \
+                sl_ = k_;                                                                                             \
+                hit_ = 1;                                                                                             \
+            }                                                                                                         \
+        }                                                                                                             \
+        if (!hit_) {                                                                                                  \
+            sl_ = svict;                                                                                              \
+            svict = (svict + 1u == MZ_LZMA_SLOTS) ? 0u : svict + 1u;                                                  \
+            uint32_t old_ = 0;                                                                                        \
+            _Pragma("unroll") for (uint32_t k_ = 0; k_ < MZ_LZMA_SLOTS; k_++) {                                       \
+                if (k_ == sl_) {                                                                                      \
+                    old_ = stag[k_];                                                                                  \
+                    stag[k_] = cx_;                                                                                   \
+                }                                                                                                     \
+            }                                                                                                         \
+            uint16_t *const sp_ = pr + LZ_LIT + 0x300u * sl_;                                                         \
+            MZ_LANES {                                                                                                \
+                for (uint32_t i_ = (uint32_t)lane; i_ < 0x300u / 4u; i_ += 64u) {                                     \
+                    uint64_t v_;                                                                                      \
+                    if (old_ != 0xFFFFFFFFu) {                                                                        \
+                        __builtin_memcpy(&v_, sp_ + 4u * i_, 8);                                                      \
+                        __builtin_memcpy(prx + 0x300u * old_ + 4u * i_, &v_, 8);                                      \
+                    }                                                                                                 \
+                    __builtin_memcpy(&v_, prx + 0x300u * cx_ + 4u * i_, 8);                                           \
+                    __builtin_memcpy(sp_ + 4u * i_, &v_, 8);                                                          \
+                }                                                                                                     \
+            }                                                                                                         \
+            MZ_WAVE_SYNC();                                                                                           \
+            if (++sswaps > 64u + (opos >> 7)) { /* more than a swap per 128 bytes: not this kernel's data */          \
+                status = MZHIP_RETRY;                                                                                 \
+                goto finish;                                                                                          \
+            }                                                                                                         \
+        }                                                                                                             \
+        const uint32_t lbase = LZ_LIT + 0x300u * sl_;                                                                 \
+        LZ_LITERAL(LZ_BIT);                                                                                           \
+    } while (0)
+
 /* The packet loop, shared by K3 (LZMA1 to the end marker: lzma2 = 0, dict_start = 0) and the .xz kernel
  * (LZMA2 chunk with a known uncompressed size: lzma2 = 1, stops at opos == chunk_end).  Expects the coder,
  * model and output locals of its caller by name; leaves through `goto finish` with `status` on any failure. */
@@ -221,13 +291,8 @@ typedef struct mz_lzma_result {
         LZ_BIT(bit, LZ_IS_MATCH + state * 16 + ps);                                                                   \
         if (!bit) {                                                                                                   \
             /* literal */                                                                                             \
-            const uint32_t lbase = LZ_LIT + 0x300u * (((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));            \
             uint32_t sym = 1;                                                                                         \
-            if (lbase < LZ_NUM_PROBS) {                                                                               \
-                LZ_LITERAL(LZ_BIT);                                                                                   \
-            } else { /* lc + lp = 4, upper half of the literal model */                                               \
-                LZ_LITERAL(LZ_BIT_X);                                                                                 \
-            }                                                                                                         \
+            LZ_LITERAL_SITE(sym);                                                                                     \
             if (eof) goto finish;                                                                                     \
             if (opos == out_cap) {                                                                                    \
                 status = MZHIP_OUT_FULL;                                                                              \
@@ -370,6 +435,9 @@ typedef struct mz_lzma_result {
  *                    vector ports of the four SIMDs, only the uniform branches remain scalar.
  * Measured for one full round of 2304 resident 1 MiB entries: scalar 480 ms, vector see DESIGN.md K3.  The kernel
  * runs MZ_LZMA_VPORT_OF_8 of every 8 workgroups on the vector build.  The host emulation builds the first only. */
+#define LZ_LITERAL_SITE(sym) LZ_LITERAL_SITE_FULL(sym)
+#define LZ_LDS_T mz_lzma_lds
+#define LZ_ENTRY_PROBS LZ_NUM_PROBS
 #define LZ_U(x) MZ_UNIFORM(x)
 #define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
 #define LZ_ENTRY_NAME mz_lzma_entry
@@ -387,6 +455,32 @@ typedef struct mz_lzma_result {
 #undef LZ_WIN_DW
 #undef LZ_ENTRY_NAME
 #endif
+
+/* the slot build: vector-port form on the device, scalar form in the host emulation */
+#undef LZ_LITERAL_SITE
+#undef LZ_LDS_T
+#undef LZ_ENTRY_PROBS
+#define LZ_LITERAL_SITE(sym) LZ_LITERAL_SITE_SLOT(sym)
+#define LZ_LDS_T mz_lzma_lds_s
+#define LZ_ENTRY_PROBS LZ_NUM_PROBS_S
+#define LZ_SLOTS_BUILD 1
+#if defined(MZHIP_HOST_EMUL)
+#define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
+#else
+#define LZ_U(x) (x)
+#define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
+#endif
+#define LZ_ENTRY_NAME mz_lzma_entry_s
+#include "lzma_entry.inc"
+#undef LZ_U
+#undef LZ_WIN_DW
+#undef LZ_ENTRY_NAME
+#undef LZ_SLOTS_BUILD
+#undef LZ_LITERAL_SITE
+#undef LZ_LDS_T
+#undef LZ_ENTRY_PROBS
+#define LZ_LITERAL_SITE(sym) LZ_LITERAL_SITE_FULL(sym)
 
 /* for code that expands the coder macros outside the two entry builds (xz_core.h): vector-port forms on the device */
 #if defined(MZHIP_HOST_EMUL)

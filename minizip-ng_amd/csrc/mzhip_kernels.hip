@@ -183,6 +183,9 @@ struct LzmaArgs {
     const mzhip_crc_tables *tabs;
     const uint64_t *tab64; // CRC-64 byte table (.xz kernel only)
     uint16_t *xprobs;      // MZ_LZMA_XPROBS u16 per resident wave: upper half of the literal model when lc + lp = 4
+    uint16_t *sprobs;      // slot kernel: MZ_LZMA_SPROBS u16 per resident wave, the whole literal model
+    uint32_t *retry_list;  // slot kernel: entries given back (MZHIP_RETRY) are appended here, ...
+    uint32_t *retry_n;     // ... counted here; the full-model kernel then decodes exactly those (list != null: n = *retry_n)
 };
 
 #ifndef MZ_LZMA_VPORT_OF_8
@@ -200,10 +203,12 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
+    const uint32_t n_here = a.retry_list ? MZ_UNIFORM(*a.retry_n) : a.n; // second launch: the entries the slot kernel gave back
     for (;;) {
         uint32_t e;
         MZ_WAVE_FETCH_ADD(e, a.counter);
-        if (e >= a.n) break;
+        if (e >= n_here) break;
+        if (a.retry_list) e = MZ_UNIFORM(a.retry_list[e]);
         mz_lzma_result r;
         // how many of every 8 workgroups run the vector-port build of the decoder (measured: 0/8 520 ms, 5/8 511 ms,
         // 8/8 469 ms for one full round of 2304 resident 1 MiB entries)
@@ -215,6 +220,41 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
             mz_lzma_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
                           a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
                           a.xprobs + (size_t)blockIdx.x * MZ_LZMA_XPROBS, &r);
+        // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
+        a.out_len[e] = r.out_len;
+        a.in_used[e] = r.in_used;
+        a.crc[e] = r.crc;
+        a.status[e] = r.status;
+    }
+}
+
+// K3, main kernel: the slot build of the decoder (lzma_core.h LZ_LITERAL_SITE_SLOT) -- 9.6 KiB of LDS per wave, 16 waves
+// per CU (registers held to 128 by the launch bounds).  Streams whose literal contexts do not fit the slots are given
+// back through retry_list and decoded by k_lzma_batch right behind this launch.
+__global__ __launch_bounds__(256, 4) void k_lzma_slot_batch(LzmaArgs a) {
+    // four waves per workgroup, each with its own model slice, one CRC table between them: 4 x 9840 + 1024 bytes = four
+    // workgroups per CU (single-wave workgroups with a table each come to 15 waves)
+    __shared__ __attribute__((aligned(16))) mz_lzma_lds_s lds4[4];
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    const uint32_t wave = threadIdx.x >> 6;
+    mz_lzma_lds_s &lds = lds4[wave];
+    const size_t wave_id = (size_t)blockIdx.x * 4u + wave;
+    for (;;) {
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
+        if (e >= a.n) break;
+        mz_lzma_result r;
+        mz_lzma_entry_s(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
+                        a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
+                        a.sprobs + wave_id * MZ_LZMA_SPROBS, &r);
+        if (r.status == MZHIP_RETRY) {
+            uint32_t slot;
+            MZ_WAVE_FETCH_ADD(slot, a.retry_n);
+            a.retry_list[slot] = e; // (uniform store)
+        }
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -791,6 +831,41 @@ static int32_t lzma_family_batch(int xz, const void *d_in, const uint64_t *d_in_
     uint32_t grid = n < resident ? n : resident;
     int slot = -1;
     void *scratch = nullptr; /* 12 KiB per resident wave: the literal model's upper half for streams with lc + lp = 4 */
+    a.sprobs = nullptr;
+    a.retry_list = nullptr;
+    a.retry_n = nullptr;
+#if defined(MZ_LZMA_NO_SLOT_KERNEL)
+    const bool two_step = false;
+#else
+    const bool two_step = !xz;
+#endif
+    if (two_step) {
+        /* K3: the slot kernel over every entry (16 waves per CU), then the full-model kernel over the entries it gave back */
+        const uint32_t res_s = (uint32_t)c->cu_count * 4u; /* workgroups of four waves */
+        const uint32_t grid_s = (n + 3u) / 4u < res_s ? (n + 3u) / 4u : res_s;
+        const size_t sp_bytes = (size_t)grid_s * 4u * MZ_LZMA_SPROBS * sizeof(uint16_t);
+        const size_t xp_bytes = (size_t)grid * MZ_LZMA_XPROBS * sizeof(uint16_t);
+        rc = scratch_acquire(c, sp_bytes + xp_bytes + (size_t)n * 4 + 256, s, &slot, &scratch);
+        if (rc) return rc;
+        a.sprobs = (uint16_t *)scratch;
+        a.xprobs = (uint16_t *)((uint8_t *)scratch + sp_bytes);
+        uint32_t *list = (uint32_t *)((uint8_t *)scratch + sp_bytes + xp_bytes);
+        a.retry_list = list + 64;
+        a.retry_n = list; /* one word, zeroed with the launch */
+        hipError_t he = hipMemsetAsync(list, 0, 256, s);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_lzma_slot_batch, dim3(grid_s), dim3(256), 0, s, a);
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) {
+            a.counter = lease.p + 1; /* the second head of the lease */
+            hipLaunchKernelGGL(k_lzma_batch, dim3(grid), dim3(64), 0, s, a);
+            he = hipGetLastError();
+        }
+        rc = scratch_release(c, slot, s);
+        if (he != hipSuccess) return fail("k_lzma_slot_batch", he);
+        return rc;
+    }
     rc = scratch_acquire(c, (size_t)grid * MZ_LZMA_XPROBS * sizeof(uint16_t), s, &slot, &scratch);
     if (rc) return rc;
     a.xprobs = (uint16_t *)scratch;

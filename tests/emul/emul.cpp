@@ -237,6 +237,25 @@ extern "C" int32_t emul_lzma(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     *crc = r.crc;
     return r.status;
 }
+/* K3's slot build (MZ_LZMA_SLOTS literal contexts in LDS, the model in the scratch); -300 = MZHIP_RETRY: the stream swaps
+ * too much and belongs to the full-model kernel.  *swapped: whether it was given back. */
+extern "C" int32_t emul_lzma_slots(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
+                                   uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
+    ready();
+    mz_lzma_lds_s *L = (mz_lzma_lds_s *)malloc(sizeof(mz_lzma_lds_s));
+    memset(L, 0xA5, sizeof(*L));
+    mz_lzma_result r;
+    uint16_t *prx = (uint16_t *)malloc(MZ_LZMA_SPROBS * sizeof(uint16_t));
+    memset(prx, 0x5A, MZ_LZMA_SPROBS * sizeof(uint16_t));
+    mz_lzma_entry_s(in, in_len, out, out_cap, max_out, L, g_tabs.byte_tab, &g_tabs, prx, &r);
+    free(prx);
+    free(L);
+    *out_len = r.out_len;
+    *in_used = r.in_used;
+    *crc = r.crc;
+    return r.status;
+}
+extern "C" uint32_t emul_lzma_slots_lds_bytes(void) { return (uint32_t)sizeof(mz_lzma_lds_s); }
 extern "C" uint32_t emul_lzma_lds_bytes(void) { return (uint32_t)sizeof(mz_lzma_lds); }
 
 #include "deflate_core.h"

@@ -179,6 +179,42 @@ def test_inflate_out_cap(emu):
     assert st == -200
 
 
+def test_lzma_slot_build(emu):
+    """K3's main kernel keeps MZ_LZMA_SLOTS literal contexts in LDS and the literal model in HBM (lzma_core.h
+    LZ_LITERAL_SITE_SLOT): whatever it decodes itself must be what the full-model build decodes -- bytes, consumed count,
+    CRC, verdicts of corrupted streams -- and what it gives back (MZHIP_RETRY = -300: the contexts keep swapping) must be
+    data that deserves it: text at the parameters every ZIP writer uses is never given back, random bytes always."""
+    import lzma as pylzma
+    import random
+
+    emu.emul_lzma_slots.argtypes = emu.emul_lzma.argtypes
+    assert emu.emul_lzma_slots_lds_bytes() * 4 + 1024 <= 40 * 1024          # four waves + one CRC table per workgroup, four per CU
+    text, _ = synth.bench_corpus()
+    rnd = random.Random(4)
+    noise = bytes(rnd.getrandbits(8) for _ in range(40000))
+    cases = [("empty", b""), ("one", b"a"), ("text", text[:250000]), ("markov", synth.markov_entries(1, 300000, 5, text)[0]),
+             ("noise", noise), ("run", b"A" * 100000), ("mixed", text[1000:70000] + noise[:3000] + text[:50000])]
+    back = {}
+    for name, d in cases:
+        for lc, lp, pb in ((3, 0, 2), (0, 0, 2), (4, 0, 0), (1, 2, 2), (0, 4, 1)):
+            raw = pylzma.compress(d, format=pylzma.FORMAT_ALONE, filters=[dict(id=pylzma.FILTER_LZMA1, preset=6, lc=lc, lp=lp, pb=pb)])
+            z = bytes([5, 2, 5, 0]) + raw[:5] + raw[13:]
+            a = _run(emu.emul_lzma, z, len(d) + 10, C.c_int64(len(d)))
+            b = _run(emu.emul_lzma_slots, z, len(d) + 10, C.c_int64(len(d)))
+            back[(name, lc, lp)] = b[0] == -300
+            if b[0] != -300:
+                assert a == b and a[2] == d and a[3] == zlib.crc32(d), (name, lc, lp, pb, a[0], b[0])
+        z = bytearray(_zip_lzma(d))
+        if len(z) > 40:
+            z[len(z) // 2] ^= 0x21
+            a = _run(emu.emul_lzma, bytes(z), len(d) + 100, C.c_int64(-1))
+            b = _run(emu.emul_lzma_slots, bytes(z), len(d) + 100, C.c_int64(-1))
+            if b[0] != -300:
+                assert a[:3] == b[:3], (name, "corrupt", a[0], b[0])
+    assert not back[("text", 3, 0)] and not back[("markov", 3, 0)] and not back[("run", 3, 0)] and not back[("text", 0, 0)]
+    assert back[("noise", 3, 0)] and back[("text", 0, 4)]
+
+
 def test_lzma_cases(emu):
     c = synth.corpus()
     rnd = np.random.RandomState(11)
