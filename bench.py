@@ -69,7 +69,7 @@ CONFIGS = {
     3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=131072,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 1M x 8KiB DEFLATE entries",
             workload="BASELINE.json configs[2]: DEFLATE level-6 %d x %d B small entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
-    4: dict(entries=10000, size=1 << 20, codec="lzma", kernel="k_lzma_batch", unique=256,
+    4: dict(entries=10000, size=1 << 20, codec="lzma", kernel="k_lzma_slot_batch (+ k_lzma_batch over the streams it gives back)", unique=256,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 10k x 1MiB LZMA entries",
             workload="BASELINE.json configs[3]: LZMA (method 14, preset 6) %d x %d B entries, range decode + fused CRC32 (mzhip_lzma_batch), device-resident"),
     5: dict(entries=100000, size=65536, codec="deflate", kernel="k_deflate_batch", unique=100000,

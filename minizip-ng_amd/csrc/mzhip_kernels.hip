@@ -1058,9 +1058,26 @@ struct Scratch {
     }
 };
 // The synchronous host-buffer entry points (one entry at a time: what the vtbl shims call) run on the calling thread's
-// own stream: copies and launches are ordered on hipStreamPerThread and only that stream is waited for, so two host
+// own stream: copies and launches are ordered on it and only that stream is waited for, so two host
 // threads never serialise on the null stream or on a device-wide synchronisation.
-#define MZ_HOST_STREAM hipStreamPerThread
+// (hipStreamPerThread itself was the first choice; with two host threads decoding entries at the same time it handed
+// back garbage result words now and then -- tests/test_gpu_dropin.py::test_archives_through_unmodified_mz_zip, one run in
+// three -- so the per-thread stream is one this library creates: a non-blocking stream per (host thread, device), made
+// on first use and left to the process's end.)
+struct ThreadStreams {
+    hipStream_t s[kMaxDevices] = {};
+};
+static thread_local ThreadStreams t_streams;
+static hipStream_t mz_host_stream() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
+    if (!t_streams.s[d] && hipStreamCreateWithFlags(&t_streams.s[d], hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        t_streams.s[d] = nullptr; /* the null stream still works, only slower */
+    }
+    return t_streams.s[d];
+}
+#define MZ_HOST_STREAM mz_host_stream()
 static inline hipError_t mz_h2d(void *dst, const void *src, size_t n) {
     return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, MZ_HOST_STREAM); // (pageable source: staged before the call returns)
 }
