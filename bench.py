@@ -366,7 +366,10 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
       vtbl_end_to_end_T    the same with T = all host cores reader threads, one mz_zip_reader each
                            (integration/extract_threads.c: the shape of the cpu_baseline leg)"""
     out = {"kernel": round(kernel_gib, 2)}
-    n = min(len(in_len), 20000)
+    # chunks of one launch round each: a launch keeps 4096 waves resident (16 per CU) and a wave decodes one entry, so a
+    # chunk of 5000 entries would pay a second, 22 % full round
+    per = 4096
+    n = min(len(in_len), 5 * per)
     end = int(in_off[n - 1] + (in_len[n - 1] + 15) // 16 * 16)
     hp = torch.from_numpy(h_in[:end]).pin_memory()
     d_in = torch.empty(end, dtype=torch.uint8, device=dev)
@@ -375,8 +378,8 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
     d_out = torch.empty(n * size, dtype=torch.uint8, device=dev)
     d_oo = torch.arange(n, dtype=torch.int64, device=dev) * size
     d_oc = torch.full((n,), size, dtype=torch.int32, device=dev)
-    nchunk = 4
-    cuts = [n * i // nchunk for i in range(nchunk + 1)]
+    nchunk = (n + per - 1) // per
+    cuts = [min(n, per * i) for i in range(nchunk + 1)]
     h_parts = [torch.empty((3, cuts[i + 1] - cuts[i]), dtype=torch.int32).pin_memory() for i in range(nchunk)]  # contiguous targets
     streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
     best = None

@@ -29,12 +29,15 @@
  * need); it is only reported once every decoded byte has been served, so a
  * caller that stops early does not trip the CRC comparison at mz_zip.c:2116.
  *
- * COMPRESS_WINDOW (mz_strm_zlib.c:80,104): -15 = raw (what mz_zip.c uses), 15 = zlib wrapper (RFC 1950),
- * 15+16 = gzip wrapper (RFC 1952; minigzip.c:80), 15+32 = detect on READ.  The wrappers are framing around
+ * COMPRESS_WINDOW (mz_strm_zlib.c:80,104): every value zlib's inflateInit2 / deflateInit2 accept: -8..-15 = raw (-15 is
+ * what mz_zip.c uses), 8..15 = zlib wrapper (RFC 1950), 24..31 = gzip wrapper (RFC 1952; minigzip.c:80), 40..47 = detect
+ * on READ, 0 = window from the zlib header on READ.  The wrappers are framing around
  * the same device path: header fields are parsed/emitted here, the trailer is checked against / filled from
  * the checksums the device computed (fused CRC-32, K5 Adler-32).  Error numbering follows zlib's inflate():
  * a bad header or trailer is Z_DATA_ERROR (-3), a preset dictionary request is Z_NEED_DICT (2), input that
- * ends inside the header or trailer is Z_BUF_ERROR (-5).  Other window sizes answer MZ_SUPPORT_ERROR.
+ * ends inside the header or trailer is Z_BUF_ERROR (-5).  A value outside those ranges fails open() the way zlib's init
+ * does (Z_STREAM_ERROR -> the reference's open() returns MZ_OPEN_ERROR); a stream whose header asks for a larger window
+ * than the one set is Z_DATA_ERROR, as in inflate().
  */
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copy what profiles/final_run.sh produced under gpurun_out/ into profiles/<round>/ (the judged, tracked copies):
-#   bash profiles/harvest.sh r2
+#   bash profiles/harvest.sh r3
 set -u
-r=${1:-r2}
+r=${1:-r3}
 d=profiles/$r
 mkdir -p $d
 cp gpurun_out/final/kernel_stats.csv $d/kernel_stats_final.csv
