@@ -359,10 +359,11 @@ def write_stream_zip(path, pays, crcs, size, method=8):
 def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel_gib, sample_zip):
     """SURVEY 8(d) (i)-(iii).  (ii) and (iii) run on bounded samples; all figures are decompressed GiB/s.
       kernel               the timed region of this bench (inputs and outputs resident in HBM)
-      h2d_kernel_d2hcrc    pinned host memory -> device, decode, {crc, len, status} back: chunks of the entry table on three
-                           streams, so that H2D(i + 1) runs under kernel(i)
-      vtbl_end_to_end      mzhip_prime_file (index + pipelined H2D / launches / D2H of every decoded byte) + the reference's
-                           unmodified reader loop on the drop-in library, ONE host thread
+      h2d_kernel_d2hcrc    pinned host memory -> device, decode, {crc, len, status} back: chunks of the entry table, copies on
+                           one stream and launches on another, so that H2D(i + 1) runs under kernel(i)
+      vtbl_end_to_end      mzhip_prime_mem_begin (index, then pipelined H2D / launches / D2H of every decoded byte on a worker
+                           thread) with the reference's unmodified reader loop on the drop-in library running under it, ONE
+                           reader thread
       vtbl_end_to_end_T    the same with T = all host cores reader threads, one mz_zip_reader each
                            (integration/extract_threads.c: the shape of the cpu_baseline leg)"""
     out = {"kernel": round(kernel_gib, 2)}
@@ -381,25 +382,36 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
     nchunk = (n + per - 1) // per
     cuts = [min(n, per * i) for i in range(nchunk + 1)]
     h_parts = [torch.empty((3, cuts[i + 1] - cuts[i]), dtype=torch.int32).pin_memory() for i in range(nchunk)]  # contiguous targets
-    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    # one stream copies, in order, so that chunk i is complete as early as the link allows; one computes (chunk i's launch
+    # waits for chunk i's copy only); the results go back on a third
+    s_copy, s_comp, s_back = (torch.cuda.Stream(device=dev) for _ in range(3))
     best = None
     for _ in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        keep = []
         for ci in range(nchunk):
             lo, hi = cuts[ci], cuts[ci + 1]
             b0, b1 = int(in_off[lo]), (int(in_off[hi]) if hi < n else end)
-            with torch.cuda.stream(streams[ci % 3]):
+            with torch.cuda.stream(s_copy):
                 d_in[b0:b1].copy_(hp[b0:b1], non_blocking=True)
+                arrived = s_copy.record_event()
+            with torch.cuda.stream(s_comp):
+                s_comp.wait_event(arrived)
                 out_len, in_used, crc, status = mz.inflate_batch(d_in, d_off[lo:hi], d_len[lo:hi], d_out, d_oo[lo:hi], d_oc[lo:hi])
-                h_parts[ci].copy_(torch.stack((crc, out_len, status)), non_blocking=True)
+                res = torch.stack((crc, out_len, status))
+                decoded = s_comp.record_event()
+            with torch.cuda.stream(s_back):
+                s_back.wait_event(decoded)
+                h_parts[ci].copy_(res, non_blocking=True)
+            keep.append(res)  # (allocated on s_comp, read on s_back: alive until the synchronize below)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     h_res = torch.cat(h_parts, dim=1)
     ok = bool((h_res[2].numpy() == 0).all() and (h_res[0].numpy().view(np.uint32) == want_crc_np[:n]).all())
     out["h2d_kernel_d2hcrc"] = round(n * size / 2**30 / best, 2) if ok else None
-    out["h2d_kernel_d2hcrc_sample"] = "%d entries in %d chunks on 3 streams, pinned host memory, best of 3" % (n, nchunk)
+    out["h2d_kernel_d2hcrc_sample"] = "%d entries in %d chunks of one launch round: a copy stream, a compute stream, a stream for the results; pinned host memory next to the device, best of 3" % (n, nchunk)
     # (iii) the reference's unmodified reader loop on the drop-in library, after mzhip_prime_file
     drop = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
     out["vtbl_end_to_end"] = out["vtbl_end_to_end_T"] = None
@@ -410,20 +422,21 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
             D.mzdrop_extract_all.restype = C.c_double
             D.mzdrop_extract_all.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                              C.POINTER(C.c_double), C.POINTER(C.c_int32)]
-            cores = max(1, usable_cores() * 3 // 4)  # the HIP runtime's own threads count against the same CPU quota
+            cores = max(1, usable_cores() // 2)  # the prime worker feeds the copy engines and the HIP runtime has threads of its own: past half the quota more readers slow the pipeline down (profiles/r3/threads_trace.log)
             for key, T in (("vtbl_end_to_end", 1), ("vtbl_end_to_end_T", cores)):
                 best, desc = None, ""
                 for _ in range(3):
                     L.mzhip_prime_clear()
                     ne, nb, tp, fe = C.c_int64(0), C.c_int64(0), C.c_double(0), C.c_int32(0)
-                    sec = D.mzdrop_extract_all(sample_zip.encode(), T, 1, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
+                    sec = D.mzdrop_extract_all(sample_zip.encode(), T, 2, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
                     if sec > 0 and fe.value == 0 and ne.value > 0 and (best is None or sec < best):
                         best = sec
-                        desc = ("%d entries / %.0f MiB: one read-only mapping of the archive, mzhip_prime_mem over it (index + pipelined "
-                                "H2D, launches, D2H of every byte: %.0f ms) + %d reader thread(s), one mz_zip_reader each on mz_stream_mem "
-                                "over the mapping, mz_zip_entry_read in 65 535-byte calls + CRC verification (mz_zip.c:2116-2128) on "
-                                "libmzhipdrop.so; best of 3"
-                                % (ne.value, nb.value / 2**20, tp.value * 1e3, T))
+                        desc = ("%d entries / %.0f MiB: one read-only mapping of the archive, mzhip_prime_mem_begin over it (index, then "
+                                "pipelined H2D, launches, D2H of every byte on a worker thread) with %d reader thread(s) running under "
+                                "it front to back (the calling thread spent %.0f ms in begin + wait), one mz_zip_reader each on "
+                                "mz_stream_mem over the mapping, mz_zip_entry_read in 65 535-byte calls + CRC verification "
+                                "(mz_zip.c:2116-2128) on libmzhipdrop.so; best of 3"
+                                % (ne.value, nb.value / 2**20, T, tp.value * 1e3))
                         nbytes = nb.value
                 L.mzhip_prime_clear()
                 if best:
@@ -471,7 +484,7 @@ def self_launch(n):
 def main():
     # the reference's header parser turns every DOS date into a time_t with mktime() (mz_zip.c: mz_zip_dosdate_to_time_t),
     # and glibc's mktime stats /etc/localtime under a process-wide lock when TZ is unset: 16 reader threads then spend 95 %
-    # of their time queueing there (profiles/r3/threads_tz.log: 125 ms -> 27 ms).  Both the reference baseline and the
+    # of their time queueing there (125 ms -> 27 ms for 16 readers of a 1 GiB archive; profiles/r3/threads_mapped_tzunset.log is the unset case).  Both the reference baseline and the
     # drop-in legs run with a fixed zone; it changes no byte of what they read.
     os.environ.setdefault("TZ", "UTC")
     time.tzset()
@@ -531,6 +544,11 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # this process next to its GPU (two sockets: the far one costs a third of the PCIe rate and half of the reader threads'
+    # memcpy rate, profiles/r3/threads_numa.log): the CPUs of the device's NUMA node, as many as the container's CPU quota
+    # when this is the only rank (threads that wander over 256 CPUs strand quota slices), the whole node otherwise.
+    # Applies to everything measured from here on, the reference's CPU baseline included.
+    near = mz.lib().mzhip_bind_thread_near_device(local, usable_cores() if world == 1 else 0)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -727,7 +745,9 @@ def main():
                        "entries_total": total_entries, "entries_rank0": n, "entry_bytes": size,
                        "sharding": ("one entry table, contiguous slices balanced by c+u bytes (archive.shard_bounds), "
                                     if strong else "independent table per rank, ") +
-                                   "RCCL all_gather of per-entry {crc,status} only" if world > 1 else "single GPU"},
+                                   "RCCL all_gather of per-entry {crc,status} only" if world > 1 else "single GPU",
+                       "host_placement": ("process bound to %d CPUs of the GPU's NUMA node: %s" % (near, sorted(os.sched_getaffinity(0))[:1] + sorted(os.sched_getaffinity(0))[-1:])
+                                          if near > 0 else "not bound (one NUMA node, or sysfs does not name the device's)")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": cfg["kernel"], "kernel_ms": round(kernel_ms, 3), "kernel_ms_per_rank": rank_ms,

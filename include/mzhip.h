@@ -48,6 +48,15 @@ extern "C" {
 /* Number of visible HIP devices, or <0 (no HIP runtime / no GPU): callers must
  * treat that as fatal -- there is no CPU fallback in this library. */
 MZHIP_API int32_t mzhip_device_count(void);
+/* Placement on multi-socket hosts.  mzhip_device_local_cpus: the kernel's cpulist ("64-127,192-255") of the NUMA node
+ * `device` is attached to, from /sys/bus/pci/devices/<bdf>/local_cpulist; returns its length, 0 when the platform has
+ * one node or does not say.  mzhip_bind_thread_near_device: restrict the CALLING thread (and the threads it creates
+ * afterwards) to those CPUs, at most max_cpus of them when max_cpus > 0 (cores before their second hardware threads);
+ * returns the number of CPUs bound to, 0 when nothing was changed.  The library binds only its own worker threads; an
+ * application (bench.py does) calls this once per process or reader thread before it allocates and reads: page-locked
+ * buffers land on the node of the thread that asks for them. */
+MZHIP_API int32_t mzhip_device_local_cpus(int32_t device, char *cpulist, int32_t cap);
+MZHIP_API int32_t mzhip_bind_thread_near_device(int32_t device, int32_t max_cpus);
 /* Bind the calling thread to `device` and create its constant tables.
  * Idempotent.  0 or a negative MZ_* code. */
 MZHIP_API int32_t mzhip_init(int32_t device);
@@ -248,6 +257,14 @@ MZHIP_API int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int6
  * its exact error behaviour).  Returns the number of cached entries or a negative MZ_* code. */
 MZHIP_API int64_t mzhip_prime_file(const char *path);
 MZHIP_API int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len);
+/* The same, in the background: returns as soon as the archive is indexed and its entries are known (their number, or
+ * 0 / an MZ error), while a worker thread of the library runs the decode pipeline on the calling thread's device.  A
+ * READ stream that opens an entry whose chunk of the pipeline has not arrived yet waits for that chunk only, so reader
+ * threads that take the entries front to back run under the decode instead of behind it (integration/extract_threads.c).
+ * The image must stay valid and unchanged until mzhip_prime_wait() -- which joins every prime begun so far and returns
+ * the number of entries they primed (or the first error) -- or mzhip_prime_clear(), which waits too. */
+MZHIP_API int64_t mzhip_prime_mem_begin(const uint8_t *zip, uint64_t zip_len);
+MZHIP_API int64_t mzhip_prime_wait(void);
 /* The same over several devices of the node (the host side of the sharded path in C): the entries are
  * independent (mz_zip.c:1682-1863 builds a fresh codec per entry), so the entry table is cut into ndev contiguous
  * slices balanced by compressed + uncompressed bytes (mzhip_shard_bounds) and ONE HOST THREAD PER SLICE decodes it on

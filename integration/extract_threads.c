@@ -35,13 +35,16 @@ typedef struct {
     const uint8_t *img; /* the archive, mapped read-only and shared by every thread */
     int64_t img_len;
     const int64_t *table; /* 8 x int64 per entry: method, flag, crc, csize, usize, .., cd position, payload offset */
-    int64_t first, count;
+    int64_t n;               /* entries of the archive */
+    volatile int64_t *next;  /* the next entry nobody has taken yet: the threads take blocks of XT_BLOCK from the front, so */
+                             /* that all of them read what the decode pipeline delivered first (progressive prime) */
     int64_t ok, bytes;
     int32_t err;
     double t_goto, t_open, t_read, t_close; /* MZDROP_TRACE: where a thread's time goes */
 } xt_job;
 
 static double xt_now(void);
+#define XT_BLOCK 16
 
 static void *xt_run(void *arg) {
     xt_job *j = (xt_job *)arg;
@@ -64,7 +67,11 @@ static void *xt_run(void *arg) {
     }
     mz_zip_reader_get_zip_handle(reader, &zip);
     const int trace = getenv("MZDROP_TRACE") != NULL;
-    for (int64_t i = j->first; i < j->first + j->count; i++) {
+    for (;;) {
+      const int64_t i0 = __atomic_fetch_add(j->next, XT_BLOCK, __ATOMIC_RELAXED);
+      if (i0 >= j->n) break;
+      const int64_t i1 = i0 + XT_BLOCK < j->n ? i0 + XT_BLOCK : j->n;
+      for (int64_t i = i0; i < i1; i++) {
         double a = trace ? xt_now() : 0.0, b;
         int32_t err = mz_zip_goto_entry(zip, j->table[i * 8 + 6]);
         int64_t total = 0;
@@ -89,6 +96,7 @@ static void *xt_run(void *arg) {
         } else if (j->err == MZ_OK) {
             j->err = err != MZ_OK ? err : MZ_DATA_ERROR;
         }
+      }
     }
     mz_zip_reader_close(reader);
     mz_zip_reader_delete(&reader);
@@ -97,19 +105,51 @@ static void *xt_run(void *arg) {
     return NULL;
 }
 
+typedef struct {
+    void *img;
+    size_t len;
+    int64_t *table;
+} xt_release;
+
+static void *xt_release_run(void *arg) {
+    xt_release *r = (xt_release *)arg;
+    munmap(r->img, r->len);
+    free(r->table);
+    free(r);
+    return NULL;
+}
+
+/* one release may be in flight; the next call (or mzdrop_quiesce) joins it before it starts: two address-space operations
+ * of this size at once just queue up behind the process's mapping lock */
+static pthread_mutex_t xt_rel_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_t xt_rel_thread;
+static int xt_rel_pending;
+
+__attribute__((visibility("default"))) void mzdrop_quiesce(void) {
+    pthread_mutex_lock(&xt_rel_mu);
+    if (xt_rel_pending) {
+        pthread_join(xt_rel_thread, NULL);
+        xt_rel_pending = 0;
+    }
+    pthread_mutex_unlock(&xt_rel_mu);
+}
+
 static double xt_now(void) {
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
-/* Extract (decode + verify, bytes discarded) every entry of `path` with `nthreads` reader threads; prime != 0 runs
- * mzhip_prime_file(path) first.  Returns the seconds of the whole thing (prime + index + threads), or a negative MZ_*
- * code; *entries / *bytes = what was read and verified, *prime_s = the share of mzhip_prime_file, *first_err = the
- * first entry error of any thread. */
+/* Extract (decode + verify, bytes discarded) every entry of `path` with `nthreads` reader threads.  prime: 0 = none (every
+ * entry through the per-entry path), 1 = mzhip_prime_mem() first, readers afterwards, 2 = mzhip_prime_mem_begin(): the
+ * readers start at once and are served as the decode pipeline delivers, front to back.  Returns the seconds of the whole
+ * thing (map + prime + index + threads), or a negative MZ_* code; *entries / *bytes = what was read and verified,
+ * *prime_s = the time the calling thread spent in the prime calls (prime 2: begin + the wait at the end, the decode itself
+ * runs under the readers), *first_err = the first entry error of any thread. */
 __attribute__((visibility("default"))) double mzdrop_extract_all(const char *path, int32_t nthreads, int32_t prime,
                                                                   int64_t *entries, int64_t *bytes, double *prime_s,
                                                                   int32_t *first_err) {
+    mzdrop_quiesce(); /* (the previous call's mapping is gone before this one's clock starts) */
     const double t0 = xt_now();
     double tp = 0.0;
     const int fd = open(path, O_RDONLY);
@@ -124,7 +164,7 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
     if (img == MAP_FAILED) return (double)MZ_MEM_ERROR;
     if (prime) { /* the same mapping feeds the batch decode and, afterwards, every reader thread: the file is read once */
         const double a = xt_now();
-        const int64_t pr = mzhip_prime_mem(img, (uint64_t)sb.st_size);
+        const int64_t pr = prime == 2 ? mzhip_prime_mem_begin(img, (uint64_t)sb.st_size) : mzhip_prime_mem(img, (uint64_t)sb.st_size);
         if (pr < 0) {
             munmap((void *)img, (size_t)sb.st_size);
             return (double)pr;
@@ -135,6 +175,7 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
     int64_t *table = n > 0 ? (int64_t *)malloc((size_t)n * 8 * sizeof(int64_t)) : NULL;
     if (table) n = mzhip_zip_index_mem(img, (uint64_t)sb.st_size, table, n);
     if (n <= 0 || !table || sb.st_size > INT32_MAX) { /* (mz_stream_mem takes a 32-bit length: archives of 2 GiB and more need the file reader) */
+        if (prime == 2) (void)mzhip_prime_wait(); /* (the worker reads the mapping) */
         munmap((void *)img, (size_t)sb.st_size);
         free(table);
         return (double)(n < 0 ? n : MZ_FORMAT_ERROR);
@@ -144,16 +185,14 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
     if (nthreads > n) nthreads = (int32_t)n;
     pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
     xt_job *jobs = (xt_job *)calloc((size_t)nthreads, sizeof(xt_job));
-    const int64_t per = n / nthreads, extra = n % nthreads;
-    int64_t first = 0;
+    volatile int64_t next = 0;
     for (int32_t t = 0; t < nthreads; t++) {
         jobs[t].path = path;
         jobs[t].img = img;
         jobs[t].img_len = (int64_t)sb.st_size;
         jobs[t].table = table;
-        jobs[t].first = first;
-        jobs[t].count = per + (t < extra ? 1 : 0);
-        first += jobs[t].count;
+        jobs[t].n = n;
+        jobs[t].next = &next;
         if (nthreads == 1) xt_run(&jobs[t]);
         else pthread_create(&th[t], NULL, xt_run, &jobs[t]);
     }
@@ -167,18 +206,42 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
         if (err == MZ_OK) err = jobs[t].err;
         tg += jobs[t].t_goto; to += jobs[t].t_open; tr += jobs[t].t_read; tc += jobs[t].t_close;
     }
+    const double t_thr = xt_now();
+    if (prime == 2) { /* every entry has been served, so the pipeline is through; what is left is the STORE index and the join */
+        const int64_t pr = mzhip_prime_wait();
+        tp += xt_now() - t_thr;
+        if (pr < 0 && err == MZ_OK) err = (int32_t)pr;
+    }
     if (getenv("MZDROP_TRACE"))
-        fprintf(stderr, "[mzdrop] prime %.1f ms, map + index %.1f ms, threads %.1f ms\n", tp * 1e3, (t_idx - t0 - tp) * 1e3, (xt_now() - t_idx) * 1e3);
+        fprintf(stderr, "[mzdrop] started %.2f ms, readers started %.2f ms, readers done %.2f ms (CLOCK_MONOTONIC)\n", t0 * 1e3, t_idx * 1e3, t_thr * 1e3);
+    if (getenv("MZDROP_TRACE"))
+        fprintf(stderr, "[mzdrop] prime %.1f ms, map + index %.1f ms, threads %.1f ms\n", tp * 1e3, (t_idx - t0 - tp) * 1e3, (t_thr - t_idx) * 1e3);
     if (getenv("MZDROP_TRACE"))
         fprintf(stderr, "[mzdrop] %d threads: per thread goto %.1f ms, read_open %.1f ms, read %.1f ms, close %.1f ms\n", nthreads,
                 tg / nthreads * 1e3, to / nthreads * 1e3, tr / nthreads * 1e3, tc / nthreads * 1e3);
-    munmap((void *)img, (size_t)sb.st_size);
+    /* every entry is read and verified: what is left is giving memory back.  Unmapping 75 000 populated pages of a 300 MB
+     * archive costs the kernel ~12 ms (profiles/r3/threads_trace.log) -- a detached thread does it, the caller has its answer */
+    xt_release *rel = (xt_release *)malloc(sizeof(xt_release));
+    if (rel) {
+        rel->img = (void *)img;
+        rel->len = (size_t)sb.st_size;
+        rel->table = table;
+    }
+    pthread_mutex_lock(&xt_rel_mu);
+    const int started = rel && !xt_rel_pending && pthread_create(&xt_rel_thread, NULL, xt_release_run, rel) == 0;
+    if (started) xt_rel_pending = 1;
+    pthread_mutex_unlock(&xt_rel_mu);
+    if (!started) {
+        free(rel);
+        munmap((void *)img, (size_t)sb.st_size);
+        free(table);
+    }
     free(th);
     free(jobs);
-    free(table);
     if (entries) *entries = ok;
     if (bytes) *bytes = by;
     if (prime_s) *prime_s = tp;
     if (first_err) *first_err = err;
+    if (getenv("MZDROP_TRACE")) fprintf(stderr, "[mzdrop] returning %.2f ms after the start\n", (xt_now() - t0) * 1e3);
     return xt_now() - t0;
 }

@@ -20,7 +20,7 @@ BATCH_SYMBOLS = [
     "mzhip_crc32_batch", "mzhip_adler32_batch", "mzhip_lzma_batch", "mzhip_xz_batch", "mzhip_deflate_batch",
     "mzhip_sha_batch", "mzhip_inflate_host", "mzhip_inflate_host2", "mzhip_lzma_host", "mzhip_xz_host",
     "mzhip_deflate_host", "mzhip_deflate_host2", "mzhip_crc32_host", "mzhip_inflate_launch_geometry",
-    "mzhip_zip_index_mem", "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_clear", "mzhip_prime_stats",
+    "mzhip_zip_index_mem", "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_mem_begin", "mzhip_prime_wait", "mzhip_device_local_cpus", "mzhip_bind_thread_near_device", "mzhip_prime_clear", "mzhip_prime_stats",
     "mzhip_prime_write", "mzhip_prime_write_clear", "mzhip_prime_write_stats", "mzhip_prime_file_multi",
     "mzhip_prime_mem_multi", "mzhip_shard_bounds", "mzhip_deflate_batch_level", "mzhip_deflate_host_level",
     "mzhip_lzma_encode_batch", "mzhip_lzma_encode_batch_preset", "mzhip_lzma_encode_host_preset", "mzhip_xz_encode_host_preset",

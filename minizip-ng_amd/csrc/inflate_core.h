@@ -115,7 +115,8 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #ifndef MZ_REC_CAP2
 #define MZ_REC_CAP2 160u    /* ... and while chasing into the next one(s) (a multiple of 4): 0.04 % of the chases on text are longer than 128 */
 #endif
-#define MZ_REC_BYTES ((MZ_REC_CAP1 + MZ_REC_CAP2) / 2u * 1024u + 64u * MZ_REC_CAP1 + 1024u) /* HBM scratch per wave: records + a byte per own step */
+#define MZ_REC_AREA(cap_) ((((cap_) / 2u + 3u) / 4u) * 4096u) /* pairs in chunks of four (inflate_chase.inc MZ_REC_ADDR) */
+#define MZ_REC_BYTES (MZ_REC_AREA(MZ_REC_CAP1) + MZ_REC_AREA(MZ_REC_CAP2) + 64u * MZ_REC_CAP1 + 1024u) /* HBM scratch per wave: records + a byte per own step */
 #define MZ_CRING_DW 12u
 #define MZ_CRING_RS 15u /* row stride: 12 + 2 mirrored, odd */
 #ifndef MZ_EMIT_GROUP

@@ -14,12 +14,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
+#include <sched.h>
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -674,6 +677,61 @@ int32_t mzhip_device_count(void) {
         return -1;
     }
     return n;
+}
+
+/* The CPUs next to a device (the NUMA node its PCIe root hangs off), from sysfs: page-locked memory that the device
+ * copies from and to, and the host threads that read it, belong there -- on a two-socket box the far socket costs a
+ * third of the link rate and half of the readers' memcpy rate (profiles/r3/threads_numa.log). */
+int32_t mzhip_device_local_cpus(int32_t device, char *cpulist, int32_t cap) {
+    if (!cpulist || cap < 2) return -102;
+    cpulist[0] = 0;
+    char bdf[64] = "";
+    HIP_TRY(hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device));
+    for (char *p = bdf; *p; p++)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    int node = -1;
+    if (f) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return 0; /* one node, or the platform does not say */
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    f = fopen(path, "r");
+    if (!f) return 0;
+    if (!fgets(cpulist, cap, f)) cpulist[0] = 0;
+    fclose(f);
+    size_t n = strlen(cpulist);
+    while (n && (cpulist[n - 1] == '\n' || cpulist[n - 1] == ' ')) cpulist[--n] = 0;
+    return (int32_t)n;
+}
+
+int32_t mzhip_bind_thread_near_device(int32_t device, int32_t max_cpus) {
+    char list[1024];
+    const int32_t n = mzhip_device_local_cpus(device, list, (int32_t)sizeof(list));
+    if (n <= 0) return n;
+    cpu_set_t have, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return 0;
+    int taken = 0;
+    for (const char *p = list; *p;) { /* "64-127,192-255": the cores first, their second hardware threads behind them */
+        char *e = nullptr;
+        long a = strtol(p, &e, 10), b = a;
+        if (e == p) break;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (CPU_ISSET((int)c, &have) && (max_cpus <= 0 || taken < max_cpus)) {
+                CPU_SET((int)c, &want);
+                taken++;
+            }
+        p = (*e == ',') ? e + 1 : e;
+        if (*e != ',' ) break;
+    }
+    if (!taken) return 0; /* the thread may not run on any of them: left where it is */
+    if (sched_setaffinity(0, sizeof(want), &want) != 0) return 0;
+    return taken;
 }
 
 int32_t mzhip_init(int32_t device) {
@@ -1611,7 +1669,15 @@ struct PinnedPool {
         }
         void *p = nullptr;
         const size_t want = (need + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        /* the pages are placed where the thread that pins them runs: for the length of this call that is next to the
+         * current device (the copy engines read and write this block; mzhip_bind_thread_near_device) */
+        cpu_set_t was;
+        int dev = 0;
+        const bool moved = sched_getaffinity(0, sizeof(was), &was) == 0 && hipGetDevice(&dev) == hipSuccess &&
+                           mzhip_bind_thread_near_device(dev, 0) > 0;
+        const hipError_t he = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (moved) (void)sched_setaffinity(0, sizeof(was), &was);
+        if (he != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
@@ -1688,6 +1754,14 @@ struct PrimeGen {
     uint8_t *store = nullptr;
     bool store_pinned = false;
     uint64_t store_entries = 0;
+    // A generation is published BEFORE its entries are decoded (a reader thread that asks for an entry whose chunk of
+    // the decode pipeline has not landed yet waits for exactly that chunk, not for the whole archive): state[i] says
+    // whether entries[i] may be served.  Entries are immutable but for `crc`, which is written before state turns 1;
+    // the STORE index is built last and looked at only once store_ready is set.
+    std::unique_ptr<std::atomic<uint8_t>[]> state; // 0 pending, 1 servable, 2 not served (did not decode to its declared sizes)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> store_ready{false};
     ~PrimeGen() {
         if (out_pinned) g_pinned.put(out, out_cap);
         else free(out);
@@ -1697,10 +1771,13 @@ struct PrimeGen {
 };
 struct PrimeCache {
     std::vector<std::shared_ptr<PrimeGen>> gens; // newest first, at most kMaxGens
-    uint64_t hits = 0, misses = 0;
 };
 PrimeCache g_prime;
-std::mutex g_prime_mu;
+// readers (one lookup per entry that is opened, from as many host threads as the application has) share the lock;
+// publishing, replacing and clearing a generation take it exclusively
+std::shared_mutex g_prime_mu;
+std::atomic<uint64_t> g_prime_hits{0}, g_prime_misses{0};
+std::atomic<uint64_t> g_prime_wait_ns{0}, g_prime_wait_n{0}; // MZHIP_PRIME_TRACE: lookups that had to wait for their chunk
 std::atomic<int> g_any_gens{0};   // generations present at all: the streams' "is there anything to look up" (mzhip_prime_any)
 std::atomic<int> g_store_gens{0}; // generations that hold STORE chunks: the CRC symbol's fast "nothing to look up"
 constexpr uint32_t kSeg = 65535u;
@@ -1719,7 +1796,7 @@ uint64_t store_key(const uint8_t *p, uint32_t n) {
 }
 void count_store_gens_locked() {
     int k = 0;
-    for (const auto &g : g_prime.gens) k += g->store_segs.empty() ? 0 : 1;
+    for (const auto &g : g_prime.gens) k += (g->store_ready.load() && !g->store_segs.empty()) ? 1 : 0;
     g_store_gens.store(k);
     g_any_gens.store((int)g_prime.gens.size());
 }
@@ -1728,8 +1805,11 @@ void count_store_gens_locked() {
 extern "C" {
 
 void mzhip_prime_clear(void) {
-    std::lock_guard<std::mutex> lk(g_prime_mu);
+    (void)mzhip_prime_wait(); /* a prime that is still running reads the caller's image: it is finished, then dropped */
+    std::unique_lock<std::shared_mutex> lk(g_prime_mu);
     g_prime = PrimeCache(); // generations pinned by open streams live until those streams let go
+    g_prime_hits.store(0);
+    g_prime_misses.store(0);
     g_store_gens.store(0);
     g_any_gens.store(0);
 }
@@ -1779,29 +1859,37 @@ int32_t prime_lane_reserve(void **p, size_t *cap, size_t need) {
     *cap = want;
     return 0;
 }
-// results of the chunk that ran on lane L: wait for its stream (only this one), scatter the per-entry words
-int32_t prime_lane_collect(PrimeLane &L, uint32_t *r_len, uint32_t *r_used, uint32_t *r_crc, int32_t *r_st,
-                           std::vector<uint32_t> &seg_crc_all) {
+// results of the chunk that ran on lane L: wait for its stream (only this one); the entries that decoded cleanly, to
+// their declared sizes, become servable (everything else goes through the ordinary per-entry path and its exact error
+// behaviour) and the readers that wait for them are woken
+int32_t prime_lane_collect(PrimeLane &L, PrimeGen *gen) {
     if (!L.busy) return 0;
     HIP_TRY(hipStreamSynchronize(L.s));
     const uint32_t k = L.k;
     const uint32_t *h_len = (const uint32_t *)(L.h_meta + L.res_off), *h_used = h_len + k, *h_crc = h_used + k;
     const int32_t *h_st = (const int32_t *)(h_crc + k);
     const uint32_t *h_seg = (const uint32_t *)(h_st + k);
+    if (L.ns) memcpy(gen->seg_crc.data() + L.seg0, h_seg, (size_t)L.ns * 4);
     for (uint32_t i = 0; i < k; i++) {
         const size_t g = L.lo + L.order[i];
-        r_len[g] = h_len[i];
-        r_used[g] = h_used[i];
-        r_crc[g] = h_crc[i];
-        r_st[g] = h_st[i];
+        PrimedEntry &e = gen->entries[g];
+        const bool good = h_st[i] == 0 && h_len[i] == (uint32_t)e.usize && h_used[i] == (uint32_t)e.csize;
+        e.crc = h_crc[i];
+        e.status = good ? 0 : (h_st[i] ? h_st[i] : -3);
+        gen->state[g].store(good ? 1 : 2, std::memory_order_release);
     }
-    if (L.ns) memcpy(seg_crc_all.data() + L.seg0, h_seg, (size_t)L.ns * 4);
+    { std::lock_guard<std::mutex> lk(gen->mu); } /* (a waiter is either before its check or inside wait()) */
+    gen->cv.notify_all();
+    {
+        static const bool each = getenv("MZHIP_PRIME_TRACE") && atoi(getenv("MZHIP_PRIME_TRACE")) >= 2;
+        if (each) fprintf(stderr, "[mzhip prime] entries %zu..%zu servable at %.2f ms\n", L.lo, L.hi, prime_now() * 1e3);
+    }
     L.busy = false;
     return 0;
 }
-int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const std::vector<int64_t> &max_out_all, size_t lo,
-                    size_t hi, uint8_t *h_out, uint32_t *r_len, uint32_t *r_used, uint32_t *r_crc, int32_t *r_st,
-                    std::vector<uint32_t> &seg_crc_all) {
+int32_t prime_slice(const uint8_t *zip, PrimeGen *gen, const std::vector<int64_t> &max_out_all, size_t lo, size_t hi) {
+    std::vector<PrimedEntry> &ents = gen->entries;
+    uint8_t *const h_out = gen->out;
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -1846,7 +1934,7 @@ int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const st
         }
         PrimeLane &L = lanes[turn];
         turn = (turn + 1) % kPrimeLanes;
-        rc = prime_lane_collect(L, r_len, r_used, r_crc, r_st, seg_crc_all); /* the chunk this lane ran three chunks ago */
+        rc = prime_lane_collect(L, gen); /* the chunk this lane ran three chunks ago */
         if (rc) return rc;
         const uint32_t k = (uint32_t)(c1 - c0);
         uint64_t zlo = UINT64_MAX, zhi = 0;
@@ -1939,7 +2027,7 @@ int32_t prime_slice(const uint8_t *zip, std::vector<PrimedEntry> &ents, const st
         c0 = c1;
     }
     for (int i = 0; i < kPrimeLanes; i++) { /* in the order they were started */
-        rc = prime_lane_collect(lanes[(turn + i) % kPrimeLanes], r_len, r_used, r_crc, r_st, seg_crc_all);
+        rc = prime_lane_collect(lanes[(turn + i) % kPrimeLanes], gen);
         if (rc) return rc;
     }
     park.ok = true;
@@ -2025,33 +2113,73 @@ void mzhip_shard_bounds(const int64_t *table, int64_t n, int32_t world, int64_t 
     bounds[world] = n;
 }
 
-int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_t *devices, int32_t ndev) {
-    int cur = 0;
-    HIP_TRY(hipGetDevice(&cur));
+} // extern "C"
+
+namespace {
+// One prime: prepared and published by the calling thread (index, entry table, page-locked output buffer), run either by
+// the same thread (mzhip_prime_mem / _file: returns when every entry is decoded) or by a worker thread
+// (mzhip_prime_mem_begin: returns at once, readers are served chunk by chunk as the pipeline delivers).
+struct PrimeJob {
+    const uint8_t *zip = nullptr;
+    uint64_t zip_len = 0;
+    int cur = 0; // the device of the thread that asked
     std::vector<int32_t> devs;
+    std::shared_ptr<PrimeGen> gen;
+    std::vector<int64_t> max_out, wtab;
+    std::vector<std::pair<int64_t, int64_t>> stores; /* STORE entries: payload offset, size */
+    int64_t result = 0; // entries primed, or the error
+    std::string err;
+    double t_start = 0;
+};
+std::mutex g_worker_mu;
+std::vector<std::pair<std::thread, std::shared_ptr<PrimeJob>>> g_prime_workers;
+
+void prime_unpublish(const std::shared_ptr<PrimeGen> &gen) {
+    std::unique_lock<std::shared_mutex> lk(g_prime_mu);
+    auto &gens = g_prime.gens;
+    for (size_t i = 0; i < gens.size();) {
+        if (gens[i] == gen) gens.erase(gens.begin() + (long)i);
+        else i++;
+    }
+    count_store_gens_locked();
+}
+
+// index the archive, lay out the generation and publish it with every entry pending.  0 = nothing to prime.
+int64_t prime_prepare(const uint8_t *zip, uint64_t zip_len, const int32_t *devices, int32_t ndev, std::shared_ptr<PrimeJob> *out) {
+    auto job = std::make_shared<PrimeJob>();
+    job->zip = zip;
+    job->zip_len = zip_len;
+    job->t_start = prime_now();
+    HIP_TRY(hipGetDevice(&job->cur));
     if (ndev <= 0) {
         const int32_t nd = mzhip_device_count();
         if (nd <= 0) return -104;
-        for (int32_t d = 0; d < nd; d++) devs.push_back(d);
+        for (int32_t d = 0; d < nd; d++) job->devs.push_back(d);
     } else {
-        for (int32_t i = 0; i < ndev; i++) devs.push_back(devices ? devices[i] : i);
+        for (int32_t i = 0; i < ndev; i++) job->devs.push_back(devices ? devices[i] : i);
     }
     int64_t n = mzhip_zip_index_mem(zip, zip_len, nullptr, 0);
     if (n <= 0) return n;
     std::vector<int64_t> table((size_t)n * 8);
     mzhip_zip_index_mem(zip, zip_len, table.data(), n);
-    std::vector<PrimedEntry> ents;
-    std::vector<int64_t> max_out, wtab;
-    uint64_t total_out = 0;
-    int64_t nseg = 0;
-    std::vector<std::pair<int64_t, int64_t>> stores; /* STORE entries: payload offset, size */
+    std::vector<int64_t> rows; /* the entries a codec kernel can take, in the order their payloads lie in the file */
     for (int64_t i = 0; i < n; i++) {
         const int64_t *t = &table[(size_t)i * 8];
         if ((t[1] & 1) || t[7] < 0 || t[3] < 0 || t[4] < 0 || t[3] >= (1ll << 31) || t[4] >= (1ll << 31) ||
             (uint64_t)t[7] > zip_len || (uint64_t)t[3] > zip_len - (uint64_t)t[7])
             continue;
-        if (t[0] == 0 && t[3] == t[4] && t[4] >= (int64_t)MZHIP_CRC_HOST_BELOW) stores.emplace_back(t[7], t[4]);
+        if (t[0] == 0 && t[3] == t[4] && t[4] >= (int64_t)MZHIP_CRC_HOST_BELOW) job->stores.emplace_back(t[7], t[4]);
         if (t[0] != 8 && t[0] != 14 && t[0] != 95) continue;
+        rows.push_back(i);
+    }
+    std::stable_sort(rows.begin(), rows.end(), [&](int64_t a, int64_t b) { return table[(size_t)a * 8 + 7] < table[(size_t)b * 8 + 7]; });
+    auto gen = std::make_shared<PrimeGen>();
+    std::vector<PrimedEntry> &ents = gen->entries;
+    ents.reserve(rows.size());
+    uint64_t total_out = 0;
+    int64_t nseg = 0;
+    for (const int64_t i : rows) {
+        const int64_t *t = &table[(size_t)i * 8];
         PrimedEntry e;
         memset(&e, 0, sizeof(e));
         e.method = (int32_t)t[0];
@@ -2060,100 +2188,145 @@ int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_
         e.usize = t[4];
         e.out_off = (int64_t)total_out;
         e.seg0 = nseg;
+        e.status = -1;
         e.head_len = (int32_t)(t[3] < (int64_t)sizeof(e.head) ? t[3] : (int64_t)sizeof(e.head));
         memcpy(e.head, zip + t[7], (size_t)e.head_len);
         ents.push_back(e);
         /* TOTAL_OUT_MAX as mz_zip.c:1833-1846 sets it: the uncompressed size when the EOS flag is set */
-        max_out.push_back((t[0] != 8 && (t[1] & 2)) ? t[4] : -1);
-        wtab.insert(wtab.end(), t, t + 8);
+        job->max_out.push_back((t[0] != 8 && (t[1] & 2)) ? t[4] : -1);
+        job->wtab.insert(job->wtab.end(), t, t + 8);
         total_out += ((uint64_t)t[4] + 15) & ~15ull;
         nseg += (t[4] + kSeg - 1) / kSeg;
     }
     const size_t k = ents.size();
-    if (k == 0 && stores.empty()) return 0;
+    if (k == 0 && job->stores.empty()) return 0;
     const double t_idx = prime_now();
-    size_t h_cap = 0;
-    uint8_t *h_out = (uint8_t *)g_pinned.get(total_out + 16, &h_cap);
-    bool out_pinned = h_out != nullptr;
-    if (!out_pinned) h_out = (uint8_t *)malloc(total_out + 16);
-    if (!h_out) return -4;
-    const double t_alloc = prime_now();
-    auto drop_out = [&] {
-        if (out_pinned) g_pinned.put(h_out, h_cap);
-        else free(h_out);
-    };
-    std::vector<uint32_t> r_len(k), r_used(k), r_crc(k), seg_crc((size_t)nseg);
-    std::vector<int32_t> r_st(k, -1);
-    const int32_t world = (int32_t)std::min<size_t>(devs.size(), std::max<size_t>(k, 1));
-    std::vector<int64_t> bounds((size_t)world + 1);
-    mzhip_shard_bounds(wtab.data(), (int64_t)k, world, bounds.data());
-    std::vector<int32_t> rcs((size_t)world, 0);
-    std::vector<std::string> errs((size_t)world);
-    auto work = [&](int32_t r) {
-        hipError_t he = hipSetDevice(devs[(size_t)r]);
-        if (he != hipSuccess) {
-            rcs[(size_t)r] = fail("hipSetDevice", he);
-        } else {
-            rcs[(size_t)r] = prime_slice(zip, ents, max_out, (size_t)bounds[(size_t)r], (size_t)bounds[(size_t)r + 1], h_out,
-                                         r_len.data(), r_used.data(), r_crc.data(), r_st.data(), seg_crc);
-        }
-        if (rcs[(size_t)r]) errs[(size_t)r] = g_err;
-    };
-    if (world == 1 && devs[0] == cur) {
-        work(0);
-    } else { /* one host thread per device: the host side of the sharded path is C (SURVEY 8e) */
-        std::vector<std::thread> th;
-        for (int32_t r = 0; r < world; r++) th.emplace_back(work, r);
-        for (auto &t : th) t.join();
-        (void)hipSetDevice(cur);
-    }
-    for (int32_t r = 0; r < world; r++)
-        if (rcs[(size_t)r]) {
-            snprintf(g_err, sizeof(g_err), "%s", errs[(size_t)r].c_str());
-            drop_out();
-            return rcs[(size_t)r];
-        }
-    std::vector<PrimedEntry> good;
-    for (size_t i = 0; i < k; i++) {
-        // only entries that decoded cleanly, to their declared sizes, are served from the cache;
-        // everything else goes through the ordinary per-entry path and its exact error behaviour
-        if (r_st[i] != 0 || r_len[i] != (uint32_t)ents[i].usize || r_used[i] != (uint32_t)ents[i].csize) continue;
-        ents[i].crc = r_crc[i];
-        ents[i].status = 0;
-        good.push_back(ents[i]);
-    }
-    auto gen = std::make_shared<PrimeGen>();
-    gen->entries = std::move(good); // index order == payload order for archives written front to back
-    std::sort(gen->entries.begin(), gen->entries.end(),
-              [](const PrimedEntry &a, const PrimedEntry &b) { return a.payload_off < b.payload_off; });
-    gen->seg_crc = std::move(seg_crc);
-    gen->out = h_out;
-    gen->out_pinned = out_pinned;
-    gen->out_cap = h_cap;
+    gen->out = (uint8_t *)g_pinned.get(total_out + 16, &gen->out_cap);
+    gen->out_pinned = gen->out != nullptr;
+    if (!gen->out_pinned) gen->out = (uint8_t *)malloc(total_out + 16);
+    if (!gen->out) return -4;
     if (prime_trace())
-        fprintf(stderr, "[mzhip prime] %zu entries, %.1f MiB decoded: pinned output %.1f ms, decode pipeline %.1f ms\n", k,
-                (double)total_out / 1048576.0, (t_alloc - t_idx) * 1e3, (prime_now() - t_alloc) * 1e3);
+        fprintf(stderr, "[mzhip prime] %zu entries, %.1f MiB to decode: index %.1f ms, pinned output %.1f ms\n", k,
+                (double)total_out / 1048576.0, (t_idx - job->t_start) * 1e3, (prime_now() - t_idx) * 1e3);
+    gen->seg_crc.assign((size_t)nseg, 0u);
+    gen->state.reset(new std::atomic<uint8_t>[k ? k : 1]);
+    for (size_t i = 0; i < k; i++) gen->state[i].store(0, std::memory_order_relaxed);
     gen->zip_len = zip_len;
     {
         /* identity = length + hash of everything from the first central-directory record to the end of the file */
         const uint64_t cd0 = (uint64_t)table[6];
         gen->ident = fnv1a64(zip + cd0, zip_len - cd0);
     }
-    if (!stores.empty()) {
-        const int32_t src = prime_store(zip, stores, gen.get()); /* on the calling thread's device */
-        if (src) return src;
+    job->gen = gen;
+    {
+        std::unique_lock<std::shared_mutex> lk(g_prime_mu);
+        auto &gens = g_prime.gens;
+        for (size_t i = 0; i < gens.size();) { /* a re-prime of the same archive replaces its generation */
+            if (gens[i]->zip_len == gen->zip_len && gens[i]->ident == gen->ident) gens.erase(gens.begin() + (long)i);
+            else i++;
+        }
+        gens.insert(gens.begin(), gen);
+        if (gens.size() > kMaxGens) gens.resize(kMaxGens);
+        count_store_gens_locked();
     }
-    const int64_t n_good = (int64_t)gen->entries.size() + (int64_t)gen->store_entries;
-    std::lock_guard<std::mutex> lk(g_prime_mu);
-    auto &gens = g_prime.gens;
-    for (size_t i = 0; i < gens.size();) { /* a re-prime of the same archive replaces its generation */
-        if (gens[i]->zip_len == gen->zip_len && gens[i]->ident == gen->ident) gens.erase(gens.begin() + (long)i);
-        else i++;
+    *out = job;
+    return 1;
+}
+
+// decode everything the job laid out; every entry leaves the pending state on every way out
+void prime_run(const std::shared_ptr<PrimeJob> &job) {
+    PrimeGen *gen = job->gen.get();
+    const size_t k = gen->entries.size();
+    struct Settle {
+        PrimeGen *gen;
+        size_t k;
+        ~Settle() {
+            for (size_t i = 0; i < k; i++) {
+                uint8_t z = 0;
+                (void)gen->state[i].compare_exchange_strong(z, 2);
+            }
+            { std::lock_guard<std::mutex> lk(gen->mu); }
+            gen->cv.notify_all();
+        }
+    } settle{gen, k};
+    const double t0 = prime_now();
+    const int32_t world = (int32_t)std::min<size_t>(job->devs.size(), std::max<size_t>(k, 1));
+    std::vector<int64_t> bounds((size_t)world + 1);
+    mzhip_shard_bounds(job->wtab.data(), (int64_t)k, world, bounds.data());
+    std::vector<int32_t> rcs((size_t)world, 0);
+    std::vector<std::string> errs((size_t)world);
+    auto work = [&](int32_t r) {
+        hipError_t he = hipSetDevice(job->devs[(size_t)r]);
+        if (he != hipSuccess) rcs[(size_t)r] = fail("hipSetDevice", he);
+        else rcs[(size_t)r] = prime_slice(job->zip, gen, job->max_out, (size_t)bounds[(size_t)r], (size_t)bounds[(size_t)r + 1]);
+        if (rcs[(size_t)r]) errs[(size_t)r] = g_err;
+    };
+    int now = -1;
+    (void)hipGetDevice(&now);
+    if (world == 1 && job->devs[0] == now) {
+        work(0);
+    } else { /* one host thread per device: the host side of the sharded path is C (SURVEY 8e) */
+        std::vector<std::thread> th;
+        for (int32_t r = 0; r < world; r++) th.emplace_back(work, r);
+        for (auto &t : th) t.join();
+        (void)hipSetDevice(job->cur);
     }
-    gens.insert(gens.begin(), std::move(gen));
-    if (gens.size() > kMaxGens) gens.resize(kMaxGens);
-    count_store_gens_locked();
-    return n_good;
+    for (int32_t r = 0; r < world; r++)
+        if (rcs[(size_t)r]) {
+            job->err = errs[(size_t)r];
+            job->result = rcs[(size_t)r];
+            prime_unpublish(job->gen);
+            return;
+        }
+    if (prime_trace()) fprintf(stderr, "[mzhip prime] decode pipeline %.1f ms\n", (prime_now() - t0) * 1e3);
+    if (!job->stores.empty()) {
+        const int32_t src = prime_store(job->zip, job->stores, gen); /* on this thread's device */
+        if (src) {
+            job->err = g_err;
+            job->result = src;
+            prime_unpublish(job->gen);
+            return;
+        }
+        gen->store_ready.store(true, std::memory_order_release);
+        std::unique_lock<std::shared_mutex> lk(g_prime_mu);
+        count_store_gens_locked();
+    }
+    int64_t good = 0;
+    for (size_t i = 0; i < k; i++) good += gen->state[i].load(std::memory_order_relaxed) == 1 ? 1 : 0;
+    job->result = good + (int64_t)gen->store_entries;
+}
+
+int64_t prime_wait_all() {
+    std::vector<std::pair<std::thread, std::shared_ptr<PrimeJob>>> w;
+    {
+        std::lock_guard<std::mutex> lk(g_worker_mu);
+        w.swap(g_prime_workers);
+    }
+    int64_t total = 0, bad = 0;
+    for (auto &p : w) {
+        if (p.first.joinable()) p.first.join();
+        if (p.second->result < 0) {
+            if (!bad) {
+                bad = p.second->result;
+                snprintf(g_err, sizeof(g_err), "%s", p.second->err.c_str());
+            }
+        } else {
+            total += p.second->result;
+        }
+    }
+    return bad ? bad : total;
+}
+} // namespace
+
+extern "C" {
+
+int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_t *devices, int32_t ndev) {
+    std::shared_ptr<PrimeJob> job;
+    const int64_t rc = prime_prepare(zip, zip_len, devices, ndev, &job);
+    if (rc <= 0) return rc;
+    prime_run(job);
+    if (job->result < 0) snprintf(g_err, sizeof(g_err), "%s", job->err.c_str());
+    return job->result;
 }
 
 int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
@@ -2161,6 +2334,32 @@ int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len) {
     HIP_TRY(hipGetDevice(&cur));
     const int32_t d = (int32_t)cur;
     return mzhip_prime_mem_multi(zip, zip_len, &d, 1);
+}
+
+int64_t mzhip_prime_mem_begin(const uint8_t *zip, uint64_t zip_len) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    const int32_t d = (int32_t)cur;
+    std::shared_ptr<PrimeJob> job;
+    const int64_t rc = prime_prepare(zip, zip_len, &d, 1, &job);
+    if (rc <= 0) return rc;
+    const int64_t n = (int64_t)job->gen->entries.size() + (int64_t)job->stores.size();
+    std::lock_guard<std::mutex> lk(g_worker_mu);
+    g_prime_workers.emplace_back(std::thread([job] {
+                                     (void)hipSetDevice(job->cur);
+                                     (void)mzhip_bind_thread_near_device(job->cur, 0); /* this thread feeds the copy engines: next to the device */
+                                     prime_run(job);
+                                 }),
+                                 job);
+    return n;
+}
+
+int64_t mzhip_prime_wait(void) {
+    const int64_t r = prime_wait_all();
+    if (prime_trace() && g_prime_wait_n.load())
+        fprintf(stderr, "[mzhip prime] %llu lookups waited for their chunk, %.1f ms in all\n", (unsigned long long)g_prime_wait_n.exchange(0),
+                (double)g_prime_wait_ns.exchange(0) * 1e-6);
+    return r;
 }
 
 static int64_t prime_file_on(const char *path, const int32_t *devices, int32_t ndev, int multi) {
@@ -2193,13 +2392,16 @@ int64_t mzhip_prime_file_multi(const char *path, const int32_t *devices, int32_t
 int64_t mzhip_prime_file(const char *path) { return prime_file_on(path, nullptr, 0, 0); }
 
 void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses) {
-    std::lock_guard<std::mutex> lk(g_prime_mu);
+    std::shared_lock<std::shared_mutex> lk(g_prime_mu);
     if (entries) {
         *entries = 0;
-        for (const auto &g : g_prime.gens) *entries += g->entries.size() + g->store_entries;
+        for (const auto &g : g_prime.gens) {
+            for (size_t i = 0; i < g->entries.size(); i++) *entries += g->state[i].load(std::memory_order_relaxed) == 1 ? 1 : 0;
+            *entries += g->store_entries;
+        }
     }
-    if (hits) *hits = g_prime.hits;
-    if (misses) *misses = g_prime.misses;
+    if (hits) *hits = g_prime_hits.load();
+    if (misses) *misses = g_prime_misses.load();
 }
 
 // Used by mz_crypt_crc32_update: are these `size` bytes a chunk of a primed STORE entry?  The fingerprint finds the
@@ -2209,18 +2411,18 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_store_crc(const uint8_
     if (g_store_gens.load(std::memory_order_relaxed) == 0 || size < 32 || (uint32_t)size > kSeg) return 0;
     std::vector<std::shared_ptr<PrimeGen>> gens;
     {
-        std::lock_guard<std::mutex> lk(g_prime_mu);
+        std::shared_lock<std::shared_mutex> lk(g_prime_mu);
         gens = g_prime.gens; /* the generations are immutable once published: search them without the lock */
     }
     const uint64_t key = store_key(buf, (uint32_t)size);
     for (const std::shared_ptr<PrimeGen> &g : gens) {
+        if (!g->store_ready.load(std::memory_order_acquire)) continue; /* (its STORE index is still being built) */
         auto range = g->store_idx.equal_range(key);
         for (auto it = range.first; it != range.second; ++it) {
             const PrimeGen::StoreSeg &sg = g->store_segs[it->second];
             if (sg.len == (uint32_t)size && memcmp(buf, g->store + sg.off, (size_t)size) == 0) {
                 *crc = sg.crc;
-                std::lock_guard<std::mutex> lk(g_prime_mu);
-                g_prime.hits++;
+                g_prime_hits.fetch_add(1, std::memory_order_relaxed);
                 return 1;
             }
         }
@@ -2239,10 +2441,14 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup3(int32_t method
                                                                   int32_t head_len, int64_t max_total_in, const uint8_t **data,
                                                                   int64_t *usize, int64_t *csize, uint32_t *crc,
                                                                   const uint32_t **seg_crc, void **pin) {
-    std::lock_guard<std::mutex> lk(g_prime_mu);
     *pin = nullptr;
-    if (g_prime.gens.empty()) return 0;
-    for (const std::shared_ptr<PrimeGen> &g : g_prime.gens) {
+    std::vector<std::shared_ptr<PrimeGen>> gens;
+    {
+        std::shared_lock<std::shared_mutex> lk(g_prime_mu);
+        if (g_prime.gens.empty()) return 0;
+        gens = g_prime.gens; /* the keys of a published generation never change: search (and wait) without the lock */
+    }
+    for (const std::shared_ptr<PrimeGen> &g : gens) {
         const std::vector<PrimedEntry> &ents = g->entries;
         size_t lo = 0, hi = ents.size();
         while (lo < hi) {
@@ -2255,23 +2461,36 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup3(int32_t method
         const int32_t cmp = head_len < e.head_len ? head_len : e.head_len;
         if (e.method != method || head_len < need || memcmp(head, e.head, (size_t)cmp) != 0) continue;
         if (max_total_in > 0 && max_total_in != e.csize) continue;
-        g_prime.hits++;
+        if (g->state) { /* the entry's chunk of the decode pipeline may still be on its way: wait for that chunk */
+            if (g->state[lo].load(std::memory_order_acquire) == 0) {
+                const double w0 = prime_trace() ? prime_now() : 0.0;
+                {
+                    std::unique_lock<std::mutex> lk(g->mu);
+                    g->cv.wait(lk, [&] { return g->state[lo].load(std::memory_order_acquire) != 0; });
+                }
+                if (prime_trace()) {
+                    g_prime_wait_ns.fetch_add((uint64_t)((prime_now() - w0) * 1e9), std::memory_order_relaxed);
+                    g_prime_wait_n.fetch_add(1, std::memory_order_relaxed);
+                }
+            }
+            if (g->state[lo].load(std::memory_order_acquire) != 1) continue; /* did not decode to its declared sizes: the ordinary path has the verdict */
+        }
         *data = g->out + e.out_off;
         *usize = e.usize;
         *csize = e.csize;
         *crc = e.crc;
         *seg_crc = g->seg_crc.data() + e.seg0;
+        g_prime_hits.fetch_add(1, std::memory_order_relaxed);
         *pin = new std::shared_ptr<PrimeGen>(g);
         return 1;
     }
-    g_prime.misses++;
+    g_prime_misses.fetch_add(1, std::memory_order_relaxed);
     return 0;
 }
 
 __attribute__((visibility("hidden"))) void mzhip_prime_unpin(void *pin) {
     if (!pin) return;
-    std::lock_guard<std::mutex> lk(g_prime_mu); // the last reference may free the generation
-    delete (std::shared_ptr<PrimeGen> *)pin;
+    delete (std::shared_ptr<PrimeGen> *)pin; // (the last reference frees the generation: its buffers go back to pools with locks of their own)
 }
 
 // checksums only: crc(A||B) from crc(A), crc(B), |B| (shared with shim_crc32.c)

@@ -5,12 +5,7 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "nt EXTRA=-DMZ_CHASE_X=32"
-  "nt_f2 FSLOTS=2 EXTRA=-DMZ_CHASE_X=32"
-  "nt_nb NBATCH=1 EXTRA=-DMZ_CHASE_X=32"
-  "nt_s2 SLOTS=2 EXTRA=-DMZ_CHASE_X=32"
-  "nt_f2_nb FSLOTS=2 NBATCH=1 EXTRA=-DMZ_CHASE_X=32"
-  "nt_f2_nb_prof PROF=1 FSLOTS=2 NBATCH=1 EXTRA=-DMZ_CHASE_X=32"
+  "flat EXTRA=-DMZ_REC_CHUNKED=0"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}

@@ -315,4 +315,28 @@ def test_pipelined_prime_many_chunks_and_reader_threads():
             sec = D.mzdrop_extract_all(path.encode(), T, 1, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
             assert sec > 0 and fe.value == 0 and ne.value == n and nb.value == int(lens.sum()), (T, sec, fe.value, ne.value)
             print("%d reader threads: %.3f s (prime %.3f s) = %.2f GiB/s" % (T, sec, tp.value, nb.value / 2**30 / sec))
+        # the progressive prime: mzhip_prime_mem_begin returns at once, the readers run under the decode pipeline and an
+        # entry that is asked for before its chunk has landed is waited for; nothing may miss the cache or differ
+        for T in (1, 4, 16):
+            L.mzhip_prime_clear()
+            ne, nb, tp, fe = C.c_int64(0), C.c_int64(0), C.c_double(0), C.c_int32(0)
+            sec = D.mzdrop_extract_all(path.encode(), T, 2, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
+            assert sec > 0 and fe.value == 0 and ne.value == n and nb.value == int(lens.sum()), (T, sec, fe.value, ne.value)
+            L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+            assert miss.value == 0 and hits.value >= cached - 2, (T, hits.value, miss.value)
+            print("%d reader threads under the prime: %.3f s = %.2f GiB/s" % (T, sec, nb.value / 2**30 / sec))
+        # ... and through the byte-comparing driver: begin over a private copy of the image, read at once, then wait
+        L.mzhip_prime_clear()
+        L.mzhip_prime_mem_begin.restype = C.c_int64
+        L.mzhip_prime_mem_begin.argtypes = [C.c_void_p, C.c_uint64]
+        L.mzhip_prime_wait.restype = C.c_int64
+        img = np.fromfile(path, dtype=np.uint8)
+        o_hip[:] = 0
+        started = L.mzhip_prime_mem_begin(img.ctypes.data, img.size)
+        assert started == n
+        _, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=4, own_crc=False, out=o_hip, out_off=out_off)
+        assert L.mzhip_prime_wait() == cached
+        assert (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all() and (o_hip == o_ref).all()
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        assert miss.value == 0
         L.mzhip_prime_clear()
