@@ -476,7 +476,22 @@ struct DeviceCtx {
     uint32_t next_counter = 0;
     int cu_count = 0;
     int inflate_wgs_per_cu = 1;
+    // the four-candidate classes of K4 / the LZ tokenizer need > 64 KiB of dynamic LDS per workgroup: asked for once per
+    // device; 0 = not asked yet, 1 = granted, -1 = refused (the one-candidate class is used instead)
+    std::atomic<int> big_lds_deflate{0}, big_lds_tok{0};
 };
+
+// may this device run `kernel` with `bytes` of dynamic LDS per workgroup?  (asked once per device and kernel)
+bool big_lds_ok(std::atomic<int> &state, const void *kernel, size_t bytes) {
+    int st = state.load(std::memory_order_acquire);
+    if (st == 0) {
+        const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+        if (!ok) (void)hipGetLastError(); /* (a launch that is refused all the same turns the state to -1, too) */
+        st = ok ? 1 : -1;
+        state.store(st, std::memory_order_release);
+    }
+    return st > 0;
+}
 
 constexpr int kMaxDevices = 16;
 DeviceCtx g_ctx[kMaxDevices];
@@ -1016,13 +1031,13 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
     /* compression classes (mz_strm_zlib.c:87 hands `level` to deflateInit2): 0-3 fast = one candidate per hash bucket,
      * everything else (4-9, and -1 = Z_DEFAULT_COMPRESSION) = MZ_DEF_WAYS_BEST candidates + a two-position lazy rule */
     a.ways = (level >= 0 && level <= 3) ? 1u : MZ_DEF_WAYS_BEST;
+    /* the default class needs 134 KiB of dynamic LDS per workgroup: a device (or runtime) that does not grant it gets the
+     * one-candidate class -- a valid stream with a worse ratio, not a launch error */
+    if (a.ways > 1u && !big_lds_ok(c->big_lds_deflate, (const void *)k_deflate_batch,
+                                   MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + MZ_DEF_XHEAD_BYTES)))
+        a.ways = 1u;
     a.max_dist = (1u << window_log2) - 262u; /* zlib's MAX_DIST(s) = w_size - MIN_LOOKAHEAD */
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
-    static std::once_flag big_lds;
-    std::call_once(big_lds, [] { /* the default class needs 134 KiB of dynamic LDS per workgroup */
-        (void)hipFuncSetAttribute((const void *)k_deflate_batch, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + MZ_DEF_XHEAD_BYTES)));
-    });
     uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
     uint32_t resident = (uint32_t)c->cu_count * (a.ways > 1u ? 1u : 4u); /* 38.3 / 134 KiB LDS per workgroup -> 4 / 1 per CU */
     const uint32_t grid = wgs < resident ? wgs : resident;
@@ -1032,7 +1047,13 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
     if (rc) return rc;
     a.tok = (uint32_t *)scratch;
     hipLaunchKernelGGL(k_deflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
-    const hipError_t le = hipGetLastError();
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess && a.ways > 1u) { /* the device does not take 134 KiB of LDS per workgroup after all */
+        c->big_lds_deflate.store(-1, std::memory_order_release);
+        a.ways = 1u;
+        hipLaunchKernelGGL(k_deflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE, s, a);
+        le = hipGetLastError();
+    }
     rc = scratch_release(c, slot, s);
     if (le != hipSuccess) return fail("k_deflate_batch", le);
     return rc;
@@ -1067,6 +1088,8 @@ int32_t mzhip_lzma_encode_batch_preset(const void *d_in, const uint64_t *d_in_of
     a.n = n;
     a.maxb = max_in_len ? (max_in_len + MZ_DEF_BLOCK - 1) / MZ_DEF_BLOCK : 1u;
     a.ways = (preset >= 0 && preset <= 3) ? 1u : MZ_DEF_WAYS_BEST;
+    if (a.ways > 1u && !big_lds_ok(c->big_lds_tok, (const void *)k_lz_tokenize_batch, MZ_WAVES_PER_WG * (sizeof(mz_lz_tok_lds) + MZ_DEF_XHEAD_BYTES)))
+        a.ways = 1u; /* (128 KiB of dynamic LDS per workgroup not granted: the one-candidate class) */
     a.out_len = d_out_len;
     a.crc = d_crc;
     a.status = d_status;
@@ -1091,10 +1114,14 @@ int32_t mzhip_lzma_encode_batch_preset(const void *d_in, const uint64_t *d_in_of
         uint32_t wgs = (uint32_t)((items + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG);
         const size_t lds = MZ_WAVES_PER_WG * (sizeof(mz_lz_tok_lds) + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
         uint32_t resident = (uint32_t)c->cu_count * (a.ways > 1u ? 1u : 4u); /* 32 KiB (128 KiB) of LDS per workgroup */
-        if (a.ways > 1u)
-            (void)hipFuncSetAttribute((const void *)k_lz_tokenize_batch, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(MZ_WAVES_PER_WG * (sizeof(mz_lz_tok_lds) + MZ_DEF_XHEAD_BYTES)));
         hipLaunchKernelGGL(k_lz_tokenize_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+        if (a.ways > 1u && hipGetLastError() != hipSuccess) { /* 128 KiB of LDS per workgroup refused after all: the one-candidate class */
+            c->big_lds_tok.store(-1, std::memory_order_release);
+            a.ways = 1u;
+            resident = (uint32_t)c->cu_count * 4u;
+            hipLaunchKernelGGL(k_lz_tokenize_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64),
+                               MZ_WAVES_PER_WG * sizeof(mz_lz_tok_lds), s, a);
+        }
     }
     {
         uint32_t resident = (uint32_t)c->cu_count * 9u; /* 17 KiB LDS per single-wave workgroup */
@@ -2448,20 +2475,23 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup3(int32_t method
         if (g_prime.gens.empty()) return 0;
         gens = g_prime.gens; /* the keys of a published generation never change: search (and wait) without the lock */
     }
-    for (const std::shared_ptr<PrimeGen> &g : gens) {
+    /* the entry of generation g that this stream could be, settled (its chunk of the decode pipeline has landed): its
+     * index, or -1.  What a stream can present is where its payload starts, the codec, the compressed size the zip
+     * layer told it and the first bytes it pulled. */
+    auto candidate = [&](const std::shared_ptr<PrimeGen> &g) -> int64_t {
         const std::vector<PrimedEntry> &ents = g->entries;
         size_t lo = 0, hi = ents.size();
         while (lo < hi) {
             size_t mid = (lo + hi) / 2;
             if (ents[mid].payload_off < payload_off) lo = mid + 1; else hi = mid;
         }
-        if (lo == ents.size() || ents[lo].payload_off != payload_off) continue;
+        if (lo == ents.size() || ents[lo].payload_off != payload_off) return -1;
         const PrimedEntry &e = ents[lo];
         const int32_t need = e.head_len < 16 ? e.head_len : 16;
         const int32_t cmp = head_len < e.head_len ? head_len : e.head_len;
-        if (e.method != method || head_len < need || memcmp(head, e.head, (size_t)cmp) != 0) continue;
-        if (max_total_in > 0 && max_total_in != e.csize) continue;
-        if (g->state) { /* the entry's chunk of the decode pipeline may still be on its way: wait for that chunk */
+        if (e.method != method || head_len < need || memcmp(head, e.head, (size_t)cmp) != 0) return -1;
+        if (max_total_in > 0 && max_total_in != e.csize) return -1;
+        if (g->state) { /* the entry's chunk may still be on its way: wait for that chunk */
             if (g->state[lo].load(std::memory_order_acquire) == 0) {
                 const double w0 = prime_trace() ? prime_now() : 0.0;
                 {
@@ -2473,8 +2503,26 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup3(int32_t method
                     g_prime_wait_n.fetch_add(1, std::memory_order_relaxed);
                 }
             }
-            if (g->state[lo].load(std::memory_order_acquire) != 1) continue; /* did not decode to its declared sizes: the ordinary path has the verdict */
+            if (g->state[lo].load(std::memory_order_acquire) != 1) return -1; /* did not decode to its declared sizes: the ordinary path has the verdict */
         }
+        return (int64_t)lo;
+    };
+    for (size_t gi = 0; gi < gens.size(); gi++) {
+        const std::shared_ptr<PrimeGen> &g = gens[gi];
+        const int64_t at = candidate(g);
+        if (at < 0) continue;
+        const PrimedEntry &e = g->entries[(size_t)at];
+        /* Several archives may be primed at once (two versions of one file ...), and entries of two of them can agree in
+         * everything a stream presents while their payloads differ past the 256th byte.  Then nobody can say whose
+         * stream this is: it is not served (the ordinary per-entry path decodes what the stream really holds). */
+        bool ambiguous = false;
+        for (size_t gj = gi + 1; gj < gens.size() && !ambiguous; gj++) {
+            const int64_t o = candidate(gens[gj]);
+            if (o < 0) continue;
+            const PrimedEntry &f = gens[gj]->entries[(size_t)o];
+            ambiguous = f.crc != e.crc || f.usize != e.usize;
+        }
+        if (ambiguous) break;
         *data = g->out + e.out_off;
         *usize = e.usize;
         *csize = e.csize;

@@ -340,3 +340,52 @@ def test_pipelined_prime_many_chunks_and_reader_threads():
         L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
         assert miss.value == 0
         L.mzhip_prime_clear()
+
+
+def test_two_primed_archives_that_agree_in_what_a_stream_presents():
+    """a stream identifies itself by payload offset, codec, compressed size and its first 256 bytes.  Two
+    archives primed at the same time (two versions of one file) whose entries differ only further in must not be served
+    each other's bytes: the ambiguous entry goes through the ordinary path, every other entry stays served."""
+    import struct
+    import sys
+    import zlib
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    sys.path.insert(0, ROOT)
+    import bench
+    hip = oracle.MzDriver(DROP)
+    L = mz.lib()
+    L.mzhip_prime_file.restype = C.c_int64
+    L.mzhip_prime_file.argtypes = [C.c_char_p]
+    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    rnd = np.random.RandomState(5)
+    size = 20000
+
+    def stored(d):  # a raw DEFLATE stream of one stored block: the payload is the data behind 5 bytes of header
+        return struct.pack("<BHH", 1, len(d), len(d) ^ 0xFFFF) + d
+
+    datas = [rnd.randint(0, 256, size=size, dtype=np.uint8).tobytes() for _ in range(6)]
+    other = list(datas)
+    b = bytearray(datas[3])
+    b[9000] ^= 0x55                      # differs past the 256th payload byte, same sizes everywhere
+    other[3] = bytes(b)
+    with tempfile.TemporaryDirectory() as tmp:
+        pa, pb = os.path.join(tmp, "a.zip"), os.path.join(tmp, "b.zip")
+        for path, ds in ((pa, datas), (pb, other)):
+            bench.write_stream_zip(path, [stored(d) for d in ds], [zlib.crc32(d) for d in ds], size, 8)
+        L.mzhip_prime_clear()
+        assert L.mzhip_prime_file(pa.encode()) == 6
+        assert L.mzhip_prime_file(pb.encode()) == 6   # the central directories differ (one CRC): a second generation
+        for path, ds in ((pa, datas), (pb, other)):
+            table = oracle.ref().zip_index(path)
+            out = np.zeros(6 * size + 1, dtype=np.uint8)
+            out_off = np.arange(6, dtype=np.int64) * size
+            _, crc, ulen, st = hip.zip_read_all(path, table[:, 6].copy(), nthreads=1, own_crc=False, out=out, out_off=out_off)
+            assert (st == 0).all(), st          # MZ_CRC_ERROR (-105) here = served the other archive's bytes
+            assert out[:6 * size].tobytes() == b"".join(ds)
+        ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        assert hits.value == 10 and miss.value == 2   # the ambiguous entry of either archive took the ordinary path
+        L.mzhip_prime_clear()
