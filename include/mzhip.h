@@ -168,9 +168,11 @@ MZHIP_API int32_t mzhip_deflate_batch(const void *d_in, const uint64_t *d_in_off
                                       const uint8_t *d_final, uint32_t n, uint32_t *d_out_len, uint32_t *d_crc,
                                       int32_t *d_status, void *stream);
 /* the same with the compression level the stream was given (mz_stream_zlib_set_prop_int64 COMPRESS_LEVEL ->
- * deflateInit2(level, ...), mz_strm_zlib.c:87,339-343).  Two classes: 0..3 = fast (one candidate per hash bucket: the
- * ratio of zlib levels 1-2), anything else (4..9 and -1 = default) = four candidates per bucket and a two-position lazy
- * rule (between zlib levels 3 and 6; 3-4x the work).  window_log2 = 9..15: matches reach at most 2^window_log2 - 262
+ * deflateInit2(level, ...), mz_strm_zlib.c:87,339-343).  Three classes: 0..3 = fast (one candidate per hash bucket: the
+ * ratio of zlib levels 1-2); 4..6 and -1 (the default) = four candidates per bucket, matches handed on to the next
+ * positions, and a two-position lazy rule (between zlib levels 3 and 6; 3-4x the work); 7..9 = the same candidates and a
+ * cost parse over every 64 KiB block (a backward dynamic programme priced with the block's own code lengths: within 3 %
+ * of zlib-9's output, 3x the time of level 6 -- as in zlib, the top levels pay for ratio).  window_log2 = 9..15: matches reach at most 2^window_log2 - 262
  * bytes back (zlib's MAX_DIST), so an inflater with that window decodes the stream.  mzhip_deflate_batch == level 1, 15. */
 MZHIP_API int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,

@@ -317,11 +317,18 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
 /* ways / xhead: the match finder keeps the `ways` most recent positions of every hash bucket (1 = the fast class: zlib
  * levels 1-3; MZ_DEF_WAYS_BEST = the default class: levels 4-9 and -1, mz_strm_zlib.c:87,339-343).  Way 0 is L->u.head;
  * ways 1.. are xhead[(w - 1) << MZ_DEF_HBITS | hash], extra LDS behind the wave's mz_deflate_lds (may be NULL for 1).
- * max_dist: the largest distance a match may use = window - 262 (zlib's MAX_DIST; 32 506 for the 32 KiB window). */
+ * max_dist: the largest distance a match may use = window - 262 (zlib's MAX_DIST; 32 506 for the 32 KiB window).
+ * parse (needs ways > 1): 0 = the lazy rule decides inside every step of 64 positions (levels 4-6 and the default);
+ * 1 = COST PARSE (levels 7-9): pass 1 only records every position's best match and counts the lazy choice; the code lengths of that
+ * count are the price list of a backward dynamic programme over the block -- the cheapest way from every position to
+ * the block's end, a match free to end early (any length from 4 up to the one found is a valid match at the same
+ * distance) -- whose choices are then picked up front to back and counted again for the real codes.  What zlib's lazy
+ * matching cannot do (shorten a match so that a better one can start, price a far distance against three literals)
+ * is worth 3.3 % of the output on the bench corpus with the same match finder (tests/study/enc_parse.c). */
 #define MZ_DEF_WAYS_BEST 4u
 MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
                              uint32_t *tok, mz_deflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                             uint32_t ways, uint16_t *xhead, uint32_t max_dist, mz_deflate_result *res) {
+                             uint32_t ways, uint16_t *xhead, uint32_t max_dist, uint32_t parse, mz_deflate_result *res) {
     MZ_LANE_DECL
     int32_t status = MZHIP_OK;
     uint32_t obyte = 0; /* whole bytes already written to out */
@@ -455,6 +462,25 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 P(pk) = mlen | ((mlen ? dist : 0u) << 9);
                 P(lit) = (P(hh) != 0xFFFFFFFFu) ? (P(own) & 0xFFu) : (uint32_t)in[pos < blk_end ? pos : blk];
             }
+            if (ways > 1u) {
+                /* a match of length L at position q is a match of length L - k at q + k, same distance: a position whose own
+                 * bucket had lost that candidate inherits it from the lanes 1 and 2 (then up to 3) below -- worth 1.2 % of
+                 * the output under the lazy rule (tests/study/enc_parse.c INH=3) */
+                for (uint32_t sh = 1u; sh <= 2u; sh <<= 1) {
+                    PV(uint32_t, pin);
+                    MZ_GATHER4(pin, pk, 4u * (((uint32_t)lane - sh) & 63u));
+                    MZ_LANES {
+                        const uint32_t il = P(pin) & 511u;
+                        if ((uint32_t)lane >= sh && (uint32_t)lane < nv && il >= MZ_DEF_MINMATCH + sh && il - sh > (P(pk) & 511u))
+                            P(pk) = (il - sh) | (P(pin) & ~511u);
+                    }
+                }
+            }
+            if (parse) {
+                MZ_LANES {
+                    if ((uint32_t)lane < nv) tok[(p - blk) + (uint32_t)lane] = P(pk); /* the cost parse looks at every position's match */
+                }
+            }
             MZ_DPROF_MARK(18); /* match measurement */
             /* lazy evaluation (what zlib does from level 4 up): a match yields to a longer one starting at the
              * next position -- this position then goes out as a literal */
@@ -471,65 +497,148 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                 const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
                 P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);
             }
-            /* greedy selection: lane r <- r-th element of the chain start, f(start), f(f(start)), ... */
-            PV(uint32_t, g2);
-            PV(uint32_t, g4);
-            PV(uint32_t, g8);
-            PV(uint32_t, g16);
-            PV(uint32_t, g32);
-            PV(uint32_t, gt);
-            PV(uint32_t, ct);
-            PV(uint32_t, cpos);
-            MZ_LANES { P(cpos) = (skip >= nv) ? (0x1000u | (4u * skip)) : (4u * skip); }
-#define MZ_DEF_ROUND(gin, gout, bit)                                                         \
-    MZ_GATHER4(gt, gin, P(gin));                                                             \
-    MZ_GATHER4(ct, gin, P(cpos));                                                            \
-    MZ_LANES {                                                                               \
-        P(gout) = (P(gin) & 0x1000u) ? P(gin) : P(gt);                                       \
-        P(cpos) = (((uint32_t)lane & (bit)) && !(P(cpos) & 0x1000u)) ? P(ct) : P(cpos);      \
-    }
-            MZ_DEF_ROUND(g1, g2, 1u)
-            MZ_DEF_ROUND(g2, g4, 2u)
-            MZ_DEF_ROUND(g4, g8, 4u)
-            MZ_DEF_ROUND(g8, g16, 8u)
-            MZ_DEF_ROUND(g16, g32, 16u)
-            MZ_GATHER4(ct, g32, P(cpos));
-            MZ_LANES { P(cpos) = (((uint32_t)lane & 32u) && !(P(cpos) & 0x1000u)) ? P(ct) : P(cpos); }
-#undef MZ_DEF_ROUND
-            uint64_t live;
-            MZ_BALLOT(live, !(P(cpos) & 0x1000u));
-            MZ_DPROF_MARK(19); /* lazy rule + greedy selection */
-            const uint32_t ntok = mz_popc64(live); /* tokens sit in lanes 0..ntok-1 */
-            PV(uint32_t, tpk);
-            MZ_GATHER4(tpk, pk, P(cpos));
-            if (ntok) { /* where the chain left this step: position of the last token + its length */
-                const uint32_t lastpos = MZ_READLANE(cpos, ntok - 1u) >> 2;
-                const uint32_t lastpk = MZ_READLANE(tpk, ntok - 1u);
-                const uint32_t nx = lastpos + ((lastpk & 511u) ? (lastpk & 511u) : 1u);
-                skip = nx > 64u ? nx - 64u : 0u;
-            } else {
-                skip = skip > 64u ? skip - 64u : 0u;
-            }
-            MZ_LANES {
-                if ((uint32_t)lane < ntok) {
-                    const uint32_t t = P(tpk), mlen = t & 511u;
-                    tok[ntokens + (uint32_t)lane] = t;
-                    if (mlen == 0u) {
-                        MZ_LDS_ATOMIC_INC(&L->freq[t >> 9]);
-                    } else {
-                        uint32_t ex, xv, dx;
-                        MZ_LDS_ATOMIC_INC(&L->freq[mz_len_sym(mlen, &ex, &xv)]);
-                        MZ_LDS_ATOMIC_INC(&L->freq[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &dx, &xv)]);
-                        P(xbits) += ex + dx;
-                    }
-                }
-            }
-            ntokens += ntok;
+#define MZ_DEF_STORE_TOKENS (!parse)
+#include "deflate_select.inc"
+#undef MZ_DEF_STORE_TOKENS
             MZ_DPROF_MARK(20); /* tokens out, histograms */
             MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, (p + nv), crc_tab, tabs->kx);
             MZ_DPROF_MARK(21); /* CRC of the input */
         }
 #undef MZ_DEF_LOOKUP
+        if (parse && blk_end > blk) {
+            /* ================= cost parse (see the comment above mz_deflate_piece) ================= */
+            const uint32_t n = blk_end - blk;
+            MZ_LANES { L->freq[256] = 1u; }
+            MZ_WAVE_SYNC();
+            mz_huff_build(L, 0u, MZ_DEF_NLIT, 15u);
+            mz_huff_build(L, MZ_DEF_DIST0, MZ_DEF_NDIST, 15u);
+            /* the hash ways are dead: a ring of the cheapest cost from the next 512 positions to the block's end, and the
+             * price of every match length (symbol + extra bits); a symbol the lazy parse never used costs a default */
+            MZ_DPROF_MARK(24); /* cost parse: the price list (two code constructions) */
+            uint32_t *const cst = (uint32_t *)xhead;
+            uint8_t *const lcost = (uint8_t *)(cst + 512);
+            const uint8_t *const lens = L->u.hb.lens;
+            MZ_LANES {
+                for (uint32_t l = 3u + (uint32_t)lane; l <= MZ_DEF_MAXMATCH; l += 64u) {
+                    uint32_t ex, xv;
+                    const uint32_t c = lens[mz_len_sym(l, &ex, &xv)];
+                    lcost[l] = (uint8_t)((c ? c : 13u) + ex);
+                }
+                if (lane < 8) cst[(n + (uint32_t)lane) & 511u] = 0u;
+            }
+            MZ_WAVE_SYNC();
+            uint32_t cnext = 0; /* (the cost from the block's end) */
+            PV(uint32_t, lcf);  /* the price of this lane's first length to try, 4 + lane % 16 */
+            MZ_LANES { P(lcf) = lcost[4u + ((uint32_t)lane & 15u)]; }
+            for (int32_t R = (int32_t)(((n - 1u) >> 6) << 6); R >= 0; R -= 64) {
+                PV(uint32_t, pkb); /* this lane's position: its match, */
+                PV(uint32_t, lcb); /* the price of its literal, */
+                PV(uint32_t, dcb); /* of its distance, */
+                PV(uint32_t, chb); /* and what the programme chooses for it (0 = the literal) */
+                MZ_LANES {
+                    const uint32_t r = (uint32_t)R + (uint32_t)lane;
+                    uint32_t t = 0, lc = 0, dc = 0;
+                    if (r < n) {
+                        t = tok[r];
+                        const uint32_t c = lens[in[blk + r]];
+                        lc = c ? c : 13u;
+                        if (t & 511u) {
+                            uint32_t ex, xv;
+                            const uint32_t cd = lens[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &ex, &xv)];
+                            dc = (cd ? cd : 10u) + ex;
+                        }
+                    }
+                    P(pkb) = t;
+                    P(lcb) = lc;
+                    P(dcb) = dc;
+                    P(chb) = 0u;
+                }
+                uint64_t hasm;
+                MZ_BALLOT(hasm, (P(pkb) & 511u) != 0u);
+                MZ_DPROF_MARK(27); /* cost parse: a block of 64 positions fetched */
+                /* four positions at a time, last first: a match is at least 4 long, so what the four may jump to is
+                 * settled; 16 lanes try the lengths of one position each (lengths 4 .. 19 in one go: the ring is read
+                 * while the position's match is still on its way across the lanes), the literal steps are four scalar
+                 * additions.  cnext = the cost from the position behind the group: the previous group's first result. */
+                for (int32_t gl = 15; gl >= 0; gl--) {
+                    const uint32_t r0 = (uint32_t)R + 4u * (uint32_t)gl;
+                    if (r0 >= n) continue;
+                    const uint32_t l0 = MZ_READLANE(lcb, 4 * gl), l1 = MZ_READLANE(lcb, 4 * gl + 1), l2 = MZ_READLANE(lcb, 4 * gl + 2),
+                                   l3 = MZ_READLANE(lcb, 4 * gl + 3);
+                    uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu, m3 = 0xFFFFFFFFu;
+                    if ((hasm >> (4 * gl)) & 15ull) {
+                        PV(uint32_t, gp);
+                        PV(uint32_t, gd);
+                        PV(uint32_t, best);
+                        MZ_GATHER4(gp, pkb, 4u * (4u * (uint32_t)gl + ((uint32_t)lane >> 4)));
+                        MZ_GATHER4(gd, dcb, 4u * (4u * (uint32_t)gl + ((uint32_t)lane >> 4)));
+                        MZ_LANES {
+                            const uint32_t r = r0 + ((uint32_t)lane >> 4);
+                            uint32_t l = 4u + ((uint32_t)lane & 15u);
+                            const uint32_t cf = cst[(r + l) & 511u]; /* (does not wait for gp / gd) */
+                            const uint32_t mlen = P(gp) & 511u;
+                            uint32_t b = (l <= mlen) ? (((P(lcf) + P(gd) + cf) << 9) | l) : 0xFFFFFFFFu;
+                            for (l += 16u; l <= mlen; l += 16u) {
+                                const uint32_t v = (((uint32_t)lcost[l] + P(gd) + cst[(r + l) & 511u]) << 9) | l;
+                                b = v < b ? v : b;
+                            }
+                            P(best) = b;
+                        }
+                        MZ_ROW16_PMIN(best, best);
+                        m0 = MZ_READLANE(best, 15);
+                        m1 = MZ_READLANE(best, 31);
+                        m2 = MZ_READLANE(best, 47);
+                        m3 = MZ_READLANE(best, 63);
+                    }
+                    /* a tie goes to the match: fewer tokens */
+                    const uint32_t t3 = cnext + l3, k3 = (m3 >> 9) <= t3 ? 1u : 0u, c3 = k3 ? (m3 >> 9) : t3;
+                    const uint32_t t2 = c3 + l2, k2 = (m2 >> 9) <= t2 ? 1u : 0u, c2 = k2 ? (m2 >> 9) : t2;
+                    const uint32_t t1 = c2 + l1, k1 = (m1 >> 9) <= t1 ? 1u : 0u, c1 = k1 ? (m1 >> 9) : t1;
+                    const uint32_t t0 = c1 + l0, k0 = (m0 >> 9) <= t0 ? 1u : 0u, c0 = k0 ? (m0 >> 9) : t0;
+                    cnext = c0;
+                    MZ_LANES {
+                        if (lane < 4) cst[(r0 + (uint32_t)lane) & 511u] = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
+                        if (lane == 4 * gl) P(chb) = k0 ? (m0 & 511u) : 0u;
+                        if (lane == 4 * gl + 1) P(chb) = k1 ? (m1 & 511u) : 0u;
+                        if (lane == 4 * gl + 2) P(chb) = k2 ? (m2 & 511u) : 0u;
+                        if (lane == 4 * gl + 3) P(chb) = k3 ? (m3 & 511u) : 0u;
+                    }
+                    MZ_WAVE_SYNC();
+                }
+                MZ_LANES {
+                    const uint32_t r = (uint32_t)R + (uint32_t)lane;
+                    if (r < n) tok[r] = P(chb) ? (P(chb) | (P(pkb) & ~511u)) : 0u;
+                }
+                MZ_DPROF_MARK(25); /* cost parse: the dynamic programme */
+            }
+            /* the choices, front to back: the same selection as in pass 1, this time the tokens are kept (token i never
+             * lands behind position i, so the list grows over the per-position words it has already read) */
+            MZ_LANES {
+                for (uint32_t i = (uint32_t)lane; i < MZ_DEF_NLIT + MZ_DEF_NDIST; i += 64u) L->freq[i] = 0u;
+                P(xbits) = 0u;
+            }
+            MZ_WAVE_SYNC();
+            ntokens = 0;
+            skip = 0;
+            for (uint32_t p = blk; p < blk_end; p += 64u) {
+                const uint32_t nv = (blk_end - p < 64u) ? (blk_end - p) : 64u;
+                PV(uint32_t, pk);
+                PV(uint32_t, g1);
+                MZ_LANES {
+                    uint32_t t = 0;
+                    if ((uint32_t)lane < nv) t = tok[(p - blk) + (uint32_t)lane];
+                    const uint32_t mlen = t & 511u;
+                    P(pk) = mlen ? t : ((uint32_t)in[(uint32_t)lane < nv ? p + (uint32_t)lane : blk] << 9);
+                    const uint32_t nx = (uint32_t)lane + (mlen ? mlen : 1u);
+                    P(g1) = ((uint32_t)lane >= nv || nx >= nv) ? (0x1000u | (4u * nx)) : (4u * nx);
+                }
+                MZ_WAVE_SYNC();
+#define MZ_DEF_STORE_TOKENS 1
+#include "deflate_select.inc"
+#undef MZ_DEF_STORE_TOKENS
+                MZ_DPROF_MARK(26); /* cost parse: the choices picked up (the selection of this pass is counted there, not under 19 / 20) */
+            }
+        }
         MZ_LANES { L->freq[256] = 1u; } /* end of block */
         MZ_WAVE_SYNC();
         uint32_t extra_total;

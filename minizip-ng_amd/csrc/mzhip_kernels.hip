@@ -346,6 +346,7 @@ struct DeflateArgs {
     const mzhip_crc_tables *tabs;
     uint32_t *tok; // token scratch: MZ_DEF_BLOCK words per resident wave
     uint32_t ways; // hash-bucket depth of the match finder: 1 (levels 1-3) or MZ_DEF_WAYS_BEST (levels 4-9, -1)
+    uint32_t parse; // 1: cost parse over every block (levels 7-9), 0: the lazy rule per step (levels 4-6 and -1; always with ways == 1)
     uint32_t max_dist; // largest match distance: window - 262
 };
 
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateA
         mz_deflate_result r;
         mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
                          a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs,
-                         MZ_UNIFORM(a.ways), xhead, MZ_UNIFORM(a.max_dist), &r);
+                         MZ_UNIFORM(a.ways), xhead, MZ_UNIFORM(a.max_dist), MZ_UNIFORM(a.parse), &r);
         a.out_len[e] = r.out_len;
         a.crc[e] = r.crc;
         a.status[e] = r.status;
@@ -1037,6 +1038,7 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
                                    MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + MZ_DEF_XHEAD_BYTES)))
         a.ways = 1u;
     a.max_dist = (1u << window_log2) - 262u; /* zlib's MAX_DIST(s) = w_size - MIN_LOOKAHEAD */
+    a.parse = (a.ways > 1u && level >= 7) ? 1u : 0u; /* levels 7-9 pay for ratio as they do in zlib: 3x the time of level 6 */
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
     uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
     uint32_t resident = (uint32_t)c->cu_count * (a.ways > 1u ? 1u : 4u); /* 38.3 / 134 KiB LDS per workgroup -> 4 / 1 per CU */
@@ -1051,6 +1053,7 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
     if (le != hipSuccess && a.ways > 1u) { /* the device does not take 134 KiB of LDS per workgroup after all */
         c->big_lds_deflate.store(-1, std::memory_order_release);
         a.ways = 1u;
+        a.parse = 0u;
         hipLaunchKernelGGL(k_deflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE, s, a);
         le = hipGetLastError();
     }

@@ -91,6 +91,17 @@
             dst[lane] = _sc;                                         \
         }                                                            \
     } while (0)
+/* inclusive prefix MINIMUM inside every row of 16 lanes: lanes 15, 31, 47, 63 end up with their row's minimum */
+#define MZ_ROW16_PMIN(dst, src)                                      \
+    do {                                                             \
+        for (int _r = 0; _r < 64; _r += 16) {                        \
+            uint32_t _m = 0xFFFFFFFFu;                               \
+            for (int _k = 0; _k < 16; ++_k) {                        \
+                _m = src[_r + _k] < _m ? src[_r + _k] : _m;          \
+                dst[_r + _k] = _m;                                   \
+            }                                                        \
+        }                                                            \
+    } while (0)
 MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
 MZ_DEV uint32_t mz_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 MZ_DEV uint32_t mz_clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); } /* v != 0 */
@@ -172,6 +183,17 @@ __device__ __forceinline__ uint32_t mz_wave_incl_scan(uint32_t x, int lane) {
     x += MZ_DPP(x, 0x143, 0xc); /* row_bcast:31 into rows 2 and 3 */
     return x;
 }
+/* inclusive prefix minimum inside every row of 16 lanes (row_shr 1, 2, 4, 8; a lane with nothing to its left keeps its own) */
+#define MZ_DPP_KEEP(x, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(x), (int)(x), (ctrl), 0xf, 0xf, false))
+__device__ __forceinline__ uint32_t mz_row16_prefix_min(uint32_t x) {
+    uint32_t y;
+    y = MZ_DPP_KEEP(x, 0x111); x = y < x ? y : x;
+    y = MZ_DPP_KEEP(x, 0x112); x = y < x ? y : x;
+    y = MZ_DPP_KEEP(x, 0x114); x = y < x ? y : x;
+    y = MZ_DPP_KEEP(x, 0x118); x = y < x ? y : x;
+    return x;
+}
+#define MZ_ROW16_PMIN(dst, src) ((dst) = mz_row16_prefix_min(src))
 #define MZ_INCL_SCAN(dst, src) ((dst) = mz_wave_incl_scan((src), lane))
 #define MZ_WAVE_SUM(dst, name) ((dst) = (uint32_t)__builtin_amdgcn_readlane((int)mz_wave_incl_scan((name), lane), 63))
 MZ_DEV uint32_t mz_popc64(uint64_t v) { return (uint32_t)__popcll(v); }

@@ -11,6 +11,7 @@ cp gpurun_out/final/bench.log $d/bench_cfg2.log
 for c in 3 4 5; do cp gpurun_out/final/bench_cfg$c.log $d/bench_cfg$c.log; done
 cp gpurun_out/final/gputest.log $d/gputest_final.log
 cp gpurun_out/final/fuzz_gpu.log $d/fuzz_gpu_final.log
+cp gpurun_out/final/k4_levels.log gpurun_out/final/k4_levels_sections.log $d/ 2>/dev/null
 for t in final_sq:k1 final_sq_k3:k3 final_sq_k4:k4; do src=${t%%:*}; k=${t##*:}; for i in 1 2 3; do cp gpurun_out/$src/pmc_sq$i.csv $d/pmc_sq${i}_${k}_final.csv; done; done
 python3 - "$d" <<'PY'
 import csv, json, sys

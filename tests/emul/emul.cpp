@@ -263,7 +263,7 @@ extern "C" uint32_t emul_lzma_lds_bytes(void) { return (uint32_t)sizeof(mz_lzma_
 static uint32_t g_def_max_dist = 32768u - 262u;
 extern "C" void emul_deflate_window(uint32_t window_log2) { g_def_max_dist = (1u << window_log2) - 262u; }
 static int32_t emul_deflate_ways(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
-                                 uint32_t ways, uint32_t *out_len, uint32_t *crc) {
+                                 uint32_t ways, uint32_t parse, uint32_t *out_len, uint32_t *crc) {
     ready();
     mz_deflate_lds *L = (mz_deflate_lds *)malloc(sizeof(mz_deflate_lds));
     memset(L, 0xA5, sizeof(*L));
@@ -271,7 +271,7 @@ static int32_t emul_deflate_ways(const uint8_t *in, uint32_t in_len, uint8_t *ou
     memset(xh, 0x5A, (MZ_DEF_WAYS_BEST - 1u) * sizeof(uint16_t) << MZ_DEF_HBITS);
     mz_deflate_result r;
     uint32_t *tok = (uint32_t *)malloc(MZ_DEF_BLOCK * sizeof(uint32_t));
-    mz_deflate_piece(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, &r);
+    mz_deflate_piece(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, parse, &r);
     free(tok);
     free(xh);
     free(L);
@@ -281,11 +281,16 @@ static int32_t emul_deflate_ways(const uint8_t *in, uint32_t in_len, uint8_t *ou
 }
 extern "C" int32_t emul_deflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
                                 uint32_t *out_len, uint32_t *crc) {
-    return emul_deflate_ways(in, in_len, out, out_cap, final, 1u, out_len, crc);
+    return emul_deflate_ways(in, in_len, out, out_cap, final, 1u, 0u, out_len, crc);
 }
-/* the default compression class (levels 4-9 and -1): four candidates per hash bucket */
+/* levels 7-9: four candidates per hash bucket, cost parse */
 extern "C" int32_t emul_deflate_best(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
                                      uint32_t *out_len, uint32_t *crc) {
-    return emul_deflate_ways(in, in_len, out, out_cap, final, MZ_DEF_WAYS_BEST, out_len, crc);
+    return emul_deflate_ways(in, in_len, out, out_cap, final, MZ_DEF_WAYS_BEST, 1u, out_len, crc);
+}
+/* the default compression class (levels 4-6 and -1): four candidates, the lazy rule decides inside every step */
+extern "C" int32_t emul_deflate_lazy(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
+                                     uint32_t *out_len, uint32_t *crc) {
+    return emul_deflate_ways(in, in_len, out, out_cap, final, MZ_DEF_WAYS_BEST, 0u, out_len, crc);
 }
 extern "C" uint32_t emul_deflate_lds_bytes(void) { return (uint32_t)sizeof(mz_deflate_lds); }

@@ -56,7 +56,7 @@ MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, ui
     for (uint32_t i = 0; i < np; i++) {
         const uint32_t off = in_len ? i * piece : 0u, len = in_len - off < piece ? in_len - off : piece;
         uint32_t ol = 0, pc = 0;
-        const int32_t st = ((level >= 0 && level <= 3) ? emul_deflate : emul_deflate_best)(in_len ? in + off : &dummy, len, out + total, out_cap - total, (i + 1 == np && final) ? 1u : 0u, &ol, &pc);
+        const int32_t st = ((level >= 0 && level <= 3) ? emul_deflate : (level >= 7) ? emul_deflate_best : emul_deflate_lazy)(in_len ? in + off : &dummy, len, out + total, out_cap - total, (i + 1 == np && final) ? 1u : 0u, &ol, &pc);
         if (st) return st;
         total += ol;
         k = i == 0 ? pc : mzhip_crc32_combine_host(k, pc, len);

@@ -93,6 +93,42 @@ if which in ("deflate", "both", "all"):
     print("DEFLATE encode: %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.3f  ok=%s" % (
         n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), ok), flush=True)
 
+if which in ("deflate", "both", "all", "deflate_levels"):
+    # the classes behind COMPRESS_LEVEL: 1 = fast, 4 = four candidates + lazy rule, 6 = + cost parse; zlib's own ratios beside them
+    L.mzhip_deflate_batch_level.restype = C.c_int32
+    L.mzhip_deflate_batch_level.argtypes = [C.c_void_p] * 7 + [C.c_uint32, C.c_int32, C.c_int32] + [C.c_void_p] * 4
+    n_unique, n_total, size = 512, 8192, 65536
+    datas = synth.slices(n_unique, size, 1234)
+    idx = np.arange(n_total) % n_unique
+    b = gpu_util.make_batch([datas[i] for i in idx], [size + size // 8 + 64] * n_total)
+    out_len, crc, status = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(3))
+    def k4_sections():
+        if not hasattr(L, "mzhip_prof_read"): return
+        buf = (C.c_ulonglong * 32)()
+        L.mzhip_prof_read(buf, 1)
+        names = {16: "block set-up", 17: "hash, candidates, bucket update", 18: "match measurement", 19: "lazy rule + greedy selection",
+                 20: "tokens out, histograms", 21: "CRC of the input", 22: "codes, block costs, header", 23: "pass 2 (bits out)",
+                 24: "cost parse: price list", 25: "cost parse: dynamic programme", 26: "cost parse: choices picked up", 27: "cost parse: block fetch"}
+        tot = float(sum(buf[i] for i in names)) or 1.0
+        for i in sorted(names, key=lambda k: -buf[k]):
+            if buf[i]: print("  %-36s %5.1f %%" % (names[i], 100.0 * buf[i] / tot))
+    for level in (1, 4, 6, 9):
+        k4_sections() if False else (hasattr(L, "mzhip_prof_read") and L.mzhip_prof_read((C.c_ulonglong * 32)(), 1))
+        def runl():
+            assert L.mzhip_deflate_batch_level(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(),
+                                               b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None,
+                                               n_total, level, 15, out_len.data_ptr(), crc.data_ptr(), status.data_ptr(), None) == 0
+        ms = timed(runl)
+        ol = out_len.cpu().numpy()
+        h = b["d_out"].cpu().numpy()
+        ok = bool((status.cpu().numpy() == 0).all())
+        for i in range(0, n_total, 211):
+            ok = ok and zlib.decompress(gpu_util.entry_bytes(b, h, i, int(ol[i])), -15) == datas[idx[i]]
+        zr = sum(len(zlib.compress(d, level)) - 6 for d in datas) / (n_unique * size)
+        print("DEFLATE encode level %d: %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.4f (zlib-%d: %.4f)  ok=%s" % (
+            level, n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), level, zr, ok), flush=True)
+        k4_sections()
+
 if which in ("xz", "all"):
     import lzma as pylzma
 
@@ -190,7 +226,8 @@ if which in ("deflate", "both", "all") and hasattr(L, "mzhip_prof_read"):
     buf = (C.c_ulonglong * 32)()
     L.mzhip_prof_read(buf, 1)
     names = {16: "block set-up", 17: "hash, candidates, bucket update", 18: "match measurement", 19: "lazy rule + greedy selection",
-             20: "tokens out, histograms", 21: "CRC of the input", 22: "codes, block costs, header", 23: "pass 2 (bits out)"}
+             20: "tokens out, histograms", 21: "CRC of the input", 22: "codes, block costs, header", 23: "pass 2 (bits out)",
+             24: "cost parse: price list", 25: "cost parse: dynamic programme", 26: "cost parse: choices picked up", 27: "cost parse: block fetch"}
     tot = float(sum(buf[i] for i in names)) or 1.0
     for i in sorted(names, key=lambda k: -buf[k]):
         print("  %-36s %5.1f %%" % (names[i], 100.0 * buf[i] / tot))

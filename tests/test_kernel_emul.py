@@ -627,21 +627,30 @@ def test_inflate_moving_view():
 
 
 def test_deflate_default_class_roundtrip(emu):
-    """K4's default compression class (levels 4-9, -1: four candidates per hash bucket, two-position lazy rule) in the
-    emulation: zlib inflates the bytes back, and they are smaller than the fast class's."""
+    """K4's classes above the fast one in the emulation -- "lazy" (levels 4-6, -1: four candidates per hash bucket, matches
+    handed on to the next positions, two-position lazy rule) and "best" (levels 7-9: the cost parse on top): zlib inflates
+    the bytes back, every class is smaller than the one below, and the cost parse lands within 4 % of zlib-9."""
     emu.emul_deflate_best.argtypes = emu.emul_deflate.argtypes
+    emu.emul_deflate_lazy.argtypes = emu.emul_deflate.argtypes
     text, _ = synth.bench_corpus()
     rnd = np.random.RandomState(12)
     datas = [text[o:o + 65536] for o in rnd.randint(0, len(text) - 65536, size=6)]
-    datas += [b"", b"a", b"abcabcabcabc" * 300, bytes(70000), text[:200000], rnd.bytes(4000), b"ab" * 40000]
-    tot = {"fast": 0, "best": 0}
+    datas += [b"", b"a", b"abc", b"abcd", b"abcabcabcabc" * 300, bytes(70000), text[:200000], rnd.bytes(4000), b"ab" * 40000,
+              text[:65], text[:259], bytes(rnd.randint(0, 2, size=5000, dtype=np.uint8))]
+    tot = {"fast": 0, "lazy": 0, "best": 0, "zlib9": 0}
     for d in datas:
         a = np.frombuffer(d, dtype=np.uint8).copy() if d else np.zeros(1, np.uint8)
-        for name, fn in (("fast", emu.emul_deflate), ("best", emu.emul_deflate_best)):
-            out = np.zeros(len(d) + len(d) // 8 + 1000, np.uint8)
-            ol, crc = C.c_uint32(), C.c_uint32()
-            st = fn(a.ctypes.data_as(_u8p), len(d), out.ctypes.data_as(_u8p), len(out), 1, C.byref(ol), C.byref(crc))
-            assert st == 0 and zlib.decompress(out[:ol.value].tobytes(), -15) == d and crc.value == zlib.crc32(d), (name, len(d))
-            if len(d) == 65536:
-                tot[name] += ol.value
-    assert tot["best"] < 0.93 * tot["fast"] and tot["best"] <= 0.32 * 6 * 65536, tot
+        for name, fn in (("fast", emu.emul_deflate), ("lazy", emu.emul_deflate_lazy), ("best", emu.emul_deflate_best)):
+            for final in (1, 0):
+                out = np.zeros(len(d) + len(d) // 8 + 1000, np.uint8)
+                ol, crc = C.c_uint32(), C.c_uint32()
+                st = fn(a.ctypes.data_as(_u8p), len(d), out.ctypes.data_as(_u8p), len(out), final, C.byref(ol), C.byref(crc))
+                z = out[:ol.value].tobytes()
+                back = zlib.decompress(z, -15) if final else zlib.decompressobj(-15).decompress(z)
+                assert st == 0 and back == d and crc.value == zlib.crc32(d), (name, final, len(d))
+                if len(d) == 65536 and final:
+                    tot[name] += ol.value
+        if len(d) == 65536:
+            tot["zlib9"] += len(zlib.compress(d, 9)) - 6
+    assert tot["lazy"] < 0.92 * tot["fast"] and tot["lazy"] <= 0.32 * 6 * 65536, tot
+    assert tot["best"] < 0.985 * tot["lazy"] and tot["best"] <= 1.04 * tot["zlib9"], tot
