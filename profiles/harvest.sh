@@ -26,7 +26,10 @@ t["write_bytes_per_launch"] = int(mean(d + "/pmc_write_size.csv"))
 b = json.loads(open(d + "/bench_cfg2.log").read().strip().splitlines()[-1])
 t["algorithmic_bytes_per_launch"] = b["roofline"]["algorithmic_bytes_per_launch"]
 t["kernel_ms_per_launch"] = b["roofline"]["kernel_ms"]
+import subprocess
+t["commit"] = subprocess.run(["git", "log", "-1", "--format=%h"], capture_output=True, text=True).stdout.strip()
 json.dump(t, open(p, "w"), indent=1)
 print(t["fetch_bytes_per_launch"], t["write_bytes_per_launch"], t["kernel_ms_per_launch"])
 PY
+python3 profiles/resource_usage.py > $d/kernel_resource_usage.txt   # (compiler remarks of the default build at HEAD: no GPU needed)
 head -2 $d/kernel_stats_final.csv | cut -c1-120
