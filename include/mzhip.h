@@ -97,6 +97,14 @@ MZHIP_API int32_t mzhip_inflate_resume_batch(const void *d_in, const uint64_t *d
 MZHIP_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                             const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
                                             uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+/* ... and the CRC-32 of the new bytes in the pieces a caller hands on to a checksum (mz_zip_entry_read ->
+ * mz_crypt_crc32_update, 65 535 bytes per call, mz_zip_rw.c:55): the first seg_first new bytes (what completes the piece
+ * the previous window left open; 0 = none), then seg_stride at a time, then the rest.  seg_crc[0 .. *nseg) from the
+ * device's copy of the window, one launch; *nseg = 0 when seg_cap is too small (the window itself is still valid). */
+MZHIP_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                                const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
+                                                uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t seg_first,
+                                                uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg);
 
 MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,

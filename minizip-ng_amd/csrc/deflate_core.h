@@ -326,9 +326,10 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
  * matching cannot do (shorten a match so that a better one can start, price a far distance against three literals)
  * is worth 3.3 % of the output on the bench corpus with the same match finder (tests/study/enc_parse.c). */
 #define MZ_DEF_WAYS_BEST 4u
+template <uint32_t parse> /* (a template argument: the cost parse needs 160 registers, the other classes run four waves per SIMD on 128) */
 MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
                              uint32_t *tok, mz_deflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
-                             uint32_t ways, uint16_t *xhead, uint32_t max_dist, uint32_t parse, mz_deflate_result *res) {
+                             uint32_t ways, uint16_t *xhead, uint32_t max_dist, mz_deflate_result *res) {
     MZ_LANE_DECL
     int32_t status = MZHIP_OK;
     uint32_t obyte = 0; /* whole bytes already written to out */
@@ -512,105 +513,155 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             MZ_WAVE_SYNC();
             mz_huff_build(L, 0u, MZ_DEF_NLIT, 15u);
             mz_huff_build(L, MZ_DEF_DIST0, MZ_DEF_NDIST, 15u);
-            /* the hash ways are dead: a ring of the cheapest cost from the next 512 positions to the block's end, and the
+            /* the hash ways are dead: per chain a ring of the cheapest cost from the next 512 positions to the end, and the
              * price of every match length (symbol + extra bits); a symbol the lazy parse never used costs a default */
             MZ_DPROF_MARK(24); /* cost parse: the price list (two code constructions) */
-            uint32_t *const cst = (uint32_t *)xhead;
-            uint8_t *const lcost = (uint8_t *)(cst + 512);
+            /* Four chains: the block is cut into four runs of SB positions and the programme runs over all four at once,
+             * each as if the block ended behind its run (a match may reach over the end of a run: what it reaches costs
+             * nothing -- the choice is a little too fond of such matches for the last dozen positions of three runs, 0.0x %
+             * of the output).  One chain is a string of dependent cross-lane and scalar steps with ONE wave per SIMD to
+             * hide them (this class runs one workgroup per CU): ~850 cycles per group of four positions; four
+             * independent strings in the same instruction stream fill each other's gaps. */
+            uint32_t *const cst0 = (uint32_t *)xhead, *const cst1 = cst0 + 512, *const cst2 = cst0 + 1024, *const cst3 = cst0 + 1536;
+            uint8_t *const lcost = (uint8_t *)(cst0 + 2048);
             const uint8_t *const lens = L->u.hb.lens;
+            const uint32_t nch = (n >= 4096u) ? 4u : 1u;
+            const uint32_t SB = (nch == 4u) ? (((n + 255u) >> 8) << 6) : (((n + 63u) >> 6) << 6); /* a multiple of 64; nch * SB >= n */
             MZ_LANES {
                 for (uint32_t l = 3u + (uint32_t)lane; l <= MZ_DEF_MAXMATCH; l += 64u) {
                     uint32_t ex, xv;
                     const uint32_t c = lens[mz_len_sym(l, &ex, &xv)];
                     lcost[l] = (uint8_t)((c ? c : 13u) + ex);
                 }
-                if (lane < 8) cst[(n + (uint32_t)lane) & 511u] = 0u;
+                for (uint32_t i = (uint32_t)lane; i < 2048u; i += 64u) cst0[i] = 0u; /* (behind the end of a run everything costs nothing) */
             }
             MZ_WAVE_SYNC();
-            uint32_t cnext = 0; /* (the cost from the block's end) */
-            PV(uint32_t, lcf);  /* the price of this lane's first length to try, 4 + lane % 16 */
-            MZ_LANES { P(lcf) = lcost[4u + ((uint32_t)lane & 15u)]; }
-            for (int32_t R = (int32_t)(((n - 1u) >> 6) << 6); R >= 0; R -= 64) {
-                PV(uint32_t, pkb); /* this lane's position: its match, */
-                PV(uint32_t, lcb); /* the price of its literal, */
-                PV(uint32_t, dcb); /* of its distance, */
-                PV(uint32_t, chb); /* and what the programme chooses for it (0 = the literal) */
-                MZ_LANES {
-                    const uint32_t r = (uint32_t)R + (uint32_t)lane;
-                    uint32_t t = 0, lc = 0, dc = 0;
-                    if (r < n) {
-                        t = tok[r];
-                        const uint32_t c = lens[in[blk + r]];
-                        lc = c ? c : 13u;
-                        if (t & 511u) {
-                            uint32_t ex, xv;
-                            const uint32_t cd = lens[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &ex, &xv)];
-                            dc = (cd ? cd : 10u) + ex;
-                        }
-                    }
-                    P(pkb) = t;
-                    P(lcb) = lc;
-                    P(dcb) = dc;
-                    P(chb) = 0u;
-                }
+            PV(uint32_t, lcf);  /* the prices of this lane's first two lengths to try, 4 + lane % 16 and 16 more */
+            PV(uint32_t, lcf2);
+            MZ_LANES {
+                P(lcf) = lcost[4u + ((uint32_t)lane & 15u)];
+                P(lcf2) = lcost[20u + ((uint32_t)lane & 15u)];
+            }
+            uint32_t cn0 = 0, cn1 = 0, cn2 = 0, cn3 = 0; /* the cost from the position behind the group: the previous group's first result */
+#define MZ_DP_DECL(c)                                                                        \
+            PV(uint32_t, pkb##c); /* this lane's position: its match, */                     \
+            PV(uint32_t, lcb##c); /* the price of its literal, */                            \
+            PV(uint32_t, dcb##c); /* of its distance, */                                     \
+            PV(uint32_t, chb##c); /* and what the programme chooses for it (0 = the literal) */ \
+            PV(uint32_t, gp##c);                                                             \
+            PV(uint32_t, gd##c);                                                             \
+            PV(uint32_t, best##c);
+#define MZ_DP_LOAD(c)                                                                        \
+            MZ_LANES {                                                                       \
+                const uint32_t r = (c) * SB + (uint32_t)R + (uint32_t)lane;                  \
+                uint32_t t = 0, lc = 0, dc = 0;                                              \
+                if ((c) < nch && r < n) {                                                    \
+                    t = tok[r];                                                              \
+                    const uint32_t c_ = lens[in[blk + r]];                                   \
+                    lc = c_ ? c_ : 13u;                                                      \
+                    if (t & 511u) {                                                          \
+                        uint32_t ex, xv;                                                     \
+                        const uint32_t cd = lens[MZ_DEF_DIST0 + mz_dist_sym(t >> 9, &ex, &xv)]; \
+                        dc = (cd ? cd : 10u) + ex;                                           \
+                    }                                                                        \
+                }                                                                            \
+                P(pkb##c) = t;                                                               \
+                P(lcb##c) = lc;                                                              \
+                P(dcb##c) = dc;                                                              \
+                P(chb##c) = 0u;                                                              \
+            }
+            /* 16 lanes try the lengths of one position each: 4 .. 35 in one go (the ring is read while the position's match
+             * is still on its way across the lanes), the rest in a loop that few groups enter */
+#define MZ_DP_EVAL(c)                                                                        \
+            MZ_GATHER4(gp##c, pkb##c, 4u * (4u * (uint32_t)gl + ((uint32_t)lane >> 4)));    \
+            MZ_GATHER4(gd##c, dcb##c, 4u * (4u * (uint32_t)gl + ((uint32_t)lane >> 4)));    \
+            MZ_LANES {                                                                       \
+                const uint32_t r = (c) * SB + (uint32_t)R + 4u * (uint32_t)gl + ((uint32_t)lane >> 4); \
+                const uint32_t l = 4u + ((uint32_t)lane & 15u);                              \
+                const uint32_t cfa = cst##c[(r + l) & 511u], cfb = cst##c[(r + l + 16u) & 511u]; \
+                const uint32_t mlen = P(gp##c) & 511u;                                       \
+                const uint32_t va = (l <= mlen) ? (((P(lcf) + P(gd##c) + cfa) << 9) | l) : 0xFFFFFFFFu; \
+                const uint32_t vb = (l + 16u <= mlen) ? (((P(lcf2) + P(gd##c) + cfb) << 9) | (l + 16u)) : 0xFFFFFFFFu; \
+                P(best##c) = va < vb ? va : vb;                                              \
+                P(lng) |= (mlen > 35u) ? 1u : 0u;                                            \
+            }
+#define MZ_DP_TAIL(c)                                                                        \
+            MZ_LANES {                                                                       \
+                const uint32_t r = (c) * SB + (uint32_t)R + 4u * (uint32_t)gl + ((uint32_t)lane >> 4); \
+                const uint32_t mlen = P(gp##c) & 511u;                                       \
+                uint32_t b = P(best##c);                                                     \
+                for (uint32_t l = 36u + ((uint32_t)lane & 15u); l <= mlen; l += 16u) {       \
+                    const uint32_t v = (((uint32_t)lcost[l] + P(gd##c) + cst##c[(r + l) & 511u]) << 9) | l; \
+                    b = v < b ? v : b;                                                       \
+                }                                                                            \
+                P(best##c) = b;                                                              \
+            }
+#define MZ_DP_MIN(c)                                                                         \
+            MZ_ROW16_PMIN(best##c, best##c);                                                 \
+            m0_##c = MZ_READLANE(best##c, 15);                                               \
+            m1_##c = MZ_READLANE(best##c, 31);                                               \
+            m2_##c = MZ_READLANE(best##c, 47);                                               \
+            m3_##c = MZ_READLANE(best##c, 63);
+            /* the literal steps are four scalar additions per chain; a tie goes to the match: fewer tokens */
+#define MZ_DP_STEP(c)                                                                        \
+            {                                                                                \
+                const uint32_t l0 = MZ_READLANE(lcb##c, 4 * gl), l1 = MZ_READLANE(lcb##c, 4 * gl + 1),    \
+                               l2 = MZ_READLANE(lcb##c, 4 * gl + 2), l3 = MZ_READLANE(lcb##c, 4 * gl + 3); \
+                const uint32_t t3 = cn##c + l3, k3 = (m3_##c >> 9) <= t3 ? 1u : 0u, c3 = k3 ? (m3_##c >> 9) : t3; \
+                const uint32_t t2 = c3 + l2, k2 = (m2_##c >> 9) <= t2 ? 1u : 0u, c2 = k2 ? (m2_##c >> 9) : t2;    \
+                const uint32_t t1 = c2 + l1, k1 = (m1_##c >> 9) <= t1 ? 1u : 0u, c1 = k1 ? (m1_##c >> 9) : t1;    \
+                const uint32_t t0 = c1 + l0, k0 = (m0_##c >> 9) <= t0 ? 1u : 0u, c0 = k0 ? (m0_##c >> 9) : t0;    \
+                cn##c = c0;                                                                  \
+                MZ_LANES {                                                                   \
+                    if (lane < 4) cst##c[((c) * SB + (uint32_t)R + 4u * (uint32_t)gl + (uint32_t)lane) & 511u] = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3; \
+                    if (lane == 4 * gl) P(chb##c) = k0 ? (m0_##c & 511u) : 0u;               \
+                    if (lane == 4 * gl + 1) P(chb##c) = k1 ? (m1_##c & 511u) : 0u;           \
+                    if (lane == 4 * gl + 2) P(chb##c) = k2 ? (m2_##c & 511u) : 0u;           \
+                    if (lane == 4 * gl + 3) P(chb##c) = k3 ? (m3_##c & 511u) : 0u;           \
+                }                                                                            \
+            }
+#define MZ_DP_STORE(c)                                                                       \
+            MZ_LANES {                                                                       \
+                const uint32_t r = (c) * SB + (uint32_t)R + (uint32_t)lane;                  \
+                if ((c) < nch && r < n) tok[r] = P(chb##c) ? (P(chb##c) | (P(pkb##c) & ~511u)) : 0u; \
+            }
+            for (int32_t R = (int32_t)SB - 64; R >= 0; R -= 64) { /* (R counts inside a run: chain c is at c * SB + R) */
+                MZ_DP_DECL(0) MZ_DP_DECL(1) MZ_DP_DECL(2) MZ_DP_DECL(3)
+                MZ_DP_LOAD(0) MZ_DP_LOAD(1) MZ_DP_LOAD(2) MZ_DP_LOAD(3)
                 uint64_t hasm;
-                MZ_BALLOT(hasm, (P(pkb) & 511u) != 0u);
-                MZ_DPROF_MARK(27); /* cost parse: a block of 64 positions fetched */
-                /* four positions at a time, last first: a match is at least 4 long, so what the four may jump to is
-                 * settled; 16 lanes try the lengths of one position each (lengths 4 .. 19 in one go: the ring is read
-                 * while the position's match is still on its way across the lanes), the literal steps are four scalar
-                 * additions.  cnext = the cost from the position behind the group: the previous group's first result. */
+                MZ_BALLOT(hasm, ((P(pkb0) | P(pkb1) | P(pkb2) | P(pkb3)) & 511u) != 0u);
+                MZ_DPROF_MARK(27); /* cost parse: 4 x 64 positions fetched */
+                /* four positions of every chain at a time, last first: a match is at least 4 long, so what the four may
+                 * jump to is settled */
                 for (int32_t gl = 15; gl >= 0; gl--) {
-                    const uint32_t r0 = (uint32_t)R + 4u * (uint32_t)gl;
-                    if (r0 >= n) continue;
-                    const uint32_t l0 = MZ_READLANE(lcb, 4 * gl), l1 = MZ_READLANE(lcb, 4 * gl + 1), l2 = MZ_READLANE(lcb, 4 * gl + 2),
-                                   l3 = MZ_READLANE(lcb, 4 * gl + 3);
-                    uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu, m3 = 0xFFFFFFFFu;
+                    uint32_t m0_0 = 0xFFFFFFFFu, m1_0 = 0xFFFFFFFFu, m2_0 = 0xFFFFFFFFu, m3_0 = 0xFFFFFFFFu;
+                    uint32_t m0_1 = 0xFFFFFFFFu, m1_1 = 0xFFFFFFFFu, m2_1 = 0xFFFFFFFFu, m3_1 = 0xFFFFFFFFu;
+                    uint32_t m0_2 = 0xFFFFFFFFu, m1_2 = 0xFFFFFFFFu, m2_2 = 0xFFFFFFFFu, m3_2 = 0xFFFFFFFFu;
+                    uint32_t m0_3 = 0xFFFFFFFFu, m1_3 = 0xFFFFFFFFu, m2_3 = 0xFFFFFFFFu, m3_3 = 0xFFFFFFFFu;
                     if ((hasm >> (4 * gl)) & 15ull) {
-                        PV(uint32_t, gp);
-                        PV(uint32_t, gd);
-                        PV(uint32_t, best);
-                        MZ_GATHER4(gp, pkb, 4u * (4u * (uint32_t)gl + ((uint32_t)lane >> 4)));
-                        MZ_GATHER4(gd, dcb, 4u * (4u * (uint32_t)gl + ((uint32_t)lane >> 4)));
-                        MZ_LANES {
-                            const uint32_t r = r0 + ((uint32_t)lane >> 4);
-                            uint32_t l = 4u + ((uint32_t)lane & 15u);
-                            const uint32_t cf = cst[(r + l) & 511u]; /* (does not wait for gp / gd) */
-                            const uint32_t mlen = P(gp) & 511u;
-                            uint32_t b = (l <= mlen) ? (((P(lcf) + P(gd) + cf) << 9) | l) : 0xFFFFFFFFu;
-                            for (l += 16u; l <= mlen; l += 16u) {
-                                const uint32_t v = (((uint32_t)lcost[l] + P(gd) + cst[(r + l) & 511u]) << 9) | l;
-                                b = v < b ? v : b;
-                            }
-                            P(best) = b;
+                        PV(uint32_t, lng);
+                        MZ_LANES { P(lng) = 0u; }
+                        MZ_DP_EVAL(0) MZ_DP_EVAL(1) MZ_DP_EVAL(2) MZ_DP_EVAL(3)
+                        uint64_t longm;
+                        MZ_BALLOT(longm, P(lng) != 0u);
+                        if (longm) {
+                            MZ_DP_TAIL(0) MZ_DP_TAIL(1) MZ_DP_TAIL(2) MZ_DP_TAIL(3)
                         }
-                        MZ_ROW16_PMIN(best, best);
-                        m0 = MZ_READLANE(best, 15);
-                        m1 = MZ_READLANE(best, 31);
-                        m2 = MZ_READLANE(best, 47);
-                        m3 = MZ_READLANE(best, 63);
+                        MZ_DP_MIN(0) MZ_DP_MIN(1) MZ_DP_MIN(2) MZ_DP_MIN(3)
                     }
-                    /* a tie goes to the match: fewer tokens */
-                    const uint32_t t3 = cnext + l3, k3 = (m3 >> 9) <= t3 ? 1u : 0u, c3 = k3 ? (m3 >> 9) : t3;
-                    const uint32_t t2 = c3 + l2, k2 = (m2 >> 9) <= t2 ? 1u : 0u, c2 = k2 ? (m2 >> 9) : t2;
-                    const uint32_t t1 = c2 + l1, k1 = (m1 >> 9) <= t1 ? 1u : 0u, c1 = k1 ? (m1 >> 9) : t1;
-                    const uint32_t t0 = c1 + l0, k0 = (m0 >> 9) <= t0 ? 1u : 0u, c0 = k0 ? (m0 >> 9) : t0;
-                    cnext = c0;
-                    MZ_LANES {
-                        if (lane < 4) cst[(r0 + (uint32_t)lane) & 511u] = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
-                        if (lane == 4 * gl) P(chb) = k0 ? (m0 & 511u) : 0u;
-                        if (lane == 4 * gl + 1) P(chb) = k1 ? (m1 & 511u) : 0u;
-                        if (lane == 4 * gl + 2) P(chb) = k2 ? (m2 & 511u) : 0u;
-                        if (lane == 4 * gl + 3) P(chb) = k3 ? (m3 & 511u) : 0u;
-                    }
+                    MZ_DP_STEP(0) MZ_DP_STEP(1) MZ_DP_STEP(2) MZ_DP_STEP(3)
                     MZ_WAVE_SYNC();
                 }
-                MZ_LANES {
-                    const uint32_t r = (uint32_t)R + (uint32_t)lane;
-                    if (r < n) tok[r] = P(chb) ? (P(chb) | (P(pkb) & ~511u)) : 0u;
-                }
+                MZ_DP_STORE(0) MZ_DP_STORE(1) MZ_DP_STORE(2) MZ_DP_STORE(3)
                 MZ_DPROF_MARK(25); /* cost parse: the dynamic programme */
             }
+#undef MZ_DP_DECL
+#undef MZ_DP_LOAD
+#undef MZ_DP_EVAL
+#undef MZ_DP_TAIL
+#undef MZ_DP_MIN
+#undef MZ_DP_STEP
+#undef MZ_DP_STORE
             /* the choices, front to back: the same selection as in pass 1, this time the tokens are kept (token i never
              * lands behind position i, so the list grows over the per-position words it has already read) */
             MZ_LANES {

@@ -356,7 +356,8 @@ struct DeflateArgs {
 // table and bit staging once pass 1 is over; histograms) and 256 KiB of token scratch in HBM per resident wave.  The
 // default compression class adds (MZ_DEF_WAYS_BEST - 1) x 8 KiB of older bucket entries per wave behind those.
 #define MZ_DEF_XHEAD_BYTES ((MZ_DEF_WAYS_BEST - 1u) * (sizeof(uint16_t) << MZ_DEF_HBITS))
-__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateArgs a) {
+template <uint32_t kParse>
+__device__ __forceinline__ void deflate_batch_body(const DeflateArgs &a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *crc_tab = (uint32_t *)smem;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
@@ -375,14 +376,17 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateA
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
         const uint32_t fin = a.final_flag ? MZ_UNIFORM((uint32_t)a.final_flag[e]) : 1u;
         mz_deflate_result r;
-        mz_deflate_piece(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
+        mz_deflate_piece<kParse>(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
                          a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs,
-                         MZ_UNIFORM(a.ways), xhead, MZ_UNIFORM(a.max_dist), MZ_UNIFORM(a.parse), &r);
+                         MZ_UNIFORM(a.ways), xhead, MZ_UNIFORM(a.max_dist), &r);
         a.out_len[e] = r.out_len;
         a.crc[e] = r.crc;
         a.status[e] = r.status;
     }
 }
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_batch(DeflateArgs a) { deflate_batch_body<0u>(a); }
+// levels 7-9: the same piece loop with the cost parse compiled in (160 VGPRs; this class runs one workgroup per CU anyway)
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_deflate_cost_batch(DeflateArgs a) { deflate_batch_body<1u>(a); }
 
 struct LzmaEncArgs {
     const uint8_t *in;
@@ -479,7 +483,7 @@ struct DeviceCtx {
     int inflate_wgs_per_cu = 1;
     // the four-candidate classes of K4 / the LZ tokenizer need > 64 KiB of dynamic LDS per workgroup: asked for once per
     // device; 0 = not asked yet, 1 = granted, -1 = refused (the one-candidate class is used instead)
-    std::atomic<int> big_lds_deflate{0}, big_lds_tok{0};
+    std::atomic<int> big_lds_deflate{0}, big_lds_deflate_cost{0}, big_lds_tok{0};
 };
 
 // may this device run `kernel` with `bytes` of dynamic LDS per workgroup?  (asked once per device and kernel)
@@ -1034,11 +1038,16 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
     a.ways = (level >= 0 && level <= 3) ? 1u : MZ_DEF_WAYS_BEST;
     /* the default class needs 134 KiB of dynamic LDS per workgroup: a device (or runtime) that does not grant it gets the
      * one-candidate class -- a valid stream with a worse ratio, not a launch error */
-    if (a.ways > 1u && !big_lds_ok(c->big_lds_deflate, (const void *)k_deflate_batch,
-                                   MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + MZ_DEF_XHEAD_BYTES)))
-        a.ways = 1u;
+    a.parse = (a.ways > 1u && level >= 7) ? 1u : 0u; /* levels 7-9 pay for ratio as they do in zlib */
+    {
+        const size_t big = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + MZ_DEF_XHEAD_BYTES);
+        if (a.ways > 1u && !(a.parse ? big_lds_ok(c->big_lds_deflate_cost, (const void *)k_deflate_cost_batch, big)
+                                     : big_lds_ok(c->big_lds_deflate, (const void *)k_deflate_batch, big))) {
+            a.ways = 1u;
+            a.parse = 0u;
+        }
+    }
     a.max_dist = (1u << window_log2) - 262u; /* zlib's MAX_DIST(s) = w_size - MIN_LOOKAHEAD */
-    a.parse = (a.ways > 1u && level >= 7) ? 1u : 0u; /* levels 7-9 pay for ratio as they do in zlib: 3x the time of level 6 */
     const size_t lds = MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * (MZ_DEF_LDS_STRIDE + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
     uint32_t wgs = (n + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
     uint32_t resident = (uint32_t)c->cu_count * (a.ways > 1u ? 1u : 4u); /* 38.3 / 134 KiB LDS per workgroup -> 4 / 1 per CU */
@@ -1048,10 +1057,11 @@ int32_t mzhip_deflate_batch_level(const void *d_in, const uint64_t *d_in_off, co
     rc = scratch_acquire(c, (size_t)grid * MZ_WAVES_PER_WG * MZ_DEF_BLOCK * sizeof(uint32_t), s, &slot, &scratch);
     if (rc) return rc;
     a.tok = (uint32_t *)scratch;
-    hipLaunchKernelGGL(k_deflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+    if (a.parse) hipLaunchKernelGGL(k_deflate_cost_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+    else hipLaunchKernelGGL(k_deflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess && a.ways > 1u) { /* the device does not take 134 KiB of LDS per workgroup after all */
-        c->big_lds_deflate.store(-1, std::memory_order_release);
+        (a.parse ? c->big_lds_deflate_cost : c->big_lds_deflate).store(-1, std::memory_order_release);
         a.ways = 1u;
         a.parse = 0u;
         hipLaunchKernelGGL(k_deflate_batch, dim3(grid), dim3(MZ_WAVES_PER_WG * 64), MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE, s, a);
@@ -1197,14 +1207,24 @@ struct Staging {
 int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                   const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
                                   uint32_t *in_used, uint32_t *crc) {
+    return mzhip_inflate_resume_host_seg(in, in_len, buf, buf_cap, state_in, state_out, out_len, in_used, crc, 0, 0, nullptr, 0, nullptr);
+}
+
+int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                      const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                      uint32_t *in_used, uint32_t *crc, uint32_t seg_first, uint32_t seg_stride,
+                                      uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
     const uint32_t hist = state_in ? state_in->out_pos : 0u;
     if (hist > buf_cap) return -102; /* MZ_PARAM_ERROR */
-    // layout: [meta 128 B][in (16-aligned)][buf]
+    // layout: [meta 128 B][in (16-aligned)][buf][segment arrays]
     const size_t in_pad = ((size_t)in_len + 15) & ~(size_t)15;
-    const size_t total = 128 + in_pad + buf_cap + 16;
+    const size_t buf_pad = ((size_t)buf_cap + 16 + 15) & ~(size_t)15;
+    const size_t seg_max = (seg_stride && seg_crc) ? (size_t)buf_cap / seg_stride + 3 : 0;
+    const size_t total = 128 + in_pad + buf_pad + seg_max * 16;
+    if (nseg) *nseg = 0;
     Staging sc;
     rc = sc.get(c, total);
     if (rc) return rc;
@@ -1231,6 +1251,38 @@ int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *b
     if (rc) return rc;
     HIP_TRY(mz_d2h(&m, base, sizeof(m)));
     if (m.out_len > hist) HIP_TRY(mz_d2h(buf + hist, base + m.out_off + hist, m.out_len - hist));
+    if (seg_max && m.out_len > hist) {
+        /* CRC-32 of the new bytes in the pieces the caller will hand to mz_crypt_crc32_update: the first seg_first bytes
+         * (what completes the piece the previous window left open), then seg_stride at a time, the rest; computed from the
+         * device's copy of the window, one launch */
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> len;
+        uint32_t pos = hist;
+        uint32_t first = seg_first < m.out_len - hist ? seg_first : m.out_len - hist;
+        if (first) {
+            off.push_back(m.out_off + pos);
+            len.push_back(first);
+            pos += first;
+        }
+        while (pos < m.out_len) {
+            const uint32_t n = m.out_len - pos < seg_stride ? m.out_len - pos : seg_stride;
+            off.push_back(m.out_off + pos);
+            len.push_back(n);
+            pos += n;
+        }
+        const uint32_t ns = (uint32_t)len.size();
+        if (ns <= seg_cap && ns <= seg_max) {
+            uint8_t *sm = base + 128 + in_pad + buf_pad;
+            uint64_t *d_off = (uint64_t *)sm;
+            uint32_t *d_len = (uint32_t *)(sm + seg_max * 8), *d_crc = d_len + seg_max;
+            HIP_TRY(mz_h2d(d_off, off.data(), (size_t)ns * 8));
+            HIP_TRY(mz_h2d(d_len, len.data(), (size_t)ns * 4));
+            rc = mzhip_crc32_batch(base, d_off, d_len, ns, nullptr, d_crc, MZ_HOST_STREAM);
+            if (rc) return rc;
+            HIP_TRY(mz_d2h(seg_crc, d_crc, (size_t)ns * 4));
+            if (nseg) *nseg = ns;
+        }
+    }
     if (out_len) *out_len = m.out_len;
     if (in_used) *in_used = m.in_used;
     if (crc) *crc = m.crc;

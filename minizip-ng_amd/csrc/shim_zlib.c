@@ -87,6 +87,18 @@ typedef struct mzhip_zlib_s {
     int8_t stream_end;      /* the device has seen the end of the stream */
     mzhip_inflate_state sst; /* where the decode goes on (bit positions from in[0]) */
     int64_t in_dropped;     /* compressed bytes dropped from the front of in[] */
+    /* ... and the device's CRC-32 of every window in the pieces the caller reads it in (the size of its read() calls:
+     * 65 535 from mz_zip_entry_read), so that the mz_crypt_crc32_update behind a read() that was served exactly such
+     * pieces is answered from them instead of launching for 64 KiB (3 GiB entry: 22 s -> see DESIGN 4) */
+    int64_t g0;             /* offset inside the entry of out[0] */
+    int32_t read_stride;    /* the size of the caller's read() calls (0: none seen, or too small to be worth pieces) */
+    struct mzh_piece {
+        int64_t g;          /* offset inside the entry */
+        uint32_t len, crc;
+    } *pc;
+    int32_t pc_n, pc_cap, pc_head;
+    uint32_t *pc_tmp;
+    int32_t pc_tmp_cap;
     /* write side */
     uint8_t *wbuf;
     int64_t wlen, wcap;
@@ -111,6 +123,12 @@ static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
 
 static void free_buffers(mzhip_zlib *z) {
     free(z->in);
+    free(z->pc);
+    free(z->pc_tmp);
+    z->pc = NULL;
+    z->pc_tmp = NULL;
+    z->pc_n = z->pc_cap = z->pc_head = z->pc_tmp_cap = 0;
+    z->g0 = 0;
     if (!z->out_borrowed)
         free(z->out);
     mzhip_prime_unpin(z->prime_pin);
@@ -355,6 +373,72 @@ static int32_t stream_drop_input(mzhip_zlib *z) {
     return 0;
 }
 
+/* the pieces of one decode call: the same cut as mzhip_inflate_resume_host_seg makes (first, stride ..., rest) */
+static void stream_pieces_add(mzhip_zlib *z, int64_t g, int64_t nbytes, uint32_t first, uint32_t stride, uint32_t nseg) {
+    if (nbytes <= 0 || !stride)
+        return;
+    /* drop what has been served already, make room */
+    const int64_t served_to = z->g0 + z->out_served;
+    while (z->pc_head < z->pc_n && z->pc[z->pc_head].g + z->pc[z->pc_head].len <= served_to)
+        z->pc_head++;
+    if (z->pc_head > 0) {
+        memmove(z->pc, z->pc + z->pc_head, (size_t)(z->pc_n - z->pc_head) * sizeof(z->pc[0]));
+        z->pc_n -= z->pc_head;
+        z->pc_head = 0;
+    }
+    if (z->pc_n + (int32_t)nseg > z->pc_cap) {
+        const int32_t ncap = z->pc_n + (int32_t)nseg + 64;
+        struct mzh_piece *np = (struct mzh_piece *)realloc(z->pc, (size_t)ncap * sizeof(z->pc[0]));
+        if (!np) {
+            z->pc_n = 0; /* no pieces: the checksum calls take the ordinary path */
+            return;
+        }
+        z->pc = np;
+        z->pc_cap = ncap;
+    }
+    int64_t left = nbytes;
+    uint32_t i = 0;
+    uint32_t n = first < (uint64_t)left ? first : (uint32_t)left;
+    if (n) {
+        z->pc[z->pc_n].g = g;
+        z->pc[z->pc_n].len = n;
+        z->pc[z->pc_n++].crc = z->pc_tmp[i++];
+        g += n;
+        left -= n;
+    }
+    while (left > 0 && i < nseg) {
+        n = (uint64_t)left < stride ? (uint32_t)left : stride;
+        z->pc[z->pc_n].g = g;
+        z->pc[z->pc_n].len = n;
+        z->pc[z->pc_n++].crc = z->pc_tmp[i++];
+        g += n;
+        left -= n;
+    }
+}
+
+/* CRC-32 of out[out_served .. out_served + n) from the pieces, when these bytes are exactly a run of whole pieces: 1 */
+static int32_t stream_pieces_crc(mzhip_zlib *z, int32_t n, uint32_t *crc) {
+    const int64_t a = z->g0 + z->out_served, b = a + n;
+    int32_t i = z->pc_head;
+    while (i < z->pc_n && z->pc[i].g + z->pc[i].len <= a)
+        i++;
+    z->pc_head = i;
+    if (i >= z->pc_n || z->pc[i].g != a)
+        return 0;
+    uint32_t c = 0;
+    int64_t at = a;
+    for (; i < z->pc_n && at < b; i++) {
+        if (z->pc[i].g != at || at + z->pc[i].len > b)
+            return 0;
+        c = (at == a) ? z->pc[i].crc : mzhip_crc32_combine(c, z->pc[i].crc, z->pc[i].len);
+        at += z->pc[i].len;
+    }
+    if (at != b)
+        return 0;
+    *crc = c;
+    return 1;
+}
+
 /* window mode: make more decoded bytes available behind out_served.  Returns 0 (bytes, the stream end or a verdict are
  * there) or a negative MZ error. */
 static int32_t stream_next(mzhip_zlib *z) {
@@ -368,6 +452,7 @@ static int32_t stream_next(mzhip_zlib *z) {
             memmove(z->out, z->out + from, (size_t)(z->out_len - from));
             z->out_len -= from;
             z->out_served -= from;
+            z->g0 += from;
         }
     }
     for (;;) {
@@ -384,9 +469,24 @@ static int32_t stream_next(mzhip_zlib *z) {
         z->sst.out_pos = (uint32_t)z->out_len;
         z->sst.flags = 1;
         mzhip_inflate_state nst;
-        uint32_t out_len = 0, in_used = 0, crc = 0;
-        int32_t st = mzhip_inflate_resume_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
-                                               &in_used, &crc);
+        uint32_t out_len = 0, in_used = 0, crc = 0, nseg = 0;
+        /* the new bytes start at offset gnew of the entry; pieces end where the caller's read() calls end */
+        const int64_t gnew = z->g0 + z->out_len;
+        const uint32_t stride = (uint32_t)z->read_stride;
+        const uint32_t seg_first = stride ? (uint32_t)((stride - gnew % stride) % stride) : 0u;
+        if (stride) {
+            const int32_t want = (int32_t)(z->out_cap / stride) + 4;
+            if (want > z->pc_tmp_cap) {
+                free(z->pc_tmp);
+                z->pc_tmp = (uint32_t *)malloc((size_t)want * sizeof(uint32_t));
+                z->pc_tmp_cap = z->pc_tmp ? want : 0;
+            }
+        }
+        int32_t st = mzhip_inflate_resume_host_seg(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
+                                                   &in_used, &crc, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
+                                                   (uint32_t)z->pc_tmp_cap, &nseg);
+        if (nseg)
+            stream_pieces_add(z, gnew, (int64_t)out_len - z->out_len, seg_first, stride, nseg);
         if (st == MZHIP_STATUS_BUF_ERROR && z->base_eof && (nst.flags & 1u)) {
             /* the stream really ends short.  What this call decoded stays; then once more from where it stopped, without
              * the "all or nothing" rule of a resumable decode, so that what the reference would still have produced (the
@@ -541,6 +641,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         z->error = MZH_STREAM_ERROR; /* a checksum call before this one met a device failure */
     if (z->error != 0)
         return z->error; /* mz_strm_zlib.c:186-189 */
+    z->read_stride = size >= 16384 ? size : 0; /* (window mode cuts its CRC pieces where these calls end) */
 
     if (!z->tried_cache && z->in_len == 0) {
         mzhip_stream *b = z->stream.base;
@@ -595,6 +696,11 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             const int64_t av = z->out_len - z->out_served;
             const int32_t k = (int32_t)(av < size - got ? av : size - got);
             if (k > 0) {
+                uint32_t pcrc;
+                if (got == 0 && z->pc_n > z->pc_head && stream_pieces_crc(z, k, &pcrc) && (k == size || av == k))
+                    mzhip_served_set(buf, k, pcrc, z->out + z->out_served); /* (dropped again below if the call goes on into the next window) */
+                else if (got != 0)
+                    mzhip_served_drop();
                 memcpy((uint8_t *)buf + got, z->out + z->out_served, (size_t)k);
                 z->out_served += k;
                 z->total_out += k;
@@ -836,6 +942,12 @@ int32_t mz_stream_zlib_close(void *stream) {
     }
     z->initialized = 0;
     free(z->in);
+    free(z->pc);
+    free(z->pc_tmp);
+    z->pc = NULL;
+    z->pc_tmp = NULL;
+    z->pc_n = z->pc_cap = z->pc_head = z->pc_tmp_cap = 0;
+    z->g0 = 0;
     if (!z->out_borrowed)
         free(z->out);
     mzhip_prime_unpin(z->prime_pin);
@@ -914,6 +1026,14 @@ void mz_stream_zlib_delete(void **stream) {
     z = (mzhip_zlib *)*stream;
     if (z) {
         free(z->in);
+        free(z->pc);
+        free(z->pc_tmp);
+    free(z->pc);
+    free(z->pc_tmp);
+    z->pc = NULL;
+    z->pc_tmp = NULL;
+    z->pc_n = z->pc_cap = z->pc_head = z->pc_tmp_cap = 0;
+    z->g0 = 0;
         if (!z->out_borrowed)
             free(z->out);
         mzhip_prime_unpin(z->prime_pin);

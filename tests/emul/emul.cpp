@@ -271,7 +271,8 @@ static int32_t emul_deflate_ways(const uint8_t *in, uint32_t in_len, uint8_t *ou
     memset(xh, 0x5A, (MZ_DEF_WAYS_BEST - 1u) * sizeof(uint16_t) << MZ_DEF_HBITS);
     mz_deflate_result r;
     uint32_t *tok = (uint32_t *)malloc(MZ_DEF_BLOCK * sizeof(uint32_t));
-    mz_deflate_piece(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, parse, &r);
+    if (parse) mz_deflate_piece<1u>(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, &r);
+    else mz_deflate_piece<0u>(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, &r);
     free(tok);
     free(xh);
     free(L);

@@ -40,6 +40,38 @@ MOCK_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, u
     if (crc) *crc = k;
     return st;
 }
+// ... with the CRCs of the new bytes in the caller's pieces (the device does this with one k_crc32_batch launch)
+static int g_mock_seg_calls = 0;
+MOCK_API int mzmock_seg_calls(void) { return g_mock_seg_calls; }
+MOCK_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                               const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                               uint32_t *in_used, uint32_t *crc, uint32_t seg_first, uint32_t seg_stride,
+                                               uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
+    const uint32_t hist = state_in ? state_in->out_pos : 0u;
+    uint32_t ol = 0;
+    const int32_t st = mzhip_inflate_resume_host(in, in_len, buf, buf_cap, state_in, state_out, &ol, in_used, crc);
+    if (out_len) *out_len = ol;
+    if (nseg) *nseg = 0;
+    if (seg_stride && seg_crc && ol > hist) {
+        uint32_t pos = hist, n = 0;
+        const uint32_t first = seg_first < ol - hist ? seg_first : ol - hist;
+        const uint32_t count = (first ? 1u : 0u) + (ol - hist - first + seg_stride - 1) / seg_stride;
+        if (count <= seg_cap) {
+            if (first) {
+                seg_crc[n++] = emul_crc32(buf + pos, first);
+                pos += first;
+            }
+            while (pos < ol) {
+                const uint32_t k = ol - pos < seg_stride ? ol - pos : seg_stride;
+                seg_crc[n++] = emul_crc32(buf + pos, k);
+                pos += k;
+            }
+            if (nseg) *nseg = n;
+            g_mock_seg_calls++;
+        }
+    }
+    return st;
+}
 MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                                     uint32_t *in_used, uint32_t *crc) {
     return mzhip_inflate_host2(in, in_len, out, out_cap, out_len, in_used, crc, nullptr);
@@ -112,8 +144,11 @@ MOCK_API int32_t mzhip_xz_encode_host_preset(const uint8_t *, uint32_t, int32_t,
     return MZHIP_STATUS_UNSUPPORTED;
 }
 
+static int g_mock_crc_calls = 0; // checksum calls that would have been a launch on the device
+MOCK_API int mzmock_crc_host_calls(void) { return g_mock_crc_calls; }
 MOCK_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
     uint32_t v = value;
+    if (size >= MZHIP_CRC_HOST_BELOW) g_mock_crc_calls++;
     for (size_t pos = 0; pos < size;) { /* the emulated kernel takes 32-bit lengths */
         const size_t n = size - pos < ((size_t)1 << 30) ? size - pos : ((size_t)1 << 30);
         v = emul_crc32_super(buf + pos, (uint32_t)n, v);

@@ -140,3 +140,26 @@ def test_window_mode_streams():
             zz = bytearray(z)
             zz[len(zz) * 2 // 3] ^= 0x10
             assert ref.stream_decode(8, bytes(zz), len(d) + 10) == hip.stream_decode(8, bytes(zz), len(d) + 10), (i, lvl, "flip")
+    # ... and through the zip layer: mz_zip_entry_read hands every 65 535 bytes it read to mz_crypt_crc32_update, and in window
+    # mode those calls are answered from the CRCs the device computed of each window in exactly those pieces -- all but the
+    # reads that straddle two windows (a launch per 64 KiB call made a 3 GiB entry take 22 s)
+    import ctypes as C
+    import tempfile
+    import numpy as np
+    L = C.CDLL(os.path.join(ROOT, "tests", "emul", "_build_small", "libmockdrop.so"))
+    datas = [text[:450000] * 3, bytes(700000), text[:70000]]
+    blob = np.frombuffer(b"".join(datas), dtype=np.uint8)
+    lens = np.array([len(d) for d in datas], dtype=np.int32)
+    offs = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "w.zip")
+        ref.zip_write(path, blob, offs, lens, method=8, level=6)
+        table = ref.zip_index(path)
+        out = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        c0, s0 = L.mzmock_crc_host_calls(), L.mzmock_seg_calls()
+        _, crc, ulen, st = hip.zip_read_all(path, table[:, 6].copy(), nthreads=1, own_crc=False, out=out, out_off=offs)
+        assert (st == 0).all() and (ulen == lens).all() and out[:-1].tobytes() == blob.tobytes()   # st 0 = the zip layer's CRC check passed
+        launches, windows = L.mzmock_crc_host_calls() - c0, L.mzmock_seg_calls() - s0
+        reads = int(sum((int(n) + 65534) // 65535 for n in lens))
+        print("window mode through the zip layer: %d reads, %d windows, %d checksum launches" % (reads, windows, launches))
+        assert windows >= 8 and launches <= windows + 4 and launches < reads // 2, (launches, windows, reads)
