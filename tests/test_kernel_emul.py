@@ -654,3 +654,37 @@ def test_deflate_default_class_roundtrip(emu):
             tot["zlib9"] += len(zlib.compress(d, 9)) - 6
     assert tot["lazy"] < 0.92 * tot["fast"] and tot["lazy"] <= 0.32 * 6 * 65536, tot
     assert tot["best"] < 0.985 * tot["lazy"] and tot["best"] <= 1.04 * tot["zlib9"], tot
+
+
+def test_deflate_classes_fuzz(emu):
+    """Round trips of the lazy class and the cost parse (deflate_core.h, deflate_select.inc) over the shapes that break
+    parsers: every length around the step (64), the group (4) and the match limits (3, 4, 258, 259), runs, short periods,
+    two-symbol noise, incompressible bytes, blocks beyond 64 KiB, final and non-final pieces, small windows."""
+    import random
+
+    emu.emul_deflate_best.argtypes = emu.emul_deflate.argtypes
+    emu.emul_deflate_lazy.argtypes = emu.emul_deflate.argtypes
+    c = synth.corpus()
+    rnd = random.Random(20)
+    sizes = [0, 1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 66, 127, 128, 129, 255, 256, 257, 258, 259, 260, 511, 512, 513, 4095, 4096, 4097,
+             16383, 16384, 16385, 65535, 65536, 65537, 70001]
+    for it in range(72):
+        n = sizes[it % len(sizes)] if it < 2 * len(sizes) else rnd.randrange(1, 140000)
+        k = it % 6
+        if k == 0: d = c[rnd.randrange(len(c) - n):][:n]
+        elif k == 1: d = bytes(rnd.randrange(256) for _ in range(min(n, 6000)))
+        elif k == 2: d = bytes([rnd.randrange(3)]) * n
+        elif k == 3: d = (c[rnd.randrange(1000):][:rnd.randrange(1, 300)] * 2000)[:n]
+        elif k == 4: d = bytes(rnd.choice(b"ab") for _ in range(min(n, 20000)))
+        else: d = (bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 40))) * 70000)[:n]
+        emu.emul_deflate_window(rnd.choice([9, 12, 15, 15]))
+        a = np.frombuffer(d, dtype=np.uint8).copy() if d else np.zeros(1, np.uint8)
+        for name, fn in (("best", emu.emul_deflate_best), ("lazy", emu.emul_deflate_lazy)):
+            final = (it + (name == "lazy")) & 1
+            out = np.zeros(len(d) + len(d) // 8 + 1024, np.uint8)
+            ol, crc = C.c_uint32(), C.c_uint32()
+            st = fn(a.ctypes.data_as(_u8p), len(d), out.ctypes.data_as(_u8p), len(out), final, C.byref(ol), C.byref(crc))
+            z = out[:ol.value].tobytes()
+            back = zlib.decompress(z, -15) if final else zlib.decompressobj(-15).decompress(z)
+            assert st == 0 and back == d and crc.value == zlib.crc32(d), (it, name, final, len(d))
+    emu.emul_deflate_window(15)
