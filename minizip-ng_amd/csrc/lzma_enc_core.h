@@ -129,6 +129,22 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
         }
         PV(uint32_t, pkn);
         PV(uint32_t, pkn2);
+#ifndef MZ_LZE_INHERIT
+#define MZ_LZE_INHERIT 1
+#endif
+        if (MZ_LZE_INHERIT && ways > 1u) {
+            /* a match of length L at position q is a match of length L - k at q + k, same distance: a position whose own
+             * bucket had lost that candidate inherits it from the lanes 1 and 2 below (deflate_core.h does the same) */
+            for (uint32_t sh = 1u; sh <= 2u; sh <<= 1) {
+                PV(uint32_t, pin);
+                MZ_GATHER4(pin, pk, 4u * (((uint32_t)lane - sh) & 63u));
+                MZ_LANES {
+                    const uint32_t il = P(pin) & 511u;
+                    if ((uint32_t)lane >= sh && (uint32_t)lane < nv && il >= MZ_DEF_MINMATCH + sh && il - sh > (P(pk) & 511u))
+                        P(pk) = (il - sh) | (P(pin) & ~511u);
+                }
+            }
+        }
         MZ_GATHER4(pkn, pk, 4u * ((uint32_t)lane + 1u));
         MZ_GATHER4(pkn2, pk, 4u * ((uint32_t)lane + 2u));
         MZ_LANES {

@@ -118,6 +118,21 @@ def test_preset_selects_the_parse_class(gpu):
         sizes[preset] = tot
     assert sizes[0] == sizes[3] and sizes[4] == sizes[6] == sizes[9] == sizes[-1]
     assert sizes[6] < 0.95 * sizes[3]
+    # ratio bars against liblzma itself at preset 6.  One 64 KiB piece: the same history for both,
+    # what differs is the parse (liblzma prices every choice; K6 = four hash candidates + inheritance + lazy rule).
+    # A longer stream: K6 looks back 32 KiB across its 64 KiB blocks, liblzma over the whole stream (8 MiB dictionary):
+    # held against liblzma on the same 64 KiB pieces for the parse, against liblzma on the whole stream for the record.
+    def raw6(b):
+        return len(lzma.compress(b, format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA1, "preset": 6}]))
+    for d, bar in ((c[:65536], 1.15), (c[100000:300000], 1.12)):
+        cap = len(d) + len(d) // 8 + 4096
+        out = np.zeros(cap, dtype=np.uint8)
+        ol, crc = C.c_uint32(), C.c_uint32()
+        assert L.mzhip_lzma_encode_host_preset(d, len(d), 6, out.ctypes.data, cap, C.byref(ol), C.byref(crc)) == 0
+        pieces = sum(raw6(d[o:o + 65536]) for o in range(0, len(d), 65536))
+        print("LZMA preset 6, %d bytes: %d (liblzma on the same 64 KiB pieces: %d = x%.3f; on the whole stream: %d = x%.3f)"
+              % (len(d), ol.value, pieces, ol.value / pieces, raw6(d), ol.value / raw6(d)))
+        assert ol.value <= bar * pieces, (len(d), ol.value, pieces)
 
 
 @pytest.fixture(scope="module")
