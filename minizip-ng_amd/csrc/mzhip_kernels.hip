@@ -2214,7 +2214,9 @@ struct PrimeJob {
     double t_start = 0;
 };
 std::mutex g_worker_mu;
-std::vector<std::pair<std::thread, std::shared_ptr<PrimeJob>>> g_prime_workers;
+// (on the heap and never destroyed: a process that exits with a prime still running must not meet std::terminate in the
+// destructor of a joinable thread -- and the HIP runtime may be gone by the time static destructors run)
+auto &g_prime_workers = *new std::vector<std::pair<std::thread, std::shared_ptr<PrimeJob>>>();
 
 void prime_unpublish(const std::shared_ptr<PrimeGen> &gen) {
     std::unique_lock<std::shared_mutex> lk(g_prime_mu);
@@ -2426,13 +2428,21 @@ int64_t mzhip_prime_mem_begin(const uint8_t *zip, uint64_t zip_len) {
     const int64_t rc = prime_prepare(zip, zip_len, &d, 1, &job);
     if (rc <= 0) return rc;
     const int64_t n = (int64_t)job->gen->entries.size() + (int64_t)job->stores.size();
-    std::lock_guard<std::mutex> lk(g_worker_mu);
-    g_prime_workers.emplace_back(std::thread([job] {
-                                     (void)hipSetDevice(job->cur);
-                                     (void)mzhip_bind_thread_near_device(job->cur, 0); /* this thread feeds the copy engines: next to the device */
-                                     prime_run(job);
-                                 }),
-                                 job);
+    try {
+        std::lock_guard<std::mutex> lk(g_worker_mu);
+        g_prime_workers.emplace_back(std::thread([job] {
+                                         (void)hipSetDevice(job->cur);
+                                         (void)mzhip_bind_thread_near_device(job->cur, 0); /* this thread feeds the copy engines: next to the device */
+                                         prime_run(job);
+                                     }),
+                                     job);
+    } catch (...) { /* no thread to be had: the entries must not stay pending -- decode here and now */
+        prime_run(job);
+        if (job->result < 0) {
+            snprintf(g_err, sizeof(g_err), "%s", job->err.c_str());
+            return job->result;
+        }
+    }
     return n;
 }
 

@@ -390,7 +390,7 @@ static void stream_pieces_add(mzhip_zlib *z, int64_t g, int64_t nbytes, uint32_t
         const int32_t ncap = z->pc_n + (int32_t)nseg + 64;
         struct mzh_piece *np = (struct mzh_piece *)realloc(z->pc, (size_t)ncap * sizeof(z->pc[0]));
         if (!np) {
-            z->pc_n = 0; /* no pieces: the checksum calls take the ordinary path */
+            z->pc_n = z->pc_head = 0; /* no pieces: the checksum calls take the ordinary path */
             return;
         }
         z->pc = np;
