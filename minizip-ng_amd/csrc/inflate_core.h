@@ -648,10 +648,56 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
  * One step of a walk at window-relative bit `rel` (the same table walk as phase 1 of the step loop): the token that
  * starts there, or, when that is a literal of fewer than `room` bits, the literal (*pre = its table entry, else 0) and
  * the token behind it. */
+#ifndef MZ_TOKEN_SELECT
+#define MZ_TOKEN_SELECT 0 /* 1: the measurement variant below (selects instead of branches), not measured on the GPU yet */
+#endif
 MZ_DEV uint32_t mz_span_token3(const mz_inflate_lds *L, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t rel, uint32_t room,
                                uint32_t *pre) {
     /* d0, d1, d2 = the stream dword that holds bit `rel` (only rel & 31 is looked at) and the two behind it */
     uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
+#if MZ_TOKEN_SELECT
+    /* The same decode with SELECTS where the version below branches: with 64 lanes in a step, some lane takes every
+     * path of it almost every time, so the wave runs all of them anyway -- and pays 14 divergent branches per step for
+     * the privilege (285 instructions per step in the compiled walk loop, 57 s_cbranch_execz per trip of four steps;
+     * DESIGN 9).  Both table levels are read whether needed or not (index 0 of the second level when not), the second
+     * token is looked up whether the first was a literal or not (with nothing shifted out it is the first one again),
+     * the distance part is computed for every lane and kept for those that have a length.  Only the long distance
+     * codes (rare) stay behind a branch.  Two more LDS reads per step. */
+    {
+        const uint32_t m = (1u << MZ_LROOT) - 1u;
+        uint32_t e = L->lit_fast[w0 & m];
+        {
+            const uint32_t sub = (e & MZ_E_SUB) ? 1u : 0u;
+            const uint32_t es = L->lit_sub[sub ? ((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u) : 0u];
+            e = sub ? es : e;
+        }
+        const uint32_t islit = (MZ_SPAN_PRELIT && (e & (MZ_E_LEN | 0x80u)) == 0x80u && (e & 63u) < room) ? 1u : 0u;
+        const uint32_t n1 = islit ? (e & 63u) : 0u;
+        *pre = islit ? e : 0u;
+        const uint32_t v0 = mz_funnel(w1, w0, n1), v1 = w1 >> n1;
+        uint32_t f = L->lit_fast[v0 & m];
+        {
+            const uint32_t sub = (f & MZ_E_SUB) ? 1u : 0u;
+            const uint32_t fs = L->lit_sub[sub ? ((f >> 8) & 0x1FFu) + mz_bfe(v0, MZ_LROOT, f & 7u) : 0u];
+            f = sub ? fs : f;
+        }
+        const uint32_t haslen = (f & MZ_E_LEN) ? 1u : 0u;
+        const uint32_t nb = f & 63u, ex = mz_bfe(f, 16, 4);
+        const uint32_t lenl = mz_bfe(f, 7, 9) + mz_bfe(mz_funnel(v1, v0, nb), 0, ex);
+        const uint32_t nb2 = nb + ex;
+        const uint32_t dl = mz_funnel(v1, v0, nb2);
+        uint32_t dd = L->dist_fast[dl & ((1u << MZ_DROOT) - 1u)];
+        MZ_STAT(19, haslen);
+        if (haslen && dd == 0u) {
+            MZ_STAT(20, 1);
+            dd = mz_long_code(dl, MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
+        }
+        const uint32_t dn = dd & 15u, dex = mz_bfe(dd, 4, 4);
+        const uint32_t dist = mz_bfe(dd, 8, 15) + mz_bfe(dl, dn, dex);
+        const uint32_t tok = ((int32_t)dd <= 0) ? 0u : ((nb2 + dn + dex) | (lenl << 7) | (dist << 16));
+        return haslen ? tok : f;
+    }
+#endif
     uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
     if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
     /* A literal that does not end the lane's walk takes the token behind it along in the same step: the slowest

@@ -490,7 +490,8 @@ def emu_staged():
             _build_variant("c_caps", ["-DMZ_REC_CAP1=16u", "-DMZ_REC_CAP2=8u", "-DMZ_CHASE_SMAX=512u"]),
             _build_variant("c_short", ["-DMZ_CHASE_SMAX=128u", "-DMZ_REC_CAP2=4u", "-DMZ_EMIT_GROUP=2u"]),
             _build_variant("c_pool", ["-DMZ_POOL_BYTES=656u", "-DMZ_EMIT_GROUP=4u", "-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"]),
-            _build_variant("c_knobs", ["-DMZ_NEAR_SLOTS=2", "-DMZ_NEAR_FRONTIER=1", "-DMZ_CHASE_SMAX=1024u"])]
+            _build_variant("c_knobs", ["-DMZ_NEAR_SLOTS=2", "-DMZ_NEAR_FRONTIER=1", "-DMZ_CHASE_SMAX=1024u"]),
+            _build_variant("c_select", ["-DMZ_TOKEN_SELECT=1", "-DMZ_REC_CHUNKED=1"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
