@@ -1,4 +1,13 @@
-/* study: where K4's ratio gap to zlib-6 comes from.  Models the token choice of deflate_core.h (hash of 4 bytes, HB bits,
+/* Not part of the product or of the test suite.
+ *   python -c "import sys; sys.path.insert(0, '.'); from tests import synth; open('/tmp/corpus.bin','wb').write(bytes(synth.bench_corpus()[0]))"
+ *   gcc -O2 -o /tmp/enc_parse tests/study/enc_parse.c -lm && /tmp/enc_parse /tmp/corpus.bin [HB=12] [W=4] [MINM=4] [STEP=64]
+ *       [PARSE=0 greedy | 1 lazy (K4 levels 4-6) | 2 cost parse over the block (levels 7-9) | 3 cost-aware lazy heuristics]
+ *       [INTCOST=1 integer prices] [ITER=n] [SEQ=1 candidates of the own step visible] [INH=3 matches handed on] [HASH3=1]
+ * Round-3 results on 24 x 64 KiB of the bench corpus (entropy-priced, so ~1.5 % below the real streams): shipped r2 design
+ * 0.2961; +inheritance 0.2927; cost parse 0.2866 (integer prices, one iteration); 8 ways at 11 hash bits 0.2908 (with cost
+ * parse 0.2831); candidates 16 positions at a time 0.2932; zlib's own matcher depth (32 ways, 15 bits) 0.2797; zlib-6: 0.2823.
+ *
+ * study: where K4's ratio gap to zlib-6 comes from.  Models the token choice of deflate_core.h (hash of 4 bytes, HB bits,
  * W ways, candidates looked up for 64 positions at once BEFORE those positions are inserted, lazy rules) and variants; the
  * cost of a parse = entropy of its symbols (dynamic Huffman, one block per 64 KiB) + extra bits + a 60-byte header. */
 #include <math.h>
