@@ -172,7 +172,9 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_NEAR_BATCHED 0 /* near copies whose source ends in front of the destination issue all loads first */
 #endif
 #ifndef MZ_SPAN_PRELIT
-#define MZ_SPAN_PRELIT 1 /* a walk step takes a leading literal and the token behind it (0: one token per step) */
+#define MZ_SPAN_PRELIT 1 /* a walk step takes a leading literal and the token behind it (0: one token per step; 2: up to two
+                           leading literals -- chase window only, not timed on the GPU yet: 160 -> 135 steps for the slowest
+                           lane of a 64 KiB entry's window, tests/study/span_multi.c) */
 #endif
 #ifndef MZ_ABLATE
 #define MZ_ABLATE 0 /* measurement builds only (wrong output): 1 no match copies, 2 no far loads, 4 no CRC, 8 no store */
@@ -648,6 +650,8 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
  * One step of a walk at window-relative bit `rel` (the same table walk as phase 1 of the step loop): the token that
  * starts there, or, when that is a literal of fewer than `room` bits, the literal (*pre = its table entry, else 0) and
  * the token behind it. */
+/* bytes in front of a step's token: what its leading literal(s) produce (`pre` as mz_span_token3 returns it) */
+#define MZ_PRE_COUNT(pr) ((pr) ? 1u + ((MZ_SPAN_PRELIT >= 2) ? (((pr) >> 6) & 1u) : 0u) : 0u)
 #ifndef MZ_TOKEN_SELECT
 #define MZ_TOKEN_SELECT 0 /* 1: the measurement variant below (selects instead of branches), not measured on the GPU yet */
 #endif
@@ -655,7 +659,7 @@ MZ_DEV uint32_t mz_span_token3(const mz_inflate_lds *L, uint32_t d0, uint32_t d1
                                uint32_t *pre) {
     /* d0, d1, d2 = the stream dword that holds bit `rel` (only rel & 31 is looked at) and the two behind it */
     uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
-#if MZ_TOKEN_SELECT
+#if MZ_TOKEN_SELECT && MZ_SPAN_PRELIT < 2
     /* The same decode with SELECTS where the version below branches: with 64 lanes in a step, some lane takes every
      * path of it almost every time, so the wave runs all of them anyway -- and pays 14 divergent branches per step for
      * the privilege (285 instructions per step in the compiled walk loop, 57 s_cbranch_execz per trip of four steps;
@@ -712,6 +716,18 @@ MZ_DEV uint32_t mz_span_token3(const mz_inflate_lds *L, uint32_t d0, uint32_t d1
         w1 >>= n1;
         e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
         if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
+#if MZ_SPAN_PRELIT >= 2
+        /* ... and a second one, when the two codes are 16 bits at most (the 64 bits then still hold the longest token
+         * behind them): *pre = bits of both | 0x80 | 0x40 | first byte << 16 | second byte << 24 (MZ_PRE_COUNT) */
+        if ((e & (MZ_E_LEN | 0x80u)) == 0x80u && n1 + (e & 63u) <= 16u && n1 + (e & 63u) < room) {
+            const uint32_t n2 = e & 63u;
+            p = (n1 + n2) | 0xC0u | (p & 0x00FF0000u) | ((e & 0x00FF0000u) << 8);
+            w0 = mz_funnel(w1, w0, n2);
+            w1 >>= n2;
+            e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
+            if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
+        }
+#endif
     }
     *pre = p;
     if (!(e & MZ_E_LEN)) return e; /* literal, end of block, or an invalid code (0 bits) */

@@ -491,7 +491,8 @@ def emu_staged():
             _build_variant("c_short", ["-DMZ_CHASE_SMAX=128u", "-DMZ_REC_CAP2=4u", "-DMZ_EMIT_GROUP=2u"]),
             _build_variant("c_pool", ["-DMZ_POOL_BYTES=656u", "-DMZ_EMIT_GROUP=4u", "-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"]),
             _build_variant("c_knobs", ["-DMZ_NEAR_SLOTS=2", "-DMZ_NEAR_FRONTIER=1", "-DMZ_CHASE_SMAX=1024u"]),
-            _build_variant("c_select", ["-DMZ_TOKEN_SELECT=1", "-DMZ_REC_CHUNKED=1"])]
+            _build_variant("c_select", ["-DMZ_TOKEN_SELECT=1", "-DMZ_REC_CHUNKED=1"]),
+            _build_variant("c_prelit2", ["-DMZ_SPAN_PRELIT=2"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
