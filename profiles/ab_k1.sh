@@ -5,7 +5,10 @@
 # Variants: "<tag> <make variables>".  The .so files are git-ignored but travel with the gpurun snapshot.
 set -u
 VARIANTS=(
-  "flat EXTRA=-DMZ_REC_CHUNKED=0"
+  "base"
+  "sel EXTRA=-DMZ_TOKEN_SELECT=1"
+  "pre2 PRELIT=2"
+  "chunked EXTRA=-DMZ_REC_CHUNKED=1"
 )
 root=$(cd "$(dirname "$0")/.." && pwd)
 mode=${1:-run}
