@@ -31,23 +31,23 @@ def main():
     start = next(i for i, l in enumerate(text) if re.match(r"^_Z\d+%s\w*:" % re.escape(kernel), l))
     end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
     body = text[start:end + 1]
-    # loops: a header comment "=> This (Inner) Loop Header: Depth=N" opens a loop at its label; the loop ends at the last
-    # backward branch to that label
-    labels = {}
-    for i, l in enumerate(body):
-        m = re.match(r"^(\.LBB\d+_\d+):", l)
-        if m:
-            labels[m.group(1)] = i
+    # loops: a header comment "=> This (Inner) Loop Header: Depth=N" follows the loop's label; every other block of the loop
+    # (and of the loops inside it) is annotated "in Loop: Header=BBx_y" / "Parent Loop BBx_y": the loop runs from its
+    # label to the end of the last block that names it
+    label_at = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
     loops = []
     for i, l in enumerate(body):
         m = re.search(r"Loop Header: Depth=(\d+)", l)
         if not m:
             continue
-        lab_i = max(j for j in labels.values() if j <= i)
-        lab = next(k for k, v in labels.items() if v == lab_i)
-        last = max((j for j, t in enumerate(body) if j > lab_i and re.search(r"s_cbranch\w*\s+%s\b" % re.escape(lab), t)), default=None)
-        if last is not None:
-            loops.append((lab, int(m.group(1)), lab_i, last))
+        lab_i = max(j for j in label_at if j <= i)
+        lab = re.match(r"^\.(LBB\d+_\d+):", body[lab_i]).group(1)[1:]  # "BB0_898"
+        named = [j for j, t in enumerate(body) if j > lab_i and re.search(r"(Header=|Parent Loop )%s\b" % re.escape(lab), t)]
+        if not named:
+            continue
+        last_block = max(j for j in label_at if j <= max(named))
+        nxt = [j for j in label_at if j > last_block]
+        loops.append(("." + "L" + lab, int(m.group(1)), lab_i, (nxt[0] - 1) if nxt else len(body) - 1))
 
     def is_op(t):
         t = t.strip()
