@@ -173,8 +173,8 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #endif
 #ifndef MZ_SPAN_PRELIT
 #define MZ_SPAN_PRELIT 1 /* a walk step takes a leading literal and the token behind it (0: one token per step; 2: up to two
-                           leading literals -- chase window only, not timed on the GPU yet: 160 -> 135 steps for the slowest
-                           lane of a 64 KiB entry's window, tests/study/span_multi.c) */
+                           leading literals -- chase window only: 160 -> 128 steps for the slowest lane of a 64 KiB entry's
+                           window, and 2 % slower on the GPU, profiles/r3/ab_token_variants.log) */
 #endif
 #ifndef MZ_ABLATE
 #define MZ_ABLATE 0 /* measurement builds only (wrong output): 1 no match copies, 2 no far loads, 4 no CRC, 8 no store */
@@ -653,7 +653,7 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
 /* bytes in front of a step's token: what its leading literal(s) produce (`pre` as mz_span_token3 returns it) */
 #define MZ_PRE_COUNT(pr) ((pr) ? 1u + ((MZ_SPAN_PRELIT >= 2) ? (((pr) >> 6) & 1u) : 0u) : 0u)
 #ifndef MZ_TOKEN_SELECT
-#define MZ_TOKEN_SELECT 0 /* 1: the measurement variant below (selects instead of branches), not measured on the GPU yet */
+#define MZ_TOKEN_SELECT 0 /* 1: the measurement variant below (selects instead of branches): no gain on the GPU, profiles/r3/ab_token_variants.log */
 #endif
 MZ_DEV uint32_t mz_span_token3(const mz_inflate_lds *L, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t rel, uint32_t room,
                                uint32_t *pre) {
