@@ -286,6 +286,13 @@ MZHIP_API int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, co
 /* bounds[0 .. world]: slice r = entries [bounds[r], bounds[r+1]) of an mzhip_zip_index_mem table (8 x int64 per entry) */
 MZHIP_API void mzhip_shard_bounds(const int64_t *table, int64_t n, int32_t world, int64_t *bounds);
 MZHIP_API void mzhip_prime_clear(void);
+
+/* Memory bound of the drop-in READ streams (shim_zlib.c window mode; the reference stages any entry through 32 767 bytes,
+ * mz_strm_zlib.c:51,116-193): an entry whose decoded size passes `window_bytes` is decoded window by window with
+ * `gulp_bytes` of compressed input pulled ahead of each launch.  Defaults 64 MiB / 16 MiB (or MZHIP_STREAM_WINDOW /
+ * MZHIP_STREAM_GULP in the environment); floors 128 KiB / 32 KiB; 0 = back to the default.  Applies to streams opened
+ * afterwards. */
+MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes);
 MZHIP_API void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
 
 /* Write-side prime (SURVEY 8b "Batching", BASELINE config 5) ------------------------------- */

@@ -40,6 +40,7 @@ typedef struct {
                              /* that all of them read what the decode pipeline delivered first (progressive prime) */
     int64_t ok, bytes;
     int32_t err;
+    int32_t started; /* the job runs on a thread of its own (to be joined) */
     double t_goto, t_open, t_read, t_close; /* MZDROP_TRACE: where a thread's time goes */
 } xt_job;
 
@@ -193,14 +194,15 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
         jobs[t].table = table;
         jobs[t].n = n;
         jobs[t].next = &next;
-        if (nthreads == 1) xt_run(&jobs[t]);
-        else pthread_create(&th[t], NULL, xt_run, &jobs[t]);
+        jobs[t].started = 0;
+        if (nthreads > 1 && pthread_create(&th[t], NULL, xt_run, &jobs[t]) == 0) jobs[t].started = 1;
+        else xt_run(&jobs[t]); /* one thread, or a thread that could not be created: the caller's thread does the job */
     }
     int64_t ok = 0, by = 0;
     int32_t err = MZ_OK;
     double tg = 0, to = 0, tr = 0, tc = 0;
     for (int32_t t = 0; t < nthreads; t++) {
-        if (nthreads > 1) pthread_join(th[t], NULL);
+        if (jobs[t].started) pthread_join(th[t], NULL);
         ok += jobs[t].ok;
         by += jobs[t].bytes;
         if (err == MZ_OK) err = jobs[t].err;
@@ -221,7 +223,9 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
                 tg / nthreads * 1e3, to / nthreads * 1e3, tr / nthreads * 1e3, tc / nthreads * 1e3);
     /* every entry is read and verified: what is left is giving memory back.  Unmapping 75 000 populated pages of a 300 MB
      * archive costs the kernel ~12 ms (profiles/r3/threads_trace.log) -- a detached thread does it, the caller has its answer */
-    xt_release *rel = (xt_release *)malloc(sizeof(xt_release));
+    /* ... but ONLY when MZDROP_ASYNC_RELEASE is set: the CPU baseline it is compared with (mz_driver.c drv_zip_read_all)
+     * unmaps inside its clock, so by default this function does too (the two sides are timed the same way) */
+    xt_release *rel = getenv("MZDROP_ASYNC_RELEASE") ? (xt_release *)malloc(sizeof(xt_release)) : NULL;
     if (rel) {
         rel->img = (void *)img;
         rel->len = (size_t)sb.st_size;

@@ -110,6 +110,33 @@ DRV_EXPORT int32_t drv_stream_decode(int32_t method, const uint8_t *in, int32_t 
     return n_rets;
 }
 
+/* A stream that is deleted WITHOUT close() after `nreads` read() calls of `chunk` bytes: legal in the reference
+ * (mz_strm_zlib.c:364-371 frees the struct; zlib's state leaks) and must not corrupt the heap in the drop-in
+ * (the window-mode piece tables were freed twice).  Returns the bytes read. */
+DRV_EXPORT int32_t drv_stream_delete_unclosed(int32_t method, const uint8_t *in, int32_t in_len, uint8_t *out,
+                                              int32_t out_cap, int32_t chunk, int32_t nreads) {
+    void *mem = mz_stream_mem_create();
+    void *codec = codec_create(method);
+    int32_t produced = 0;
+    if (!mem || !codec)
+        return MZ_MEM_ERROR;
+    mz_stream_mem_set_buffer(mem, (void *)(intptr_t)in, in_len);
+    mz_stream_open(mem, NULL, MZ_OPEN_MODE_READ);
+    mz_stream_set_base(codec, mem);
+    if (mz_stream_open(codec, NULL, MZ_OPEN_MODE_READ) == MZ_OK) {
+        for (int32_t k = 0; k < nreads && produced < out_cap; k++) {
+            int32_t want = chunk < out_cap - produced ? chunk : out_cap - produced;
+            int32_t r = mz_stream_read(codec, out + produced, want);
+            if (r <= 0)
+                break;
+            produced += r;
+        }
+    }
+    mz_stream_delete(&codec); /* no close() */
+    mz_stream_mem_delete(&mem);
+    return produced;
+}
+
 /* Encode `in` through the codec stream into a growable memory stream using
  * `chunk`-byte write() calls (mz_zip.c:2062).  Returns compressed length or <0.
  * info[0]=TOTAL_IN info[1]=TOTAL_OUT info[2]=close() info[3]=error() info[5]=open() */

@@ -115,16 +115,17 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #ifndef MZ_REC_CAP2
 #define MZ_REC_CAP2 160u    /* ... and while chasing into the next one(s) (a multiple of 4): 0.04 % of the chases on text are longer than 128 */
 #endif
-#define MZ_REC_AREA(cap_) ((((cap_) / 2u + 3u) / 4u) * 4096u) /* pairs in chunks of four (inflate_chase.inc MZ_REC_ADDR) */
-#define MZ_REC_BYTES (MZ_REC_AREA(MZ_REC_CAP1) + MZ_REC_AREA(MZ_REC_CAP2) + 64u * MZ_REC_CAP1 + 1024u) /* HBM scratch per wave: records + a byte per own step */
-#define MZ_CRING_DW 12u
-#define MZ_CRING_RS 15u /* row stride: 12 + 2 mirrored, odd */
+#define MZ_REC_AREA(cap_) (((cap_) / 4u) * 1024u) /* records: 4 bytes a step, four steps of a lane = one 16-byte quad, [quad][lane] (inflate_chase.inc MZ_REC_ADDR) */
+#define MZ_REC_BYTES (MZ_REC_AREA(MZ_REC_CAP1) + MZ_REC_AREA(MZ_REC_CAP2) + 64u * MZ_REC_CAP1 + 64u * MZ_REC_CAP2 + 1024u) /* HBM scratch per wave: records + a byte per step */
+#define MZ_REC_ADDR(quad_, lane_) ((((quad_) * 64u) + (lane_)) << 4) /* where the quad lives inside its area */
+#define MZ_CRING_DW 16u /* a power of two: the slot of a stream dword is its index & 15, nothing to keep track of */
+#define MZ_CRING_RS 19u /* row stride: 16 + 2 mirrored, odd */
 #ifndef MZ_EMIT_GROUP
-#define MZ_EMIT_GROUP 8u /* records one lane turns into bytes per emit round (a multiple of 2: records are stored in pairs) */
+#define MZ_EMIT_GROUP 8u /* records one lane turns into bytes per emit round (4 or 8: records are stored in quads) */
 #endif
 #ifndef MZ_POOL_BYTES
 #if MZ_WINDOW_CHASE
-#define MZ_POOL_BYTES 2288u /* what the rings leave of the 9984 bytes a wave may have at 16 waves per CU */
+#define MZ_POOL_BYTES 1264u /* what the rings leave of the 9984 bytes a wave may have at 16 waves per CU */
 #else
 #define MZ_POOL_BYTES 3264u
 #endif
@@ -752,6 +753,53 @@ MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *wrow, uin
     const uint32_t a = rel >> 5;
     return mz_span_token3(L, wrow[a], wrow[a + 1u], wrow[a + 2u], rel, room, pre);
 }
+/* One step of a chase-window walk (inflate_chase.inc) as its RECORD: the same table walk as mz_span_token3 with one
+ * leading literal, but what comes out is what the emit needs and nothing else, in five bytes instead of eight:
+ *   *rec  [7:0] the leading literal and [31] "there is one"; [15:8] the token's literal byte, or match length - 3;
+ *         [30:16] match distance - 1
+ *   K     (returned) [5:0] bits of the whole step, 1 .. 63 (leading literal <= 15, token <= 48); 0 = no valid step starts
+ *         here (an unused or invalid code: the leading literal stays undecoded too); [7:6] the token: 0 match, 1 literal,
+ *         2 end of block */
+#define MZ_K_LIT 0x40u
+#define MZ_K_EOB 0x80u
+MZ_DEV uint32_t mz_chase_step(const mz_inflate_lds *L, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t rel, uint32_t room,
+                              uint32_t *rec) {
+    uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
+    uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
+    if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
+    uint32_t r = 0, pb = 0;
+    if ((e & (MZ_E_LEN | 0x80u)) == 0x80u && (e & 63u) < room) { /* a literal that does not end the lane's walk takes the token behind it along */
+        pb = e & 63u;
+        r = 0x80000000u | mz_bfe(e, 16, 8);
+        w0 = mz_funnel(w1, w0, pb);
+        w1 >>= pb;
+        e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
+        if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
+    }
+    if (!(e & MZ_E_LEN)) { /* a literal (0x80 | byte << 16 | bits), the end of the block (0x40 | bits), or nothing valid (no bits) */
+        const uint32_t nb = e & 63u;
+        *rec = r | ((e >> 8) & 0xFF00u);
+        return nb ? ((nb + pb) | ((e & 0x80u) ? MZ_K_LIT : MZ_K_EOB)) : 0u;
+    }
+    const uint32_t nb = e & 63u, ex = mz_bfe(e, 16, 4);
+    const uint32_t lenl = mz_bfe(e, 7, 9) + mz_bfe(mz_funnel(w1, w0, nb), 0, ex);
+    const uint32_t nb2 = nb + ex;
+    const uint32_t dl = mz_funnel(w1, w0, nb2);
+    uint32_t dd = L->dist_fast[dl & ((1u << MZ_DROOT) - 1u)];
+    MZ_STAT(19, 1);
+    if (dd == 0u) {
+        MZ_STAT(20, 1);
+        dd = mz_long_code(dl, MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
+    }
+    if ((int32_t)dd <= 0) { /* unused / 30 / 31 distance code */
+        *rec = 0u;
+        return 0u;
+    }
+    const uint32_t dn = dd & 15u, dex = mz_bfe(dd, 4, 4);
+    const uint32_t dist = mz_bfe(dd, 8, 15) + mz_bfe(dl, dn, dex);
+    *rec = r | ((lenl - 3u) << 8) | ((dist - 1u) << 16);
+    return nb2 + dn + dex + pb;
+}
 /* dwords d .. d + 3 of the aligned stream (see mz_load_stream_dword), bytes outside the input read as zero */
 typedef struct { uint32_t v[4]; } mz_dw4;
 MZ_DEV mz_dw4 mz_load_stream_dw4(const uint8_t *in_al, uint32_t in_mis, uint32_t in_len, uint32_t d) {
@@ -767,6 +815,10 @@ MZ_DEV mz_dw4 mz_load_stream_dw4(const uint8_t *in_al, uint32_t in_mis, uint32_t
 }
 #endif
 
+
+#if MZ_SPAN_DW && MZ_WINDOW_CHASE
+#include "inflate_walk.inc"
+#endif
 
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out, uint32_t out_cap,

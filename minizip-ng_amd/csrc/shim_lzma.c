@@ -165,8 +165,13 @@ static int32_t pull_chunk(mzhip_lzma *z) {
     /* the first pull of a stream that may be served from a primed archive asks for no more than the bytes the lookup
      * compares (the size of a pull is not observable: the zip layer positions the base stream itself, mz_zip.c:1713);
      * a primed 64 KiB entry costs a 256-byte copy instead of 32 KiB, and the pages behind it are never touched */
-    if (z->in_len == 0 && !z->tried_cache && mzhip_prime_any())
+    if ((z->in_len == 0 || (z->method == MZH_COMPRESS_METHOD_LZMA && z->in_len == LZMA_MAGIC_SIZE + 5)) && !z->tried_cache && mzhip_prime_any())
         want = 256;
+    /* method 14: the reference first asks for exactly what is missing of the 5 header bytes behind the magic
+     * (mz_strm_lzma.c:181-183) and hands them to liblzma before it reads on: a properties byte that is refused leaves the
+     * base stream at 9 bytes */
+    if (z->method == MZH_COMPRESS_METHOD_LZMA && z->in_len < LZMA_MAGIC_SIZE + 5)
+        want = (int32_t)(LZMA_MAGIC_SIZE + 5 - z->in_len);
     if (z->max_total_in > 0) {
         int64_t left = z->max_total_in - z->in_len;
         if (left < want)
@@ -237,6 +242,17 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
             z->base_err = rd;
             z->base_eof = 1;
         }
+        if (z->method == MZH_COMPRESS_METHOD_LZMA && z->in_len == LZMA_MAGIC_SIZE + 5 && !z->base_eof) {
+            const uint32_t d = z->in[4];
+            if (d >= 9 * 5 * 5 || (d % 9) + ((d / 9) % 5) > 4) { /* refused by lzma_alone_decoder: nothing more is read */
+                z->dev_status = MZHIP_STATUS_DATA_ERROR;
+                z->out_len = 0;
+                z->dev_in_used = z->in_len;
+                z->decoded = 1;
+                break;
+            }
+            continue; /* (the header alone decides nothing else: pull the stream) */
+        }
         if (!z->tried_cache) {
             /* was this entry decoded by mzhip_prime_*()?  (payload offset + first payload bytes must agree) */
             z->tried_cache = 1;
@@ -272,6 +288,16 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         z->error = z->dev_status == MZHIP_STATUS_BUF_ERROR ? 10 : 9; /* LZMA_BUF_ERROR : LZMA_DATA_ERROR */
         z->total_in = z->dev_in_used;
         z->total_out = z->out_len;
+        if (z->method == MZH_COMPRESS_METHOD_LZMA && z->in_len >= 5 && z->out_len == 0) {
+            /* a properties byte lzma_alone_decoder refuses: LZMA_FORMAT_ERROR before a byte is consumed.  The reference's
+             * accounting then shows its header trick (mz_strm_lzma.c:197-205): with the 5 header bytes in hand it has
+             * already taken the 8 bytes of the size field it appends off TOTAL_IN -> 4 - 8 = -4; with fewer, 4 */
+            const uint32_t d = z->in[4];
+            if (d >= 9 * 5 * 5 || (d % 9) + ((d / 9) % 5) > 4) {
+                z->error = 7; /* LZMA_FORMAT_ERROR */
+                z->total_in = z->in_len >= 9 ? -4 : 4;
+            }
+        }
         if (z->base_err != 0 && z->dev_status == MZHIP_STATUS_BUF_ERROR)
             return z->base_err;
         return MZH_DATA_ERROR;

@@ -359,6 +359,32 @@ static int32_t parse_wrapper_header(mzhip_zlib *z) {
 #ifndef MZH_STREAM_GULP
 #define MZH_STREAM_GULP (16 << 20) /* compressed bytes pulled ahead of a window's launch */
 #endif
+/* The two sizes are the defaults of a run-time knob (mzhip_set_stream_window(), or MZHIP_STREAM_WINDOW / MZHIP_STREAM_GULP
+ * in the environment of the first stream that asks): the memory bound of one READ stream is window + gulp + one block.
+ * Small values are what the GPU tests use to cross many windows with streams of a few hundred KiB. */
+static int64_t mzh_win_bytes, mzh_gulp_bytes; /* 0 = not decided yet */
+static int64_t mzh_env_bytes(const char *name, int64_t dflt, int64_t floor) {
+    const char *e = getenv(name);
+    int64_t v = e ? strtoll(e, NULL, 0) : 0;
+    if (v <= 0)
+        v = dflt;
+    return v < floor ? floor : v;
+}
+MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes) {
+    /* a window holds at least the 32 KiB history plus something to decode into; 0 = back to the default / environment */
+    mzh_win_bytes = window_bytes > 0 ? (window_bytes < (128 << 10) ? (128 << 10) : window_bytes) : 0;
+    mzh_gulp_bytes = gulp_bytes > 0 ? (gulp_bytes < (32 << 10) ? (32 << 10) : gulp_bytes) : 0;
+}
+static int64_t mzh_stream_window(void) {
+    if (!mzh_win_bytes)
+        mzh_win_bytes = mzh_env_bytes("MZHIP_STREAM_WINDOW", MZH_STREAM_WINDOW, 128 << 10);
+    return mzh_win_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : mzh_win_bytes;
+}
+static int64_t mzh_stream_gulp(void) {
+    if (!mzh_gulp_bytes)
+        mzh_gulp_bytes = mzh_env_bytes("MZHIP_STREAM_GULP", MZH_STREAM_GULP, 32 << 10);
+    return mzh_gulp_bytes;
+}
 
 static int32_t stream_drop_input(mzhip_zlib *z) {
     /* everything in front of the current block's header is done with (dword granular: the device addresses dwords) */
@@ -457,7 +483,7 @@ static int32_t stream_next(mzhip_zlib *z) {
     }
     for (;;) {
         /* compressed bytes for about a window: pull ahead (each pull <= 32767 bytes like the reference's) */
-        while (!z->base_eof && z->in_len < MZH_STREAM_GULP) {
+        while (!z->base_eof && z->in_len < mzh_stream_gulp()) {
             const int32_t rd = pull_chunk(z);
             if (rd < 0) {
                 if (z->in_len == 0)
@@ -535,7 +561,7 @@ static int32_t stream_next(mzhip_zlib *z) {
             continue;
         }
         /* input ended inside the window and the base stream has more: go on with it (what was decoded so far stays) */
-        if (z->in_len >= MZH_STREAM_GULP) { /* a single block larger than the gulp: let the input buffer grow */
+        if (z->in_len >= mzh_stream_gulp()) { /* a single block larger than the gulp: let the input buffer grow */
             int tries = 0;
             while (!z->base_eof && tries++ < 512) {
                 const int32_t rd = pull_chunk(z);
@@ -571,7 +597,7 @@ static int32_t attempt_decode(mzhip_zlib *z) {
         int32_t st = mzhip_inflate_host2(z->in + z->hdr_len, (uint32_t)(z->in_len - z->hdr_len), z->out,
                                          (uint32_t)z->out_cap, &out_len, &in_used, &z->out_crc,
                                          z->wrap == 1 ? &z->out_adler : NULL);
-        if (st == MZHIP_STATUS_OUT_FULL && z->wrap == 0 && z->out_cap >= MZH_STREAM_WINDOW) {
+        if (st == MZHIP_STATUS_OUT_FULL && z->wrap == 0 && z->out_cap >= mzh_stream_window()) {
             /* more than a window of output: from here on the entry is decoded window by window.  The first window once
              * more, this time asking where it stops */
             z->streaming = 1;
@@ -588,8 +614,8 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
             int64_t ncap = z->out_cap * 4;
-            if (z->wrap == 0 && ncap > MZH_STREAM_WINDOW)
-                ncap = MZH_STREAM_WINDOW;
+            if (z->wrap == 0 && ncap > mzh_stream_window())
+                ncap = mzh_stream_window();
             if (ncap > 0x7FFFFFFF)
                 ncap = 0x7FFFFFFF;
             free(z->out);
@@ -1025,20 +1051,7 @@ void mz_stream_zlib_delete(void **stream) {
         return;
     z = (mzhip_zlib *)*stream;
     if (z) {
-        free(z->in);
-        free(z->pc);
-        free(z->pc_tmp);
-    free(z->pc);
-    free(z->pc_tmp);
-    z->pc = NULL;
-    z->pc_tmp = NULL;
-    z->pc_n = z->pc_cap = z->pc_head = z->pc_tmp_cap = 0;
-    z->g0 = 0;
-        if (!z->out_borrowed)
-            free(z->out);
-        mzhip_prime_unpin(z->prime_pin);
-        z->prime_pin = NULL;
-        free(z->wbuf);
+        free_buffers(z); /* delete without close is legal (the reference only leaks there): every buffer once, pins dropped */
         free(z);
     }
     *stream = NULL;

@@ -33,6 +33,13 @@
 #define MZ_LANES for (int lane = 0; lane < 64; ++lane)
 #define PV(type, name) type name[64]
 #define PV2(type, name, n) type name[64][n] /* small per-lane array */
+#define MZ_DEV_NOINLINE static
+typedef uintptr_t mz_lds_handle;
+typedef uintptr_t mz_glb_handle;
+#define MZ_LDS_HANDLE(p) ((uintptr_t)(p))
+#define MZ_GLB_HANDLE(p) ((uintptr_t)(p))
+#define MZ_LDS_FROM(T, h) ((T *)(h))
+#define MZ_GLB_FROM(T, h) ((T *)(h))
 #define P(name) name[lane]
 #define MZ_READLANE(name, idx) (name[(idx)])
 #define MZ_WRITELANE(name, idx, val) (name[(idx)] = (val)) /* one wave-uniform value into lane idx */
@@ -121,6 +128,16 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
 #define MZ_LANES
 #define PV(type, name) type name
 #define PV2(type, name, n) type name[n]
+/* a function that is NOT inlined gets generic pointers and would address LDS and global memory through flat
+ * instructions; so pointers cross the call as integers and are re-made inside in their real address space
+ * (infer-address-spaces then rewrites every use) */
+#define MZ_DEV_NOINLINE __device__ __attribute__((noinline))
+typedef uint32_t mz_lds_handle; /* an LDS address is 32 bits */
+typedef uint64_t mz_glb_handle;
+#define MZ_LDS_HANDLE(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(p))
+#define MZ_GLB_HANDLE(p) ((uint64_t)(uintptr_t)(p))
+#define MZ_LDS_FROM(T, h) ((T *)(__attribute__((address_space(3))) T *)(h))
+#define MZ_GLB_FROM(T, h) ((T *)(__attribute__((address_space(1))) T *)(h))
 #define P(name) name
 #define MZ_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
 #define MZ_WRITELANE(name, idx, val) ((name) = ((uint32_t)lane == (uint32_t)(idx)) ? (uint32_t)(val) : (name)) /* a select, not a branch */

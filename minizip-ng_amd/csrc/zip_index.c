@@ -7,7 +7,7 @@
  * this is the "next" row f1 of SURVEY 8(f), restated as one pass over a memory image of the archive.
  * Format: doc/zip/appnote.txt sections 4.3.7 (local header), 4.3.12 (central header), 4.3.14-4.3.16
  * (ZIP64 end records / locator / end record), 4.5.3 (ZIP64 extended information extra field).
- * Row layout (8 x int64) equals oracle/mz_driver.c drv_zip_index, which walks the archive with the
+ * Row layout (8 x int64) equals integration/mz_driver.c drv_zip_index, which walks the archive with the
  * reference's own API -- tests/test_zip_index.py compares the two row for row.
  */
 #include <string.h>

@@ -4,7 +4,7 @@ Two checkers live here:
 
 * ``liboracle``  -- this repo's CPU restatement (oracle/crc32.c, inflate.c, lzma_dec.c).
 * ``libmzref``   -- the unmodified reference compiled from /root/reference together with
-  oracle/mz_driver.c (zlib 1.2.11 + liblzma 5.2.5 behind mz_strm_zlib.c / mz_strm_lzma.c /
+  integration/mz_driver.c (zlib 1.2.11 + liblzma 5.2.5 behind mz_strm_zlib.c / mz_strm_lzma.c /
   mz_crypt.c).  Built by oracle/Makefile in the build container; travels to the GPU box as
   a prebuilt file under oracle/_ref/.
 
@@ -124,7 +124,7 @@ def lzma_zip_decode(data, out_cap, max_out=-1):
 
 
 class MzDriver:
-    """Binding of the drv_* entry points of oracle/mz_driver.c.  The same class binds
+    """Binding of the drv_* entry points of integration/mz_driver.c.  The same class binds
     oracle/_ref/libmzref.so (reference codecs) and integration/_build/libmzhipdrop.so
     (reference zip layer + HIP codecs): identical signatures, comparable results."""
 
@@ -166,6 +166,13 @@ class MzDriver:
         produced = sum(r for r in rl if r > 0)
         return dict(rets=rl, out=out[:produced].tobytes(), total_in=int(info[0]), total_out=int(info[1]),
                     close=int(info[2]), error=int(info[3]), base_pos=int(info[4]), open=int(info[5]))
+
+    def stream_delete_unclosed(self, method, data, out_cap, chunk=65535, nreads=4):
+        """read() a few chunks, then delete() the codec stream without close(): -> the bytes read"""
+        a = _as_u8(data)
+        out = np.zeros(max(out_cap, 1), dtype=np.uint8)
+        n = self.L.drv_stream_delete_unclosed(method, _ptr(a), a.size, _ptr(out), out_cap, chunk, nreads)
+        return out[:max(n, 0)].tobytes()
 
     def stream_encode(self, method, data, level=6, chunk=65535, window_bits=0):
         a = _as_u8(data)

@@ -1,6 +1,6 @@
 """GPU tests of the DROP-IN boundary: the reference's own mz_zip.c / mz_zip_rw.c / mz_strm*.c, compiled
 unmodified and linked against libmzhip.so instead of mz_strm_zlib.o / mz_strm_lzma.o / the CRC symbol
-(integration/_build/libmzhipdrop.so), are driven through the same oracle/mz_driver.c entry points as the
+(integration/_build/libmzhipdrop.so), are driven through the same integration/mz_driver.c entry points as the
 all-reference build (oracle/_ref/libmzref.so).  Every read() return value, TOTAL_IN/TOTAL_OUT, close() and
 error() code and every output byte must agree."""
 import os
@@ -67,6 +67,135 @@ def test_zlib_stream_error_parity(libs):
     a = hip.stream_decode(8, z, len(data) + 64, max_in=len(z) // 2)
     b = ref.stream_decode(8, z, len(data) + 64, max_in=len(z) // 2)
     assert (a["rets"], a["close"], a["error"]) == (b["rets"], b["close"], b["error"]) == ([-5], -112, -5)
+
+
+ALL = ("rets", "out", "total_in", "total_out", "close", "error", "base_pos", "open")
+
+
+def _appendix_b_deflate():
+    text, _ = synth.bench_corpus()
+    d = text[:65536]
+    return d, synth.deflate_raw(d)
+
+
+def _check_truncations_deflate(hip, ref, chunks=(65535,)):
+    """what TOTAL_IN / TOTAL_OUT, the read() sequence, the bytes, close(), error() and the base
+    stream's position are after the input ran out -- every field against the all-reference build, the two rows of the
+    appendix as literals (the entry is the appendix's own: the first 65 536 bytes of appnote.txt, 16 778 bytes at level 6)."""
+    d, z = _appendix_b_deflate()
+    for chunk in chunks:
+        for how in ("eof", "max_in"):
+            kw = dict(chunk=chunk)
+            cut = len(z) // 2
+            a = hip.stream_decode(8, z[:cut] if how == "eof" else z, len(d) + 64, max_in=cut if how == "max_in" else 0, **kw)
+            b = ref.stream_decode(8, z[:cut] if how == "eof" else z, len(d) + 64, max_in=cut if how == "max_in" else 0, **kw)
+            assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (how, chunk, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+            if len(z) == 16778 and chunk == 65535:  # the reference corpus travelled: the appendix's numbers themselves
+                assert (a["rets"], a["close"], a["error"], a["total_in"], a["total_out"], a["base_pos"]) == ([-5], -112, -5, 8389, 28634, 8389)
+        for cut in (0, 1, 2, 5, 100, len(z) // 4, len(z) // 2 + 1, len(z) - 300, len(z) - 3, len(z) - 1):
+            a = hip.stream_decode(8, z[:cut], len(d) + 64, chunk=chunk)
+            b = ref.stream_decode(8, z[:cut], len(d) + 64, chunk=chunk)
+            assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (cut, chunk, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+
+
+def test_truncation_accounting_deflate(libs):
+    hip, ref = libs
+    _check_truncations_deflate(hip, ref, chunks=(65535, 16384, 1000))
+
+
+def test_bitflip_verdicts_deflate(libs):
+    """One flipped bit anywhere: the same read() sequence, bytes, close() and error().  TOTAL_IN / TOTAL_OUT after a data
+    error are zlib's internal detection point ("treat as best-effort"): compared, counted, not asserted."""
+    import random
+
+    hip, ref = libs
+    d, z = _appendix_b_deflate()
+    rnd = random.Random(11)
+    same_totals = n = 0
+    for k in range(24):
+        i = len(z) // 3 if k == 0 else rnd.randrange(len(z))
+        bad = z[:i] + bytes([z[i] ^ (0x55 if k == 0 else 1 << rnd.randrange(8))]) + z[i + 1:]
+        for chunk in (65535, 4096):
+            a = hip.stream_decode(8, bad, len(d) + 70000, chunk=chunk)
+            b = ref.stream_decode(8, bad, len(d) + 70000, chunk=chunk)
+            assert (a["rets"], a["out"], a["close"], a["error"]) == (b["rets"], b["out"], b["close"], b["error"]), (i, chunk, a["rets"], b["rets"])
+            n += 1
+            same_totals += (a["total_in"], a["total_out"]) == (b["total_in"], b["total_out"])
+    print("bit flips: %d of %d cases also agree in TOTAL_IN / TOTAL_OUT (best-effort fields)" % (same_totals, n))
+
+
+def test_truncation_accounting_window_mode(libs):
+    """The same truncations with the READ stream in window mode (a 192 KiB window, 48 KiB gulps: mzhip_set_stream_window),
+    on the device: entries of a few hundred KiB cross several windows, whole, cut at a dozen places, bit-flipped."""
+    import ctypes as C
+
+    hip, ref = libs
+    L = hip.L  # (libmzhipdrop.so resolves the symbol in libmzhip.so, which it is linked against)
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    L.mzhip_set_stream_window(192 << 10, 48 << 10)
+    try:
+        text, _ = synth.bench_corpus()
+        for d in (text[:450000], text[1000:150000] + bytes(250000) + text[:90000]):
+            for lvl in (6, 0):
+                z = synth.deflate_raw(d, lvl)
+                for chunk in (65535, 300000):
+                    a = hip.stream_decode(8, z, len(d) + 10, chunk=chunk)
+                    b = ref.stream_decode(8, z, len(d) + 10, chunk=chunk)
+                    assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (lvl, chunk)
+                for cut in (len(z) // 5, len(z) // 2, len(z) * 4 // 5, len(z) - 3, len(z) - 1):
+                    for how in ("eof", "max_in"):
+                        a = hip.stream_decode(8, z[:cut] if how == "eof" else z, len(d) + 10, max_in=cut if how == "max_in" else 0)
+                        b = ref.stream_decode(8, z[:cut] if how == "eof" else z, len(d) + 10, max_in=cut if how == "max_in" else 0)
+                        assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (lvl, cut, how, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+                zz = bytearray(z)
+                zz[len(zz) * 2 // 3] ^= 0x10
+                a = hip.stream_decode(8, bytes(zz), len(d) + 10)
+                b = ref.stream_decode(8, bytes(zz), len(d) + 10)
+                assert (a["rets"], a["out"], a["close"], a["error"]) == (b["rets"], b["out"], b["close"], b["error"]), (lvl, "flip")
+        _check_truncations_deflate(hip, ref)  # (the appendix entry is smaller than a window: the one-buffer path, knob set)
+        # delete() without close() after reads that went into window mode (ADVICE r3: the piece tables were freed twice)
+        d = text[:450000] * 2
+        z = synth.deflate_raw(d, 6)
+        got = hip.stream_delete_unclosed(8, z, len(d), chunk=65535, nreads=6)
+        assert got == d[:6 * 65535]
+    finally:
+        L.mzhip_set_stream_window(0, 0)
+
+
+def test_truncation_accounting_lzma(libs):
+    """SURVEY Appendix B, mz_stream_lzma READ: the first 150 000 bytes of appnote.txt written by the reference's own WRITE
+    stream (34 458 bytes); cut in half the reference returns 65 535, then -3, with TOTAL_IN / TOTAL_OUT = 17 229 / 74 787."""
+    hip, ref = libs
+    text, _ = synth.bench_corpus()
+    d = text[:150000]
+    z, _ = ref.stream_encode(14, d, level=6)
+    for chunk in (65535, 10000):
+        for how in ("eof", "max_in"):
+            cut = len(z) // 2
+            a = hip.stream_decode(14, z[:cut] if how == "eof" else z, len(d) + 64, chunk=chunk, max_in=cut if how == "max_in" else 0)
+            b = ref.stream_decode(14, z[:cut] if how == "eof" else z, len(d) + 64, chunk=chunk, max_in=cut if how == "max_in" else 0)
+            assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (how, chunk, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+            if len(z) == 34458 and chunk == 65535:
+                assert (a["rets"], a["close"], a["error"], a["total_in"], a["total_out"]) == ([65535, -3], -112, 10, 17229, 74787)
+        for cut in (0, 3, 9, 12, 13, 14, 100, len(z) // 4, len(z) - 500, len(z) - 6, len(z) - 1):
+            a = hip.stream_decode(14, z[:cut], len(d) + 64, chunk=chunk)
+            b = ref.stream_decode(14, z[:cut], len(d) + 64, chunk=chunk)
+            assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (cut, chunk, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+    # bit flips: verdicts compared, TOTAL_* best-effort (liblzma's detection point)
+    import random
+
+    rnd = random.Random(5)
+    same = n = 0
+    for k in range(10):
+        i = len(z) // 3 if k == 0 else rnd.randrange(13, len(z))
+        bad = z[:i] + bytes([z[i] ^ (0x55 if k == 0 else 1 << rnd.randrange(8))]) + z[i + 1:]
+        a = hip.stream_decode(14, bad, len(d) + 70000)
+        b = ref.stream_decode(14, bad, len(d) + 70000)
+        assert (a["rets"], a["out"], a["close"], a["error"]) == (b["rets"], b["out"], b["close"], b["error"]), (i, a["rets"], b["rets"], a["error"], b["error"])
+        n += 1
+        same += (a["total_in"], a["total_out"]) == (b["total_in"], b["total_out"])
+    print("lzma bit flips: %d of %d cases also agree in TOTAL_IN / TOTAL_OUT" % (same, n))
 
 
 def test_lzma_stream_parity(libs):

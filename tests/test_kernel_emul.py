@@ -485,14 +485,12 @@ def emu_staged():
             _build_variant("fused", r2 + ["-DMZ_FUSED_EMIT=1", "-DMZ_EMIT_MIN_LANES=8u"]),
             _build_variant("frontier", r2 + ["-DMZ_NEAR_FRONTIER=1", "-DMZ_CL_PARALLEL=0"]),
             # the chase window (the default build is `emu` itself): record caps and span limits so low that every window
-            # runs into them, chases cross several spans and the span limit halves; 2 and 4 records per lane and emit round
+            # runs into them, chases cross several spans and the span limit halves; 4 records per lane and emit round
             # in a pool that cuts every round; the r2 knobs of the shared commit code
             _build_variant("c_caps", ["-DMZ_REC_CAP1=16u", "-DMZ_REC_CAP2=8u", "-DMZ_CHASE_SMAX=512u"]),
-            _build_variant("c_short", ["-DMZ_CHASE_SMAX=128u", "-DMZ_REC_CAP2=4u", "-DMZ_EMIT_GROUP=2u"]),
+            _build_variant("c_short", ["-DMZ_CHASE_SMAX=128u", "-DMZ_REC_CAP2=4u", "-DMZ_EMIT_GROUP=4u"]),
             _build_variant("c_pool", ["-DMZ_POOL_BYTES=656u", "-DMZ_EMIT_GROUP=4u", "-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"]),
-            _build_variant("c_knobs", ["-DMZ_NEAR_SLOTS=2", "-DMZ_NEAR_FRONTIER=1", "-DMZ_CHASE_SMAX=1024u"]),
-            _build_variant("c_select", ["-DMZ_TOKEN_SELECT=1", "-DMZ_REC_CHUNKED=1"]),
-            _build_variant("c_prelit2", ["-DMZ_SPAN_PRELIT=2"])]
+            _build_variant("c_knobs", ["-DMZ_NEAR_SLOTS=2", "-DMZ_NEAR_FRONTIER=1", "-DMZ_CHASE_SMAX=1024u"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
