@@ -818,6 +818,7 @@ MZ_DEV mz_dw4 mz_load_stream_dw4(const uint8_t *in_al, uint32_t in_mis, uint32_t
 
 #if MZ_SPAN_DW && MZ_WINDOW_CHASE
 #include "inflate_walk.inc"
+#include "inflate_emit.inc"
 #endif
 
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
@@ -849,6 +850,20 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
         bitpos = MZ_UNIFORM(rs->hdr_bit);
         resume_at = MZ_UNIFORM(rs->bit);
     }
+    /* the two groups of four stream dwords that do not lie entirely inside the input, masked (the chase window's refills,
+     * inflate_walk.inc): lanes 0 .. 3 the group of dword 0, lanes 4 .. 7 the group with the last dword.  Once per view, so
+     * that no window waits for these loads */
+#if MZ_SPAN_DW && MZ_WINDOW_CHASE
+    PV(uint32_t, edge_ev);
+#define MZ_EDGE_GROUPS()                                                                               \
+    MZ_LANES {                                                                                         \
+        const uint32_t _gl4 = ((in_mis + in_len) >> 2) & ~3u;                                          \
+        P(edge_ev) = (lane < 8) ? mz_load_stream_dword(in_al, in_mis, in_len, (lane < 4) ? (uint32_t)lane : _gl4 + ((uint32_t)lane & 3u)) : 0u; \
+    }
+#else
+#define MZ_EDGE_GROUPS() ((void)0)
+#endif
+    MZ_EDGE_GROUPS();
 #define MZ_REBASE(also)                                                \
     if (bitpos >= MZ_REBASE_BITS) {                                    \
         const uint32_t _adv = (bitpos >> 3) & ~3u;                     \
@@ -860,6 +875,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
             in_len = in_rem < MZ_VIEW_MAX ? in_rem : MZ_VIEW_MAX;      \
             total_bits = in_len * 8u;                                  \
             bitpos -= _adv * 8u;                                       \
+            MZ_EDGE_GROUPS();                                          \
             also;                                                      \
         }                                                              \
     }

@@ -1161,17 +1161,45 @@ struct Scratch {
 // (hipStreamPerThread itself was the first choice; with two host threads decoding entries at the same time it handed
 // back garbage result words now and then -- tests/test_gpu_dropin.py::test_archives_through_unmodified_mz_zip, one run in
 // three -- so the per-thread stream is one this library creates: a non-blocking stream per (host thread, device), made
-// on first use and left to the process's end.)
+// on first use.)
+// A thread that exits hands its streams to a free list instead of leaking them (an application that makes a reader pool
+// per archive used to leave one stream per exited thread behind); they are recycled, never destroyed: the
+// scratch and work-queue caches remember stream identities ("the next launch is on the stream that used it last"), and a
+// recycled stream keeps the order that reasoning relies on, where a destroyed one's handle could come back as a stranger.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> idle[kMaxDevices];
+};
+static StreamPool *stream_pool() {
+    static StreamPool *p = new StreamPool(); // (never deleted: thread_local destructors may run after static ones)
+    return p;
+}
 struct ThreadStreams {
     hipStream_t s[kMaxDevices] = {};
+    ~ThreadStreams() {
+        StreamPool *p = stream_pool();
+        std::lock_guard<std::mutex> g(p->mu);
+        for (int d = 0; d < kMaxDevices; d++)
+            if (s[d]) p->idle[d].push_back(s[d]);
+    }
 };
 static thread_local ThreadStreams t_streams;
 static hipStream_t mz_host_stream() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
-    if (!t_streams.s[d] && hipStreamCreateWithFlags(&t_streams.s[d], hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
-        t_streams.s[d] = nullptr; /* the null stream still works, only slower */
+    if (!t_streams.s[d]) {
+        StreamPool *p = stream_pool();
+        {
+            std::lock_guard<std::mutex> g(p->mu);
+            if (!p->idle[d].empty()) {
+                t_streams.s[d] = p->idle[d].back();
+                p->idle[d].pop_back();
+            }
+        }
+        if (!t_streams.s[d] && hipStreamCreateWithFlags(&t_streams.s[d], hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            t_streams.s[d] = nullptr; /* the null stream still works, only slower */
+        }
     }
     return t_streams.s[d];
 }
@@ -1247,7 +1275,11 @@ int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_
     Meta *dm = (Meta *)base;
     rc = mzhip_inflate_resume_batch(base, &dm->in_off, &dm->in_len, base, &dm->out_off, &dm->out_cap, 1, &dm->out_len,
                                     &dm->in_used, &dm->crc, &dm->status, (const mzhip_inflate_state *)&dm->rs,
-                                    (mzhip_inflate_state *)&dm->st, MZ_HOST_STREAM);
+                                    /* no state asked for = the last call of a stream that ended short: the kernel then drops the
+                                     * resumable rules (a stored block is taken as far as it goes) -- the pointer used to be
+                                     * passed regardless, and a truncated stored stream in window mode lost its last bytes
+                                     * (found by tests/test_gpu_dropin.py::test_truncation_accounting_window_mode, round 4) */
+                                    state_out ? (mzhip_inflate_state *)&dm->st : nullptr, MZ_HOST_STREAM);
     if (rc) return rc;
     HIP_TRY(mz_d2h(&m, base, sizeof(m)));
     if (m.out_len > hist) HIP_TRY(mz_d2h(buf + hist, base + m.out_off + hist, m.out_len - hist));
@@ -1751,14 +1783,20 @@ struct PinnedPool {
         }
         void *p = nullptr;
         const size_t want = (need + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
-        /* the pages are placed where the thread that pins them runs: for the length of this call that is next to the
-         * current device (the copy engines read and write this block; mzhip_bind_thread_near_device) */
-        cpu_set_t was;
+        /* the pages are placed where the thread that pins them runs, and that should be next to the current device (the
+         * copy engines read and write this block): a thread of the library's own binds itself there for the allocation.
+         * (It used to be the caller's thread, re-bound for the length of the call: runtime helper threads spawned in that
+         * window inherited the narrow mask) */
         int dev = 0;
-        const bool moved = sched_getaffinity(0, sizeof(was), &was) == 0 && hipGetDevice(&dev) == hipSuccess &&
-                           mzhip_bind_thread_near_device(dev, 0) > 0;
-        const hipError_t he = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (moved) (void)sched_setaffinity(0, sizeof(was), &was);
+        hipError_t he = hipGetDevice(&dev);
+        if (he == hipSuccess) {
+            std::thread t([&] {
+                (void)mzhip_bind_thread_near_device(dev, 0);
+                he = hipSetDevice(dev);
+                if (he == hipSuccess) he = hipHostMalloc(&p, want, hipHostMallocDefault);
+            });
+            t.join();
+        }
         if (he != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;

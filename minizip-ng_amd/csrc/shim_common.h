@@ -38,22 +38,34 @@ typedef struct mzhip_served_s {
     int32_t size;
     uint32_t crc;
     int32_t valid;
+    uint32_t slot, epoch; /* the stream that set the hint and the epoch of its slot at that moment: a close / delete /
+                        re-open of that stream since -- from any thread -- makes the hint stale, so src is never read after
+                        its owner may have given it back.  Slots are shared by streams created 4096 apart: a
+                        stranger's close costs the fast path once, never correctness */
     const void *src; /* the primed bytes that were served (or that a written buffer was found equal to): compared again, byte
                         for byte, when the checksum is asked for -- a caller that changed the buffer in between gets the CRC of
                         what the buffer holds now.  Valid while the hint is: the stream that set it pins the primed generation
                         and every shim call, close and delete included, drops the hint first */
 } mzhip_served;
 extern __thread mzhip_served mzhip_last_served;
+#define MZHIP_STREAM_SLOTS 4096u
+extern uint32_t mzhip_stream_epoch[MZHIP_STREAM_SLOTS]; /* bumped (atomically) whenever the slot's stream gives buffers back */
+extern uint32_t mzhip_stream_slot_next;
+static inline uint32_t mzhip_stream_slot_new(void) { return __atomic_fetch_add(&mzhip_stream_slot_next, 1u, __ATOMIC_RELAXED) % MZHIP_STREAM_SLOTS; }
 /* record / drop the hint; every shim read, write and open drops it first, so it only ever describes the bytes the
  * immediately preceding codec call produced */
-static inline void mzhip_served_set(const void *buf, int32_t size, uint32_t crc, const void *src) {
+static inline void mzhip_served_set(const void *buf, int32_t size, uint32_t crc, const void *src, uint32_t slot) {
     mzhip_last_served.buf = buf;
     mzhip_last_served.size = size;
     mzhip_last_served.crc = crc;
     mzhip_last_served.src = src;
+    mzhip_last_served.slot = slot % MZHIP_STREAM_SLOTS;
+    mzhip_last_served.epoch = __atomic_load_n(&mzhip_stream_epoch[slot % MZHIP_STREAM_SLOTS], __ATOMIC_ACQUIRE);
     mzhip_last_served.valid = 1;
 }
 static inline void mzhip_served_drop(void) { mzhip_last_served.valid = 0; }
+/* the stream of this slot is about to free (or re-use) buffers a hint of some thread may point into */
+static inline void mzhip_buffers_released(uint32_t slot) { (void)__atomic_add_fetch(&mzhip_stream_epoch[slot % MZHIP_STREAM_SLOTS], 1u, __ATOMIC_ACQ_REL); }
 
 #define MZHIP_PRIME_SEGMENT 65535 /* the reader's buffer size, mz_zip_rw.c:55 */
 #endif

@@ -17,6 +17,8 @@
 #include "shim_common.h"
 
 __thread mzhip_served mzhip_last_served;
+uint32_t mzhip_stream_epoch[MZHIP_STREAM_SLOTS];
+uint32_t mzhip_stream_slot_next;
 
 uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int32_t size) {
     if (size <= 0 || !buf)
@@ -26,7 +28,8 @@ uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int32_t size)
          * those bytes was computed on the device.  The record is dropped by every other codec call, and the bytes are
          * compared with the primed ones once more, so a buffer that changed in between is never answered from the cache */
         mzhip_last_served.valid = 0;
-        if (memcmp(buf, mzhip_last_served.src, (size_t)size) == 0)
+        if (mzhip_last_served.epoch == __atomic_load_n(&mzhip_stream_epoch[mzhip_last_served.slot], __ATOMIC_ACQUIRE) &&
+            memcmp(buf, mzhip_last_served.src, (size_t)size) == 0)
             return mzhip_crc32_combine(value, mzhip_last_served.crc, (uint64_t)size);
     }
     mzhip_last_served.valid = 0;

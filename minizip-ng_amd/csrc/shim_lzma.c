@@ -60,6 +60,7 @@ typedef struct mzhip_lzma_s {
     /* write side: the whole entry is collected, coded at close() */
     uint8_t *wbuf;
     int64_t wlen, wcap;
+    uint32_t slot; /* this stream's cell of mzhip_stream_epoch[] (shim_common.h) */
 } mzhip_lzma;
 
 static mzhip_stream_vtbl mzhip_lzma_vtbl = {
@@ -92,6 +93,7 @@ static int32_t grow_in(mzhip_lzma *z, int64_t need) {
 int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
     mzhip_served_drop();
+    mzhip_buffers_released(((mzhip_lzma *)stream)->slot);
     (void)path;
     z->total_in = z->total_out = 0;
     z->error = 0;
@@ -308,7 +310,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: its device-computed CRC answers the mz_crypt_crc32_update that follows */
-            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served);
+            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served, z->slot);
         }
         z->out_served += n;
         z->total_out += n;
@@ -380,7 +382,7 @@ int32_t mz_stream_lzma_write(void *stream, const void *buf, int32_t size) {
             z->wp_pos += size;
             z->total_in += size;
             if (have_crc) { /* answers the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) */
-                mzhip_served_set(buf, size, crc, wsrc);
+                mzhip_served_set(buf, size, crc, wsrc, z->slot);
             }
             return size;
         }
@@ -465,6 +467,7 @@ int32_t mz_stream_lzma_seek(void *stream, int64_t offset, int32_t origin) {
 
 int32_t mz_stream_lzma_close(void *stream) {
     mzhip_served_drop(); /* (the hint points into a primed generation this stream pins) */
+    mzhip_buffers_released(((mzhip_lzma *)stream)->slot);
     mzhip_lzma *z = (mzhip_lzma *)stream;
     if ((z->mode & MZH_OPEN_MODE_WRITE) && z->initialized == 1 && finish_write(z) != MZH_OK)
         z->error = 11; /* LZMA_PROG_ERROR: reported as MZ_CLOSE_ERROR below */
@@ -540,6 +543,7 @@ int32_t mz_stream_lzma_set_prop_int64(void *stream, int32_t prop, int64_t value)
 void *mz_stream_lzma_create(void) {
     mzhip_lzma *z = (mzhip_lzma *)calloc(1, sizeof(mzhip_lzma));
     if (z) {
+        z->slot = mzhip_stream_slot_new();
         z->stream.vtbl = &mzhip_lzma_vtbl;
         z->method = MZH_COMPRESS_METHOD_LZMA;
         z->preset = 6;
@@ -550,6 +554,8 @@ void *mz_stream_lzma_create(void) {
 
 void mz_stream_lzma_delete(void **stream) {
     mzhip_served_drop();
+    if (stream && *stream)
+        mzhip_buffers_released(((mzhip_lzma *)*stream)->slot);
     mzhip_lzma *z;
     if (!stream)
         return;

@@ -105,6 +105,7 @@ typedef struct mzhip_zlib_s {
     uint32_t w_crc, w_adler;
     int64_t w_total;   /* uncompressed bytes already handed to the device */
     int8_t w_header_done;
+    uint32_t slot; /* this stream's cell of mzhip_stream_epoch[] (shim_common.h) */
 } mzhip_zlib;
 
 static mzhip_stream_vtbl mzhip_zlib_vtbl = {
@@ -143,6 +144,7 @@ static void free_buffers(mzhip_zlib *z) {
 int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     mzhip_zlib *z = (mzhip_zlib *)stream;
     mzhip_served_drop();
+    mzhip_buffers_released(((mzhip_zlib *)stream)->slot);
     (void)path;
     z->total_in = 0;
     z->total_out = 0;
@@ -724,7 +726,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             if (k > 0) {
                 uint32_t pcrc;
                 if (got == 0 && z->pc_n > z->pc_head && stream_pieces_crc(z, k, &pcrc) && (k == size || av == k))
-                    mzhip_served_set(buf, k, pcrc, z->out + z->out_served); /* (dropped again below if the call goes on into the next window) */
+                    mzhip_served_set(buf, k, pcrc, z->out + z->out_served, z->slot); /* (dropped again below if the call goes on into the next window) */
                 else if (got != 0)
                     mzhip_served_drop();
                 memcpy((uint8_t *)buf + got, z->out + z->out_served, (size_t)k);
@@ -765,7 +767,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         if (z->out_borrowed && z->out_served % MZHIP_PRIME_SEGMENT == 0 &&
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: remember its device-computed CRC for the mz_crypt_crc32_update that follows */
-            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served);
+            mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served, z->slot);
         }
         z->out_served += n;
         z->total_out += n;
@@ -924,7 +926,7 @@ int32_t mz_stream_zlib_write(void *stream, const void *buf, int32_t size) {
             z->wp_pos += size;
             z->total_in += size;
             if (have_crc) { /* the mz_crypt_crc32_update that follows (mz_zip.c:2062-2064) is answered from the cache */
-                mzhip_served_set(buf, size, crc, wsrc);
+                mzhip_served_set(buf, size, crc, wsrc, z->slot);
             }
             return size;
         }
@@ -953,6 +955,7 @@ int32_t mz_stream_zlib_seek(void *stream, int64_t offset, int32_t origin) {
 
 int32_t mz_stream_zlib_close(void *stream) {
     mzhip_served_drop(); /* (the hint points into a primed generation this stream pins) */
+    mzhip_buffers_released(((mzhip_zlib *)stream)->slot);
     mzhip_zlib *z = (mzhip_zlib *)stream;
     if (z->mode & MZH_OPEN_MODE_WRITE) {
         const uint8_t *src = NULL, *out = NULL;
@@ -1037,6 +1040,7 @@ int32_t mz_stream_zlib_set_prop_int64(void *stream, int32_t prop, int64_t value)
 void *mz_stream_zlib_create(void) {
     mzhip_zlib *z = (mzhip_zlib *)calloc(1, sizeof(mzhip_zlib));
     if (z) {
+        z->slot = mzhip_stream_slot_new();
         z->stream.vtbl = &mzhip_zlib_vtbl;
         z->level = -1;
         z->window_bits = -15;
@@ -1046,6 +1050,8 @@ void *mz_stream_zlib_create(void) {
 
 void mz_stream_zlib_delete(void **stream) {
     mzhip_served_drop();
+    if (stream && *stream)
+        mzhip_buffers_released(((mzhip_zlib *)*stream)->slot);
     mzhip_zlib *z;
     if (!stream)
         return;

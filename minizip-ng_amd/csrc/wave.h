@@ -34,6 +34,7 @@
 #define PV(type, name) type name[64]
 #define PV2(type, name, n) type name[64][n] /* small per-lane array */
 #define MZ_DEV_NOINLINE static
+#define PVIN(type, name) const type (&name)[64] /* a per-lane value of the caller, as a function parameter */
 typedef uintptr_t mz_lds_handle;
 typedef uintptr_t mz_glb_handle;
 #define MZ_LDS_HANDLE(p) ((uintptr_t)(p))
@@ -132,6 +133,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
  * instructions; so pointers cross the call as integers and are re-made inside in their real address space
  * (infer-address-spaces then rewrites every use) */
 #define MZ_DEV_NOINLINE __device__ __attribute__((noinline))
+#define PVIN(type, name) type name
 typedef uint32_t mz_lds_handle; /* an LDS address is 32 bits */
 typedef uint64_t mz_glb_handle;
 #define MZ_LDS_HANDLE(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(p))

@@ -54,14 +54,14 @@ def main():
         return t and not t.startswith(";") and not t.startswith(".") and not t.endswith(":")
 
     print("%s (%s): %d instructions" % (kernel, " ".join(extra) or "default build", sum(1 for t in body if is_op(t))))
-    print("%-12s %5s %7s %8s %6s %5s %7s %6s %7s" % ("loop", "depth", "instr", "branches", "waits", "lds", "global", "moves", "selects"))
+    print("%-12s %5s %7s %8s %6s %5s %7s %7s %6s %7s" % ("loop", "depth", "instr", "branches", "waits", "lds", "global", "scratch", "moves", "selects"))
     for lab, depth, a, b in loops:
         ops = [t.split()[0] for t in body[a:b + 1] if is_op(t)]
         if len(ops) < floor:
             continue
         c = lambda p: sum(1 for o in ops if re.match(p, o))  # noqa: E731
-        print("%-12s %5d %7d %8d %6d %5d %7d %6d %7d" % (lab, depth, len(ops), c(r"s_cbranch"), c(r"s_waitcnt"), c(r"ds_"), c(r"global_|scratch_|buffer_"),
-                                                          c(r"v_mov"), c(r"v_cndmask")))
+        print("%-12s %5d %7d %8d %6d %5d %7d %7d %6d %7d" % (lab, depth, len(ops), c(r"s_cbranch"), c(r"s_waitcnt"), c(r"ds_"), c(r"global_|buffer_|flat_"),
+                                                              c(r"scratch_"), c(r"v_mov"), c(r"v_cndmask")))
 
 
 if __name__ == "__main__":
