@@ -223,6 +223,23 @@ MZHIP_API int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uin
                                          uint32_t *out_len, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
                                        uint32_t *out_len, uint32_t *crc);
+/* Resumable LZMA1 decode (ZIP method 14) -- entries decoded window by window in bounded memory, as the reference streams
+ * any entry through 32 767 bytes (mz_strm_lzma.c:147-241).  `state` is sixteen words: flags (in: bit 0 take the stream up
+ * from this state, else a fresh stream whose header comes first; bit 1 the input given is the stream's last.  out: 1 = the
+ * decoder stopped in front of a packet and can go on from here), the range coder, the four repeat distances, the
+ * properties, out_pos (in: bytes of dictionary in front of the room in buf; out: bytes valid in buf) and in_pos (out: bytes
+ * of `in` that are done with).  `model` (mzhip_lzma_model_bytes() bytes, the caller's) carries the adaptive model from call
+ * to call.  With a state_out the decoder stops when fewer than 274 bytes of room or (bit 1 clear) 64 bytes of input are
+ * left: MZHIP_STATUS_OUT_FULL / MZHIP_STATUS_BUF_ERROR with flags = 1.  Between calls the caller keeps at least
+ * min(everything produced, dictionary size) bytes in front of the buffer and drops a multiple of 16.  No CRC is computed. */
+typedef struct mzhip_lzma_state {
+    uint32_t flags, range, code, state, rep0, rep1, rep2, rep3, props, dict, out_pos, in_pos, pad[4];
+} mzhip_lzma_state;
+MZHIP_API uint32_t mzhip_lzma_model_bytes(void);
+MZHIP_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                         const mzhip_lzma_state *state_in, mzhip_lzma_state *state_out, void *model,
+                                         uint32_t *out_len, uint32_t *in_used);
+
 /* ... at a preset (see mzhip_lzma_encode_batch_preset); what mz_stream_lzma_write / _close use */
 MZHIP_API int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out,
                                                 uint32_t out_cap, uint32_t *out_len, uint32_t *crc);

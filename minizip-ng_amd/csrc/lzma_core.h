@@ -66,6 +66,24 @@ typedef struct mz_lzma_lds_s {
     uint16_t probs[(LZ_NUM_PROBS_S + 1) & ~1u];
 } mz_lzma_lds_s;
 
+/* Where an LZMA1 decode can be taken up again (the resumable build of lzma_entry.inc; mzhip.h declares the same sixteen
+ * words as mzhip_lzma_state).  The adaptive model travels beside it: MZ_LZMA_MODEL_U16 probabilities in global memory. */
+typedef struct mz_lzma_state {
+    uint32_t flags;   /* in: bit 0 take the stream up from this state (else a fresh stream, header first), bit 1 the input
+                         given is the stream's last; out: 1 = stopped in front of a packet, the state is one to go on from */
+    uint32_t range, code, state;
+    uint32_t rep0, rep1, rep2, rep3;
+    uint32_t props;   /* lc | lp << 8 | pb << 16 */
+    uint32_t dict;    /* the header's dictionary size */
+    uint32_t out_pos; /* in: bytes of dictionary in front of the output; out: bytes valid in the buffer */
+    uint32_t in_pos;  /* out: bytes of the given input that are done with */
+    uint32_t pad[4];
+} mz_lzma_state;
+#define MZ_LZMA_MODEL_U16 (((LZ_NUM_PROBS + 1u) & ~1u) + MZ_LZMA_XPROBS)
+
+/* the packet loop's stop test: nothing in the one-shot builds */
+#define LZ_RESUME_CHECK() ((void)0)
+
 typedef struct mz_lzma_result {
     int32_t status;
     uint32_t out_len;
@@ -248,9 +266,16 @@ typedef struct mz_lzma_result {
             }                                                                                                         \
         }                                                                                                             \
         if (!hit_) {                                                                                                  \
-            sl_ = svict;                                                                                              \
-            svict = (svict + 1u == MZ_LZMA_SLOTS) ? 0u : svict + 1u;                                                  \
-            uint32_t old_ = 0;                                                                                        \
+            /* the slot that was used longest ago makes room (round 3 took them in turn: a fifth context that shows up \
+             * now and then -- text with a few bytes above 0x7F -- then threw out a busy one every time, and 30 % of    \
+             * config 4's entries were given back to the full-model kernel) */                                        \
+            uint32_t old_ = 0, best_ = 0xFFFFFFFFu;                                                                   \
+            _Pragma("unroll") for (uint32_t k_ = 0; k_ < MZ_LZMA_SLOTS; k_++) {                                       \
+                if (sage[k_] < best_) {                                                                               \
+                    best_ = sage[k_];                                                                                 \
+                    sl_ = k_;                                                                                         \
+                }                                                                                                     \
+            }                                                                                                         \
             _Pragma("unroll") for (uint32_t k_ = 0; k_ < MZ_LZMA_SLOTS; k_++) {                                       \
                 if (k_ == sl_) {                                                                                      \
                     old_ = stag[k_];                                                                                  \
@@ -275,6 +300,8 @@ typedef struct mz_lzma_result {
                 goto finish;                                                                                          \
             }                                                                                                         \
         }                                                                                                             \
+        _Pragma("unroll") for (uint32_t k_ = 0; k_ < MZ_LZMA_SLOTS; k_++)                                             \
+            if (k_ == sl_) sage[k_] = opos + 1u; /* (0 = never used) */                                               \
         const uint32_t lbase = LZ_LIT + 0x300u * sl_;                                                                 \
         LZ_LITERAL(LZ_BIT);                                                                                           \
     } while (0)
@@ -286,6 +313,7 @@ typedef struct mz_lzma_result {
     for (;;) {                                                                                                        \
         if (eof) goto finish; /* truncated input */                                                                   \
         if (lzma2 && opos == chunk_end) break; /* LZMA2: the chunk's uncompressed size has been produced */           \
+        LZ_RESUME_CHECK();                                                                                            \
         const uint32_t ps = opos & pb_mask;                                                                           \
         uint32_t bit;                                                                                                 \
         LZ_BIT(bit, LZ_IS_MATCH + state * 16 + ps);                                                                   \
@@ -481,6 +509,39 @@ typedef struct mz_lzma_result {
 #undef LZ_LDS_T
 #undef LZ_ENTRY_PROBS
 #define LZ_LITERAL_SITE(sym) LZ_LITERAL_SITE_FULL(sym)
+
+/* the resumable build (full model; vector-port form on the device, scalar form in the host emulation): stops in front of a
+ * packet when the output buffer or -- unless it is the stream's last -- the input runs low */
+#if defined(MZHIP_HOST_EMUL)
+#define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
+#else
+#define LZ_U(x) (x)
+#define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
+#endif
+#define LZ_LDS_T mz_lzma_lds
+#define LZ_ENTRY_PROBS LZ_NUM_PROBS
+#define LZ_RESUME_BUILD 1
+#undef LZ_RESUME_CHECK
+#define LZ_RESUME_CHECK()                                                                                   \
+    if (st && (opos + 274u > out_cap || (!last_input && in_pos + 64u > rc_len))) {                          \
+        status = (opos + 274u > out_cap) ? MZHIP_OUT_FULL : MZHIP_BUF_ERROR;                                \
+        goto stop_here;                                                                                     \
+    }
+#pragma push_macro("LZ_CRC_LIMIT")
+#undef LZ_CRC_LIMIT
+#define LZ_CRC_LIMIT(o) 0u /* no fused CRC in this build */
+#define LZ_ENTRY_NAME mz_lzma_entry_r
+#include "lzma_entry.inc"
+#undef LZ_ENTRY_NAME
+#pragma pop_macro("LZ_CRC_LIMIT")
+#undef LZ_RESUME_CHECK
+#define LZ_RESUME_CHECK() ((void)0)
+#undef LZ_RESUME_BUILD
+#undef LZ_U
+#undef LZ_WIN_DW
+#undef LZ_LDS_T
+#undef LZ_ENTRY_PROBS
 
 /* for code that expands the coder macros outside the two entry builds (xz_core.h): vector-port forms on the device */
 #if defined(MZHIP_HOST_EMUL)

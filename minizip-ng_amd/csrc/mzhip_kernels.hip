@@ -231,6 +231,33 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
     }
 }
 
+// K3, resumable: ONE stream taken up where the call before left it (the window mode of the drop-in READ stream,
+// shim_lzma.c).  The coder state travels in a 64-byte record, the adaptive model in global memory beside it.
+struct LzmaResumeArgs {
+    const uint8_t *in;
+    uint32_t in_len;
+    uint8_t *buf; // [dictionary so far | room for this window]
+    uint32_t buf_cap;
+    const mz_lzma_state *rs;
+    mz_lzma_state *st; // null: decode to the end of what there is, no state kept
+    uint16_t *model;   // MZ_LZMA_MODEL_U16 probabilities, in and out
+    uint32_t *out_len;
+    uint32_t *in_used;
+    int32_t *status;
+    const mzhip_crc_tables *tabs;
+};
+__global__ __launch_bounds__(64) void k_lzma_resume(LzmaResumeArgs a) {
+    __shared__ __attribute__((aligned(16))) mz_lzma_lds lds;
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    mz_lzma_result r;
+    mz_lzma_entry_r(a.in, a.in_len, a.buf, a.buf_cap, (int64_t)-1, &lds, crc_tab, a.tabs, a.model, a.rs, a.st, &r);
+    *a.out_len = r.out_len; // wave-uniform results: stored by all lanes
+    *a.in_used = r.in_used;
+    *a.status = r.status;
+}
+
 // K3, main kernel: the slot build of the decoder (lzma_core.h LZ_LITERAL_SITE_SLOT) -- 9.6 KiB of LDS per wave, 16 waves
 // per CU (registers held to 128 by the launch bounds).  Streams whose literal contexts do not fit the slots are given
 // back through retry_list and decoded by k_lzma_batch right behind this launch.
@@ -1418,6 +1445,56 @@ int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32
 int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                       uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
     return lzma_family_host(1, in, in_len, out, out_cap, max_out, out_len, in_used, crc);
+}
+
+uint32_t mzhip_lzma_model_bytes(void) { return (uint32_t)(MZ_LZMA_MODEL_U16 * sizeof(uint16_t)); }
+
+// One window of one ZIP method-14 payload (include/mzhip.h).  buf[0 .. state_in->out_pos) is the dictionary so far.
+int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap, const mzhip_lzma_state *state_in,
+                               mzhip_lzma_state *state_out, void *model, uint32_t *out_len, uint32_t *in_used) {
+    static_assert(sizeof(mzhip_lzma_state) == sizeof(mz_lzma_state), "mzhip.h and lzma_core.h describe the same sixteen words");
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    if (!model || !state_in) return -102; /* MZ_PARAM_ERROR */
+    const uint32_t hist = state_in->out_pos;
+    if (hist > buf_cap) return -102;
+    const size_t model_bytes = (MZ_LZMA_MODEL_U16 * sizeof(uint16_t) + 15) & ~(size_t)15;
+    const size_t in_pad = ((size_t)in_len + 15 + 16) & ~(size_t)15;
+    const size_t total = 256 + model_bytes + in_pad + (size_t)buf_cap + 16;
+    Staging sc;
+    rc = sc.get(c, total);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)sc.p;
+    struct Meta {
+        mz_lzma_state rs, st;
+        uint32_t out_len, in_used;
+        int32_t status;
+    } m;
+    static_assert(sizeof(Meta) <= 256, "meta block");
+    memset(&m, 0, sizeof(m));
+    memcpy(&m.rs, state_in, sizeof(m.rs));
+    uint8_t *d_model = base + 256, *d_in = d_model + model_bytes, *d_buf = d_in + in_pad;
+    HIP_TRY(mz_h2d(base, &m, sizeof(m)));
+    if (state_in->flags & 1u) HIP_TRY(mz_h2d(d_model, model, MZ_LZMA_MODEL_U16 * sizeof(uint16_t)));
+    if (in_len) HIP_TRY(mz_h2d(d_in, in, in_len));
+    if (hist) HIP_TRY(mz_h2d(d_buf, buf, hist));
+    Meta *dm = (Meta *)base;
+    LzmaResumeArgs a{d_in, in_len, d_buf, buf_cap, &dm->rs, state_out ? &dm->st : nullptr, (uint16_t *)d_model,
+                     &dm->out_len, &dm->in_used, &dm->status, c->d_tabs};
+    hipLaunchKernelGGL(k_lzma_resume, dim3(1), dim3(64), 0, MZ_HOST_STREAM, a);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail("k_lzma_resume", le);
+    HIP_TRY(hipStreamSynchronize(MZ_HOST_STREAM));
+    HIP_TRY(mz_d2h(&m, base, sizeof(m)));
+    if (m.out_len > hist && m.out_len <= buf_cap) HIP_TRY(mz_d2h(buf + hist, d_buf + hist, m.out_len - hist));
+    if (state_out) {
+        memcpy(state_out, &m.st, sizeof(m.st));
+        if (m.st.flags & 1u) HIP_TRY(mz_d2h(model, d_model, MZ_LZMA_MODEL_U16 * sizeof(uint16_t)));
+    }
+    if (out_len) *out_len = m.out_len;
+    if (in_used) *in_used = m.in_used;
+    return m.status;
 }
 
 // One ZIP method-14 payload from a host buffer.

@@ -67,5 +67,10 @@ static inline void mzhip_served_drop(void) { mzhip_last_served.valid = 0; }
 /* the stream of this slot is about to free (or re-use) buffers a hint of some thread may point into */
 static inline void mzhip_buffers_released(uint32_t slot) { (void)__atomic_add_fetch(&mzhip_stream_epoch[slot % MZHIP_STREAM_SLOTS], 1u, __ATOMIC_ACQ_REL); }
 
+/* the memory bound of one READ stream (shim_zlib.c; mzhip_set_stream_window): bytes decoded per window, compressed bytes
+ * pulled ahead of a window's launch */
+int64_t mzh_stream_window(void);
+int64_t mzh_stream_gulp(void);
+
 #define MZHIP_PRIME_SEGMENT 65535 /* the reader's buffer size, mz_zip_rw.c:55 */
 #endif

@@ -61,6 +61,18 @@ typedef struct mzhip_lzma_s {
     uint8_t *wbuf;
     int64_t wlen, wcap;
     uint32_t slot; /* this stream's cell of mzhip_stream_epoch[] (shim_common.h) */
+    /* read side, method 14, entries larger than one window (mzh_stream_window): decoded window by window by the resumable
+     * build of K3.  out[] then holds [the dictionary so far | the window's bytes]; consumed input is dropped */
+    int8_t streaming;      /* window mode is on */
+    int8_t resumed;        /* lst is a state to go on from */
+    int8_t stream_end;     /* the end marker has been decoded */
+    int32_t s_err;         /* the device's verdict once the stream cannot go on: served when the bytes in front of it are */
+    mzhip_lzma_state lst;
+    void *model;           /* mzhip_lzma_model_bytes(): the adaptive model between calls */
+    int64_t hist;          /* bytes of dictionary at the front of out[] */
+    int64_t out_abs;       /* position in the decoded stream of out[0] (a multiple of 16) */
+    int64_t in_dropped;    /* compressed bytes consumed and dropped from the front of in[] */
+    int64_t dict_keep;     /* dictionary bytes kept between windows */
 } mzhip_lzma;
 
 static mzhip_stream_vtbl mzhip_lzma_vtbl = {
@@ -116,6 +128,11 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->dev_status = 0;
     z->dev_in_used = 0;
     z->next_attempt = 0;
+    z->streaming = z->resumed = z->stream_end = 0;
+    z->s_err = 0;
+    z->hist = z->out_abs = z->in_dropped = z->dict_keep = 0;
+    free(z->model);
+    z->model = NULL;
     free(z->wbuf);
     z->wbuf = NULL;
     z->wlen = z->wcap = 0;
@@ -172,10 +189,10 @@ static int32_t pull_chunk(mzhip_lzma *z) {
     /* method 14: the reference first asks for exactly what is missing of the 5 header bytes behind the magic
      * (mz_strm_lzma.c:181-183) and hands them to liblzma before it reads on: a properties byte that is refused leaves the
      * base stream at 9 bytes */
-    if (z->method == MZH_COMPRESS_METHOD_LZMA && z->in_len < LZMA_MAGIC_SIZE + 5)
+    if (z->method == MZH_COMPRESS_METHOD_LZMA && z->in_dropped == 0 && z->in_len < LZMA_MAGIC_SIZE + 5)
         want = (int32_t)(LZMA_MAGIC_SIZE + 5 - z->in_len);
     if (z->max_total_in > 0) {
-        int64_t left = z->max_total_in - z->in_len;
+        int64_t left = z->max_total_in - (z->in_dropped + z->in_len);
         if (left < want)
             want = (int32_t)(left < 0 ? 0 : left);
     }
@@ -194,10 +211,15 @@ static int32_t pull_chunk(mzhip_lzma *z) {
     return rd;
 }
 
+static int32_t lz_stream_start(mzhip_lzma *z);
 static int32_t attempt_decode(mzhip_lzma *z) {
     for (;;) {
         if (z->out_cap == 0) {
             z->out_cap = z->max_total_out >= 0 ? z->max_total_out + 16 : z->in_len * 6 + 65536;
+            if (z->method == MZH_COMPRESS_METHOD_LZMA && z->out_cap > mzh_stream_window() && z->in_len >= LZMA_MAGIC_SIZE + 5) {
+                z->out_cap = 0;
+                return lz_stream_start(z); /* larger than a window: decoded window by window from the start */
+            }
             z->out = (uint8_t *)malloc((size_t)z->out_cap);
             if (!z->out)
                 return MZH_MEM_ERROR;
@@ -206,9 +228,13 @@ static int32_t attempt_decode(mzhip_lzma *z) {
         int32_t st = (z->method == MZH_COMPRESS_METHOD_XZ ? mzhip_xz_host : mzhip_lzma_host)(
             z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, z->max_total_out, &out_len, &in_used, &crc);
         if (st == MZHIP_STATUS_OUT_FULL) {
+            if (z->method == MZH_COMPRESS_METHOD_LZMA && z->out_cap >= mzh_stream_window())
+                return lz_stream_start(z); /* more than a window of output: once more, this time window by window */
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
             int64_t ncap = z->out_cap * 4;
+            if (z->method == MZH_COMPRESS_METHOD_LZMA && ncap > mzh_stream_window())
+                ncap = mzh_stream_window();
             if (ncap > 0x7FFFFFFF)
                 ncap = 0x7FFFFFFF;
             free(z->out);
@@ -228,6 +254,153 @@ static int32_t attempt_decode(mzhip_lzma *z) {
     }
 }
 
+/* ---- window mode (method 14): entries of any size in bounded memory ---------------------------------------------------
+ * The reference streams an entry through 32 767 bytes in and whatever the caller's buffer holds out (mz_strm_lzma.c:
+ * 147-241); the one-buffer path above holds the whole entry twice.  Past one window (mzh_stream_window, 64 MiB) the stream
+ * is decoded by the resumable build of K3 (mzhip_lzma_resume_host): the coder state is a 64-byte record, the adaptive
+ * model 28 KB of host memory, out[] = [the dictionary so far, at most what the header asks for | the window].  Memory:
+ * dictionary + window + one gulp of input.  One stream is one wave (an LZMA stream is one serial chain): this is about
+ * being able to read such an entry at all, not about speed. */
+#define LZ_START_STREAMING 2 /* attempt_decode(): the stream was (re)started in window mode */
+static int32_t lz_stream_start(mzhip_lzma *z) {
+    uint64_t dict = (uint64_t)z->in[5] | ((uint64_t)z->in[6] << 8) | ((uint64_t)z->in[7] << 16) | ((uint64_t)z->in[8] << 24);
+    if (dict < 4096)
+        dict = 4096;
+    dict = (dict + 15) & ~(uint64_t)15;
+    if (dict > ((uint64_t)1 << 30))
+        return MZH_MEM_ERROR; /* (a dictionary beyond 1 GiB: liblzma would allocate it; this backend does not) */
+    const int64_t cap = (int64_t)dict + mzh_stream_window() + 16;
+    if (cap > 0x7FFFFFFF)
+        return MZH_MEM_ERROR;
+    free(z->out);
+    z->out = (uint8_t *)malloc((size_t)cap);
+    if (!z->model)
+        z->model = malloc(mzhip_lzma_model_bytes());
+    if (!z->out || !z->model)
+        return MZH_MEM_ERROR;
+    z->out_cap = cap;
+    z->dict_keep = (int64_t)dict;
+    z->out_len = z->out_served = z->hist = z->out_abs = z->in_dropped = 0;
+    z->resumed = z->stream_end = 0;
+    z->s_err = 0;
+    memset(&z->lst, 0, sizeof(z->lst));
+    z->streaming = 1;
+    z->decoded = 1; /* (the one-buffer loop is done with) */
+    return LZ_START_STREAMING;
+}
+
+/* the next window: out[hist .. out_len) are new bytes, or the stream has ended / cannot go on (stream_end / s_err) */
+static int32_t lz_stream_next(mzhip_lzma *z) {
+    if (z->out_len > 0) { /* the dictionary moves to the front; a multiple of 16 goes (position contexts) */
+        int64_t keep = z->out_len < z->dict_keep ? z->out_len : z->dict_keep;
+        const int64_t drop = (z->out_len - keep) & ~(int64_t)15;
+        keep = z->out_len - drop;
+        if (drop > 0)
+            memmove(z->out, z->out + drop, (size_t)keep);
+        z->hist = keep;
+        z->out_abs += drop;
+        z->out_len = z->out_served = keep;
+    }
+    int64_t want_in = mzh_stream_gulp();
+    for (;;) {
+        while (!z->base_eof && z->in_len < want_in) {
+            const int32_t rd = pull_chunk(z);
+            if (rd < 0) {
+                if (rd == MZH_MEM_ERROR)
+                    return rd;
+                z->base_err = rd; /* a failing base read ends the input; it is the result only if the stream needs more */
+                z->base_eof = 1;
+            }
+        }
+        mzhip_lzma_state sin = z->lst, sout;
+        sin.flags = (z->resumed ? 1u : 0u) | (z->base_eof ? 2u : 0u);
+        sin.out_pos = (uint32_t)z->hist;
+        memset(&sout, 0, sizeof(sout));
+        uint32_t ol = 0, iu = 0;
+        int64_t room = z->hist + mzh_stream_window(); /* a window's worth behind the dictionary, however small that still is */
+        if (room > z->out_cap)
+            room = z->out_cap;
+        const int32_t st = mzhip_lzma_resume_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)room, &sin, &sout, z->model, &ol, &iu);
+        if (st != 0 && st != MZHIP_STATUS_OUT_FULL && st != MZHIP_STATUS_BUF_ERROR && st != MZHIP_STATUS_DATA_ERROR) {
+            z->s_err = MZHIP_STATUS_DATA_ERROR; /* device failure: never substitute a CPU result */
+            z->error = MZH_STREAM_ERROR;
+            return MZH_OK;
+        }
+        if (iu > (uint32_t)z->in_len)
+            iu = (uint32_t)z->in_len;
+        if (ol < (uint32_t)z->hist || ol > (uint32_t)z->out_cap)
+            ol = (uint32_t)z->hist;
+        if (st == 0 || (sout.flags & 1u)) { /* the consumed bytes are done with (a failed call keeps them: TOTAL_IN wants them) */
+            memmove(z->in, z->in + iu, (size_t)(z->in_len - iu));
+            z->in_len -= iu;
+            z->in_dropped += iu;
+        } else {
+            z->dev_in_used = iu;
+        }
+        z->out_len = ol;
+        z->out_served = z->hist;
+        if (st == 0) {
+            z->stream_end = 1;
+            return MZH_OK;
+        }
+        if (sout.flags & 1u) {
+            z->lst = sout;
+            z->resumed = 1;
+            if (z->out_len > z->hist)
+                return MZH_OK; /* bytes to serve; the next window goes on from the state */
+            if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof) {
+                want_in = z->in_len + mzh_stream_gulp(); /* not one packet's worth of input: more, then again */
+                continue;
+            }
+            /* no room for one packet in a window: cannot happen (a window is >= 128 KiB) */
+            z->s_err = MZHIP_STATUS_DATA_ERROR;
+            return MZH_OK;
+        }
+        z->s_err = st; /* the stream ends short (BUF_ERROR) or is malformed: served once the bytes in front of it are */
+        return MZH_OK;
+    }
+}
+
+static int32_t lz_stream_read(mzhip_lzma *z, void *buf, int32_t size) {
+    int32_t got = 0;
+    while (got < size) {
+        int64_t avail = z->out_len - z->out_served;
+        if (z->max_total_out >= 0 && z->total_out + avail > z->max_total_out)
+            avail = z->max_total_out - z->total_out > 0 ? z->max_total_out - z->total_out : 0; /* mz_strm_lzma.c:214-215 */
+        if (avail == 0) {
+            if (z->stream_end || (z->max_total_out >= 0 && z->total_out >= z->max_total_out))
+                break;
+            if (z->s_err != 0) {
+                /* liblzma failed inside this call: the reference returns the error, not the bytes of the call, and its
+                 * totals count everything the decoder took and produced */
+                z->error = z->s_err == MZHIP_STATUS_BUF_ERROR ? 10 : 9; /* LZMA_BUF_ERROR : LZMA_DATA_ERROR */
+                z->total_out = z->out_abs + z->out_len;
+                if (z->max_total_out >= 0 && z->total_out > z->max_total_out)
+                    z->total_out = z->max_total_out;
+                z->total_in = z->s_err == MZHIP_STATUS_BUF_ERROR ? z->in_dropped + z->in_len : z->in_dropped + z->dev_in_used;
+                if (z->base_err != 0 && z->s_err == MZHIP_STATUS_BUF_ERROR)
+                    return z->base_err;
+                return MZH_DATA_ERROR;
+            }
+            const int32_t rc = lz_stream_next(z);
+            if (rc != MZH_OK) {
+                z->error = 5; /* LZMA_MEM_ERROR */
+                return MZH_DATA_ERROR;
+            }
+            if (z->error != 0)
+                return MZH_DATA_ERROR;
+            continue;
+        }
+        const int32_t k = (int32_t)(avail < size - got ? avail : size - got);
+        memcpy((uint8_t *)buf + got, z->out + z->out_served, (size_t)k);
+        z->out_served += k;
+        z->total_out += k;
+        got += k;
+    }
+    z->total_in = z->in_dropped; /* exact once the end marker has been decoded (what mz_zip.c:2116 needs) */
+    return got;
+}
+
 int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
     mzhip_lzma *z = (mzhip_lzma *)stream;
     mzhip_served_drop();
@@ -235,6 +408,8 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         z->error = MZH_STREAM_ERROR; /* a checksum call before this one met a device failure */
     if (z->error != 0)
         return MZH_DATA_ERROR; /* mz_strm_lzma.c:236-237 */
+    if (z->streaming)
+        return lz_stream_read(z, buf, size);
     while (!z->decoded) {
         int32_t rd = pull_chunk(z);
         if (rd < 0) {
@@ -282,6 +457,8 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
             z->error = 5; /* LZMA_MEM_ERROR */
             return MZH_DATA_ERROR;
         }
+        if (r == LZ_START_STREAMING)
+            return lz_stream_read(z, buf, size);
         if (r == 1)
             z->next_attempt = z->in_len * 2;
     }
@@ -478,6 +655,9 @@ int32_t mz_stream_lzma_close(void *stream) {
     free(z->in);
     if (!z->out_borrowed)
         free(z->out);
+    free(z->model);
+    z->model = NULL;
+    z->streaming = 0;
     mzhip_prime_unpin(z->prime_pin);
     z->prime_pin = NULL;
     z->out_borrowed = 0;
@@ -564,6 +744,7 @@ void mz_stream_lzma_delete(void **stream) {
         free(z->in);
         if (!z->out_borrowed)
             free(z->out);
+        free(z->model);
         mzhip_prime_unpin(z->prime_pin);
         z->prime_pin = NULL;
         free(z->wbuf);

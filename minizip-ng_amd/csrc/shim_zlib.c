@@ -377,12 +377,12 @@ MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes)
     mzh_win_bytes = window_bytes > 0 ? (window_bytes < (128 << 10) ? (128 << 10) : window_bytes) : 0;
     mzh_gulp_bytes = gulp_bytes > 0 ? (gulp_bytes < (32 << 10) ? (32 << 10) : gulp_bytes) : 0;
 }
-static int64_t mzh_stream_window(void) {
+int64_t mzh_stream_window(void) {
     if (!mzh_win_bytes)
         mzh_win_bytes = mzh_env_bytes("MZHIP_STREAM_WINDOW", MZH_STREAM_WINDOW, 128 << 10);
     return mzh_win_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : mzh_win_bytes;
 }
-static int64_t mzh_stream_gulp(void) {
+int64_t mzh_stream_gulp(void) {
     if (!mzh_gulp_bytes)
         mzh_gulp_bytes = mzh_env_bytes("MZHIP_STREAM_GULP", MZH_STREAM_GULP, 32 << 10);
     return mzh_gulp_bytes;

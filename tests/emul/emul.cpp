@@ -255,6 +255,25 @@ extern "C" int32_t emul_lzma_slots(const uint8_t *in, uint32_t in_len, uint8_t *
     *crc = r.crc;
     return r.status;
 }
+/* the resumable build: state = 16 words (mz_lzma_state), model = MZ_LZMA_MODEL_U16 probabilities, both owned by the caller */
+extern "C" uint32_t emul_lzma_model_u16(void) { return MZ_LZMA_MODEL_U16; }
+extern "C" int32_t emul_lzma_resume(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap, const uint32_t *st_in,
+                                    uint32_t *st_out, uint16_t *model, uint32_t *out_len, uint32_t *in_used) {
+    ready();
+    mz_lzma_lds *L = (mz_lzma_lds *)malloc(sizeof(mz_lzma_lds));
+    memset(L, 0xA5, sizeof(*L));
+    mz_lzma_state a, b;
+    memset(&a, 0, sizeof(a));
+    memset(&b, 0, sizeof(b));
+    if (st_in) memcpy(&a, st_in, sizeof(a));
+    mz_lzma_result r;
+    mz_lzma_entry_r(in, in_len, buf, buf_cap, (int64_t)-1, L, g_tabs.byte_tab, &g_tabs, model, &a, st_out ? &b : (mz_lzma_state *)0, &r);
+    if (st_out) memcpy(st_out, &b, sizeof(b));
+    free(L);
+    *out_len = r.out_len;
+    *in_used = r.in_used;
+    return r.status;
+}
 extern "C" uint32_t emul_lzma_slots_lds_bytes(void) { return (uint32_t)sizeof(mz_lzma_lds_s); }
 extern "C" uint32_t emul_lzma_lds_bytes(void) { return (uint32_t)sizeof(mz_lzma_lds); }
 

@@ -117,6 +117,20 @@ MOCK_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *ou
     if (crc) *crc = k;
     return st;
 }
+MOCK_API uint32_t mzhip_lzma_model_bytes(void) { return emul_lzma_model_u16() * 2u; }
+static int g_mock_lzma_windows = 0;
+MOCK_API int mzmock_lzma_windows(void) { return g_mock_lzma_windows; }
+MOCK_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                        const mzhip_lzma_state *state_in, mzhip_lzma_state *state_out, void *model,
+                                        uint32_t *out_len, uint32_t *in_used) {
+    uint32_t ol = 0, iu = 0;
+    g_mock_lzma_windows++;
+    const int32_t st = emul_lzma_resume(in, in_len, buf, buf_cap, (const uint32_t *)state_in, (uint32_t *)state_out,
+                                        (uint16_t *)model, &ol, &iu);
+    if (out_len) *out_len = ol;
+    if (in_used) *in_used = iu;
+    return st;
+}
 MOCK_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
     uint32_t ol = 0, iu = 0, k = 0;

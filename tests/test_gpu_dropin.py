@@ -198,6 +198,56 @@ def test_truncation_accounting_lzma(libs):
     print("lzma bit flips: %d of %d cases also agree in TOTAL_IN / TOTAL_OUT" % (same, n))
 
 
+def test_lzma_window_mode(libs):
+    """mz_stream_lzma READ in window mode (shim_lzma.c: the resumable build of K3, a 64-byte coder state and the adaptive
+    model carried from launch to launch, out[] = dictionary so far + one window): entries of many windows -- presets whose
+    dictionary is smaller than the entry (the dictionary slides) and the default 8 MiB one -- whole, with and without the
+    limits mz_zip sets, in small and large read() calls, cut at several places, bit-flipped: every read() return value,
+    byte, TOTAL_IN / TOTAL_OUT, close() and error() as the all-reference build."""
+    import ctypes as C
+
+    hip, ref = libs
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    L.mzhip_set_stream_window(192 << 10, 48 << 10)
+    try:
+        text, _ = synth.bench_corpus()
+        d = text[:450000] + bytes(100000) + text[:300000] + bytes(range(256)) * 300
+        for level in (6, 0, 2):
+            z, _ = ref.stream_encode(14, d, level=level)
+            # (TOTAL_OUT_MAX below the stream's real size is not compared: the reference's own accounting goes negative
+            # there -- read() returns e.g. -133355 -- which no caller can rely on; mz_zip sets the exact size)
+            for kw in (dict(max_in=len(z), max_out=len(d)), dict(), dict(chunk=10000), dict(chunk=300000)):
+                a = hip.stream_decode(14, z, len(d) + 64, **kw)
+                b = ref.stream_decode(14, z, len(d) + 64, **kw)
+                assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (level, kw, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+            for cut in (len(z) // 5, len(z) // 2, len(z) - 5, len(z) - 1):
+                for how in ("eof", "max_in"):
+                    a = hip.stream_decode(14, z[:cut] if how == "eof" else z, len(d) + 64, max_in=cut if how == "max_in" else 0)
+                    b = ref.stream_decode(14, z[:cut] if how == "eof" else z, len(d) + 64, max_in=cut if how == "max_in" else 0)
+                    assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (level, cut, how, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+            bad = z[:len(z) * 2 // 3] + bytes([z[len(z) * 2 // 3] ^ 0x55]) + z[len(z) * 2 // 3 + 1:]
+            a = hip.stream_decode(14, bad, len(d) + 64)
+            b = ref.stream_decode(14, bad, len(d) + 64)
+            assert (a["rets"], a["out"], a["close"], a["error"]) == (b["rets"], b["out"], b["close"], b["error"]), (level, "flip", a["rets"], b["rets"])
+        # through the zip layer: an archive whose LZMA entries are larger than a window, CRC verified by mz_zip_entry_read_close
+        import tempfile
+        datas = [d, text[:300000] * 2]
+        blob = np.frombuffer(b"".join(datas), dtype=np.uint8)
+        lens = np.array([len(x) for x in datas], dtype=np.int32)
+        offs = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "l.zip")
+            ref.zip_write(path, blob, offs, lens, method=14, level=1)
+            table = ref.zip_index(path)
+            out = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            _, crc, ulen, st = hip.zip_read_all(path, table[:, 6].copy(), nthreads=1, own_crc=False, out=out, out_off=offs)
+            assert (st == 0).all() and (ulen == lens).all() and out[:-1].tobytes() == blob.tobytes()
+    finally:
+        L.mzhip_set_stream_window(0, 0)
+
+
 def test_lzma_stream_parity(libs):
     hip, ref = libs
     keys = ("rets", "out", "total_in", "total_out", "close", "error", "open")

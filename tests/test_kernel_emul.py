@@ -254,6 +254,73 @@ def test_lzma_cases(emu):
     assert st == -3 == oracle.lzma_zip_decode(bytes(bad), 2000, -1)[0]
 
 
+def _lzma_windows(emu, z, total, window, gulp, dict_keep):
+    """decode z window by window through the resumable build, the way shim_lzma.c does: -> (bytes, consumed, final status)"""
+    nmodel = emu.emul_lzma_model_u16()
+    model = (C.c_uint16 * nmodel)()
+    st = (C.c_uint32 * 16)()
+    out = bytearray()
+    buf = np.zeros(dict_keep + window + 16, dtype=np.uint8)
+    hist = 0
+    pos = 0       # compressed bytes done with
+    have = 0      # compressed bytes handed over so far (pos + what the next call sees)
+    resumed = False
+    for _ in range(100000):
+        have = min(len(z), max(have, pos + gulp))
+        last = have == len(z)
+        chunk = np.frombuffer(z[pos:have] + b"\0" * 8, dtype=np.uint8).copy()
+        st[0] = (1 if resumed else 0) | (2 if last else 0)
+        st[10] = hist
+        sto = (C.c_uint32 * 16)()
+        ol, iu = C.c_uint32(), C.c_uint32()
+        rc = emu.emul_lzma_resume(chunk.ctypes.data_as(_u8p), have - pos, buf.ctypes.data_as(_u8p), hist + window, st, sto, model,
+                                  C.byref(ol), C.byref(iu))
+        out += buf[hist:ol.value].tobytes()
+        pos += iu.value
+        if rc == 0 or not sto[0]:
+            return bytes(out), pos, rc
+        # stopped in front of a packet: keep the dictionary (a multiple of 16 dropped in front), go on
+        resumed = True
+        for k in range(16):
+            st[k] = sto[k]
+        keep = min(ol.value, dict_keep)
+        drop = (ol.value - keep) & ~15
+        keep = ol.value - drop
+        buf[:keep] = buf[drop:ol.value].copy()
+        hist = keep
+        if rc == -5 and last:
+            return bytes(out), pos, rc
+        if rc == -5:
+            have = min(len(z), have + gulp)
+    raise AssertionError("no progress")
+
+
+def test_lzma_resumable_build(emu):
+    """K3's resumable build (entries decoded window by window, shim_lzma.c): same bytes and consumed count as the one-shot
+    decode for windows from 300 bytes to 64 KiB, input gulps down to 100 bytes, every lc / lp / pb class, a dictionary
+    smaller than the entry; truncated streams end with -5 and the bytes up to the cut."""
+    import lzma as pylzma
+    import random
+
+    emu.emul_lzma_resume.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                     C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    rnd = random.Random(31)
+    c = synth.corpus()
+    cases = []
+    for lc, lp, pb, dsz in ((3, 0, 2, 1 << 16), (0, 2, 0, 1 << 12), (4, 0, 4, 1 << 20), (1, 3, 1, 1 << 13), (0, 4, 2, 1 << 15)):
+        d = c[rnd.randrange(1000):][:rnd.randrange(40000, 200000)] + bytes(rnd.randrange(256) for _ in range(3000)) + b"ab" * 5000
+        raw = pylzma.compress(d, format=pylzma.FORMAT_ALONE, filters=[dict(id=pylzma.FILTER_LZMA1, lc=lc, lp=lp, pb=pb, dict_size=dsz)])
+        cases.append((d, bytes([5, 2, 5, 0]) + raw[:5] + raw[13:], max(dsz, 4096)))
+    for d, z, dsz in cases:
+        for window, gulp in ((300, 100), (4096, 700), (65536, 20000), (1000, 1 << 30)):
+            got, used, rc = _lzma_windows(emu, z, len(d), window, gulp, dsz)
+            assert rc == 0 and got == d and used == len(z), (len(d), window, gulp, rc, len(got), used, len(z))
+        cut = len(z) * 2 // 3
+        got, used, rc = _lzma_windows(emu, z[:cut], len(d), 4096, 1000, dsz)
+        so, uo, oo = oracle.lzma_zip_decode(z[:cut], len(d) + 64)  # the restatement of the one-shot decode
+        assert rc == -5 and so < 0 and got == oo and d.startswith(got) and len(got) > 0, (rc, so, len(got), len(oo))
+
+
 def test_lzma_fixture(emu, fixtures):
     for e in fixtures:
         if e["method"] != 14:

@@ -60,6 +60,10 @@ def test_truncation_accounting_lzma(libs):
     D.test_truncation_accounting_lzma(libs)
 
 
+def test_lzma_window_mode(libs):
+    D.test_lzma_window_mode(libs)
+
+
 def test_archives_through_unmodified_mz_zip(libs):
     D.test_archives_through_unmodified_mz_zip(libs)
 
