@@ -236,6 +236,28 @@ typedef struct mzhip_lzma_state {
     uint32_t flags, range, code, state, rep0, rep1, rep2, rep3, props, dict, out_pos, in_pos, pad[4];
 } mzhip_lzma_state;
 MZHIP_API uint32_t mzhip_lzma_model_bytes(void);
+/* A ZIP method-14 stream written segment by segment in bounded memory (mz_strm_lzma.c:244-332 stages any entry through
+ * 32 767 bytes).  in = [skip_blocks x 64 KiB of the stream's previous bytes | the segment]: the bytes in front are match
+ * sources and literal contexts, they are not coded again.  Every segment but the last is a multiple of 64 KiB and leaves
+ * the coder in state_out (sixteen words: flags -- in: bit 0 go on from state_in, else a fresh stream whose header comes
+ * first --, the range coder with its held-back byte, the packet state, the four repeat distances) and the adaptive model in
+ * `model` (mzhip_lzma_model_bytes(), the caller's); last != 0 writes the end marker and flushes the coder.  The bytes of
+ * the segments, in order, are the payload.  No CRC is computed. */
+/* A ZIP method-95 payload (.xz) written block by block in bounded memory: every call codes one block of independent
+ * LZMA2 chunks -- behind the stream header when first != 0 -- and reports the block's unpadded size; when the entry is
+ * complete mzhip_xz_encode_finish_host writes the index over all blocks and the stream footer.  liblzma's
+ * lzma_stream_decoder (mz_strm_lzma.c:127-128) reads a stream of any number of blocks. */
+MZHIP_API int32_t mzhip_xz_encode_block_host(const uint8_t *in, uint32_t in_len, int32_t preset, int32_t first, uint8_t *out,
+                                             uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint64_t *unpadded_size);
+MZHIP_API int32_t mzhip_xz_encode_finish_host(const uint64_t *unpadded_size, const uint64_t *uncompressed_size, uint32_t nblocks,
+                                              uint8_t *out, uint32_t out_cap, uint32_t *out_len);
+typedef struct mzhip_lzma_enc_state {
+    uint32_t flags, low_lo, low_hi, range, cache, cache_size, state, rep0, rep1, rep2, rep3, pad[5];
+} mzhip_lzma_enc_state;
+MZHIP_API int32_t mzhip_lzma_encode_resume_host(const uint8_t *in, uint32_t in_len, uint32_t skip_blocks, uint32_t last,
+                                                int32_t preset, const mzhip_lzma_enc_state *state_in,
+                                                mzhip_lzma_enc_state *state_out, void *model, uint8_t *out, uint32_t out_cap,
+                                                uint32_t *out_len);
 MZHIP_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                          const mzhip_lzma_state *state_in, mzhip_lzma_state *state_out, void *model,
                                          uint32_t *out_len, uint32_t *in_used);

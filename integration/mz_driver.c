@@ -223,6 +223,54 @@ DRV_EXPORT int32_t drv_zip_write(const char *path, int32_t method, int32_t level
     return err;
 }
 
+/* ONE entry of `total` bytes -- `piece` over and over -- written through mz_zip_writer_entry_open / _write / _close in
+ * 65 535-byte calls (mz_zip_rw.c:1427-1447), so that the caller never holds the entry: the bounded-memory test of the
+ * WRITE streams.  A second, small entry follows it. */
+DRV_EXPORT int32_t drv_zip_write_repeat(const char *path, int32_t method, int32_t level, const uint8_t *piece,
+                                        int32_t piece_len, int64_t total) {
+    void *w = mz_zip_writer_create();
+    int32_t err;
+    if (!w)
+        return MZ_MEM_ERROR;
+    mz_zip_writer_set_compress_method(w, (uint16_t)method);
+    mz_zip_writer_set_compress_level(w, (int16_t)level);
+    err = mz_zip_writer_open_file(w, path, 0, 0);
+    for (int32_t i = 0; err == MZ_OK && i < 2; i++) {
+        mz_zip_file fi;
+        int64_t left = i == 0 ? total : (total < piece_len ? total : piece_len);
+        int64_t at = 0;
+        memset(&fi, 0, sizeof(fi));
+        fi.filename = i == 0 ? "huge.bin" : "small.bin";
+        fi.modified_date = 1700000000;
+        fi.version_madeby = MZ_HOST_SYSTEM_UNIX << 8 | 63;
+        fi.compression_method = (uint16_t)method;
+        fi.flag = MZ_ZIP_FLAG_UTF8;
+        fi.zip64 = MZ_ZIP64_FORCE; /* the size is not known when the local header is written */
+        err = mz_zip_writer_entry_open(w, &fi);
+        while (err == MZ_OK && left > 0) {
+            int32_t off = (int32_t)(at % piece_len);
+            int32_t n = piece_len - off;
+            if (n > UINT16_MAX)
+                n = UINT16_MAX;
+            if (n > left)
+                n = (int32_t)left;
+            int32_t wr = mz_zip_writer_entry_write(w, piece + off, n);
+            if (wr != n)
+                err = wr < 0 ? wr : MZ_WRITE_ERROR;
+            at += n;
+            left -= n;
+        }
+        if (err == MZ_OK)
+            err = mz_zip_writer_entry_close(w);
+    }
+    if (err == MZ_OK)
+        err = mz_zip_writer_close(w);
+    else
+        mz_zip_writer_close(w);
+    mz_zip_writer_delete(&w);
+    return err;
+}
+
 /* Entry table through the reference's own central-directory walk
  * (mz_zip_goto_first/next_entry, mz_zip.c:2349-2412).  Per entry, 8 int64:
  * method, flag, crc, compressed, uncompressed, local header offset, CD

@@ -347,9 +347,24 @@ typedef struct mz_lzma_enc_result {
  * MZ_DEF_BLOCK positions: block b at tok + b * MZ_DEF_BLOCK, ntok[b] of them.  mode 0: a ZIP method-14 payload
  * (4-byte magic, 5 property bytes, range-coded data, end marker); mode 1: the payload of one LZMA2 chunk (raw
  * range-coded data, no end marker).  All arguments wave-uniform. */
-MZ_DEV void mz_lzma_rc_encode(const uint8_t *in, uint32_t in_len, const uint32_t *tok, const uint32_t *ntok, uint32_t mode,
-                              uint8_t *out, uint32_t out_cap, mz_lzma_lds *L, const uint32_t *crc_tab,
-                              const mzhip_crc_tables *tabs, mz_lzma_enc_result *res) {
+/* Where a method-14 stream that is written segment by segment stands between two launches (the drop-in WRITE stream,
+ * shim_lzma.c; mzhip.h declares the same sixteen words as mzhip_lzma_enc_state): the range coder -- low, range, the byte
+ * held back for a carry and how many 0xFF follow it --, the packet state and the four repeat distances.  The adaptive model
+ * (LZ_NUM_PROBS probabilities) travels beside it in global memory. */
+typedef struct mz_lzma_enc_state {
+    uint32_t flags; /* in: bit 0 go on from this state (else a fresh stream: header first) */
+    uint32_t low_lo, low_hi, range, cache, cache_size;
+    uint32_t state, rep0, rep1, rep2, rep3;
+    uint32_t pad[5];
+} mz_lzma_enc_state;
+
+/* skip_blocks: the first blocks of in[] are the previous segment's last bytes (match sources and contexts), already coded;
+ * rs / st / model: take the coder up from / leave it in a state (st: no end marker, no flush -- the stream goes on);
+ * without them this is the one-shot coder */
+MZ_DEV void mz_lzma_rc_encode_x(const uint8_t *in, uint32_t in_len, const uint32_t *tok, const uint32_t *ntok, uint32_t mode,
+                                uint8_t *out, uint32_t out_cap, mz_lzma_lds *L, const uint32_t *crc_tab,
+                                const mzhip_crc_tables *tabs, mz_lzma_enc_result *res, uint32_t skip_blocks,
+                                const mz_lzma_enc_state *rs, mz_lzma_enc_state *st, uint16_t *model) {
     MZ_LANE_DECL
     uint16_t *pr = L->probs;
     int32_t status = MZHIP_OK;
@@ -357,17 +372,30 @@ MZ_DEV void mz_lzma_rc_encode(const uint8_t *in, uint32_t in_len, const uint32_t
     uint32_t range = 0xFFFFFFFFu, cache = 0, cache_size = 1;
     uint32_t on = 0, ow = 0; /* bytes produced, dword being assembled */
     PV(uint32_t, owin);
-    uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0, pos = 0;
+    uint32_t state = 0, rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0, pos = skip_blocks * MZ_DEF_BLOCK;
     PV(uint32_t, crc_acc);
     PV(uint32_t, crc_tmp);
     uint32_t crc_done = 0;
+    const uint32_t resuming = (rs && (MZ_UNIFORM(rs->flags) & 1u)) ? 1u : 0u;
     MZ_LANES {
         P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u;
         P(owin) = 0u;
-        for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64) ((uint32_t *)pr)[i] = 0x04000400u;
+        for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64)
+            ((uint32_t *)pr)[i] = resuming ? ((const uint32_t *)model)[i] : 0x04000400u;
     }
     MZ_WAVE_SYNC();
-    if (mode == 0u) {
+    if (resuming) {
+        low = ((uint64_t)MZ_UNIFORM(rs->low_hi) << 32) | MZ_UNIFORM(rs->low_lo);
+        range = MZ_UNIFORM(rs->range);
+        cache = MZ_UNIFORM(rs->cache);
+        cache_size = MZ_UNIFORM(rs->cache_size);
+        state = MZ_UNIFORM(rs->state);
+        rep0 = MZ_UNIFORM(rs->rep0);
+        rep1 = MZ_UNIFORM(rs->rep1);
+        rep2 = MZ_UNIFORM(rs->rep2);
+        rep3 = MZ_UNIFORM(rs->rep3);
+    }
+    if (mode == 0u && !resuming) {
         /* version 9.20, property size 5 (what liblzma-based writers put there; the reader ignores the version,
          * mz_strm_lzma.c:118-121), then lc/lp/pb and the dictionary size (appnote.txt:2232-2275) */
         LZE_OUT_BYTE(9u);
@@ -382,7 +410,7 @@ MZ_DEV void mz_lzma_rc_encode(const uint8_t *in, uint32_t in_len, const uint32_t
     }
     {
         const uint32_t nblocks = (in_len + MZ_DEF_BLOCK - 1u) / MZ_DEF_BLOCK;
-        for (uint32_t b = 0; b < nblocks; b++) {
+        for (uint32_t b = skip_blocks; b < nblocks; b++) {
             const uint32_t *bt = tok + (size_t)b * MZ_DEF_BLOCK;
             const uint32_t nt_blk = MZ_UNIFORM(ntok[b]);
             for (uint32_t t0 = 0; t0 < nt_blk; t0 += 64u) {
@@ -481,11 +509,29 @@ MZ_DEV void mz_lzma_rc_encode(const uint8_t *in, uint32_t in_len, const uint32_t
                         pos += mlen;
                     }
                 }
-                MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, pos, crc_tab, tabs->kx);
+                if (!skip_blocks && !st) MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, pos, crc_tab, tabs->kx);
             }
         }
     }
-    if (mode == 0u) {
+    if (st) {
+        /* the stream goes on in the next launch: the coder as it stands (nothing is flushed: `low` and the held-back byte
+         * are state), the model back to global memory; what this segment produced is complete bytes */
+        MZ_LANES { /* uniform stores */
+            st->flags = 1u;
+            st->low_lo = (uint32_t)low;
+            st->low_hi = (uint32_t)(low >> 32);
+            st->range = range;
+            st->cache = cache;
+            st->cache_size = cache_size;
+            st->state = state;
+            st->rep0 = rep0;
+            st->rep1 = rep1;
+            st->rep2 = rep2;
+            st->rep3 = rep3;
+            for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64) ((uint32_t *)model)[i] = ((const uint32_t *)pr)[i];
+        }
+        MZ_WAVE_SYNC();
+    } else if (mode == 0u) {
         /* end marker: a match of the minimum length at distance 0xFFFFFFFF (appnote.txt:2262-2275, flag bit 1) */
         const uint32_t ps = pos & ((1u << MZ_LZE_PB) - 1u);
         LZE_BIT(LZ_IS_MATCH + state * 16 + ps, 1u);
@@ -493,7 +539,8 @@ MZ_DEV void mz_lzma_rc_encode(const uint8_t *in, uint32_t in_len, const uint32_t
         LZE_LEN(LZ_LEN, 0u, ps);
         LZE_MATCH_DIST(0xFFFFFFFFu, 0u);
     }
-    for (int i = 0; i < 5; i++) LZE_SHIFT_LOW();
+    if (!st)
+        for (int i = 0; i < 5; i++) LZE_SHIFT_LOW();
     /* what is left in the window */
     if (on & 3u) MZ_WRITELANE(owin, (on >> 2) & 63u, ow);
     if (on & 255u) {
@@ -508,11 +555,21 @@ finish:
     res->status = status;
     res->out_len = on;
     {
-        uint32_t crc;
-        MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, in_len, crc_tab, tabs->kx);
-        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, in, in_len, crc_tab, tabs);
+        uint32_t crc = 0;
+        if (!skip_blocks && !st && !resuming) { /* (a stream written in segments gets no fused CRC: the zip layer asks for its own, mz_zip.c:2064) */
+            MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, in_len, crc_tab, tabs->kx);
+            MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, in, in_len, crc_tab, tabs);
+        } else {
+            (void)crc_tmp;
+        }
         res->crc = crc;
     }
+}
+MZ_DEV void mz_lzma_rc_encode(const uint8_t *in, uint32_t in_len, const uint32_t *tok, const uint32_t *ntok, uint32_t mode,
+                              uint8_t *out, uint32_t out_cap, mz_lzma_lds *L, const uint32_t *crc_tab,
+                              const mzhip_crc_tables *tabs, mz_lzma_enc_result *res) {
+    mz_lzma_rc_encode_x(in, in_len, tok, ntok, mode, out, out_cap, L, crc_tab, tabs, res, 0u, (const mz_lzma_enc_state *)0,
+                        (mz_lzma_enc_state *)0, (uint16_t *)0);
 }
 
 #endif

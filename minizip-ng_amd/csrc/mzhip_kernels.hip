@@ -484,6 +484,29 @@ __global__ __launch_bounds__(64) void k_lzma_rc_encode_batch(LzmaEncArgs a) {
     }
 }
 
+// LZMA encode, pass 2 of ONE stream that is written segment by segment (the drop-in WRITE stream, shim_lzma.c): the
+// coder goes on from / is left in a 64-byte state, the adaptive model travels in global memory beside it.
+struct LzmaEncResumeArgs {
+    LzmaEncArgs a;       // entry 0 of a: [history blocks | the segment], its token blocks
+    uint32_t skip_blocks;
+    const mz_lzma_enc_state *rs;
+    mz_lzma_enc_state *st; // null: the last segment -- end marker and flush
+    uint16_t *model;
+};
+__global__ __launch_bounds__(64) void k_lzma_rc_encode_resume(LzmaEncResumeArgs r) {
+    __shared__ __attribute__((aligned(16))) mz_lzma_lds lds;
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = r.a.tabs->byte_tab[i];
+    __syncthreads();
+    const LzmaEncArgs &a = r.a;
+    mz_lzma_enc_result res;
+    mz_lzma_rc_encode_x(a.in + a.in_off[0], a.in_len[0], a.tok, a.ntok, 0u, a.out + a.out_off[0], a.out_cap[0], &lds, crc_tab, a.tabs,
+                        &res, r.skip_blocks, r.rs, r.st, r.model);
+    a.out_len[0] = res.out_len; // wave-uniform results: stored by all lanes
+    a.crc[0] = res.crc;
+    a.status[0] = res.status;
+}
+
 // ---------------------------------------------------------------------------------- host
 
 namespace {
@@ -1539,6 +1562,98 @@ int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_
     return m.status;
 }
 
+// One segment of one ZIP method-14 payload (include/mzhip.h): in = [skip_blocks x 64 KiB of the stream's previous bytes |
+// the segment].
+int32_t mzhip_lzma_encode_resume_host(const uint8_t *in, uint32_t in_len, uint32_t skip_blocks, uint32_t last, int32_t preset,
+                                      const mzhip_lzma_enc_state *state_in, mzhip_lzma_enc_state *state_out, void *model,
+                                      uint8_t *out, uint32_t out_cap, uint32_t *out_len) {
+    static_assert(sizeof(mzhip_lzma_enc_state) == sizeof(mz_lzma_enc_state), "mzhip.h and lzma_enc_core.h describe the same sixteen words");
+    DeviceCtx *c = nullptr;
+    int32_t rc = ctx_for_current(&c);
+    if (rc) return rc;
+    if (!model || !state_in || (!last && !state_out) || (uint64_t)skip_blocks * MZ_DEF_BLOCK > in_len) return -102; /* MZ_PARAM_ERROR */
+    const size_t model_bytes = (((LZ_NUM_PROBS + 1u) & ~1u) * sizeof(uint16_t) + 15) & ~(size_t)15;
+    const size_t in_pad = ((size_t)in_len + 63) & ~(size_t)63;
+    const uint32_t cap = in_len + in_len / 8 + 1024;
+    const uint32_t maxb = in_len ? (in_len + MZ_DEF_BLOCK - 1) / MZ_DEF_BLOCK : 1u;
+    const size_t tok_bytes = (size_t)maxb * MZ_DEF_BLOCK * sizeof(uint32_t) + (size_t)maxb * sizeof(uint32_t) + 64;
+    Staging sc;
+    rc = sc.get(c, 256 + model_bytes + in_pad + cap + 64 + tok_bytes);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)sc.p;
+    struct Meta {
+        mz_lzma_enc_state rs, st;
+        uint64_t in_off, out_off;
+        uint32_t in_len, out_cap, out_len, crc;
+        int32_t status;
+    } m;
+    static_assert(sizeof(Meta) <= 256, "meta block");
+    memset(&m, 0, sizeof(m));
+    memcpy(&m.rs, state_in, sizeof(m.rs));
+    uint8_t *d_model = base + 256, *d_in = d_model + model_bytes, *d_out = d_in + in_pad;
+    m.in_off = (uint64_t)(d_in - base);
+    m.out_off = (uint64_t)(d_out - base);
+    m.in_len = in_len;
+    m.out_cap = cap;
+    HIP_TRY(mz_h2d(base, &m, sizeof(m)));
+    if (state_in->flags & 1u) HIP_TRY(mz_h2d(d_model, model, ((LZ_NUM_PROBS + 1u) & ~1u) * sizeof(uint16_t)));
+    if (in_len) HIP_TRY(mz_h2d(d_in, in, in_len));
+    Meta *dm = (Meta *)base;
+    hipStream_t s = MZ_HOST_STREAM;
+    LzmaEncResumeArgs r;
+    LzmaEncArgs &a = r.a;
+    a.in = base;
+    a.in_off = &dm->in_off;
+    a.in_len = &dm->in_len;
+    a.out = base;
+    a.out_off = &dm->out_off;
+    a.out_cap = &dm->out_cap;
+    a.mode = nullptr;
+    a.n = 1;
+    a.maxb = maxb;
+    a.ways = (preset >= 0 && preset <= 3) ? 1u : MZ_DEF_WAYS_BEST;
+    if (a.ways > 1u && !big_lds_ok(c->big_lds_tok, (const void *)k_lz_tokenize_batch, MZ_WAVES_PER_WG * (sizeof(mz_lz_tok_lds) + MZ_DEF_XHEAD_BYTES)))
+        a.ways = 1u;
+    a.out_len = &dm->out_len;
+    a.crc = &dm->crc;
+    a.status = &dm->status;
+    a.tabs = c->d_tabs;
+    a.tok = (uint32_t *)(d_out + ((cap + 63u) & ~63u));
+    a.ntok = a.tok + (size_t)maxb * MZ_DEF_BLOCK;
+    a.counter = a.ntok + maxb;
+    HIP_TRY(hipMemsetAsync(a.counter, 0, 2 * sizeof(uint32_t), s));
+    {
+        const uint32_t wgs = (maxb + MZ_WAVES_PER_WG - 1) / MZ_WAVES_PER_WG;
+        const size_t lds = MZ_WAVES_PER_WG * (sizeof(mz_lz_tok_lds) + (a.ways > 1u ? MZ_DEF_XHEAD_BYTES : 0));
+        uint32_t resident = (uint32_t)c->cu_count * (a.ways > 1u ? 1u : 4u);
+        hipLaunchKernelGGL(k_lz_tokenize_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64), lds, s, a);
+        if (a.ways > 1u && hipGetLastError() != hipSuccess) {
+            c->big_lds_tok.store(-1, std::memory_order_release);
+            a.ways = 1u;
+            resident = (uint32_t)c->cu_count * 4u;
+            hipLaunchKernelGGL(k_lz_tokenize_batch, dim3(wgs < resident ? wgs : resident), dim3(MZ_WAVES_PER_WG * 64),
+                               MZ_WAVES_PER_WG * sizeof(mz_lz_tok_lds), s, a);
+        }
+    }
+    r.skip_blocks = skip_blocks;
+    r.rs = &dm->rs;
+    r.st = last ? nullptr : &dm->st;
+    r.model = (uint16_t *)d_model;
+    hipLaunchKernelGGL(k_lzma_rc_encode_resume, dim3(1), dim3(64), 0, s, r);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail("k_lzma_rc_encode_resume", le);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(mz_d2h(&m, base, sizeof(m)));
+    if (m.status == 0 && m.out_len > out_cap) m.status = MZHIP_STATUS_OUT_FULL;
+    if (m.status == 0 && m.out_len) HIP_TRY(mz_d2h(out, d_out, m.out_len));
+    if (m.status == 0 && !last) {
+        memcpy(state_out, &m.st, sizeof(m.st));
+        HIP_TRY(mz_d2h(model, d_model, ((LZ_NUM_PROBS + 1u) & ~1u) * sizeof(uint16_t)));
+    }
+    if (out_len) *out_len = m.out_len;
+    return m.status;
+}
+
 // One .xz stream (single block, CRC32 check) from a host buffer: the input is cut into 48 KiB LZMA2 chunks that
 // reset dictionary, state and properties, so every chunk is an independent stream and all of them are coded in one
 // batch; framing bytes (a few per chunk) are laid out here, their CRC-32s come from the device as well.
@@ -1547,8 +1662,10 @@ int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     return mzhip_xz_encode_host_preset(in, in_len, 1, out, out_cap, out_len, crc);
 }
 
-int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out, uint32_t out_cap,
-                                    uint32_t *out_len, uint32_t *crc) {
+// part = 0: a whole .xz stream (header, one block, index, footer).  part = 1: [the stream header when `first`] + ONE block;
+// *unpadded receives the block's unpadded size for the index (mzhip_xz_encode_finish_host writes it)
+static int32_t xz_encode_impl(const uint8_t *in, uint32_t in_len, int32_t preset, int part, int first, uint8_t *out, uint32_t out_cap,
+                              uint32_t *out_len, uint32_t *crc, uint64_t *unpadded) {
     DeviceCtx *c = nullptr;
     int32_t rc = ctx_for_current(&c);
     if (rc) return rc;
@@ -1609,7 +1726,8 @@ int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t 
     le32(hdr + 8, mzhip_crc32_host(0, hdr + 6, 2));
     uint8_t bh[12] = {0x02 /* (2 + 1) * 4 bytes */, 0x00 /* one filter, no sizes */, 0x21 /* LZMA2 */, 0x01, 0x08 /* 64 KiB */, 0, 0, 0, 0, 0, 0, 0};
     le32(bh + 8, mzhip_crc32_host(0, bh, 8));
-    if (!put(hdr, 12) || !put(bh, 12)) return MZHIP_STATUS_OUT_FULL;
+    if ((!part || first) && !put(hdr, 12)) return MZHIP_STATUS_OUT_FULL;
+    if (!put(bh, 12)) return MZHIP_STATUS_OUT_FULL;
     const uint32_t data_start = pos;
     for (uint32_t i = 0; i < np; i++) {
         if (h_status[i] != 0) return h_status[i];
@@ -1633,6 +1751,12 @@ int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t 
     uint8_t chk[4];
     le32(chk, total_crc);
     if (!put(chk, 4)) return MZHIP_STATUS_OUT_FULL;
+    if (unpadded) *unpadded = 12ull + csize_blk + 4ull;
+    if (part) {
+        if (out_len) *out_len = pos;
+        if (crc) *crc = total_crc;
+        return 0;
+    }
     uint8_t idx[32];
     uint32_t k = 0;
     idx[k++] = 0x00;
@@ -1653,6 +1777,50 @@ int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t 
     if (!put(ft, 12)) return MZHIP_STATUS_OUT_FULL;
     if (out_len) *out_len = pos;
     if (crc) *crc = total_crc;
+    return 0;
+}
+
+int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out, uint32_t out_cap,
+                                    uint32_t *out_len, uint32_t *crc) {
+    return xz_encode_impl(in, in_len, preset, 0, 1, out, out_cap, out_len, crc, nullptr);
+}
+
+// A .xz stream written block by block in bounded memory (include/mzhip.h): one block per call ...
+int32_t mzhip_xz_encode_block_host(const uint8_t *in, uint32_t in_len, int32_t preset, int32_t first, uint8_t *out, uint32_t out_cap,
+                                   uint32_t *out_len, uint32_t *crc, uint64_t *unpadded_size) {
+    if (!in_len || !unpadded_size) return -102; /* MZ_PARAM_ERROR: a block holds at least one byte */
+    return xz_encode_impl(in, in_len, preset, 1, first, out, out_cap, out_len, crc, unpadded_size);
+}
+// ... then the index over all blocks and the stream footer (host arithmetic only: a few dozen bytes)
+int32_t mzhip_xz_encode_finish_host(const uint64_t *unpadded_size, const uint64_t *uncompressed_size, uint32_t nblocks, uint8_t *out,
+                                    uint32_t out_cap, uint32_t *out_len) {
+    std::vector<uint8_t> idx;
+    auto vli = [&](uint64_t v) {
+        while (v >= 0x80) { idx.push_back((uint8_t)(v | 0x80)); v >>= 7; }
+        idx.push_back((uint8_t)v);
+    };
+    auto le32 = [](uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); };
+    idx.push_back(0x00);
+    vli(nblocks);
+    for (uint32_t i = 0; i < nblocks; i++) {
+        vli(unpadded_size[i]);
+        vli(uncompressed_size[i]);
+    }
+    while (idx.size() & 3u) idx.push_back(0);
+    uint8_t c4[4];
+    le32(c4, mzhip_crc32_host(0, idx.data(), idx.size()));
+    idx.insert(idx.end(), c4, c4 + 4);
+    uint8_t ft[12];
+    le32(ft + 4, (uint32_t)(idx.size() / 4 - 1));
+    ft[8] = 0x00;
+    ft[9] = 0x01;
+    le32(ft, mzhip_crc32_host(0, ft + 4, 6));
+    ft[10] = 'Y';
+    ft[11] = 'Z';
+    if (idx.size() + 12 > out_cap) return MZHIP_STATUS_OUT_FULL;
+    memcpy(out, idx.data(), idx.size());
+    memcpy(out + idx.size(), ft, 12);
+    if (out_len) *out_len = (uint32_t)idx.size() + 12;
     return 0;
 }
 

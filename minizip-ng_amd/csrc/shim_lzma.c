@@ -73,6 +73,14 @@ typedef struct mzhip_lzma_s {
     int64_t out_abs;       /* position in the decoded stream of out[0] (a multiple of 16) */
     int64_t in_dropped;    /* compressed bytes consumed and dropped from the front of in[] */
     int64_t dict_keep;     /* dictionary bytes kept between windows */
+    /* write side, method 14, entries larger than one segment: coded segment by segment (mzhip_lzma_encode_resume_host), wbuf[]
+     * then holds [the previous segment's last 64 KiB | bytes not coded yet] */
+    int32_t w_segments;    /* segments coded so far */
+    int64_t w_hist;        /* bytes at the front of wbuf[] that are history (0 or 65536) */
+    mzhip_lzma_enc_state west;
+    /* ... and method 95: one .xz block per segment; the index at close() wants every block's sizes */
+    uint64_t *xz_unpadded, *xz_usize;
+    int32_t xz_cap;
 } mzhip_lzma;
 
 static mzhip_stream_vtbl mzhip_lzma_vtbl = {
@@ -133,6 +141,12 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->hist = z->out_abs = z->in_dropped = z->dict_keep = 0;
     free(z->model);
     z->model = NULL;
+    z->w_segments = 0;
+    z->w_hist = 0;
+    free(z->xz_unpadded);
+    free(z->xz_usize);
+    z->xz_unpadded = z->xz_usize = NULL;
+    z->xz_cap = 0;
     free(z->wbuf);
     z->wbuf = NULL;
     z->wlen = z->wcap = 0;
@@ -505,11 +519,150 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
     return n;
 }
 
-#define MZH_LZMA_WRITE_LIMIT ((int64_t)1 << 30) /* one stream = one launch: the entry is held in host memory */
+#define LZ_WRITE_BLOCK 65536 /* the tokenizer's block: segments are multiples of it, one block of history goes along */
+
+static int32_t base_write(mzhip_stream *base, const void *buf, int32_t size);
+
+/* bytes coded per launch once an entry is larger than that: an eighth of the READ window (8 MiB by default), whole blocks */
+static int64_t lz_write_segment(void) {
+    int64_t sgm = (mzh_stream_window() / 8) & ~(int64_t)(LZ_WRITE_BLOCK - 1);
+    if (sgm < 2 * LZ_WRITE_BLOCK)
+        sgm = 2 * LZ_WRITE_BLOCK;
+    if (sgm > (8 << 20))
+        sgm = 8 << 20;
+    return sgm;
+}
+
+/* Method 14 in bounded memory (mz_strm_lzma.c:244-332 stages any entry through 32 767 bytes): a segment of whole blocks is
+ * coded with the range coder's state and the adaptive model carried over (the same tokens and the same bytes as the
+ * one-shot coder would make: the LZ77 parse sees the same 32 KiB of history either way), its output goes to base, its last
+ * 64 KiB stay in front of wbuf[] as match sources and contexts for the next one. */
+static int32_t lz_write_segment_out(mzhip_lzma *z, int32_t last) {
+    const int64_t fresh = z->wlen - z->w_hist;
+    int64_t take = fresh;
+    if (!last) {
+        take = fresh & ~(int64_t)(LZ_WRITE_BLOCK - 1);
+        if (take > lz_write_segment())
+            take = lz_write_segment();
+        if (take <= 0)
+            return MZH_OK;
+    }
+    if (!z->model)
+        z->model = malloc(mzhip_lzma_model_bytes());
+    if (!z->model)
+        return MZH_MEM_ERROR;
+    const int64_t in_len = z->w_hist + take;
+    const uint32_t cap = (uint32_t)(take + take / 8 + 4096);
+    uint8_t *out = (uint8_t *)malloc(cap);
+    if (!out)
+        return MZH_MEM_ERROR;
+    mzhip_lzma_enc_state sin = z->west, sout;
+    sin.flags = z->w_segments > 0 ? 1u : 0u;
+    memset(&sout, 0, sizeof(sout));
+    uint32_t out_len = 0;
+    const int32_t st = mzhip_lzma_encode_resume_host(z->wbuf ? z->wbuf : (const uint8_t *)"", (uint32_t)in_len,
+                                                     (uint32_t)(z->w_hist / LZ_WRITE_BLOCK), (uint32_t)last, (int32_t)z->preset, &sin,
+                                                     &sout, z->model, out, cap, &out_len);
+    if (st != 0) {
+        free(out);
+        return MZH_DATA_ERROR; /* device failure: never substitute a CPU result */
+    }
+    uint32_t pos = 0;
+    while (pos < out_len) {
+        const int32_t n = (int32_t)(out_len - pos < MZH_STAGING_BYTES ? out_len - pos : MZH_STAGING_BYTES);
+        if (base_write(z->stream.base, out + pos, n) != n) {
+            free(out);
+            return MZH_WRITE_ERROR;
+        }
+        pos += (uint32_t)n;
+    }
+    free(out);
+    z->total_out += out_len;
+    z->w_segments++;
+    if (!last) {
+        z->west = sout;
+        /* the coded bytes go, but for their last block; what was not coded moves up behind it */
+        memmove(z->wbuf, z->wbuf + in_len - LZ_WRITE_BLOCK, (size_t)LZ_WRITE_BLOCK);
+        memmove(z->wbuf + LZ_WRITE_BLOCK, z->wbuf + in_len, (size_t)(z->wlen - in_len));
+        z->wlen = LZ_WRITE_BLOCK + (z->wlen - in_len);
+        z->w_hist = LZ_WRITE_BLOCK;
+    }
+    return MZH_OK;
+}
+
+/* Method 95 in bounded memory: the .xz container holds any number of blocks, and this backend's blocks are made of LZMA2
+ * chunks that reset the dictionary anyway -- so a segment is simply one block (behind the stream header when it is the
+ * first), and close() adds the index over all blocks and the footer.  Nothing is carried from segment to segment but the
+ * two sizes per block the index wants. */
+static int32_t xz_write_block_out(mzhip_lzma *z, int64_t take) {
+    if (z->w_segments >= z->xz_cap) {
+        const int32_t ncap = z->xz_cap ? z->xz_cap * 2 : 64;
+        uint64_t *a = (uint64_t *)realloc(z->xz_unpadded, (size_t)ncap * sizeof(uint64_t));
+        if (a)
+            z->xz_unpadded = a;
+        uint64_t *b = (uint64_t *)realloc(z->xz_usize, (size_t)ncap * sizeof(uint64_t));
+        if (b)
+            z->xz_usize = b;
+        if (!a || !b)
+            return MZH_MEM_ERROR;
+        z->xz_cap = ncap;
+    }
+    const uint32_t cap = (uint32_t)(take + take / 8 + 4096 + (take / 49152 + 1) * 8);
+    uint8_t *out = (uint8_t *)malloc(cap);
+    if (!out)
+        return MZH_MEM_ERROR;
+    uint32_t out_len = 0, crc = 0;
+    uint64_t unp = 0;
+    const int32_t st = mzhip_xz_encode_block_host(z->wbuf, (uint32_t)take, (int32_t)z->preset, z->w_segments == 0, out, cap, &out_len, &crc, &unp);
+    if (st != 0) {
+        free(out);
+        return MZH_DATA_ERROR; /* device failure: never substitute a CPU result */
+    }
+    uint32_t pos = 0;
+    while (pos < out_len) {
+        const int32_t n = (int32_t)(out_len - pos < MZH_STAGING_BYTES ? out_len - pos : MZH_STAGING_BYTES);
+        if (base_write(z->stream.base, out + pos, n) != n) {
+            free(out);
+            return MZH_WRITE_ERROR;
+        }
+        pos += (uint32_t)n;
+    }
+    free(out);
+    z->total_out += out_len;
+    z->xz_unpadded[z->w_segments] = unp;
+    z->xz_usize[z->w_segments] = (uint64_t)take;
+    z->w_segments++;
+    memmove(z->wbuf, z->wbuf + take, (size_t)(z->wlen - take));
+    z->wlen -= take;
+    return MZH_OK;
+}
+
+static int32_t xz_write_finish(mzhip_lzma *z) {
+    if (z->wlen > 0) {
+        const int32_t err = xz_write_block_out(z, z->wlen);
+        if (err != MZH_OK)
+            return err;
+    }
+    uint8_t tail[64];
+    uint8_t *out = tail;
+    uint32_t cap = sizeof(tail), out_len = 0;
+    if ((size_t)z->w_segments * 18 + 32 > sizeof(tail)) {
+        cap = (uint32_t)z->w_segments * 18 + 32;
+        out = (uint8_t *)malloc(cap);
+        if (!out)
+            return MZH_MEM_ERROR;
+    }
+    int32_t err = mzhip_xz_encode_finish_host(z->xz_unpadded, z->xz_usize, (uint32_t)z->w_segments, out, cap, &out_len) == 0 ? MZH_OK : MZH_DATA_ERROR;
+    if (err == MZH_OK && base_write(z->stream.base, out, (int32_t)out_len) != (int32_t)out_len)
+        err = MZH_WRITE_ERROR;
+    if (out != tail)
+        free(out);
+    if (err == MZH_OK)
+        z->total_out += out_len;
+    return err;
+}
 
 static int32_t collect(mzhip_lzma *z, const void *buf, int64_t size) {
-    if (z->wlen + size > MZH_LZMA_WRITE_LIMIT)
-        return MZH_MEM_ERROR;
     if (z->wlen + size > z->wcap) {
         int64_t ncap = z->wcap ? z->wcap * 2 : (1 << 20);
         while (ncap < z->wlen + size)
@@ -522,6 +675,14 @@ static int32_t collect(mzhip_lzma *z, const void *buf, int64_t size) {
     }
     memcpy(z->wbuf + z->wlen, buf, (size_t)size);
     z->wlen += size;
+    /* a full segment (and a block more, so that an entry of exactly one segment stays the one-shot case) is coded and leaves */
+    while (z->wlen - z->w_hist >= lz_write_segment() + LZ_WRITE_BLOCK) {
+        const int32_t err = z->method == MZH_COMPRESS_METHOD_LZMA ? lz_write_segment_out(z, 0) : xz_write_block_out(z, lz_write_segment());
+        if (err != MZH_OK) {
+            z->error = 11; /* LZMA_PROG_ERROR */
+            return err == MZH_WRITE_ERROR ? MZH_WRITE_ERROR : MZH_DATA_ERROR;
+        }
+    }
     return MZH_OK;
 }
 
@@ -605,6 +766,8 @@ static int32_t finish_write(mzhip_lzma *z) {
         if (leave_primed(z) != MZH_OK) /* a proper prefix of a primed buffer */
             return MZH_MEM_ERROR;
     }
+    if (z->w_segments > 0) /* the last segment of an entry that left in segments: end marker and flush / last block, index, footer */
+        return z->method == MZH_COMPRESS_METHOD_LZMA ? lz_write_segment_out(z, 1) : xz_write_finish(z);
     uint32_t cap = (uint32_t)(z->wlen + z->wlen / 8 + 4096 + (z->wlen / 49152 + 1) * 8);
     uint8_t *out = (uint8_t *)malloc(cap);
     if (!out)
@@ -745,6 +908,8 @@ void mz_stream_lzma_delete(void **stream) {
         if (!z->out_borrowed)
             free(z->out);
         free(z->model);
+        free(z->xz_unpadded);
+        free(z->xz_usize);
         mzhip_prime_unpin(z->prime_pin);
         z->prime_pin = NULL;
         free(z->wbuf);

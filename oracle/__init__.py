@@ -185,6 +185,14 @@ class MzDriver:
         return out[:n].tobytes(), dict(total_in=int(info[0]), total_out=int(info[1]), close=int(info[2]),
                                        error=int(info[3]), open=int(info[5]))
 
+    def zip_write_repeat(self, path, piece, total, method=8, level=6):
+        """one entry of `total` bytes (the piece repeated) + a small one, written in 65 535-byte calls"""
+        a = _as_u8(piece)
+        self.L.drv_zip_write_repeat.argtypes = [C.c_char_p, C.c_int32, C.c_int32, _u8p, C.c_int32, C.c_int64]
+        err = self.L.drv_zip_write_repeat(path.encode(), method, level, _ptr(a), a.size, total)
+        if err != 0:
+            raise RuntimeError("drv_zip_write_repeat failed: %d" % err)
+
     def zip_write(self, path, blob, offs, lens, method=8, level=6):
         b = _as_u8(blob)
         o = np.ascontiguousarray(offs, dtype=np.int64)

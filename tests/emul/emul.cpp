@@ -197,6 +197,43 @@ extern "C" int32_t emul_lzma_encode_ways(const uint8_t *in, uint32_t in_len, uin
     return r.status;
 }
 
+/* one segment of a method-14 stream written in segments (mzhip_lzma_encode_resume_host's device side): state = 16 words
+ * (mz_lzma_enc_state), model = LZ_NUM_PROBS probabilities, both the caller's */
+extern "C" int32_t emul_lzma_encode_resume(const uint8_t *in, uint32_t in_len, uint32_t skip_blocks, uint32_t last, uint32_t ways,
+                                           const uint32_t *st_in, uint32_t *st_out, uint16_t *model, uint8_t *out, uint32_t out_cap,
+                                           uint32_t *out_len) {
+    ready();
+    const uint32_t nblocks = (in_len + MZ_DEF_BLOCK - 1) / MZ_DEF_BLOCK;
+    uint32_t *tok = (uint32_t *)malloc((size_t)(nblocks ? nblocks : 1) * MZ_DEF_BLOCK * sizeof(uint32_t));
+    uint32_t *ntok = (uint32_t *)calloc(nblocks ? nblocks : 1, sizeof(uint32_t));
+    mz_lz_tok_lds *T = (mz_lz_tok_lds *)malloc(sizeof(mz_lz_tok_lds));
+    const size_t xbytes = (MZ_DEF_WAYS_BEST - 1u) * (sizeof(uint16_t) << MZ_DEF_HBITS);
+    uint16_t *xhead = (uint16_t *)malloc(xbytes);
+    for (uint32_t b = 0; b < nblocks; b++) {
+        memset(T, 0xA5, sizeof(*T));
+        memset(xhead, 0xA5, xbytes);
+        const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0);
+    }
+    free(xhead);
+    mz_lzma_lds *L = (mz_lzma_lds *)malloc(sizeof(mz_lzma_lds));
+    memset(L, 0xA5, sizeof(*L));
+    mz_lzma_enc_state a, b;
+    memset(&a, 0, sizeof(a));
+    memset(&b, 0, sizeof(b));
+    if (st_in) memcpy(&a, st_in, sizeof(a));
+    mz_lzma_enc_result r;
+    mz_lzma_rc_encode_x(in, in_len, tok, ntok, 0u, out, out_cap, L, g_tabs.byte_tab, &g_tabs, &r, skip_blocks, &a,
+                        last ? (mz_lzma_enc_state *)0 : &b, model);
+    if (!last && st_out) memcpy(st_out, &b, sizeof(b));
+    free(L);
+    free(T);
+    free(tok);
+    free(ntok);
+    *out_len = r.out_len;
+    return r.status;
+}
+
 /* the stand-alone kernel's path: 4 KiB super-tiles, then 1 KiB tiles, then the tail */
 extern "C" uint32_t emul_crc32_super(const uint8_t *buf, uint32_t n, uint32_t init) {
     ready();

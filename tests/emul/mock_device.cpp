@@ -131,6 +131,18 @@ MOCK_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint
     if (in_used) *in_used = iu;
     return st;
 }
+static int g_mock_lzma_segments = 0;
+MOCK_API int mzmock_lzma_segments(void) { return g_mock_lzma_segments; }
+MOCK_API int32_t mzhip_lzma_encode_resume_host(const uint8_t *in, uint32_t in_len, uint32_t skip_blocks, uint32_t last, int32_t preset,
+                                               const mzhip_lzma_enc_state *state_in, mzhip_lzma_enc_state *state_out, void *model,
+                                               uint8_t *out, uint32_t out_cap, uint32_t *out_len) {
+    uint32_t ol = 0;
+    g_mock_lzma_segments++;
+    const int32_t st = emul_lzma_encode_resume(in, in_len, skip_blocks, last, (preset >= 0 && preset <= 3) ? 1u : MZ_DEF_WAYS_BEST,
+                                               (const uint32_t *)state_in, (uint32_t *)state_out, (uint16_t *)model, out, out_cap, &ol);
+    if (out_len) *out_len = ol;
+    return st;
+}
 MOCK_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                uint32_t *out_len, uint32_t *in_used, uint32_t *crc) {
     uint32_t ol = 0, iu = 0, k = 0;
@@ -155,6 +167,13 @@ MOCK_API int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_le
                                  crc);
 }
 MOCK_API int32_t mzhip_xz_encode_host_preset(const uint8_t *, uint32_t, int32_t, uint8_t *, uint32_t, uint32_t *, uint32_t *) {
+    return MZHIP_STATUS_UNSUPPORTED;
+}
+MOCK_API int32_t mzhip_xz_encode_block_host(const uint8_t *, uint32_t, int32_t, int32_t, uint8_t *, uint32_t, uint32_t *, uint32_t *,
+                                            uint64_t *) {
+    return MZHIP_STATUS_UNSUPPORTED;
+}
+MOCK_API int32_t mzhip_xz_encode_finish_host(const uint64_t *, const uint64_t *, uint32_t, uint8_t *, uint32_t, uint32_t *) {
     return MZHIP_STATUS_UNSUPPORTED;
 }
 

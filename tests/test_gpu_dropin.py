@@ -248,6 +248,33 @@ def test_lzma_window_mode(libs):
         L.mzhip_set_stream_window(0, 0)
 
 
+def test_lzma_write_in_segments(libs):
+    """mz_stream_lzma WRITE in bounded memory (shim_lzma.c): an entry larger than one segment leaves in segments.  Method 14:
+    the range coder's state and the adaptive model are carried from launch to launch, so the payload is byte for byte what
+    the one-shot coder makes -- and the all-reference READ stream decodes it.  (Method 95, one .xz block per segment:
+    tests/test_gpu_lzma_enc.py, the mock has no .xz encoder.)"""
+    import ctypes as C
+
+    hip, ref = libs
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    text, _ = synth.bench_corpus()
+    d = (text[:450000] + bytes(100000) + text[:300000]) * 2 + bytes(range(256)) * 100
+    try:
+        for lvl in (1, 6):
+            L.mzhip_set_stream_window(0, 0)
+            z0, i0 = hip.stream_encode(14, d, level=lvl)              # one launch (the entry is smaller than 8 MiB)
+            L.mzhip_set_stream_window(1 << 20, 48 << 10)              # segments of 128 KiB
+            for chunk in (65535, 1000, 400000):
+                z1, i1 = hip.stream_encode(14, d, level=lvl, chunk=chunk)
+                assert z1 == z0 and i1 == i0, (lvl, chunk, len(z0), len(z1))
+            b = ref.stream_decode(14, z1, len(d) + 64, max_in=len(z1), max_out=len(d))
+            assert b["out"] == d and b["close"] == 0 and b["error"] == 0, lvl
+    finally:
+        L.mzhip_set_stream_window(0, 0)
+
+
 def test_lzma_stream_parity(libs):
     hip, ref = libs
     keys = ("rets", "out", "total_in", "total_out", "close", "error", "open")

@@ -218,3 +218,29 @@ def test_encode_decode_roundtrip_property_on_device(gpu):
     assert bool((d_crc == torch.from_numpy(want_u[idx].view(np.int32).copy()).to(dev)).all())
     for e in (0, n_total // 2, n_total - 1):
         assert out[e * size:(e + 1) * size].cpu().numpy().tobytes() == datas[idx[e]]
+
+
+def test_xz_write_in_blocks_is_read_by_the_reference(gpu):
+    """Method 95 WRITE in bounded memory (shim_lzma.c): an entry larger than one segment becomes one .xz stream of several
+    blocks (a block per segment, index and footer at close()); liblzma behind the all-reference mz_stream_lzma READ decodes
+    it, and so does this backend's own .xz kernel."""
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    text, _ = synth.bench_corpus()
+    d = (text[:450000] + bytes(100000) + text[:300000]) * 2 + bytes(range(256)) * 100
+    try:
+        L.mzhip_set_stream_window(1 << 20, 48 << 10)                  # segments of 128 KiB: 14 blocks
+        for lvl, chunk in ((1, 65535), (6, 1000), (6, 400000)):
+            z, info = hip.stream_encode(95, d, level=lvl, chunk=chunk)
+            assert info["close"] == 0 and info["total_in"] == len(d) and info["total_out"] == len(z)
+            assert lzma.decompress(z, format=lzma.FORMAT_XZ) == d     # liblzma itself (Python's module)
+            b = ref.stream_decode(95, z, len(d) + 64)
+            assert b["out"] == d and b["close"] == 0 and b["error"] == 0
+            a = hip.stream_decode(95, z, len(d) + 64)                 # ... and the .xz kernel of this backend
+            assert a["out"] == d and a["close"] == 0 and a["error"] == 0
+    finally:
+        L.mzhip_set_stream_window(0, 0)

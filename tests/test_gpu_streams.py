@@ -145,3 +145,49 @@ def test_entry_larger_than_any_window_bounded_memory(tmp_path):
     print("3 GiB entry through the drop-in: %.1f s, peak RSS %.0f MiB (the same process reading a 70 KB entry: %.0f MiB)"
           % (got["sec"], got["rss_kib"] / 1024, base["rss_kib"] / 1024))
     assert got["rss_kib"] - base["rss_kib"] < 512 * 1024                  # a 64 MiB window, 16 MiB of input, staging: not the entry
+
+
+def test_written_entry_larger_than_any_segment_bounded_memory(tmp_path):
+    """WRITE side of the same property (mz_strm_zlib.c:203-264 stages any entry through 32 767 bytes): a 3 GiB ZIP64 entry
+    is written through the unmodified mz_zip_writer on the drop-in mz_stream_zlib WRITE stream -- 8 MiB segments, one K4
+    launch each, nothing else kept -- in a process whose peak RSS stays far below the entry, and the ALL-REFERENCE reader
+    extracts it with its own CRC verification."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import oracle
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    DROP = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing")
+    path = str(tmp_path / "wbig.zip")
+    total = 3 * (1 << 30) + 4321
+    prog = (
+        "import sys, json, resource, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np, oracle\n"
+        "from tests import synth\n"
+        "hip = oracle.MzDriver(%r)\n"
+        "piece = (synth.corpus()[:300000] + bytes(700000))\n"
+        "t0 = time.time()\n"
+        "hip.zip_write_repeat(%r, piece, TOTAL, method=8, level=1)\n"
+        "print(json.dumps(dict(sec=time.time() - t0, rss_kib=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)))\n"
+        % (ROOT, DROP, path))
+    # the same process shape writing a 70 KB entry first: what the HIP runtime, numpy and the libraries cost by themselves
+    r0 = subprocess.run([sys.executable, "-c", prog.replace("TOTAL", "70000")], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    base = json.loads([l for l in r0.stdout.splitlines() if l.startswith("{")][-1])
+    r = subprocess.run([sys.executable, "-c", prog.replace("TOTAL", str(total))], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ref = oracle.ref()
+    table = ref.zip_index(path)
+    assert len(table) == 2 and int(table[0, 4]) == total
+    _, crc_r, ulen_r, st_r = ref.zip_read_all(path, table[:, 6].copy(), nthreads=1, own_crc=False)
+    assert (st_r == 0).all() and int(ulen_r[0]) == total           # st 0 = the reference's own CRC verification passed
+    print("3 GiB entry written through the drop-in: %.1f s, %.2f GiB/s, archive %.1f MiB, peak RSS %.0f MiB (a 70 KB entry: %.0f MiB)"
+          % (got["sec"], total / 2**30 / got["sec"], os.path.getsize(path) / 2**20, got["rss_kib"] / 1024, base["rss_kib"] / 1024))
+    assert got["rss_kib"] - base["rss_kib"] < 512 * 1024

@@ -64,6 +64,10 @@ def test_lzma_window_mode(libs):
     D.test_lzma_window_mode(libs)
 
 
+def test_lzma_write_in_segments(libs):
+    D.test_lzma_write_in_segments(libs)
+
+
 def test_archives_through_unmodified_mz_zip(libs):
     D.test_archives_through_unmodified_mz_zip(libs)
 
