@@ -13,6 +13,8 @@
  *   mz_stream_lzma_* (13 functions)                   mz_strm_lzma.h:20-35
  *   mz_crypt_crc32_update                             mz_crypt.h:20
  *   called from                                       mz_zip.c:1773,1792,2049,2064
+ *   mz_crypt_sha_* (7 functions, optional)            mz_crypt.h:29-35
+ *   called from                                       mz_zip_rw.c:409-451,462-467 (crypto builds)
  *
  * The stream-object contract they honour (mz_strm.h:53-72): the instance
  * starts with { vtbl*, base* }; vtbl has 12 slots in the order open, is_open,
@@ -88,6 +90,19 @@ MZHIP_API void *mz_stream_lzma_get_interface(void);
 
 /* mz_crypt.h:20 */
 MZHIP_API uint32_t mz_crypt_crc32_update(uint32_t value, const uint8_t *buf, int32_t size);
+
+/* mz_crypt.h:29-35 -- the hash the reader runs over an entry that carries a Hash extra field (mz_zip_rw.c:409-451,462-467).
+ * For an entry that mzhip_prime_*() decoded, the digest is the one the device computed in that pass (shim_sha.c); for
+ * everything else these call the reference's own implementation, which the link step keeps as mz_ref_crypt_sha_* (weak
+ * here; absent: MZ_SUPPORT_ERROR -- this library holds no second SHA for a single stream).  Optional: an application
+ * built with MZ_ZIP_NO_CRYPTO never references them. */
+MZHIP_API void mz_crypt_sha_reset(void *handle);
+MZHIP_API int32_t mz_crypt_sha_begin(void *handle);
+MZHIP_API int32_t mz_crypt_sha_update(void *handle, const void *buf, int32_t size);
+MZHIP_API int32_t mz_crypt_sha_end(void *handle, uint8_t *digest, int32_t digest_size);
+MZHIP_API int32_t mz_crypt_sha_set_algorithm(void *handle, uint16_t algorithm);
+MZHIP_API void *mz_crypt_sha_create(void);
+MZHIP_API void mz_crypt_sha_delete(void **handle);
 
 /* ---- constants restated from the reference (value, source) ---- */
 #define MZH_OK 0               /* mz.h:21 */

@@ -293,6 +293,11 @@ MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t s
  * entry at a time (mz_zip.c:947-1100, :202-479, :2402-2412); SURVEY 8(f) row 1.  Returns the entry count
  * (which may exceed max_entries: call again with a larger table) or MZ_FORMAT_ERROR (-103). */
 MZHIP_API int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table, int64_t max_entries);
+/* The Hash extra field (0x1a51) of every entry of such a table: the first one of its central-directory record (what
+ * mz_zip_reader_entry_get_first_hash picks, mz_zip_rw.c:510-540).  algorithm[i] = MZ_HASH_* or 0 (none), digest_size[i],
+ * digest + 64 * i.  Returns the number of entries that carry one. */
+MZHIP_API int64_t mzhip_zip_index_hash_mem(const uint8_t *zip, uint64_t zip_len, const int64_t *table, int64_t n,
+                                           uint16_t *algorithm, uint16_t *digest_size, uint8_t *digest);
 
 /* Prime (SURVEY 8b "Batching") ------------------------------------------------------------- */
 
@@ -333,6 +338,13 @@ MZHIP_API void mzhip_prime_clear(void);
  * afterwards. */
 MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes);
 MZHIP_API void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
+/* Entries that carry a SHA-1 / SHA-256 Hash extra field (0x1a51): the prime computes the digest of the decoded bytes on
+ * the device in the pass that decodes them (mzhip_sha_batch over the chunk in HBM) and compares it with the field's, as
+ * mz_zip_reader_entry_close does on the host (mz_zip_rw.c:439-451).  An entry whose digest differs is not served from the
+ * cache -- the ordinary path, and whoever verifies behind it, sees it.  Counters since the process started. */
+MZHIP_API void mzhip_prime_hash_stats(uint64_t *checked, uint64_t *mismatched);
+/* mz_crypt_sha_end calls that were answered with a device-computed digest (shim_sha.c) */
+MZHIP_API uint64_t mzhip_sha_primed_digests(void);
 
 /* Write-side prime (SURVEY 8b "Batching", BASELINE config 5) ------------------------------- */
 

@@ -223,6 +223,49 @@ DRV_EXPORT int32_t drv_zip_write(const char *path, int32_t method, int32_t level
     return err;
 }
 
+/* Every entry through the reader OBJECT (mz_zip_reader_goto_first/next_entry, _entry_open, _entry_read in 65 535-byte
+ * calls, _entry_close: mz_zip_rw.c:375-467) -- the layer that, in a build with crypto, hashes what it reads and compares the
+ * digest with the entry's Hash extra field when the entry is closed (mz_zip_rw.c:409-451).  status[i] = the first error of
+ * entry i (open, read or close), ulen[i] = bytes read.  Returns the number of entries walked or < 0. */
+DRV_EXPORT int64_t drv_zip_reader_walk(const char *path, int32_t *status, int64_t *ulen, int64_t max_entries) {
+    void *r = mz_zip_reader_create();
+    uint8_t *buf = (uint8_t *)malloc(UINT16_MAX);
+    int64_t n = 0;
+    int32_t err;
+    if (!r || !buf) {
+        free(buf);
+        return MZ_MEM_ERROR;
+    }
+    err = mz_zip_reader_open_file(r, path);
+    if (err == MZ_OK)
+        err = mz_zip_reader_goto_first_entry(r);
+    while (err == MZ_OK && n < max_entries) {
+        int32_t st = mz_zip_reader_entry_open(r);
+        int64_t got = 0;
+        if (st == MZ_OK) {
+            for (;;) {
+                int32_t rd = mz_zip_reader_entry_read(r, buf, UINT16_MAX);
+                if (rd < 0)
+                    st = rd;
+                if (rd <= 0)
+                    break;
+                got += rd;
+            }
+            int32_t cl = mz_zip_reader_entry_close(r);
+            if (st == MZ_OK)
+                st = cl;
+        }
+        status[n] = st;
+        ulen[n] = got;
+        n++;
+        err = mz_zip_reader_goto_next_entry(r);
+    }
+    mz_zip_reader_close(r);
+    mz_zip_reader_delete(&r);
+    free(buf);
+    return (err == MZ_OK || err == MZ_END_OF_LIST) ? n : (int64_t)err;
+}
+
 /* ONE entry of `total` bytes -- `piece` over and over -- written through mz_zip_writer_entry_open / _write / _close in
  * 65 535-byte calls (mz_zip_rw.c:1427-1447), so that the caller never holds the entry: the bounded-memory test of the
  * WRITE streams.  A second, small entry follows it. */

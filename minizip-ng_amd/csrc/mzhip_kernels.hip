@@ -2097,6 +2097,11 @@ struct PrimedEntry {
     int32_t method;
     int32_t head_len;
     uint8_t head[256]; // the first payload bytes: a stream must present the same ones to be served
+    // the entry's Hash extra field (0x1a51, mz_zip_rw.c:1398-1408), when it names SHA-1 or SHA-256 -- the two the reader
+    // verifies (mz_zip_rw.c:414-419): the digest of the decoded bytes is computed on the device in the pass that decodes
+    // them and compared with the field's; an entry whose digest differs is not served from the cache
+    uint16_t hash_alg, hash_size; // 0: no such field
+    uint8_t hash_want[32], hash_got[32];
 };
 // One primed archive.  Generations are reference-counted: an open stream that is being served from one pins it, so a
 // later prime / clear (another archive, another thread, MZHIP_AUTOPRIME) never frees memory a stream still reads.
@@ -2142,6 +2147,7 @@ PrimeCache g_prime;
 // publishing, replacing and clearing a generation take it exclusively
 std::shared_mutex g_prime_mu;
 std::atomic<uint64_t> g_prime_hits{0}, g_prime_misses{0};
+std::atomic<uint64_t> g_prime_hash_checked{0}, g_prime_hash_bad{0}; // entries whose Hash field was verified on the device / differed
 std::atomic<uint64_t> g_prime_wait_ns{0}, g_prime_wait_n{0}; // MZHIP_PRIME_TRACE: lookups that had to wait for their chunk
 std::atomic<int> g_any_gens{0};   // generations present at all: the streams' "is there anything to look up" (mzhip_prime_any)
 std::atomic<int> g_store_gens{0}; // generations that hold STORE chunks: the CRC symbol's fast "nothing to look up"
@@ -2204,6 +2210,8 @@ struct PrimeLane {
     int64_t seg0 = 0;
     std::vector<uint32_t> order;
     size_t res_off = 0; // where the result arrays start inside h_meta
+    std::vector<size_t> hash_ent; // entries of the chunk whose digests were asked for, in launch order ...
+    size_t hash_off = 0;          // ... and where their 32-byte digests land inside h_meta
     ~PrimeLane() {
         if (s) (void)hipStreamDestroy(s);
         if (h_meta) (void)hipHostFree(h_meta);
@@ -2241,7 +2249,21 @@ int32_t prime_lane_collect(PrimeLane &L, PrimeGen *gen) {
         const bool good = h_st[i] == 0 && h_len[i] == (uint32_t)e.usize && h_used[i] == (uint32_t)e.csize;
         e.crc = h_crc[i];
         e.status = good ? 0 : (h_st[i] ? h_st[i] : -3);
-        gen->state[g].store(good ? 1 : 2, std::memory_order_release);
+        if (!e.hash_alg) gen->state[g].store(good ? 1 : 2, std::memory_order_release);
+    }
+    /* entries with a SHA-1 / SHA-256 Hash field: servable only if the digest of what was decoded is the field's (the
+     * reference compares the field's digest_size bytes, mz_zip_rw.c:446-449) */
+    for (size_t j = 0; j < L.hash_ent.size(); j++) {
+        PrimedEntry &e = gen->entries[L.hash_ent[j]];
+        memcpy(e.hash_got, L.h_meta + L.hash_off + 32 * j, 32);
+        const uint32_t full = e.hash_alg == 20 ? 20u : 32u;
+        const uint32_t cmp = e.hash_size < full ? e.hash_size : full;
+        const bool same = e.status == 0 && e.hash_size <= 64 && memcmp(e.hash_got, e.hash_want, cmp) == 0;
+        if (e.status == 0) {
+            g_prime_hash_checked.fetch_add(1, std::memory_order_relaxed);
+            if (!same) g_prime_hash_bad.fetch_add(1, std::memory_order_relaxed);
+        }
+        gen->state[L.hash_ent[j]].store(same ? 1 : 2, std::memory_order_release);
     }
     { std::lock_guard<std::mutex> lk(gen->mu); } /* (a waiter is either before its check or inside wait()) */
     gen->cv.notify_all();
@@ -2317,17 +2339,26 @@ int32_t prime_slice(const uint8_t *zip, PrimeGen *gen, const std::vector<int64_t
         const size_t up = (size_t)k * 24 + (size_t)ns * 8 + (size_t)k * 8 + (size_t)ns * 4;
         const size_t down = (size_t)k * 16 + (size_t)ns * 4;
         const size_t up_al = (up + 255) & ~(size_t)255;
-        if (up_al + down > L.h_cap) {
+        /* ... and for the entries with a SHA-1 / SHA-256 Hash field: off[kh] (8 bytes), len[kh] (4) up, digest[kh] (32) down */
+        L.hash_ent.clear();
+        for (int pass = 0; pass < 2; pass++)
+            for (size_t i = c0; i < c1; i++)
+                if (ents[i].hash_alg == (pass == 0 ? 20 : 23)) L.hash_ent.push_back(i); /* SHA-1 first, then SHA-256: one launch each */
+        const size_t kh = L.hash_ent.size();
+        const size_t down_al = (down + 255) & ~(size_t)255;
+        const size_t hup = kh * 12, hup_al = (hup + 255) & ~(size_t)255, hdown = kh * 32;
+        const size_t meta_all = up_al + down_al + hup_al + hdown;
+        if (meta_all > L.h_cap) {
             if (L.h_meta) HIP_TRY(hipHostFree(L.h_meta));
             L.h_meta = nullptr;
             L.h_cap = 0;
-            const size_t want = ((up_al + down) * 2 + 4095) & ~(size_t)4095;
+            const size_t want = (meta_all * 2 + 4095) & ~(size_t)4095;
             HIP_TRY(hipHostMalloc((void **)&L.h_meta, want, hipHostMallocDefault));
             L.h_cap = want;
         }
         rc = prime_lane_reserve(&L.d_zip.p, &L.zip_cap, (size_t)(zhi - zlo) + 16);
         if (!rc) rc = prime_lane_reserve(&L.d_out.p, &L.out_cap, (size_t)out_bytes + 16);
-        if (!rc) rc = prime_lane_reserve(&L.d_meta.p, &L.meta_cap, up_al + down + 256);
+        if (!rc) rc = prime_lane_reserve(&L.d_meta.p, &L.meta_cap, meta_all + 256);
         if (rc) return rc;
         L.order.resize(k);
         for (uint32_t i = 0; i < k; i++) L.order[i] = i;
@@ -2379,6 +2410,28 @@ int32_t prime_slice(const uint8_t *zip, PrimeGen *gen, const std::vector<int64_t
         if (ns) {
             rc = mzhip_crc32_batch(L.d_out.p, d_seg_off, d_seg_len, ns, nullptr, d_seg_crc, L.s);
             if (rc) return rc;
+        }
+        if (kh) {
+            /* the digests of the decoded bytes, while they are in HBM (what mz_zip_reader_entry_read hashes 65 535 bytes at a
+             * time on the host, mz_zip_rw.c:465-466): one lane per entry, one launch per algorithm */
+            uint64_t *h_hoff = (uint64_t *)(L.h_meta + up_al + down_al);
+            uint32_t *h_hlen = (uint32_t *)(h_hoff + kh);
+            size_t n1 = 0;
+            for (size_t j = 0; j < kh; j++) {
+                const PrimedEntry &e = ents[L.hash_ent[j]];
+                h_hoff[j] = (uint64_t)(e.out_off - out_base);
+                h_hlen[j] = (uint32_t)e.usize;
+                n1 += e.hash_alg == 20 ? 1 : 0;
+            }
+            uint64_t *d_hoff = (uint64_t *)(m + up_al + down_al);
+            uint32_t *d_hlen = (uint32_t *)(d_hoff + kh);
+            uint8_t *d_dig = m + up_al + down_al + hup_al;
+            HIP_TRY(hipMemcpyAsync(d_hoff, h_hoff, hup, hipMemcpyHostToDevice, L.s));
+            if (n1) rc = mzhip_sha_batch(L.d_out.p, d_hoff, d_hlen, (uint32_t)n1, 20, d_dig, L.s);
+            if (!rc && kh > n1) rc = mzhip_sha_batch(L.d_out.p, d_hoff + n1, d_hlen + n1, (uint32_t)(kh - n1), 23, d_dig + 32 * n1, L.s);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(L.h_meta + up_al + down_al + hup_al, d_dig, hdown, hipMemcpyDeviceToHost, L.s));
+            L.hash_off = up_al + down_al + hup_al;
         }
         HIP_TRY(hipMemcpyAsync(L.h_meta + up_al, m + up_al, down, hipMemcpyDeviceToHost, L.s));
         HIP_TRY(hipMemcpyAsync(h_out + out_base, L.d_out.p, out_bytes, hipMemcpyDeviceToHost, L.s));
@@ -2543,6 +2596,10 @@ int64_t prime_prepare(const uint8_t *zip, uint64_t zip_len, const int32_t *devic
     auto gen = std::make_shared<PrimeGen>();
     std::vector<PrimedEntry> &ents = gen->entries;
     ents.reserve(rows.size());
+    std::vector<uint16_t> h_alg((size_t)n), h_dsz((size_t)n);
+    std::vector<uint8_t> h_dig((size_t)n * 64);
+    if (mzhip_zip_index_hash_mem(zip, zip_len, table.data(), n, h_alg.data(), h_dsz.data(), h_dig.data()) < 0)
+        std::fill(h_alg.begin(), h_alg.end(), (uint16_t)0);
     uint64_t total_out = 0;
     int64_t nseg = 0;
     for (const int64_t i : rows) {
@@ -2558,6 +2615,11 @@ int64_t prime_prepare(const uint8_t *zip, uint64_t zip_len, const int32_t *devic
         e.status = -1;
         e.head_len = (int32_t)(t[3] < (int64_t)sizeof(e.head) ? t[3] : (int64_t)sizeof(e.head));
         memcpy(e.head, zip + t[7], (size_t)e.head_len);
+        if (h_alg[(size_t)i] == 20 || h_alg[(size_t)i] == 23) { /* SHA-1 / SHA-256: what mz_zip_reader_entry_open sets up (mz_zip_rw.c:414-419) */
+            e.hash_alg = h_alg[(size_t)i];
+            e.hash_size = h_dsz[(size_t)i];
+            memcpy(e.hash_want, &h_dig[(size_t)i * 64], 32);
+        }
         ents.push_back(e);
         /* TOTAL_OUT_MAX as mz_zip.c:1833-1846 sets it: the uncompressed size when the EOS flag is set */
         job->max_out.push_back((t[0] != 8 && (t[1] & 2)) ? t[4] : -1);
@@ -2766,6 +2828,11 @@ int64_t mzhip_prime_file_multi(const char *path, const int32_t *devices, int32_t
 
 int64_t mzhip_prime_file(const char *path) { return prime_file_on(path, nullptr, 0, 0); }
 
+void mzhip_prime_hash_stats(uint64_t *checked, uint64_t *mismatched) {
+    if (checked) *checked = g_prime_hash_checked.load();
+    if (mismatched) *mismatched = g_prime_hash_bad.load();
+}
+
 void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses) {
     std::shared_lock<std::shared_mutex> lk(g_prime_mu);
     if (entries) {
@@ -2815,8 +2882,11 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_any(void) { return g_a
 __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup3(int32_t method, int64_t payload_off, const uint8_t *head,
                                                                   int32_t head_len, int64_t max_total_in, const uint8_t **data,
                                                                   int64_t *usize, int64_t *csize, uint32_t *crc,
-                                                                  const uint32_t **seg_crc, void **pin) {
+                                                                  const uint32_t **seg_crc, void **pin, uint16_t *hash_alg,
+                                                                  const uint8_t **hash_digest) {
     *pin = nullptr;
+    if (hash_alg) *hash_alg = 0;
+    if (hash_digest) *hash_digest = nullptr;
     std::vector<std::shared_ptr<PrimeGen>> gens;
     {
         std::shared_lock<std::shared_mutex> lk(g_prime_mu);
@@ -2876,6 +2946,10 @@ __attribute__((visibility("hidden"))) int32_t mzhip_prime_lookup3(int32_t method
         *csize = e.csize;
         *crc = e.crc;
         *seg_crc = g->seg_crc.data() + e.seg0;
+        if (e.hash_alg && hash_alg && hash_digest) { /* (served, so the device's digest is the Hash field's) */
+            *hash_alg = e.hash_alg;
+            *hash_digest = e.hash_got;
+        }
         g_prime_hits.fetch_add(1, std::memory_order_relaxed);
         *pin = new std::shared_ptr<PrimeGen>(g);
         return 1;

@@ -8,7 +8,7 @@
  * cached generation alive; hand it back with mzhip_prime_unpin() when the stream stops reading from `data`. */
 int32_t mzhip_prime_lookup3(int32_t method, int64_t payload_off, const uint8_t *head, int32_t head_len, int64_t max_total_in,
                             const uint8_t **data, int64_t *usize, int64_t *csize, uint32_t *crc, const uint32_t **seg_crc,
-                            void **pin);
+                            void **pin, uint16_t *hash_alg, const uint8_t **hash_digest);
 void mzhip_prime_unpin(void *pin);
 /* are these bytes one 65 535-byte reader chunk of a primed STORE entry?  1 = yes (*crc = its device-computed CRC-32;
  * equality was checked byte for byte against the primed payload) */
@@ -42,6 +42,13 @@ typedef struct mzhip_served_s {
                         re-open of that stream since -- from any thread -- makes the hint stale, so src is never read after
                         its owner may have given it back.  Slots are shared by streams created 4096 apart: a
                         stranger's close costs the fast path once, never correctness */
+    /* ... and for mz_crypt_sha_update (shim_sha.c), which the reader calls on the same buffer right behind the CRC symbol
+     * (mz_zip_rw.c:462-467): the served bytes are bytes [ent_off, ent_off + size) of a primed entry of ent_usize bytes whose
+     * digest (ent_alg, 32 bytes at ent_digest) the device computed and found equal to the entry's Hash field */
+    int32_t valid_sha;
+    const uint8_t *ent_base, *ent_digest;
+    int64_t ent_off, ent_usize;
+    uint16_t ent_alg;
     const void *src; /* the primed bytes that were served (or that a written buffer was found equal to): compared again, byte
                         for byte, when the checksum is asked for -- a caller that changed the buffer in between gets the CRC of
                         what the buffer holds now.  Valid while the hint is: the stream that set it pins the primed generation
@@ -62,8 +69,18 @@ static inline void mzhip_served_set(const void *buf, int32_t size, uint32_t crc,
     mzhip_last_served.slot = slot % MZHIP_STREAM_SLOTS;
     mzhip_last_served.epoch = __atomic_load_n(&mzhip_stream_epoch[slot % MZHIP_STREAM_SLOTS], __ATOMIC_ACQUIRE);
     mzhip_last_served.valid = 1;
+    mzhip_last_served.valid_sha = 0;
 }
-static inline void mzhip_served_drop(void) { mzhip_last_served.valid = 0; }
+/* (behind mzhip_served_set) the served buffer is part of a primed entry with a device-verified digest */
+static inline void mzhip_served_set_entry(const uint8_t *base, int64_t off, int64_t usize, uint16_t alg, const uint8_t *digest) {
+    mzhip_last_served.ent_base = base;
+    mzhip_last_served.ent_off = off;
+    mzhip_last_served.ent_usize = usize;
+    mzhip_last_served.ent_alg = alg;
+    mzhip_last_served.ent_digest = digest;
+    mzhip_last_served.valid_sha = (alg != 0 && digest != 0) ? 1 : 0;
+}
+static inline void mzhip_served_drop(void) { mzhip_last_served.valid = mzhip_last_served.valid_sha = 0; }
 /* the stream of this slot is about to free (or re-use) buffers a hint of some thread may point into */
 static inline void mzhip_buffers_released(uint32_t slot) { (void)__atomic_add_fetch(&mzhip_stream_epoch[slot % MZHIP_STREAM_SLOTS], 1u, __ATOMIC_ACQ_REL); }
 

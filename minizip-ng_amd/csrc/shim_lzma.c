@@ -61,6 +61,8 @@ typedef struct mzhip_lzma_s {
     uint8_t *wbuf;
     int64_t wlen, wcap;
     uint32_t slot; /* this stream's cell of mzhip_stream_epoch[] (shim_common.h) */
+    uint16_t hash_alg;          /* a primed entry's device-verified digest (shim_sha.c answers mz_crypt_sha_end with it) */
+    const uint8_t *hash_digest;
     /* read side, method 14, entries larger than one window (mzh_stream_window): decoded window by window by the resumable
      * build of K3.  out[] then holds [the dictionary so far | the window's bytes]; consumed input is dropped */
     int8_t streaming;      /* window mode is on */
@@ -124,6 +126,8 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->prime_pin = NULL;
     z->out_borrowed = 0;
     z->tried_cache = 0;
+    z->hash_alg = 0;
+    z->hash_digest = NULL;
     z->seg_crc = NULL;
     z->base_pos0 = -1;
     z->in = z->out = NULL;
@@ -453,7 +457,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
             uint32_t crc = 0;
             if (z->base_pos0 >= 0 &&
                 mzhip_prime_lookup3(z->method, z->base_pos0, z->in, (int32_t)(z->in_len < 256 ? z->in_len : 256), z->max_total_in,
-                                    &data, &usize, &csize, &crc, &z->seg_crc, &z->prime_pin) == 1 &&
+                                    &data, &usize, &csize, &crc, &z->seg_crc, &z->prime_pin, &z->hash_alg, &z->hash_digest) == 1 &&
                 (z->max_total_out < 0 || z->max_total_out >= usize)) {
                 z->out = (uint8_t *)(uintptr_t)data;
                 z->out_borrowed = 1;
@@ -502,6 +506,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: its device-computed CRC answers the mz_crypt_crc32_update that follows */
             mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served, z->slot);
+            mzhip_served_set_entry(z->out, z->out_served, z->out_len, z->hash_alg, z->hash_digest);
         }
         z->out_served += n;
         z->total_out += n;

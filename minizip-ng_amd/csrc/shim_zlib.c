@@ -106,6 +106,8 @@ typedef struct mzhip_zlib_s {
     int64_t w_total;   /* uncompressed bytes already handed to the device */
     int8_t w_header_done;
     uint32_t slot; /* this stream's cell of mzhip_stream_epoch[] (shim_common.h) */
+    uint16_t hash_alg;          /* a primed entry's device-verified digest (shim_sha.c answers mz_crypt_sha_end with it) */
+    const uint8_t *hash_digest;
 } mzhip_zlib;
 
 static mzhip_stream_vtbl mzhip_zlib_vtbl = {
@@ -162,6 +164,8 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->dev_in_used = 0;
     z->next_attempt = 0;
     z->tried_cache = 0;
+    z->hash_alg = 0;
+    z->hash_digest = NULL;
     z->base_pos0 = -1;
     z->seg_crc = NULL;
     z->hdr_len = 0;
@@ -697,7 +701,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             uint32_t crc = 0;
             if (z->wrap == 0 && z->base_pos0 >= 0 &&
                 mzhip_prime_lookup3(8, z->base_pos0, z->in, (int32_t)(z->in_len < 256 ? z->in_len : 256), z->max_total_in, &data,
-                                    &usize, &csize, &crc, &z->seg_crc, &z->prime_pin) == 1) {
+                                    &usize, &csize, &crc, &z->seg_crc, &z->prime_pin, &z->hash_alg, &z->hash_digest) == 1) {
                 z->out = (uint8_t *)(uintptr_t)data;
                 z->out_borrowed = 1;
                 z->out_len = usize;
@@ -768,6 +772,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             (n == MZHIP_PRIME_SEGMENT || z->out_served + n == z->out_len)) {
             /* a whole primed segment: remember its device-computed CRC for the mz_crypt_crc32_update that follows */
             mzhip_served_set(buf, n, z->seg_crc[z->out_served / MZHIP_PRIME_SEGMENT], z->out + z->out_served, z->slot);
+            mzhip_served_set_entry(z->out, z->out_served, z->out_len, z->hash_alg, z->hash_digest);
         }
         z->out_served += n;
         z->total_out += n;

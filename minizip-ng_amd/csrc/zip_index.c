@@ -112,3 +112,43 @@ int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int64_t *table
     }
     return n;
 }
+
+/* The Hash extra field (0x1a51, mz.h:93; written by mz_zip_writer_entry_close, mz_zip_rw.c:1398-1408) of the entries of an
+ * index: for row i of `table` (mzhip_zip_index_mem) the FIRST such field of its central-directory record -- what
+ * mz_zip_reader_entry_get_first_hash picks (mz_zip_rw.c:510-540) -- as algorithm[i] (0 = the entry has none), digest_size[i]
+ * and up to 64 digest bytes at digest + 64 * i.  Returns the number of entries that carry one, or < 0. */
+int64_t mzhip_zip_index_hash_mem(const uint8_t *zip, uint64_t zip_len, const int64_t *table, int64_t n, uint16_t *algorithm,
+                                 uint16_t *digest_size, uint8_t *digest) {
+    if (!zip || !table || !algorithm || !digest_size || !digest)
+        return -102; /* MZ_PARAM_ERROR */
+    int64_t found = 0;
+    for (int64_t i = 0; i < n; i++) {
+        algorithm[i] = 0;
+        digest_size[i] = 0;
+        memset(digest + 64 * i, 0, 64);
+        const uint64_t p = (uint64_t)table[i * 8 + 6];
+        if (!fits(p, 46, zip_len) || rd32(zip + p) != SIG_CD)
+            return -103;
+        const uint8_t *h = zip + p;
+        const uint32_t fn = rd16(h + 28), ex = rd16(h + 30);
+        if (!fits(p, 46ull + fn + ex, zip_len))
+            return -103;
+        const uint8_t *x = h + 46 + fn, *xe = x + ex;
+        while (x + 4 <= xe) {
+            const uint32_t id = rd16(x), sz = rd16(x + 2);
+            if (x + 4 + sz > xe)
+                break;
+            if (id == 0x1a51 && sz >= 4) {
+                const uint32_t alg = rd16(x + 4), dsz = rd16(x + 6);
+                algorithm[i] = (uint16_t)alg;
+                digest_size[i] = (uint16_t)dsz;
+                const uint32_t have = sz - 4 < dsz ? sz - 4 : dsz;
+                memcpy(digest + 64 * i, x + 8, have < 64 ? have : 64);
+                found++;
+                break;
+            }
+            x += 4 + sz;
+        }
+    }
+    return found;
+}

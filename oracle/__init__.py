@@ -185,6 +185,19 @@ class MzDriver:
         return out[:n].tobytes(), dict(total_in=int(info[0]), total_out=int(info[1]), close=int(info[2]),
                                        error=int(info[3]), open=int(info[5]))
 
+    def zip_reader_walk(self, path, max_entries=1 << 20):
+        """every entry through mz_zip_reader_entry_open / _read / _close (the layer that verifies Hash extra fields in a
+        crypto build): -> (status[n] i32, ulen[n] i64)"""
+        st = np.zeros(max_entries, dtype=np.int32)
+        ul = np.zeros(max_entries, dtype=np.int64)
+        self.L.drv_zip_reader_walk.restype = C.c_int64
+        self.L.drv_zip_reader_walk.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int64]
+        n = self.L.drv_zip_reader_walk(path.encode(), st.ctypes.data_as(C.POINTER(C.c_int32)), ul.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       max_entries)
+        if n < 0:
+            raise RuntimeError("drv_zip_reader_walk failed: %d" % n)
+        return st[:n].copy(), ul[:n].copy()
+
     def zip_write_repeat(self, path, piece, total, method=8, level=6):
         """one entry of `total` bytes (the piece repeated) + a small one, written in 65 535-byte calls"""
         a = _as_u8(piece)

@@ -181,3 +181,41 @@ def test_c_shard_bounds_equals_python():
             b = np.zeros(world + 1, dtype=np.int64)
             L.mzhip_shard_bounds(t.ctypes.data, n, world, b.ctypes.data)
             assert (b == archive.shard_bounds(t, world)).all(), (n, world)
+
+
+def test_hash_fields_of_a_crypto_written_archive(tmp_path):
+    """mzhip_zip_index_hash_mem: the first Hash extra field (0x1a51) of every entry, as mz_zip_reader_entry_get_first_hash
+    picks it (mz_zip_rw.c:510-540), on an archive written by the crypto-enabled reference writer (a SHA-256 field per entry)
+    and on one without any."""
+    import ctypes as C
+    import hashlib
+    import importlib
+
+    refc_so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libmzref_crypto.so")
+    if not os.path.exists(refc_so):
+        pytest.skip("oracle/_ref/libmzref_crypto.so missing (built where /root/reference exists)")
+    mz = importlib.import_module("minizip-ng_amd")
+    L = mz.lib()
+    L.mzhip_zip_index_hash_mem.restype = C.c_int64
+    c = np.frombuffer(synth.corpus(), dtype=np.uint8)
+    rnd = np.random.RandomState(8)
+    n = 25
+    lens = rnd.randint(0, 50000, size=n).astype(np.int32)
+    offs = rnd.randint(0, len(c) - 50000, size=n).astype(np.int64)
+    for drv, want_n in ((oracle.MzDriver(refc_so), n), (oracle.ref(), 0)):
+        path = str(tmp_path / ("h%d.zip" % want_n))
+        drv.zip_write(path, c, offs, lens, method=8, level=6)
+        raw = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+        table = np.ascontiguousarray(oracle.ref().zip_index(path), dtype=np.int64)
+        alg = np.zeros(n, dtype=np.uint16)
+        dsz = np.zeros(n, dtype=np.uint16)
+        dig = np.zeros((n, 64), dtype=np.uint8)
+        k = L.mzhip_zip_index_hash_mem(C.c_void_p(raw.ctypes.data), C.c_uint64(raw.size), C.c_void_p(table.ctypes.data), C.c_int64(n),
+                                       C.c_void_p(alg.ctypes.data), C.c_void_p(dsz.ctypes.data), C.c_void_p(dig.ctypes.data))
+        assert k == want_n
+        if want_n:
+            assert (alg == 23).all() and (dsz == 32).all()          # MZ_HASH_SHA256, mz_zip_rw.c:1343
+            for i in range(n):
+                assert dig[i, :32].tobytes() == hashlib.sha256(c[offs[i]:offs[i] + lens[i]].tobytes()).digest()
+        else:
+            assert (alg == 0).all()
