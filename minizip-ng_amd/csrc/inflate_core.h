@@ -10,14 +10,19 @@
  *     codes -> ranked symbols -> LDS lookup tables whose 32-bit entries are
  *     ready-made tokens / operand descriptors), see MZ_BUILD_HUFF.
  *   - Two decode front ends:
- *       SPAN PATH (inflate_window.inc, the default for all but the tail of a stream): every lane walks its own
- *       256-bit span of the compressed stream (mz_span_token: a leading literal + the token behind it per step); a
- *       walk started at an arbitrary bit meets the true token sequence after ~8 tokens, so chaining the walks (each
- *       lane restarts where its left neighbour crossed into its span) converges to the true parse in ~3 passes.
- *       Verified lanes are committed in chunks INSIDE LDS: literals to a staging byte, back-references to a list,
- *       far sources fetched from the output buffer, near ones copied LDS to LDS in dependency order, then one
- *       coalesced 16-byte store per lane.  Nothing goes through HBM twice.
- *       STEP LOOP (the last span of a stream, hand-backs, and every error verdict): lane l decodes the complete token
+ *       CHASE WINDOW (inflate_chase.inc = inflate_walk.inc + the chain + inflate_emit.inc; the default for all but what
+ *       needs a verdict): the rest of the stream is cut into <= 64 spans of up to 3072 bits, one per lane.  Pass 1: every
+ *       lane walks its span token by token (mz_chase_step: a leading literal + the token behind it per step) and RECORDS
+ *       every step -- 4 bytes + 1 byte, in the wave's HBM scratch.  Pass 2: every lane keeps walking into the next span
+ *       until it stands on a step start the lane there recorded too (a DEFLATE walk started at an arbitrary bit falls in
+ *       step with the true parse after ~8 tokens).  The chain from lane 0 then names the true records; they are taken 512
+ *       at a time, turned into staging bytes / back-reference pieces in the LDS pool, far sources fetched from the output
+ *       buffer, near ones copied LDS to LDS in dependency order, then one coalesced 16-byte store per lane.  Every token
+ *       is Huffman-decoded once (+ the resynchronisation tail of a span).  The two halves are functions of their own
+ *       (mz_chase_walk, mz_chase_emit: not inlined, their own register allocations).
+ *       (inflate_window.inc, MZ_WINDOW_CHASE = 0, is the round-2 window kept as an A/B build: 256-bit spans re-walked until
+ *       the starts stop moving.)
+ *       STEP LOOP (the last bits of a stream, hand-backs, and every error verdict): lane l decodes the complete token
  *       that would start at bit cursor+l, for all 64 bit offsets at once; which candidates are real is
  *       decided without a serial walk: f(l) = l + bits(l) is squared with cross-lane gathers and lane i
  *       composes f^i(0).  One step retires about 64 bits of input (4.6 tokens on text).  Its tokens are handed to
@@ -27,14 +32,14 @@
  *       in-order cooperative copy.
  *   - The sliding window IS the output buffer: back-references read bytes this
  *     wave wrote earlier (a wave's vector-memory operations execute in order),
- *     so no 32 KiB LDS window is needed; the step loop stages compressed input through a
- *     512-byte LDS ring with a register-held prefetch.
- *   - CRC-32 is folded from the freshly written output (still in L2) in 4 KiB super-tiles, 64 bytes per lane
- *     (crc32_core.h), so the output is never re-read from HBM.
+ *     so no 32 KiB LDS window is needed (16 waves per CU x 32 KiB would be 3 CUs' worth of LDS, and at 4 waves per CU
+ *     the kernel loses a third of its throughput: profiles/r4/ab_k1_residency.log); the step loop stages compressed
+ *     input through a 512-byte LDS ring with a register-held prefetch.
+ *   - CRC-32 is folded from the freshly written output in 4 KiB super-tiles, 64 bytes per lane (crc32_core.h).
  *   - The per-lane decode is kept to 32-bit funnel shifts (v_alignbit), bit-field extracts and table
- *     entries that need no arithmetic, and LDS is sized for residency: 9.8 KiB per wave (3.8 KiB of tables with an
- *     8-bit literal/length root, the 2.8 KiB span window, a 3.2 KiB commit pool) = 16 waves per CU, matching the
- *     128-VGPR budget of 4 waves per SIMD.
+ *     entries that need no arithmetic, and LDS is sized for residency: 9.98 KiB per wave (3.8 KiB of tables with an
+ *     8-bit literal/length root, 4.75 KiB of per-lane stream rings, a 1.2 KiB pool that runs on through the dead rings
+ *     while a window is emitted) = 16 waves per CU, matching the 128-VGPR budget of 4 waves per SIMD.
  *   - Dynamic block headers: the code lengths are decoded 64 bits at a time (MZ_CL_PARALLEL).
  *   - The 32-bit bit cursor looks at the stream through a view that moves forward (MZ_REBASE): any stream length.
  *   - MZ_STATS (host emulation only) counts windows / passes / SIMT steps / pieces; MZ_PROF (device measurement

@@ -138,7 +138,7 @@ typedef uint32_t mz_lds_handle; /* an LDS address is 32 bits */
 typedef uint64_t mz_glb_handle;
 #define MZ_LDS_HANDLE(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(p))
 #define MZ_GLB_HANDLE(p) ((uint64_t)(uintptr_t)(p))
-#define MZ_LDS_FROM(T, h) ((T *)(__attribute__((address_space(3))) T *)(h))
+#define MZ_LDS_FROM(T, h) ((T *)(__attribute__((address_space(3))) T *)(uintptr_t)(h))
 #define MZ_GLB_FROM(T, h) ((T *)(__attribute__((address_space(1))) T *)(h))
 #define P(name) name
 #define MZ_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))

@@ -17,7 +17,7 @@ cmd="python $root/bench.py $cfgflag --steps 3 --warmup 1"
 if [ $what = all ] || [ $what = bench ]; then ( cd "$root" && timeout $T $cmd > "$out/bench.log" 2> "$out/bench.err" ); tail -1 "$out/bench.log"; fi
 # the profiled passes launch the dominant kernel on the bench workload only (no legs, no CPU baseline), so that the
 # per-kernel average of --stats is the average of identical launches: 1 warm-up + 3 timed
-cmd="$cmd --no-legs --no-cpu-baseline"
+cmd="$cmd --no-legs --no-cpu-baseline --no-other-configs"
 cd /tmp
 if [ $what = all ] || [ $what = stats ]; then
   timeout -k 10 $T rocprofv3 --kernel-trace --stats -d "$out/stats" -o stats --output-format csv -- $cmd > "$out/stats.log" 2>&1
