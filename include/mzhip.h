@@ -85,7 +85,8 @@ typedef struct mzhip_inflate_state {
     uint32_t hdr_bit; /* bit position of the current block's header, from the first input byte of the call */
     uint32_t bit;     /* bit position of the next token (== hdr_bit: at the start of the block) */
     uint32_t out_pos; /* in: bytes of history at the front of the output buffer (<= 32768); out: bytes valid in it */
-    uint32_t flags;   /* bit 0 in: take the stream up at (hdr_bit, bit); out: the state is usable */
+    uint32_t flags;   /* bit 0 in: take the stream up at (hdr_bit, bit); out: the state is usable.  bit 1 in: stop in front of
+                       * the next block header (MZHIP_STATUS_OUT_FULL with bit == hdr_bit) */
 } mzhip_inflate_state;
 /* mzhip_inflate_batch with one state in / one state out per entry (device pointers, either may be NULL) */
 MZHIP_API int32_t mzhip_inflate_resume_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len, void *d_out,
@@ -105,6 +106,19 @@ MZHIP_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_l
                                                 const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
                                                 uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t seg_first,
                                                 uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg);
+
+/* One window of ONE large entry decoded by as many waves as it holds blocks (replaces the single inflate() state the
+ * reference streams an entry of any size through, mz_strm_zlib.c:116-193, where that state is the bottleneck): block
+ * headers are searched for at every bit offset, every candidate is parsed by a wave of its own, the chain of blocks that
+ * starts at state_in's header is believed, its bytes are produced as a source map and resolved by pointer jumping
+ * (csrc/inflate_parallel.inc).  Same buffers as mzhip_inflate_resume_host_seg; state_in must stand at a block header
+ * (bit == hdr_bit; NULL = the start of the stream).  Returns 0 with *blocks = blocks decoded (0: nothing a wave of its own
+ * could take -- go on with mzhip_inflate_resume_host_seg, flags bit 1 makes it stop at the next block header), *out_len =
+ * bytes valid in buf, *ended = the final block was among them, state_out = the header of the first block not decoded. */
+MZHIP_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                              const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
+                                              uint32_t *out_len, uint32_t *blocks, uint32_t *ended, uint32_t seg_first,
+                                              uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg);
 
 MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,
@@ -337,6 +351,9 @@ MZHIP_API void mzhip_prime_clear(void);
  * MZHIP_STREAM_GULP in the environment); floors 128 KiB / 32 KiB; 0 = back to the default.  Applies to streams opened
  * afterwards. */
 MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes);
+/* Window mode of mz_stream_zlib READ offers every window that starts at a block header to mzhip_inflate_parallel_host first
+ * (a wave per DEFLATE block); 0 turns that off (MZHIP_STREAM_PARALLEL=0 in the environment does the same). */
+MZHIP_API void mzhip_set_stream_parallel(int32_t on);
 MZHIP_API void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
 /* Entries that carry a SHA-1 / SHA-256 Hash extra field (0x1a51): the prime computes the digest of the decoded bytes on
  * the device in the pass that decodes them (mzhip_sha_batch over the chunk in HBM) and compares it with the field's, as

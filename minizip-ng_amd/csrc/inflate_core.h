@@ -315,7 +315,8 @@ typedef struct mz_inflate_state {
     uint32_t hdr_bit;  /* the current block's header */
     uint32_t bit;      /* the next token (== hdr_bit: the block has not been entered) */
     uint32_t out_pos;  /* in: bytes of history in front of the output (<= 32768, 0 at the start of a stream); out: bytes valid in the buffer */
-    uint32_t flags;    /* bit 0: take the stream up at (hdr_bit, bit) instead of at bit 0 */
+    uint32_t flags;    /* bit 0: take the stream up at (hdr_bit, bit) instead of at bit 0; bit 1 (in): stop in front of the next
+                        * block header (MZHIP_OUT_FULL with hdr_bit == bit): the caller wants to go on from a block boundary */
 } mz_inflate_state;
 
 /* 32 bits of (hi:lo) starting at bit (s & 31): v_alignbit_b32 */
@@ -826,14 +827,59 @@ MZ_DEV mz_dw4 mz_load_stream_dw4(const uint8_t *in_al, uint32_t in_mis, uint32_t
 #include "inflate_emit.inc"
 #endif
 
+/* ONE block of a large entry, parsed by a wave of its own (mzhip_inflate_parallel_host: every block of a window at once).
+ * The wave starts at the block's header (rs: hdr_bit = bit = the header, out_pos = where the block's bytes go), decodes that
+ * one block with the chase window, and does not copy anything: mode 1 counts the bytes the block produces (res->out_len),
+ * mode 2 writes literals to out[] and a source index per byte to ptr[] (mz_chase_emit_ptr).  st->bit = the bit behind the
+ * block's end-of-block code, res->crc = 1 when the block was the stream's last.  Anything the chase window leaves to the
+ * step loop -- an error on the path, the last bits of the stream -- ends the call with MZHIP_PAR_BAIL: that block (and
+ * what follows it) is decoded in stream order by the ordinary kernel. */
+typedef struct mz_inflate_par {
+    uint32_t mode; /* 1 count, 2 emit */
+    uint32_t *ptr; /* mode 2: source index of every byte of out[] */
+} mz_inflate_par;
+#define MZHIP_PAR_BAIL (-301)
+
+/* Stage 1 of the block search of a large entry (mzhip_inflate_parallel_host): could a dynamic-Huffman block header (or a
+ * stored block's) start at bit p of in[]?  BTYPE = 2, HLIT <= 29, HDIST <= 29, and the code-length code's lengths form a COMPLETE prefix code
+ * (zlib refuses an incomplete one: "invalid code lengths set").  About one bit offset in a few thousand of random data
+ * passes; what passes is parsed for real (the whole header, then the block) by a wave of its own, and only blocks that are
+ * reached from the known start of the window through a chain of "ends exactly where the next one starts" are believed.
+ * Per lane: one bit offset, ~40 instructions. */
+MZ_DEV uint32_t mz_block_header_plausible(const uint8_t *in, uint32_t in_len, uint32_t p) {
+    if ((uint64_t)(p >> 3) + 24u > in_len) return 0u; /* (the last bytes of the input are the serial decoder's anyway) */
+    uint64_t w = mz_bits_at(in, in_len, p);
+    const uint32_t h = (uint32_t)w;
+    if (((h >> 1) & 3u) == 0u) {
+        /* a stored block: LEN and its complement behind the padding (appnote.txt:2045-2049); one offset in 2^18 of random
+         * data passes.  Incompressible stretches of an entry are made of these, and the chain must get across them */
+        const uint32_t b = (p + 3u + 7u) >> 3;
+        const uint32_t len = (uint32_t)in[b] | ((uint32_t)in[b + 1] << 8), nlen = (uint32_t)in[b + 2] | ((uint32_t)in[b + 3] << 8);
+        return (len ^ nlen) == 0xFFFFu ? 1u : 0u;
+    }
+    if (((h >> 1) & 3u) != 2u) return 0u;
+    if (((h >> 3) & 31u) > 29u || ((h >> 8) & 31u) > 29u) return 0u;
+    const uint32_t ncode = ((h >> 13) & 15u) + 4u;
+    uint32_t kraft = 0;
+    w >>= 17; /* 47 bits left: 15 lengths of 3 bits */
+    for (uint32_t i = 0; i < ncode; i++) {
+        if (i == 15u) w = mz_bits_at(in, in_len, p + 17u + 45u);
+        const uint32_t l = (uint32_t)w & 7u;
+        w >>= 3;
+        kraft += l ? (128u >> l) : 0u;
+    }
+    return kraft == 128u ? 1u : 0u;
+}
+
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out, uint32_t out_cap,
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
                              uint32_t use_span, uint8_t *rec /* MZ_REC_BYTES of HBM scratch of this wave (chase window) */,
                              const mz_inflate_state *rs /* take the stream up here (or null) */,
                              mz_inflate_state *st /* where it can be taken up again when the output is full / the input ends (or null) */,
-                             mz_inflate_result *res) {
+                             mz_inflate_result *res, const mz_inflate_par *par /* one block, no copies (or null: the ordinary decode) */) {
     MZ_LANE_DECL
+    uint32_t par_blocks = 0; /* par: blocks completed */
     /* The bit cursor is 32 bits wide, so the decoder looks at the stream through a VIEW of at most MZ_VIEW_MAX bytes
      * ([in, in + in_len), bitpos relative to `in`) and moves the view forward (MZ_REBASE) whenever the cursor is more
      * than MZ_REBASE_BITS into it: at the top of every block and of every window / step, i.e. long before anything
@@ -851,10 +897,12 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
      * (tokens behind it are decoded but not written yet), in_header = the cursor is inside a block header */
     uint32_t hdr_bit = 0, qbit = 0, in_header = 0, unwritten = 0, resume_at = 0xFFFFFFFFu;
     const uint32_t resumable = st ? 1u : 0u;
+    uint32_t stop_at_header = 0;
     if (rs && (MZ_UNIFORM(rs->flags) & 1u)) {
         bitpos = MZ_UNIFORM(rs->hdr_bit);
         resume_at = MZ_UNIFORM(rs->bit);
     }
+    if (rs && st) stop_at_header = (MZ_UNIFORM(rs->flags) >> 1) & 1u;
     /* the two groups of four stream dwords that do not lie entirely inside the input, masked (the chase window's refills,
      * inflate_walk.inc): lanes 0 .. 3 the group of dword 0, lanes 4 .. 7 the group with the last dword.  Once per view, so
      * that no window waits for these loads */
@@ -898,9 +946,14 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
     MZ_PROF_DECL
 
     while (!last) {
+        if (par && par_blocks) goto finish; /* one block per call */
         MZ_REBASE((void)0)
         hdr_bit = bitpos;
         in_header = 1;
+        if (stop_at_header && par_blocks) { /* (the state written below is this header, with nothing of the block entered) */
+            status = MZHIP_OUT_FULL;
+            goto finish;
+        }
         /* the block header is read through a 256-byte window of the stream held one dword per lane (one coalesced
          * load instead of a global round trip per 64 bits of header); positions beyond it fall back to memory */
         const uint32_t hw0 = (bitpos + 8u * in_mis) >> 5;
@@ -936,19 +989,29 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                 status = MZHIP_OUT_FULL;
                 goto finish;
             }
-            MZ_LANES {
-                for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[out_pos + i] = in[byte + i];
+            if (par && n < len) { /* (a stored block that the input does not hold whole: stream order decides) */
+                status = MZHIP_PAR_BAIL;
+                goto finish;
             }
-            MZ_WAVE_SYNC();
+            if (!par || par->mode == 2u) {
+                MZ_LANES {
+                    for (uint32_t i = (uint32_t)lane; i < n; i += 64) {
+                        out[out_pos + i] = in[byte + i];
+                        if (par) par->ptr[out_pos + i] = out_pos + i;
+                    }
+                }
+                MZ_WAVE_SYNC();
+            }
             out_pos += n;
             bitpos += n * 8u;
             if (n < len) {
                 status = MZHIP_BUF_ERROR;
                 goto finish;
             }
-            MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out + crc_base, out_pos - crc_base, crc_tab, tabs->kx4);
+            if (!par) MZ_CRC_FOLD_SUPER_BT(crc_acc, crc_done, out + crc_base, out_pos - crc_base, crc_tab, tabs->kx4);
             in_header = 0;
             hdr_bit = bitpos;
+            par_blocks++;
             continue;
         }
         if (btype == 3) {
@@ -1213,6 +1276,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                         MZ_PROF_MARK(3); /* step loop (if any) */
 #include "inflate_chase.inc"
                     }
+                    if (par) { /* the step loop is next: not a block for a wave of its own */
+                        status = MZHIP_PAR_BAIL;
+                        goto finish;
+                    }
                     span_skip = 0;
                 }
 #elif MZ_SPAN_DW
@@ -1445,6 +1512,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                 if (eob) break;
             }
         }
+        par_blocks++;
     }
 
 finish:
@@ -1464,7 +1532,11 @@ finish:
     res->out_len = out_pos;
     res->in_used = in_adv + ((bitpos + 7u) >> 3);
     if (res->in_used > in_total) res->in_used = in_total;
-    {
+    if (par) {
+        if (status == MZHIP_OK && par_blocks == 0u) res->status = MZHIP_PAR_BAIL;
+        res->crc = last; /* (no checksum here: the window's is computed once its bytes exist) */
+        (void)crc_tmp;
+    } else {
         uint32_t crc;
 #if MZ_ABLATE & 4
         crc = 0;
@@ -1477,6 +1549,33 @@ finish:
     }
     MZ_PROF_MARK(12); /* CRC tail */
     MZ_PROF_FLUSH
+}
+
+/* One candidate block of a window by a wave of its own: res4 = {status, the bit behind the block, the out position behind
+ * its last byte (mode 1: the bytes it produces, pos = 0), BFINAL}.  The wave's view of the stream starts at the dword the
+ * header lies in, so that bit positions stay small whatever the window's size. */
+MZ_DEV void mz_inflate_one_block(const uint8_t *in, uint32_t in_len, uint32_t bit, uint32_t pos, uint32_t mode, uint8_t *out,
+                                 uint32_t *ptr, mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
+                                 uint8_t *rec, uint32_t *res4) {
+    const uint32_t base = (bit >> 5) << 2;
+    mz_inflate_state a, b;
+    a.hdr_bit = a.bit = bit - base * 8u;
+    a.out_pos = pos;
+    a.flags = 1u;
+    b.hdr_bit = b.bit = b.out_pos = b.flags = 0u;
+    mz_inflate_par par;
+    par.mode = mode;
+    par.ptr = ptr;
+    mz_inflate_result r;
+    mz_inflate_entry(in + base, in_len - base, out, 0xFFFFFFFFu, L, crc_tab, tabs, 1u, rec, &a, &b, &r, &par);
+    int32_t status = r.status;
+    if (status == MZHIP_OK && !(b.flags & 1u)) status = MZHIP_PAR_BAIL; /* (a block of more than a view: stream order) */
+    MZ_LANES { /* uniform stores */
+        res4[0] = (uint32_t)status;
+        res4[1] = b.bit + base * 8u;
+        res4[2] = r.out_len;
+        res4[3] = r.crc;
+    }
 }
 
 #endif

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
         const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
         mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, 1u, rec,
-                         a.resume ? a.resume + e : nullptr, a.stop ? a.stop + e : nullptr, &r);
+                         a.resume ? a.resume + e : nullptr, a.stop ? a.stop + e : nullptr, &r, nullptr);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -507,6 +507,89 @@ __global__ __launch_bounds__(64) void k_lzma_rc_encode_resume(LzmaEncResumeArgs 
     a.out_len[0] = res.out_len; // wave-uniform results: stored by all lanes
     a.crc[0] = res.crc;
     a.status[0] = res.status;
+}
+
+// ---- one large entry on many waves (mzhip_inflate_parallel_host; the orchestration is inflate_parallel.inc)
+struct ParFindArgs {
+    const uint8_t *in;
+    uint32_t in_len, b0, b1;
+    uint32_t *cands;
+    uint32_t cap;
+    uint32_t *count;
+};
+// every bit offset of [b0, b1): could a block header start here?  One offset per lane; what passes is appended (order
+// does not matter, the host sorts: a few thousand offsets per MiB)
+__global__ __launch_bounds__(256) void k_find_blocks(ParFindArgs a) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t p = (uint64_t)a.b0 + (uint64_t)blockIdx.x * 256u + threadIdx.x; p < a.b1; p += stride)
+        if (mz_block_header_plausible(a.in, a.in_len, (uint32_t)p)) {
+            const uint32_t k = atomicAdd(a.count, 1u);
+            if (k < a.cap) a.cands[k] = (uint32_t)p;
+        }
+}
+
+struct ParBlocksArgs {
+    const uint8_t *in;
+    uint32_t in_len;
+    uint8_t *out;
+    uint32_t *ptr;
+    const uint32_t *bits, *pos; // per candidate: the header's bit, the out position of the block's first byte
+    uint32_t n, mode;
+    uint32_t *res; // 4 words per candidate (mz_inflate_one_block)
+    uint32_t *counter;
+    const mzhip_crc_tables *tabs;
+    uint8_t *rec;
+};
+// a wave per candidate block (persistent waves over a work queue, like k_inflate_batch): mode 1 counts, mode 2 writes
+// literals and the source map
+__global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_blocks(ParBlocksArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *crc_tab = (uint32_t *)smem;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    const int wave = threadIdx.x >> 6;
+    mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
+    uint8_t *const rec = a.rec + ((size_t)blockIdx.x * MZ_WAVES_PER_WG + (size_t)wave) * MZ_REC_BYTES;
+    for (;;) {
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter);
+        if (e >= a.n) break;
+        mz_inflate_one_block(a.in, a.in_len, MZ_UNIFORM(a.bits[e]), MZ_UNIFORM(a.pos[e]), a.mode, a.out, a.ptr, L, crc_tab, a.tabs, rec,
+                             a.res + 4u * (size_t)e);
+    }
+}
+
+struct ParJumpArgs {
+    uint8_t *out;
+    uint32_t *ptr;
+    uint32_t hist, total;
+    uint32_t *changed;
+};
+// one round of pointer jumping over the source map: ptr[i] = ptr[ptr[i]] (in place: whatever a racing lane reads is an
+// ancestor of i either way).  Roots are literals (ptr[i] == i) and the history in front of the window (ptr[i] < hist).
+__global__ __launch_bounds__(256) void k_ptr_jump(ParJumpArgs a) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    uint32_t any = 0;
+    for (uint64_t i = (uint64_t)a.hist + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < a.total; i += stride) {
+        const uint32_t p = a.ptr[i];
+        if (p != (uint32_t)i && p >= a.hist) {
+            const uint32_t q = a.ptr[p];
+            if (q != p) {
+                a.ptr[i] = q;
+                any = 1;
+            }
+        }
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) *a.changed = 1u;
+}
+// ... and the bytes: every position fetches its root's (a root's byte never changes, so this is in place too)
+__global__ __launch_bounds__(256) void k_ptr_gather(ParJumpArgs a) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)a.hist + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < a.total; i += stride) {
+        const uint32_t p = a.ptr[i];
+        if (p != (uint32_t)i) a.out[i] = a.out[p];
+    }
 }
 
 #include "mzhip_runtime.inc"

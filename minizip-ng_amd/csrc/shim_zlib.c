@@ -99,6 +99,9 @@ typedef struct mzhip_zlib_s {
     int32_t pc_n, pc_cap, pc_head;
     uint32_t *pc_tmp;
     int32_t pc_tmp_cap;
+    /* ... and by many waves when the stream stands at a block header (mzhip_inflate_parallel_host) */
+    int32_t par_miss;       /* windows in a row the many-wave decode got (next to) nothing out of */
+    int32_t par_rest;       /* serial windows to go before it is tried again */
     /* write side */
     uint8_t *wbuf;
     int64_t wlen, wcap;
@@ -392,6 +395,30 @@ int64_t mzh_stream_gulp(void) {
     return mzh_gulp_bytes;
 }
 
+/* One inflate() state per entry is the reference's model and one wave per entry is this backend's; an entry that needs
+ * window mode is large, and one wave decodes 0.1 - 0.2 GB/s.  Whenever the stream stands at a block header the window is
+ * first offered to mzhip_inflate_parallel_host (a wave per DEFLATE block); what it does not take -- fixed blocks, a block
+ * larger than the window, the end of the input -- goes through the serial kernel, which is asked to stop at the next block
+ * header as long as the many-wave decode has been worth its search.  MZHIP_STREAM_PARALLEL=0 turns it off. */
+#ifndef MZH_PAR_MIN_IN
+#define MZH_PAR_MIN_IN (256 << 10) /* compressed bytes below which a window is not worth the search */
+#endif
+#ifndef MZH_PAR_MIN_ROOM
+#define MZH_PAR_MIN_ROOM (1 << 20) /* room in the window below which it is not offered; output below which an offer counts as a miss */
+#endif
+#ifndef MZH_STREAM_EARLY
+#define MZH_STREAM_EARLY (1 << 20) /* compressed bytes pulled, entry not over: window mode from here on */
+#endif
+static int8_t mzh_par_mode = -1;
+MZHIP_API void mzhip_set_stream_parallel(int32_t on) { mzh_par_mode = on ? 1 : 0; }
+static int32_t mzh_stream_parallel(void) {
+    if (mzh_par_mode < 0) {
+        const char *e = getenv("MZHIP_STREAM_PARALLEL");
+        mzh_par_mode = (e && e[0] == '0') ? 0 : 1;
+    }
+    return mzh_par_mode;
+}
+
 static int32_t stream_drop_input(mzhip_zlib *z) {
     /* everything in front of the current block's header is done with (dword granular: the device addresses dwords) */
     const int64_t drop = (int64_t)((z->sst.hdr_bit >> 3) & ~3u);
@@ -514,6 +541,49 @@ static int32_t stream_next(mzhip_zlib *z) {
                 z->pc_tmp_cap = z->pc_tmp ? want : 0;
             }
         }
+        /* (windows and gulps too small to be offered -- the tests' -- never ask the serial kernel for block boundaries either) */
+        const int32_t par_on = mzh_stream_parallel() && z->in_len < ((int64_t)1 << 28) && mzh_stream_gulp() >= MZH_PAR_MIN_IN &&
+                               z->out_cap >= 2 * (int64_t)MZH_PAR_MIN_ROOM;
+        if (par_on && z->par_rest > 0)
+            z->par_rest--;
+        else if (par_on && z->sst.bit == z->sst.hdr_bit && z->in_len >= MZH_PAR_MIN_IN && z->out_cap - z->out_len >= MZH_PAR_MIN_ROOM) {
+            uint32_t pb = 0, pended = 0, pol = 0;
+            const int32_t pr = mzhip_inflate_parallel_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &pol, &pb,
+                                                           &pended, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
+                                                           (uint32_t)z->pc_tmp_cap, &nseg);
+            if (pr < 0) {
+                z->stream_end = 1;
+                return verdict(z, MZH_STREAM_ERROR, z->in_dropped); /* device / runtime failure */
+            }
+            if (pb) {
+                const int64_t made = (int64_t)pol - z->out_len;
+                if (nseg)
+                    stream_pieces_add(z, gnew, made, seg_first, stride, nseg);
+                z->out_len = pol;
+                z->sst = nst;
+                if (pended) {
+                    z->stream_end = 1;
+                    return verdict(z, MZHIP_STATUS_OK, z->in_dropped + (((int64_t)nst.bit + 7) >> 3));
+                }
+                stream_drop_input(z);
+                z->par_miss = made >= MZH_PAR_MIN_ROOM ? 0 : z->par_miss + 1;
+            } else
+                z->par_miss++;
+            /* (next to) nothing for a wave of its own at this header: the serial kernel takes it from here.  Three such
+             * windows in a row (fixed blocks throughout, say) and the search rests for a while */
+            if (z->par_miss >= 3) {
+                z->par_miss = 2;
+                z->par_rest = 8;
+            }
+            if (pb) {
+                if (z->out_len > z->out_served)
+                    return 0;
+                continue;
+            }
+            nseg = 0;
+        }
+        if (par_on && z->par_rest == 0 && z->par_miss < 3)
+            z->sst.flags |= 2u; /* stop at the next block header: the many-wave decode goes on from there */
         int32_t st = mzhip_inflate_resume_host_seg(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
                                                    &in_used, &crc, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
                                                    (uint32_t)z->pc_tmp_cap, &nseg);
@@ -554,13 +624,14 @@ static int32_t stream_next(mzhip_zlib *z) {
             return verdict(z, MZH_STREAM_ERROR, z->in_dropped);
         }
         const int64_t had = z->out_len;
+        const int32_t moved = nst.hdr_bit != z->sst.hdr_bit || nst.bit != z->sst.bit; /* (an empty block in front of a header it was asked to stop at) */
         z->out_len = nst.out_pos;
         z->sst = nst;
         stream_drop_input(z);
         if (st == MZHIP_STATUS_OUT_FULL) {
             if (z->out_len > z->out_served)
                 return 0; /* a window (or what was left of one) is there */
-            if (z->out_len == had) { /* no room for even one token group: cannot happen with a 64 MiB window */
+            if (z->out_len == had && !moved) { /* no room for even one token group: cannot happen with a 64 MiB window */
                 z->stream_end = 1;
                 return verdict(z, MZH_STREAM_ERROR, z->in_dropped);
             }
@@ -603,7 +674,23 @@ static int32_t attempt_decode(mzhip_zlib *z) {
         int32_t st = mzhip_inflate_host2(z->in + z->hdr_len, (uint32_t)(z->in_len - z->hdr_len), z->out,
                                          (uint32_t)z->out_cap, &out_len, &in_used, &z->out_crc,
                                          z->wrap == 1 ? &z->out_adler : NULL);
-        if (st == MZHIP_STATUS_OUT_FULL && z->wrap == 0 && z->out_cap >= mzh_stream_window()) {
+        int32_t early = 0;
+        if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof && z->wrap == 0 && z->in_len >= MZH_STREAM_EARLY && mzh_stream_parallel() &&
+            z->in_len < mzh_stream_window()) {
+            /* a megabyte of compressed bytes and the entry is not over: it is large enough for the many-wave decode, which
+             * lives in window mode.  (Without it the entry would be decoded from its first byte again every time the input
+             * has doubled, by one wave.) */
+            if (z->out_cap < mzh_stream_window()) {
+                uint8_t *nb = (uint8_t *)malloc((size_t)mzh_stream_window());
+                if (nb) {
+                    free(z->out);
+                    z->out = nb;
+                    z->out_cap = mzh_stream_window();
+                }
+            }
+            early = z->out_cap >= mzh_stream_window();
+        }
+        if (early || (st == MZHIP_STATUS_OUT_FULL && z->wrap == 0 && z->out_cap >= mzh_stream_window())) {
             /* more than a window of output: from here on the entry is decoded window by window.  The first window once
              * more, this time asking where it stops */
             z->streaming = 1;

@@ -11,8 +11,12 @@ out = {"bytes_per_kernel": N, "note": "counter value x 1024 B (rocprofv3 FETCH_S
        "last launch of each kernel (the first warms the clocks)"}
 for what in ("fetch", "write"):
     rows = list(csv.DictReader(open(os.path.join(src, "cal_%s.csv" % what))))
-    for key, pat, expect in (("crc32_16B_loads", "k_crc32_batch", N if what == "fetch" else 0), ("torch_fill", "FillFunctor", 0 if what == "fetch" else N),
-                             ("torch_add_u8", "add", N)):
+    R, W = (N, 0) if what == "fetch" else (0, N)
+    for key, pat, expect in (("crc32_16B_loads", "k_crc32_batch", R), ("torch_fill_u8_vec16", "FillFunctor<unsigned char>", W),
+                             ("torch_add_u8_vec16", "add<unsigned char>", N),
+                             ("read_1B_per_lane", "k_cal_read<unsigned char>", R), ("read_4B_per_lane", "k_cal_read<unsigned int>", R),
+                             ("read_16B_per_lane", "k_cal_read16", R), ("write_1B_per_lane", "k_cal_write<unsigned char>", W),
+                             ("write_4B_per_lane", "k_cal_write<unsigned int>", W), ("write_16B_per_lane", "k_cal_write16", W)):
         v = [float(r["Counter_Value"]) * 1024 for r in rows if pat in r["Kernel_Name"]]
         if not v:
             continue

@@ -33,7 +33,7 @@ extern "C" int32_t emul_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out
     mz_inflate_result r;
     uint8_t *rec = (uint8_t *)malloc(MZ_REC_BYTES + 1024); /* the wave's HBM record scratch (chase window) */
     memset(rec, 0x5A, MZ_REC_BYTES + 1024);
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, (const mz_inflate_state *)0, (mz_inflate_state *)0, &r);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, (const mz_inflate_state *)0, (mz_inflate_state *)0, &r, (const mz_inflate_par *)0);
     free(rec);
     free(L);
     *out_len = r.out_len;
@@ -55,7 +55,7 @@ extern "C" int32_t emul_inflate_resume(const uint8_t *in, uint32_t in_len, uint8
     if (st_in) memcpy(&a, st_in, sizeof(a));
     memset(&b, 0, sizeof(b));
     mz_inflate_result r;
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, &a, st_out ? &b : (mz_inflate_state *)0, &r);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 1u, rec, &a, st_out ? &b : (mz_inflate_state *)0, &r, (const mz_inflate_par *)0);
     if (st_out) memcpy(st_out, &b, sizeof(b));
     free(rec);
     free(L);
@@ -65,6 +65,30 @@ extern "C" int32_t emul_inflate_resume(const uint8_t *in, uint32_t in_len, uint8
     return r.status;
 }
 
+/* ---- one large entry on many waves (mzhip_inflate_parallel_host): the device functions behind its steps ---- */
+extern "C" uint32_t emul_find_blocks(const uint8_t *in, uint32_t in_len, uint32_t b0, uint32_t b1, uint32_t *out, uint32_t cap) {
+    uint32_t n = 0;
+    for (uint32_t p = b0; p < b1; p++)
+        if (mz_block_header_plausible(in, in_len, p)) {
+            if (n < cap) out[n] = p;
+            n++;
+        }
+    return n;
+}
+/* one candidate block: res = {status, end bit, out position behind its last byte, BFINAL} */
+extern "C" void emul_inflate_block(const uint8_t *in, uint32_t in_len, uint32_t bit, uint32_t pos, uint32_t mode, uint8_t *out,
+                                   uint32_t *ptr, uint32_t *res4) {
+    ready();
+    mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
+    memset(L, 0xA5, sizeof(*L));
+    uint8_t *rec = (uint8_t *)malloc(MZ_REC_BYTES + 1024);
+    memset(rec, 0x5A, MZ_REC_BYTES + 1024);
+    mz_inflate_one_block(in, in_len, bit, pos, mode, out, ptr, L, g_tabs.byte_tab, &g_tabs, rec, res4);
+    free(rec);
+    free(L);
+}
+/* the serial decode with "stop in front of the next block header" is emul_inflate_resume with flags bit 1 */
+
 /* the step loop alone (the span path is off) */
 extern "C" int32_t emul_inflate_steps(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                                       uint32_t *in_used, uint32_t *crc) {
@@ -72,7 +96,7 @@ extern "C" int32_t emul_inflate_steps(const uint8_t *in, uint32_t in_len, uint8_
     mz_inflate_lds *L = (mz_inflate_lds *)malloc(sizeof(mz_inflate_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_inflate_result r;
-    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 0u, (uint8_t *)0, (const mz_inflate_state *)0, (mz_inflate_state *)0, &r);
+    mz_inflate_entry(in, in_len, out, out_cap, L, g_tabs.byte_tab, &g_tabs, 0u, (uint8_t *)0, (const mz_inflate_state *)0, (mz_inflate_state *)0, &r, (const mz_inflate_par *)0);
     free(L);
     *out_len = r.out_len;
     *in_used = r.in_used;

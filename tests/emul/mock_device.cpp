@@ -77,6 +77,106 @@ MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t 
     return mzhip_inflate_host2(in, in_len, out, out_cap, out_len, in_used, crc, nullptr);
 }
 
+// one window of one large entry, every block by a "wave" of its own (inflate_parallel.inc): the same orchestration as the
+// device's, its three steps as loops over the emulated device functions
+#include "inflate_parallel.inc"
+namespace {
+struct MockParBackend {
+    const uint8_t *in;
+    uint32_t in_len;
+    uint8_t *buf;
+    std::vector<uint32_t> ptr;
+    int32_t find(uint32_t b0, uint32_t b1, std::vector<uint32_t> &c) {
+        c.resize(1u << 16);
+        uint32_t n = emul_find_blocks(in, in_len, b0, b1, c.data(), (uint32_t)c.size());
+        if (n > c.size()) {
+            c.resize(n);
+            n = emul_find_blocks(in, in_len, b0, b1, c.data(), (uint32_t)c.size());
+        }
+        c.resize(n);
+        return 0;
+    }
+    int32_t parse(uint32_t mode, const uint32_t *bits, const uint32_t *pos, uint32_t n, MzParBlock *res) {
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t r[4];
+            emul_inflate_block(in, in_len, bits[i], pos[i], mode, buf, ptr.data(), r);
+            res[i].status = (int32_t)r[0];
+            res[i].end_bit = r[1];
+            res[i].out_end = r[2];
+            res[i].last = r[3];
+        }
+        return 0;
+    }
+    int32_t resolve(uint32_t hist, uint32_t total, uint32_t *rounds) {
+        for (uint32_t changed = 1; changed; (*rounds)++) {
+            changed = 0;
+            for (uint32_t i = hist; i < total; i++) {
+                const uint32_t p = ptr[i];
+                if (p >= hist && ptr[p] != p) {
+                    ptr[i] = ptr[p];
+                    changed = 1;
+                }
+            }
+        }
+        for (uint32_t i = hist; i < total; i++) buf[i] = buf[ptr[i]];
+        return 0;
+    }
+};
+} // namespace
+static int g_mock_par_blocks = 0, g_mock_par_calls = 0;
+MOCK_API int mzmock_par_blocks(void) { return g_mock_par_blocks; }
+MOCK_API int mzmock_par_calls(void) { return g_mock_par_calls; }
+MOCK_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                             const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                             uint32_t *blocks, uint32_t *ended, uint32_t seg_first, uint32_t seg_stride,
+                                             uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
+    const uint32_t hist = state_in ? state_in->out_pos : 0u;
+    const uint32_t start = state_in && (state_in->flags & 1u) ? state_in->hdr_bit : 0u;
+    if (nseg) *nseg = 0;
+    if (blocks) *blocks = 0;
+    if (ended) *ended = 0;
+    if (out_len) *out_len = hist;
+    if (state_in && (state_in->flags & 1u) && state_in->bit != state_in->hdr_bit) return 0; /* (inside a block: stream order) */
+    if (hist > buf_cap) return -102;
+    MockParBackend be;
+    be.in = in;
+    be.in_len = in_len;
+    be.buf = buf;
+    be.ptr.assign((size_t)buf_cap + 64, 0u);
+    MzParWindow w;
+    const int32_t rc = mz_parallel_window(be, in_len, buf_cap, start, hist, &w);
+    if (rc) return rc;
+    g_mock_par_calls++;
+    g_mock_par_blocks += (int)w.blocks;
+    if (blocks) *blocks = w.blocks;
+    if (ended) *ended = w.ended;
+    if (out_len) *out_len = w.total;
+    if (state_out) {
+        state_out->hdr_bit = state_out->bit = w.next_bit;
+        state_out->out_pos = w.total;
+        state_out->flags = 1u;
+    }
+    const uint32_t ol = w.total;
+    if (seg_stride && seg_crc && ol > hist) {
+        uint32_t pos = hist, n = 0;
+        const uint32_t first = seg_first < ol - hist ? seg_first : ol - hist;
+        const uint32_t count = (first ? 1u : 0u) + (ol - hist - first + seg_stride - 1) / seg_stride;
+        if (count <= seg_cap) {
+            if (first) {
+                seg_crc[n++] = emul_crc32(buf + pos, first);
+                pos += first;
+            }
+            while (pos < ol) {
+                const uint32_t k = ol - pos < seg_stride ? ol - pos : seg_stride;
+                seg_crc[n++] = emul_crc32(buf + pos, k);
+                pos += k;
+            }
+            if (nseg) *nseg = n;
+        }
+    }
+    return 0;
+}
+
 // one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host2 does)
 MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, int32_t window_log2,
                                           uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {

@@ -163,6 +163,65 @@ def test_truncation_accounting_window_mode(libs):
         L.mzhip_set_stream_window(0, 0)
 
 
+def test_window_mode_many_waves(libs):
+    """Window mode with a wave per DEFLATE block (mzhip_inflate_parallel_host; shim_zlib.c stream_next offers it every
+    window that starts at a block header): 4 MiB windows and 1 MiB gulps over streams of 8 - 25 MB made of dynamic, fixed and
+    stored blocks -- whole, in small and large read() calls, cut, bit-flipped: every read() return value, byte, TOTAL_IN /
+    TOTAL_OUT, close() and error() as the all-reference build; the same streams with the many-wave decode switched off."""
+    import ctypes as C
+    import random
+    import zlib
+
+    hip, ref = libs
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    L.mzhip_set_stream_window(4 << 20, 1 << 20)
+    text, _ = synth.bench_corpus()
+    rnd = random.Random(12)
+    noise = bytes(rnd.getrandbits(8) for _ in range(300000))
+
+    def blocks_of(parts):
+        out = b""
+        for i, (data, lvl, strat) in enumerate(parts):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+            out += co.compress(data) + (co.flush(zlib.Z_FULL_FLUSH) if i + 1 < len(parts) else co.flush())
+        return out
+
+    big = (text + text[::-1][:200000]) * 36 + bytes(3000000) + text[200000:400000] * 5
+    streams = [("dynamic 6", synth.deflate_raw(big, 6)), ("level 1", synth.deflate_raw(big[:12000000], 1)),
+               ("mixed", blocks_of([(text * 6, 6, 0), (text, 6, zlib.Z_FIXED), (noise, 0, 0), (text * 5, 9, 0), (noise[:70000], 6, 0),
+                                    (text * 2, 6, zlib.Z_FIXED), (text * 6, 6, 0)])),
+               ("fixed only", blocks_of([(text * 2, 6, zlib.Z_FIXED)] * 3))]
+    try:
+        for name, z in streams:
+            d = zlib.decompress(z, -15)
+            for chunk in (65535, 3000000):
+                a = hip.stream_decode(8, z, len(d) + 10, chunk=chunk)
+                b = ref.stream_decode(8, z, len(d) + 10, chunk=chunk)
+                assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (name, chunk, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+            for cut in (len(z) // 2, len(z) - 3):
+                a = hip.stream_decode(8, z[:cut], len(d) + 10)
+                b = ref.stream_decode(8, z[:cut], len(d) + 10)
+                assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (name, "cut", cut, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+            for where in (len(z) // 3, len(z) * 2 // 3):
+                zz = bytearray(z)
+                zz[where] ^= 0x10
+                cap = 2 * len(d) + (1 << 20)
+                a = hip.stream_decode(8, bytes(zz), cap)
+                b = ref.stream_decode(8, bytes(zz), cap)
+                assert all(a[k] == b[k] for k in ALL if k != "base_pos"), (name, "flip", where, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+        L.mzhip_set_stream_parallel(0)
+        name, z = streams[2]
+        d = zlib.decompress(z, -15)
+        a = hip.stream_decode(8, z, len(d) + 10)
+        b = ref.stream_decode(8, z, len(d) + 10)
+        assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, "serial windows only"
+    finally:
+        L.mzhip_set_stream_parallel(1)
+        L.mzhip_set_stream_window(0, 0)
+
+
 def test_truncation_accounting_lzma(libs):
     """SURVEY Appendix B, mz_stream_lzma READ: the first 150 000 bytes of appnote.txt written by the reference's own WRITE
     stream (34 458 bytes); cut in half the reference returns 65 535, then -3, with TOTAL_IN / TOTAL_OUT = 17 229 / 74 787."""

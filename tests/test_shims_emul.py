@@ -195,3 +195,76 @@ def test_window_mode_streams():
         reads = int(sum((int(n) + 65534) // 65535 for n in lens))
         print("window mode through the zip layer: %d reads, %d windows, %d checksum launches" % (reads, windows, launches))
         assert windows >= 8 and launches <= windows + 4 and launches < reads // 2, (launches, windows, reads)
+
+
+def test_window_mode_many_waves():
+    """A large entry is decoded by a wave per DEFLATE block whenever window mode stands at a block header
+    (mzhip_inflate_parallel_host, csrc/inflate_parallel.inc: header search, a parse per candidate, the chain from the known
+    header, source map, pointer jumping), and by the serial kernel -- asked to stop at the next block header -- where that
+    declines.  Built with a 1.5 MiB window, 256 KiB gulps and low thresholds so that streams of a few MiB go through many
+    windows of both kinds: same read() return values, bytes, TOTAL_IN / TOTAL_OUT, close() and error() as the reference for
+    whole, truncated and corrupted streams made of dynamic, fixed and stored blocks."""
+    import ctypes as C
+    import random
+    import zlib
+
+    from tests import synth
+
+    if not os.path.isdir("/root/reference") or not oracle.have_ref():
+        pytest.skip("needs the reference sources at build time")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul"), "B=_build_par",
+                    'SHIM_DEFS=-DMZH_STREAM_WINDOW="(1536<<10)" -DMZH_STREAM_GULP="(256<<10)" -DMZH_PAR_MIN_IN="(32<<10)" '
+                    '-DMZH_PAR_MIN_ROOM="(128<<10)" -DMZH_STREAM_EARLY="(64<<10)"'], check=True, capture_output=True)
+    so = os.path.join(ROOT, "tests", "emul", "_build_par", "libmockdrop.so")
+    hip = oracle.MzDriver(so)
+    L = C.CDLL(so)
+    ref = oracle.ref()
+    text, _ = synth.bench_corpus()
+    rnd = random.Random(11)
+    noise = bytes(rnd.getrandbits(8) for _ in range(200000))
+
+    def blocks_of(parts):
+        """one raw stream out of pieces compressed with their own settings (full flushes between them: every piece starts
+        on a block boundary, fixed-Huffman pieces via Z_FIXED, stored ones via level 0)"""
+        out = b""
+        for data, lvl, strat in parts[:-1]:
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+            out += co.compress(data) + co.flush(zlib.Z_FULL_FLUSH)
+        data, lvl, strat = parts[-1]
+        co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+        return out + co.compress(data) + co.flush()
+
+    big = text[:900000] * 3 + bytes(400000) + text[200000:700000]
+    cases = [
+        ("dynamic", big, synth.deflate_raw(big, 6)),
+        ("level 1", big[:2000000], synth.deflate_raw(big[:2000000], 1)),
+        ("mixed", None, blocks_of([(text[:600000], 6, 0), (text[:300000], 6, zlib.Z_FIXED), (noise, 0, 0), (text[100000:900000], 9, 0),
+                                   (noise[:70000], 6, 0), (text[:500000], 6, zlib.Z_FIXED), (text[:500000], 6, 0)])),
+        ("fixed only", None, blocks_of([(text[:700000], 6, zlib.Z_FIXED)] * 3)),
+    ]
+    for name, d, z in cases:
+        if d is None:
+            d = zlib.decompress(z, -15)
+        b0, c0 = L.mzmock_par_blocks(), L.mzmock_par_calls()
+        for chunk in (65535, 300000):
+            assert ref.stream_decode(8, z, len(d) + 10, chunk=chunk) == hip.stream_decode(8, z, len(d) + 10, chunk=chunk), (name, chunk)
+        print("%s: %d bytes -> %d; many-wave windows %d, blocks %d" % (name, len(z), len(d), L.mzmock_par_calls() - c0, L.mzmock_par_blocks() - b0))
+        if name in ("dynamic", "level 1", "mixed"):
+            assert L.mzmock_par_blocks() - b0 >= 8, name
+        for cut in (len(z) // 2, len(z) - 3):
+            assert ref.stream_decode(8, z[:cut], len(d) + 10) == hip.stream_decode(8, z[:cut], len(d) + 10), (name, "cut", cut)
+        for where in (len(z) // 3, len(z) * 2 // 3):
+            zz = bytearray(z)
+            zz[where] ^= 0x10
+            cap = 2 * len(d) + (1 << 20)   # (room for whatever the damaged stream decodes to: TOTAL_IN of a caller that stops mid-stream is an estimate, DESIGN 4)
+            a, b = ref.stream_decode(8, bytes(zz), cap), hip.stream_decode(8, bytes(zz), cap)
+            # (where the base stream stands after a data error is not compared: window mode pulls up to a gulp ahead of the decode)
+            a.pop("base_pos"), b.pop("base_pos")
+            assert a == b, (name, "flip", where)
+    # the switch: the same streams with the many-wave decode off take the serial windows only
+    L.mzhip_set_stream_parallel(0)
+    b0 = L.mzmock_par_blocks()
+    name, d, z = cases[0]
+    assert ref.stream_decode(8, z, len(d) + 10) == hip.stream_decode(8, z, len(d) + 10)
+    assert L.mzmock_par_blocks() == b0
+    L.mzhip_set_stream_parallel(1)
