@@ -157,12 +157,19 @@ def make_unique_deflate(c, n_unique, size, seed, gen_seconds, world):
     procs = max(1, usable_cores() // max(world, 1))  # ranks share the host cores
     t0 = time.time()
     out = []
-    with mp.Pool(procs, initializer=_pool_init, initargs=(c, 6)) as pool:
+    # (close + join, not the context manager's terminate: under rocprofv3 a SIGTERM to the forked workers runs the tool's
+    # signal handler in each of them, and that has left a --pmc pass hanging until its timeout twice, profiles/r4/README.md)
+    pool = mp.Pool(procs, initializer=_pool_init, initargs=(c, 6))
+    try:
         for r in pool.imap(_compress_one, offs, chunksize=64):
             out.append(r)
             if time.time() - t0 > gen_seconds and len(out) >= 256:
                 pool.terminate()
                 break
+        else:
+            pool.close()
+    finally:
+        pool.join()
     offs = offs[:len(out)]
     return offs, [p for p, _ in out], np.array([k for _, k in out], dtype=np.uint32)
 
@@ -194,7 +201,8 @@ def make_markov_lzma(c, n_unique, size, seed, gen_seconds, world):
     procs = max(1, min(usable_cores() // max(world, 1), n_unique))
     t0 = time.time()
     datas, pays, crcs = [], [], []
-    with mp.Pool(procs, initializer=_pool_init, initargs=(c, 6)) as pool:
+    pool = mp.Pool(procs, initializer=_pool_init, initargs=(c, 6))
+    try:
         for d, p, k in pool.imap(_markov_lzma_one, [(size, seed * 100003 + i) for i in range(n_unique)]):
             datas.append(d)
             pays.append(p)
@@ -202,6 +210,10 @@ def make_markov_lzma(c, n_unique, size, seed, gen_seconds, world):
             if time.time() - t0 > gen_seconds and len(datas) >= 64:
                 pool.terminate()
                 break
+        else:
+            pool.close()
+    finally:
+        pool.join()
     return datas, pays, np.array(crcs, dtype=np.uint32)
 
 

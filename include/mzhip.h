@@ -354,6 +354,10 @@ MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes)
 /* Window mode of mz_stream_zlib READ offers every window that starts at a block header to mzhip_inflate_parallel_host first
  * (a wave per DEFLATE block); 0 turns that off (MZHIP_STREAM_PARALLEL=0 in the environment does the same). */
 MZHIP_API void mzhip_set_stream_parallel(int32_t on);
+/* page-locked host memory for a READ stream's window buffer, from the library's pool (next to the current device; NULL when
+ * there is none to be had -- the caller then uses plain memory); *cap = what to hand back to mzhip_window_free */
+MZHIP_API void *mzhip_window_alloc(size_t bytes, size_t *cap);
+MZHIP_API void mzhip_window_free(void *p, size_t cap);
 MZHIP_API void mzhip_prime_stats(uint64_t *entries, uint64_t *hits, uint64_t *misses);
 /* Entries that carry a SHA-1 / SHA-256 Hash extra field (0x1a51): the prime computes the digest of the decoded bytes on
  * the device in the pass that decodes them (mzhip_sha_batch over the chunk in HBM) and compares it with the field's, as

@@ -100,6 +100,11 @@ typedef struct mzhip_zlib_s {
     uint32_t *pc_tmp;
     int32_t pc_tmp_cap;
     /* ... and by many waves when the stream stands at a block header (mzhip_inflate_parallel_host) */
+    int8_t out_pinned;      /* out[] is page-locked memory of the library's pool (mzhip_window_alloc): the device copies a window
+                             * into it at link speed, into pageable memory at a third of that */
+    size_t out_pin_cap;
+    int64_t par_in_q16;     /* compressed bytes per decoded byte of the last many-wave window (Q16; 0 = none yet): how much of
+                             * the input the next one is shown */
     int32_t par_miss;       /* windows in a row the many-wave decode got (next to) nothing out of */
     int32_t par_rest;       /* serial windows to go before it is tried again */
     /* write side */
@@ -118,6 +123,28 @@ static mzhip_stream_vtbl mzhip_zlib_vtbl = {
     mz_stream_zlib_tell,   mz_stream_zlib_seek,    mz_stream_zlib_close,          mz_stream_zlib_error,
     mz_stream_zlib_create, mz_stream_zlib_delete,  mz_stream_zlib_get_prop_int64, mz_stream_zlib_set_prop_int64};
 
+static void out_release(mzhip_zlib *z) {
+    if (z->out_pinned)
+        mzhip_window_free(z->out, z->out_pin_cap);
+    else if (!z->out_borrowed)
+        free(z->out);
+    z->out = NULL;
+    z->out_pinned = 0;
+    z->out_borrowed = 0;
+}
+/* the window buffer: page-locked when the pool has it, plain memory otherwise */
+static uint8_t *out_window_alloc(mzhip_zlib *z, int64_t bytes) {
+    size_t cap = 0;
+    uint8_t *p = (uint8_t *)mzhip_window_alloc((size_t)bytes, &cap);
+    if (p) {
+        z->out_pinned = 1;
+        z->out_pin_cap = cap;
+        return p;
+    }
+    z->out_pinned = 0;
+    return (uint8_t *)malloc((size_t)bytes);
+}
+
 /* what mz_stream_read does before dispatching (mz_strm.c:34-41) */
 static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
     if (!base || !base->vtbl || !base->vtbl->read)
@@ -135,8 +162,7 @@ static void free_buffers(mzhip_zlib *z) {
     z->pc_tmp = NULL;
     z->pc_n = z->pc_cap = z->pc_head = z->pc_tmp_cap = 0;
     z->g0 = 0;
-    if (!z->out_borrowed)
-        free(z->out);
+    out_release(z);
     mzhip_prime_unpin(z->prime_pin);
     z->prime_pin = NULL;
     z->out_borrowed = 0;
@@ -548,7 +574,16 @@ static int32_t stream_next(mzhip_zlib *z) {
             z->par_rest--;
         else if (par_on && z->sst.bit == z->sst.hdr_bit && z->in_len >= MZH_PAR_MIN_IN && z->out_cap - z->out_len >= MZH_PAR_MIN_ROOM) {
             uint32_t pb = 0, pended = 0, pol = 0;
-            const int32_t pr = mzhip_inflate_parallel_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &pol, &pb,
+            /* how much of the input the search is shown: twice what the room took at the last window's ratio (the whole
+             * gulp the first time).  Too little only ends the chain early; too much is searched and parsed for nothing */
+            int64_t show = z->in_len;
+            if (z->par_in_q16 > 0) {
+                const int64_t est = (int64_t)(z->sst.hdr_bit >> 3) + (((z->out_cap - z->out_len) * z->par_in_q16) >> 15) + (256 << 10);
+                if (est < show)
+                    show = est;
+            }
+            const int64_t bit0 = z->sst.hdr_bit;
+            const int32_t pr = mzhip_inflate_parallel_host(z->in, (uint32_t)show, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &pol, &pb,
                                                            &pended, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
                                                            (uint32_t)z->pc_tmp_cap, &nseg);
             if (pr < 0) {
@@ -559,6 +594,8 @@ static int32_t stream_next(mzhip_zlib *z) {
                 const int64_t made = (int64_t)pol - z->out_len;
                 if (nseg)
                     stream_pieces_add(z, gnew, made, seg_first, stride, nseg);
+                if (made > 0)
+                    z->par_in_q16 = ((((int64_t)nst.hdr_bit - bit0) >> 3) << 16) / made + 1;
                 z->out_len = pol;
                 z->sst = nst;
                 if (pended) {
@@ -681,12 +718,11 @@ static int32_t attempt_decode(mzhip_zlib *z) {
              * lives in window mode.  (Without it the entry would be decoded from its first byte again every time the input
              * has doubled, by one wave.) */
             if (z->out_cap < mzh_stream_window()) {
-                uint8_t *nb = (uint8_t *)malloc((size_t)mzh_stream_window());
-                if (nb) {
-                    free(z->out);
-                    z->out = nb;
-                    z->out_cap = mzh_stream_window();
-                }
+                out_release(z);
+                z->out = out_window_alloc(z, mzh_stream_window());
+                z->out_cap = z->out ? mzh_stream_window() : 0;
+                if (!z->out)
+                    return MZH_MEM_ERROR;
             }
             early = z->out_cap >= mzh_stream_window();
         }
@@ -711,10 +747,12 @@ static int32_t attempt_decode(mzhip_zlib *z) {
                 ncap = mzh_stream_window();
             if (ncap > 0x7FFFFFFF)
                 ncap = 0x7FFFFFFF;
-            free(z->out);
-            z->out = (uint8_t *)malloc((size_t)ncap);
-            if (!z->out)
+            out_release(z);
+            z->out = (z->wrap == 0 && ncap >= mzh_stream_window()) ? out_window_alloc(z, ncap) : (uint8_t *)malloc((size_t)ncap);
+            if (!z->out) {
+                z->out_cap = 0;
                 return MZH_MEM_ERROR;
+            }
             z->out_cap = ncap;
             continue;
         }
@@ -1069,8 +1107,7 @@ int32_t mz_stream_zlib_close(void *stream) {
     z->pc_tmp = NULL;
     z->pc_n = z->pc_cap = z->pc_head = z->pc_tmp_cap = 0;
     z->g0 = 0;
-    if (!z->out_borrowed)
-        free(z->out);
+    out_release(z);
     mzhip_prime_unpin(z->prime_pin);
     z->prime_pin = NULL;
     z->out_borrowed = 0;

@@ -123,6 +123,11 @@ struct MockParBackend {
     }
 };
 } // namespace
+MOCK_API void *mzhip_window_alloc(size_t bytes, size_t *cap) {
+    if (cap) *cap = bytes;
+    return getenv("MZMOCK_NO_PINNED") ? nullptr : malloc(bytes);
+}
+MOCK_API void mzhip_window_free(void *p, size_t) { free(p); }
 static int g_mock_par_blocks = 0, g_mock_par_calls = 0;
 MOCK_API int mzmock_par_blocks(void) { return g_mock_par_blocks; }
 MOCK_API int mzmock_par_calls(void) { return g_mock_par_calls; }
