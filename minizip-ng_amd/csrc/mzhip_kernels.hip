@@ -566,19 +566,28 @@ struct ParJumpArgs {
     uint32_t hist, total;
     uint32_t *changed;
 };
-// one round of pointer jumping over the source map: ptr[i] = ptr[ptr[i]] (in place: whatever a racing lane reads is an
-// ancestor of i either way).  Roots are literals (ptr[i] == i) and the history in front of the window (ptr[i] < hist).
+// one round of pointer jumping over the source map: ptr[i] = its ancestor up to four links up (in place: whatever a racing
+// lane reads is an ancestor of i either way; four dependent loads per lane instead of one cut the rounds of a window from
+// 14 to 5 for the same bytes moved per round).  Roots are literals (ptr[i] == i) and the history in front of the window
+// (ptr[i] < hist).
 __global__ __launch_bounds__(256) void k_ptr_jump(ParJumpArgs a) {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     uint32_t any = 0;
     for (uint64_t i = (uint64_t)a.hist + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < a.total; i += stride) {
-        const uint32_t p = a.ptr[i];
-        if (p != (uint32_t)i && p >= a.hist) {
+        uint32_t p = a.ptr[i];
+        if (p == (uint32_t)i || p < a.hist) continue;
+        uint32_t moved = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
             const uint32_t q = a.ptr[p];
-            if (q != p) {
-                a.ptr[i] = q;
-                any = 1;
-            }
+            if (q == p) break;
+            p = q;
+            moved = 1;
+            if (p < a.hist) break;
+        }
+        if (moved) {
+            a.ptr[i] = p;
+            any = 1;
         }
     }
     if (__any(any) && (threadIdx.x & 63) == 0) *a.changed = 1u;

@@ -39,9 +39,13 @@
  * does (Z_STREAM_ERROR -> the reference's open() returns MZ_OPEN_ERROR); a stream whose header asks for a larger window
  * than the one set is Z_DATA_ERROR, as in inflate().
  */
+#ifndef _POSIX_C_SOURCE
+#define _POSIX_C_SOURCE 200112L /* clock_gettime */
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mz_strm_hip.h"
 #include "mzhip.h"
@@ -100,11 +104,17 @@ typedef struct mzhip_zlib_s {
     uint32_t *pc_tmp;
     int32_t pc_tmp_cap;
     /* ... and by many waves when the stream stands at a block header (mzhip_inflate_parallel_host) */
+    int8_t in_pinned;       /* ... and in[] (window mode: a gulp goes to the device before every window) */
+    size_t in_pin_cap;
     int8_t out_pinned;      /* out[] is page-locked memory of the library's pool (mzhip_window_alloc): the device copies a window
                              * into it at link speed, into pageable memory at a third of that */
     size_t out_pin_cap;
     int64_t par_in_q16;     /* compressed bytes per decoded byte of the last many-wave window (Q16; 0 = none yet): how much of
                              * the input the next one is shown */
+    /* where a window-mode stream's time went (MZHIP_STREAM_STATS=1 prints it at close): seconds */
+    double t_par, t_serial, t_pull, t_open;
+    int32_t n_par, n_serial;
+    int64_t par_bytes, serial_bytes;
     int32_t par_miss;       /* windows in a row the many-wave decode got (next to) nothing out of */
     int32_t par_rest;       /* serial windows to go before it is tried again */
     /* write side */
@@ -123,6 +133,11 @@ static mzhip_stream_vtbl mzhip_zlib_vtbl = {
     mz_stream_zlib_tell,   mz_stream_zlib_seek,    mz_stream_zlib_close,          mz_stream_zlib_error,
     mz_stream_zlib_create, mz_stream_zlib_delete,  mz_stream_zlib_get_prop_int64, mz_stream_zlib_set_prop_int64};
 
+static double mzh_now(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 static void out_release(mzhip_zlib *z) {
     if (z->out_pinned)
         mzhip_window_free(z->out, z->out_pin_cap);
@@ -131,6 +146,47 @@ static void out_release(mzhip_zlib *z) {
     z->out = NULL;
     z->out_pinned = 0;
     z->out_borrowed = 0;
+}
+static void in_release(mzhip_zlib *z) {
+    if (z->in_pinned)
+        mzhip_window_free(z->in, z->in_pin_cap);
+    else
+        free(z->in);
+    z->in = NULL;
+    z->in_pinned = 0;
+}
+/* in[] grows to ncap bytes; in window mode into page-locked memory when the pool has it */
+static int32_t in_grow(mzhip_zlib *z, int64_t ncap) {
+    if (z->streaming) {
+        size_t cap = 0;
+        uint8_t *p = (uint8_t *)mzhip_window_alloc((size_t)ncap, &cap);
+        if (p) {
+            if (z->in_len > 0)
+                memcpy(p, z->in, (size_t)z->in_len);
+            in_release(z);
+            z->in = p;
+            z->in_pinned = 1;
+            z->in_pin_cap = cap;
+            z->in_cap = ncap;
+            return 0;
+        }
+    }
+    if (z->in_pinned) { /* (the pool has run dry since: back to plain memory) */
+        uint8_t *p = (uint8_t *)malloc((size_t)ncap);
+        if (!p)
+            return MZH_MEM_ERROR;
+        memcpy(p, z->in, (size_t)z->in_len);
+        in_release(z);
+        z->in = p;
+        z->in_cap = ncap;
+        return 0;
+    }
+    uint8_t *p = (uint8_t *)realloc(z->in, (size_t)ncap);
+    if (!p)
+        return MZH_MEM_ERROR;
+    z->in = p;
+    z->in_cap = ncap;
+    return 0;
 }
 /* the window buffer: page-locked when the pool has it, plain memory otherwise */
 static uint8_t *out_window_alloc(mzhip_zlib *z, int64_t bytes) {
@@ -155,7 +211,7 @@ static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
 }
 
 static void free_buffers(mzhip_zlib *z) {
-    free(z->in);
+    in_release(z);
     free(z->pc);
     free(z->pc_tmp);
     z->pc = NULL;
@@ -188,6 +244,12 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->wp_off = 0;
     z->decoded = 0;
     z->streaming = z->stream_end = 0;
+    z->t_par = z->t_serial = z->t_pull = 0.0;
+    z->t_open = mzh_now();
+    z->n_par = z->n_serial = 0;
+    z->par_bytes = z->serial_bytes = 0;
+    z->par_miss = z->par_rest = 0;
+    z->par_in_q16 = 0;
     z->in_dropped = 0;
     z->dev_status = 0;
     z->dev_in_used = 0;
@@ -282,11 +344,9 @@ static int32_t pull_chunk(mzhip_zlib *z) {
         int64_t ncap = z->in_cap ? z->in_cap * 2 : (want <= 256 ? 1024 : 65536);
         while (ncap < z->in_len + want)
             ncap *= 2;
-        uint8_t *p = (uint8_t *)realloc(z->in, (size_t)ncap);
-        if (!p)
-            return MZH_MEM_ERROR;
-        z->in = p;
-        z->in_cap = ncap;
+        const int32_t gr = in_grow(z, ncap);
+        if (gr < 0)
+            return gr;
     }
     int32_t rd = base_read(z->stream.base, z->in + z->in_len, want);
     if (rd < 0)
@@ -435,6 +495,9 @@ int64_t mzh_stream_gulp(void) {
 #ifndef MZH_STREAM_EARLY
 #define MZH_STREAM_EARLY (1 << 20) /* compressed bytes pulled, entry not over: window mode from here on */
 #endif
+#ifndef MZH_STREAM_EARLY_OUT
+#define MZH_STREAM_EARLY_OUT (4 << 20) /* ... or decoded bytes */
+#endif
 static int8_t mzh_par_mode = -1;
 MZHIP_API void mzhip_set_stream_parallel(int32_t on) { mzh_par_mode = on ? 1 : 0; }
 static int32_t mzh_stream_parallel(void) {
@@ -542,6 +605,7 @@ static int32_t stream_next(mzhip_zlib *z) {
     }
     for (;;) {
         /* compressed bytes for about a window: pull ahead (each pull <= 32767 bytes like the reference's) */
+        const double tp0 = mzh_now();
         while (!z->base_eof && z->in_len < mzh_stream_gulp()) {
             const int32_t rd = pull_chunk(z);
             if (rd < 0) {
@@ -551,6 +615,7 @@ static int32_t stream_next(mzhip_zlib *z) {
                 z->base_eof = 1;
             }
         }
+        z->t_pull += mzh_now() - tp0;
         z->sst.out_pos = (uint32_t)z->out_len;
         z->sst.flags = 1;
         mzhip_inflate_state nst;
@@ -583,15 +648,19 @@ static int32_t stream_next(mzhip_zlib *z) {
                     show = est;
             }
             const int64_t bit0 = z->sst.hdr_bit;
+            const double t0 = mzh_now();
             const int32_t pr = mzhip_inflate_parallel_host(z->in, (uint32_t)show, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &pol, &pb,
                                                            &pended, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
                                                            (uint32_t)z->pc_tmp_cap, &nseg);
+            z->t_par += mzh_now() - t0;
+            z->n_par++;
             if (pr < 0) {
                 z->stream_end = 1;
                 return verdict(z, MZH_STREAM_ERROR, z->in_dropped); /* device / runtime failure */
             }
             if (pb) {
                 const int64_t made = (int64_t)pol - z->out_len;
+                z->par_bytes += made;
                 if (nseg)
                     stream_pieces_add(z, gnew, made, seg_first, stride, nseg);
                 if (made > 0)
@@ -621,9 +690,14 @@ static int32_t stream_next(mzhip_zlib *z) {
         }
         if (par_on && z->par_rest == 0 && z->par_miss < 3)
             z->sst.flags |= 2u; /* stop at the next block header: the many-wave decode goes on from there */
+        const double ts0 = mzh_now();
         int32_t st = mzhip_inflate_resume_host_seg(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
                                                    &in_used, &crc, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
                                                    (uint32_t)z->pc_tmp_cap, &nseg);
+        z->t_serial += mzh_now() - ts0;
+        z->n_serial++;
+        if (out_len > (uint32_t)z->out_len)
+            z->serial_bytes += (int64_t)out_len - z->out_len;
         if (nseg)
             stream_pieces_add(z, gnew, (int64_t)out_len - z->out_len, seg_first, stride, nseg);
         if (st == MZHIP_STATUS_BUF_ERROR && z->base_eof && (nst.flags & 1u)) {
@@ -712,11 +786,14 @@ static int32_t attempt_decode(mzhip_zlib *z) {
                                          (uint32_t)z->out_cap, &out_len, &in_used, &z->out_crc,
                                          z->wrap == 1 ? &z->out_adler : NULL);
         int32_t early = 0;
-        if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof && z->wrap == 0 && z->in_len >= MZH_STREAM_EARLY && mzh_stream_parallel() &&
-            z->in_len < mzh_stream_window()) {
-            /* a megabyte of compressed bytes and the entry is not over: it is large enough for the many-wave decode, which
-             * lives in window mode.  (Without it the entry would be decoded from its first byte again every time the input
-             * has doubled, by one wave.) */
+        const int64_t early_out = MZH_STREAM_EARLY_OUT < mzh_stream_window() ? MZH_STREAM_EARLY_OUT : mzh_stream_window();
+        if (z->wrap == 0 && mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
+            ((st == MZHIP_STATUS_BUF_ERROR && !z->base_eof && (z->in_len >= MZH_STREAM_EARLY || (int64_t)out_len >= early_out)) ||
+             (st == MZHIP_STATUS_OUT_FULL && z->out_cap >= early_out))) {
+            /* a megabyte of compressed bytes and the entry is not over, or four of decoded ones and counting: it is large
+             * enough for the many-wave decode, which lives in window mode.  (Without it the entry would be decoded from its
+             * first byte again every time the input has doubled or the buffer has been outgrown, by one wave: 1.3 of the
+             * 2.2 s of a 3 GiB entry that compresses 300:1, profiles/r4/large_entry.log.) */
             if (z->out_cap < mzh_stream_window()) {
                 out_release(z);
                 z->out = out_window_alloc(z, mzh_stream_window());
@@ -730,6 +807,12 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             /* more than a window of output: from here on the entry is decoded window by window.  The first window once
              * more, this time asking where it stops */
             z->streaming = 1;
+            if (!z->in_pinned) { /* (room for a gulp and the pull that crosses it; grows like any in[] if a block needs more) */
+                int64_t want = mzh_stream_gulp() + 2 * MZH_STAGING_BYTES;
+                if (want < z->in_cap)
+                    want = z->in_cap;
+                (void)in_grow(z, want);
+            }
             z->in_dropped = 0;
             memset(&z->sst, 0, sizeof(z->sst));
             z->out_len = z->out_served = 0;
@@ -1099,8 +1182,17 @@ int32_t mz_stream_zlib_close(void *stream) {
         }
         z->wp_id = -1;
     }
+    if (z->streaming && (z->mode & MZH_OPEN_MODE_READ)) {
+        const char *e = getenv("MZHIP_STREAM_STATS");
+        if (e && e[0] == '1')
+            fprintf(stderr,
+                    "mzhip window mode: %.3f s open to close, %lld bytes out; many-wave windows %d (%.3f s, %lld bytes), serial windows %d "
+                    "(%.3f s, %lld bytes), pulling input %.3f s\n",
+                    mzh_now() - z->t_open, (long long)z->total_out, z->n_par, z->t_par, (long long)z->par_bytes, z->n_serial, z->t_serial,
+                    (long long)z->serial_bytes, z->t_pull);
+    }
     z->initialized = 0;
-    free(z->in);
+    in_release(z);
     free(z->pc);
     free(z->pc_tmp);
     z->pc = NULL;

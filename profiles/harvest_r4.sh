@@ -5,7 +5,11 @@ set -u
 d=profiles/r4
 mkdir -p $d
 cp gpurun_out/final/kernel_stats.csv $d/kernel_stats_final.csv
-cp gpurun_out/final/pmc_fetch_size.csv gpurun_out/final/pmc_write_size.csv $d/
+cp gpurun_out/final/pmc_fetch_size.csv $d/
+# (the WRITE_SIZE passes of configs 2 and 5 hung in the evidence run -- bench.py's worker pool was terminated under the
+# profiler, see README -- and were taken again two calls later on a tree that differs from that run's in host code only)
+cp gpurun_out/c9_w2/pmc_write_size.csv $d/pmc_write_size.csv
+mkdir -p gpurun_out/traffic_cfg5 && cp gpurun_out/c9_w5/pmc_write_size.csv gpurun_out/traffic_cfg5/pmc_write_size.csv
 cp gpurun_out/final/bench.log $d/bench_default.log
 cp gpurun_out/final/gputest.log $d/gputest_final.log
 cp gpurun_out/final/fuzz_gpu.log $d/fuzz_gpu_final.log
@@ -14,8 +18,8 @@ cp gpurun_out/final/ab_k1_records.log $d/ab_k1_records.log
 cp gpurun_out/final/bench_shard12500.log $d/bench_shard12500.log
 cp gpurun_out/c1/residency.log $d/ab_k1_residency.log 2>/dev/null
 for i in 1 2 3; do cp gpurun_out/final_sq/pmc_sq$i.csv $d/pmc_sq${i}_k1_final.csv; done
-cp gpurun_out/final/cal_fetch.csv gpurun_out/final/cal_write.csv $d/ 2>/dev/null
-python3 profiles/calibrate_harvest.py r4 gpurun_out/final
+cp gpurun_out/c8/cal_fetch.csv gpurun_out/c8/cal_write.csv $d/ 2>/dev/null
+python3 profiles/calibrate_harvest.py r4 gpurun_out/c8
 python3 profiles/traffic_harvest.py r4 3 4 5
 python3 - "$d" <<'PY'
 import csv, json, sys, subprocess
