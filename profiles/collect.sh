@@ -5,7 +5,7 @@
 # counter (never combined with other trace domains).  Copy what should be judged into profiles/<round>/.
 set -u
 tag=${1:-run}
-what=${2:-all}   # all | bench | stats | FETCH_SIZE | WRITE_SIZE | SQ (instruction mix and wait cycles, not part of `all`)
+what=${2:-all}   # all | bench | stats | FETCH_SIZE | WRITE_SIZE | SQ (instruction mix and wait cycles) | REQ (L2 memory-side requests by size); the last two are not part of `all`
 T=${MZ_COLLECT_TIMEOUT:-300}  # a pass that outlives this is killed (rocprofv3 has hung here once)
 root=$PWD
 out=$root/gpurun_out/$tag
@@ -29,6 +29,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 $T rocprofv3 --kernel-trace --pmc $c -d "$out/pmc_$lc" -o pmc --output-format csv -- $cmd > "$out/pmc_$lc.log" 2>&1
   find "$out/pmc_$lc" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|$3" "$1" > "$2"' _ {} "$out/pmc_$lc.csv" "$kern" \;
 done
+if [ $what = REQ ]; then
+  # the memory-side requests of the L2 by size: what FETCH_SIZE / WRITE_SIZE are derived from, for a kernel whose accesses are
+  # not the wide streaming ones the guide's factor was found on (bytes = 32 x n32 + 64 x n64 + 128 x n128)
+  i=0
+  for grp in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+    i=$((i+1))
+    reqcmd=${MZ_REQ_CMD:-$cmd}
+    timeout -k 10 $T rocprofv3 --kernel-trace --pmc $grp -d "$out/pmc_req$i" -o pmc --output-format csv -- $reqcmd > "$out/pmc_req$i.log" 2>&1
+    find "$out/pmc_req$i" -name '*counter_collection.csv' -exec sh -c 'grep -E "Counter_Name|$3" "$1" > "$2"' _ {} "$out/pmc_req$i.csv" "${MZ_REQ_KERNEL:-$kern}" \;
+  done
+fi
 if [ $what = SQ ]; then
   # instruction mix and stall picture of the dominant kernel; a pass per counter group (never with other trace domains);
   # MZ_SQ_CMD overrides the workload (default: the short probe, one launch is enough for counters)
