@@ -114,11 +114,20 @@ MZHIP_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_l
  * (csrc/inflate_parallel.inc).  Same buffers as mzhip_inflate_resume_host_seg; state_in must stand at a block header
  * (bit == hdr_bit; NULL = the start of the stream).  Returns 0 with *blocks = blocks decoded (0: nothing a wave of its own
  * could take -- go on with mzhip_inflate_resume_host_seg, flags bit 1 makes it stop at the next block header), *out_len =
- * bytes valid in buf, *ended = the final block was among them, state_out = the header of the first block not decoded. */
+ * bytes valid in buf, *ended = the final block was among them, state_out = the header of the first block not decoded;
+ * *crc / *adler (either may be NULL) = CRC-32 / Adler-32 of the new bytes (what the gzip / zlib trailers run over). */
 MZHIP_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                               const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
-                                              uint32_t *out_len, uint32_t *blocks, uint32_t *ended, uint32_t seg_first,
-                                              uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg);
+                                              uint32_t *out_len, uint32_t *blocks, uint32_t *ended, uint32_t *crc, uint32_t *adler,
+                                              uint32_t seg_first, uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap,
+                                              uint32_t *nseg);
+
+/* mzhip_inflate_resume_host_seg plus the Adler-32 of the new bytes (NULL: not wanted) */
+MZHIP_API int32_t mzhip_inflate_resume_host_seg2(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                                 const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
+                                                 uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t *adler,
+                                                 uint32_t seg_first, uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap,
+                                                 uint32_t *nseg);
 
 MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,

@@ -103,6 +103,9 @@ typedef struct mzhip_zlib_s {
     int32_t pc_n, pc_cap, pc_head;
     uint32_t *pc_tmp;
     int32_t pc_tmp_cap;
+    /* ... under a zlib / gzip wrapper: the trailer's checksum runs over every window (combined from the device's per-window values) */
+    uint32_t run_crc, run_adler;
+    int64_t run_n;
     /* ... and by many waves when the stream stands at a block header (mzhip_inflate_parallel_host) */
     int8_t in_pinned;       /* ... and in[] (window mode: a gulp goes to the device before every window) */
     size_t in_pin_cap;
@@ -587,6 +590,45 @@ static int32_t stream_pieces_crc(mzhip_zlib *z, int32_t n, uint32_t *crc) {
     return 1;
 }
 
+/* n new bytes with these device-computed checksums join the wrapper's running ones */
+static void stream_sum(mzhip_zlib *z, int64_t n, uint32_t wcrc, uint32_t wadler) {
+    if (z->wrap == 0 || n <= 0)
+        return;
+    if (z->wrap == 2)
+        z->run_crc = z->run_n ? mzhip_crc32_combine(z->run_crc, wcrc, (uint64_t)n) : wcrc;
+    else
+        z->run_adler = mzhip_adler32_combine(z->run_adler, wadler, (uint64_t)n);
+    z->run_n += n;
+}
+
+/* the DEFLATE payload ended cleanly `used` bytes into the stream: a raw stream is done; under a wrapper the trailer follows
+ * (gzip = CRC-32 then ISIZE, little endian; zlib = Adler-32, big endian) and is checked the way inflate() checks it */
+static int32_t stream_finish(mzhip_zlib *z, int64_t used) {
+    if (z->wrap == 0)
+        return verdict(z, MZHIP_STATUS_OK, used);
+    const int64_t tl = z->wrap == 2 ? 8 : 4;
+    const int64_t lo = used - z->in_dropped;
+    while (!z->base_eof && z->in_len < lo + tl) {
+        const int32_t rd = pull_chunk(z);
+        if (rd < 0) {
+            z->base_err = rd;
+            z->base_eof = 1;
+        }
+    }
+    if (z->in_len < lo + tl)
+        return verdict(z, MZHIP_STATUS_BUF_ERROR, z->in_dropped + z->in_len);
+    const uint8_t *t = z->in + lo;
+    if (z->wrap == 2) {
+        if (le32(t) != z->run_crc) /* "incorrect data check": inflate() stops after the CRC field */
+            return verdict(z, MZHIP_STATUS_DATA_ERROR, used + 4);
+        if (le32(t + 4) != (uint32_t)(z->g0 + z->out_len)) /* "incorrect length check" */
+            return verdict(z, MZHIP_STATUS_DATA_ERROR, used + 8);
+        return verdict(z, MZHIP_STATUS_OK, used + 8);
+    }
+    const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+    return verdict(z, want == z->run_adler ? MZHIP_STATUS_OK : MZHIP_STATUS_DATA_ERROR, used + 4);
+}
+
 /* window mode: make more decoded bytes available behind out_served.  Returns 0 (bytes, the stream end or a verdict are
  * there) or a negative MZ error. */
 static int32_t stream_next(mzhip_zlib *z) {
@@ -649,9 +691,10 @@ static int32_t stream_next(mzhip_zlib *z) {
             }
             const int64_t bit0 = z->sst.hdr_bit;
             const double t0 = mzh_now();
+            uint32_t wcrc = 0, wadler = 1;
             const int32_t pr = mzhip_inflate_parallel_host(z->in, (uint32_t)show, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &pol, &pb,
-                                                           &pended, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
-                                                           (uint32_t)z->pc_tmp_cap, &nseg);
+                                                           &pended, z->wrap == 2 ? &wcrc : NULL, z->wrap == 1 ? &wadler : NULL, seg_first,
+                                                           z->pc_tmp_cap ? stride : 0u, z->pc_tmp, (uint32_t)z->pc_tmp_cap, &nseg);
             z->t_par += mzh_now() - t0;
             z->n_par++;
             if (pr < 0) {
@@ -665,11 +708,12 @@ static int32_t stream_next(mzhip_zlib *z) {
                     stream_pieces_add(z, gnew, made, seg_first, stride, nseg);
                 if (made > 0)
                     z->par_in_q16 = ((((int64_t)nst.hdr_bit - bit0) >> 3) << 16) / made + 1;
+                stream_sum(z, made, wcrc, wadler);
                 z->out_len = pol;
                 z->sst = nst;
                 if (pended) {
                     z->stream_end = 1;
-                    return verdict(z, MZHIP_STATUS_OK, z->in_dropped + (((int64_t)nst.bit + 7) >> 3));
+                    return stream_finish(z, z->in_dropped + (((int64_t)nst.bit + 7) >> 3));
                 }
                 stream_drop_input(z);
                 z->par_miss = made >= MZH_PAR_MIN_ROOM ? 0 : z->par_miss + 1;
@@ -691,13 +735,16 @@ static int32_t stream_next(mzhip_zlib *z) {
         if (par_on && z->par_rest == 0 && z->par_miss < 3)
             z->sst.flags |= 2u; /* stop at the next block header: the many-wave decode goes on from there */
         const double ts0 = mzh_now();
-        int32_t st = mzhip_inflate_resume_host_seg(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
-                                                   &in_used, &crc, seg_first, z->pc_tmp_cap ? stride : 0u, z->pc_tmp,
-                                                   (uint32_t)z->pc_tmp_cap, &nseg);
+        uint32_t adler = 1;
+        int32_t st = mzhip_inflate_resume_host_seg2(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
+                                                    &in_used, &crc, z->wrap == 1 ? &adler : NULL, seg_first, z->pc_tmp_cap ? stride : 0u,
+                                                    z->pc_tmp, (uint32_t)z->pc_tmp_cap, &nseg);
         z->t_serial += mzh_now() - ts0;
         z->n_serial++;
-        if (out_len > (uint32_t)z->out_len)
+        if (out_len > (uint32_t)z->out_len) {
             z->serial_bytes += (int64_t)out_len - z->out_len;
+            stream_sum(z, (int64_t)out_len - z->out_len, crc, adler);
+        }
         if (nseg)
             stream_pieces_add(z, gnew, (int64_t)out_len - z->out_len, seg_first, stride, nseg);
         if (st == MZHIP_STATUS_BUF_ERROR && z->base_eof && (nst.flags & 1u)) {
@@ -711,20 +758,23 @@ static int32_t stream_next(mzhip_zlib *z) {
                 return 0; /* serve first; the next call slides the window and comes back here */
             z->sst.out_pos = (uint32_t)z->out_len;
             z->sst.flags = 1;
-            st = mzhip_inflate_resume_host(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, NULL, &out_len,
-                                           &in_used, &crc);
-            if (st == MZHIP_STATUS_OK || st == MZHIP_STATUS_BUF_ERROR || st == MZHIP_STATUS_DATA_ERROR)
+            st = mzhip_inflate_resume_host_seg2(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, NULL, &out_len,
+                                                &in_used, &crc, z->wrap == 1 ? &adler : NULL, 0, 0, NULL, 0, NULL);
+            if (st == MZHIP_STATUS_OK || st == MZHIP_STATUS_BUF_ERROR || st == MZHIP_STATUS_DATA_ERROR) {
+                stream_sum(z, (int64_t)out_len - z->out_len, crc, adler);
                 z->out_len = out_len;
-            else
+            } else
                 st = MZH_STREAM_ERROR; /* (a full window cannot be: there was room for a block) */
             z->stream_end = 1;
+            if (st == MZHIP_STATUS_OK)
+                return stream_finish(z, z->in_dropped + in_used);
             return verdict(z, st, st == MZHIP_STATUS_BUF_ERROR ? z->in_dropped + z->in_len /* inflate() has taken all there was */
                                                                : z->in_dropped + in_used);
         }
         if (st == MZHIP_STATUS_OK || st == MZHIP_STATUS_DATA_ERROR) {
             z->out_len = out_len;
             z->stream_end = 1;
-            return verdict(z, st, z->in_dropped + in_used);
+            return st == MZHIP_STATUS_OK ? stream_finish(z, z->in_dropped + in_used) : verdict(z, st, z->in_dropped + in_used);
         }
         if (st != MZHIP_STATUS_OUT_FULL && st != MZHIP_STATUS_BUF_ERROR) {
             z->stream_end = 1;
@@ -787,7 +837,7 @@ static int32_t attempt_decode(mzhip_zlib *z) {
                                          z->wrap == 1 ? &z->out_adler : NULL);
         int32_t early = 0;
         const int64_t early_out = MZH_STREAM_EARLY_OUT < mzh_stream_window() ? MZH_STREAM_EARLY_OUT : mzh_stream_window();
-        if (z->wrap == 0 && mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
+        if (mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
             ((st == MZHIP_STATUS_BUF_ERROR && !z->base_eof && (z->in_len >= MZH_STREAM_EARLY || (int64_t)out_len >= early_out)) ||
              (st == MZHIP_STATUS_OUT_FULL && z->out_cap >= early_out))) {
             /* a megabyte of compressed bytes and the entry is not over, or four of decoded ones and counting: it is large
@@ -803,7 +853,7 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             }
             early = z->out_cap >= mzh_stream_window();
         }
-        if (early || (st == MZHIP_STATUS_OUT_FULL && z->wrap == 0 && z->out_cap >= mzh_stream_window())) {
+        if (early || (st == MZHIP_STATUS_OUT_FULL && z->out_cap >= mzh_stream_window())) {
             /* more than a window of output: from here on the entry is decoded window by window.  The first window once
              * more, this time asking where it stops */
             z->streaming = 1;
@@ -814,6 +864,14 @@ static int32_t attempt_decode(mzhip_zlib *z) {
                 (void)in_grow(z, want);
             }
             z->in_dropped = 0;
+            if (z->hdr_len > 0) { /* the wrapper's header is done with: positions stay those of the whole stream */
+                memmove(z->in, z->in + z->hdr_len, (size_t)(z->in_len - z->hdr_len));
+                z->in_len -= z->hdr_len;
+                z->in_dropped = z->hdr_len;
+            }
+            z->run_crc = 0;
+            z->run_adler = 1;
+            z->run_n = 0;
             memset(&z->sst, 0, sizeof(z->sst));
             z->out_len = z->out_served = 0;
             const int32_t sr = stream_next(z);
@@ -826,12 +884,12 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
             int64_t ncap = z->out_cap * 4;
-            if (z->wrap == 0 && ncap > mzh_stream_window())
+            if (ncap > mzh_stream_window())
                 ncap = mzh_stream_window();
             if (ncap > 0x7FFFFFFF)
                 ncap = 0x7FFFFFFF;
             out_release(z);
-            z->out = (z->wrap == 0 && ncap >= mzh_stream_window()) ? out_window_alloc(z, ncap) : (uint8_t *)malloc((size_t)ncap);
+            z->out = (ncap >= mzh_stream_window()) ? out_window_alloc(z, ncap) : (uint8_t *)malloc((size_t)ncap);
             if (!z->out) {
                 z->out_cap = 0;
                 return MZH_MEM_ERROR;

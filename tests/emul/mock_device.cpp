@@ -43,15 +43,16 @@ MOCK_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, u
 // ... with the CRCs of the new bytes in the caller's pieces (the device does this with one k_crc32_batch launch)
 static int g_mock_seg_calls = 0;
 MOCK_API int mzmock_seg_calls(void) { return g_mock_seg_calls; }
-MOCK_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
-                                               const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
-                                               uint32_t *in_used, uint32_t *crc, uint32_t seg_first, uint32_t seg_stride,
-                                               uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
+MOCK_API int32_t mzhip_inflate_resume_host_seg2(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                                const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                                uint32_t *in_used, uint32_t *crc, uint32_t *adler, uint32_t seg_first, uint32_t seg_stride,
+                                                uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
     const uint32_t hist = state_in ? state_in->out_pos : 0u;
     uint32_t ol = 0;
     const int32_t st = mzhip_inflate_resume_host(in, in_len, buf, buf_cap, state_in, state_out, &ol, in_used, crc);
     if (out_len) *out_len = ol;
     if (nseg) *nseg = 0;
+    if (adler) *adler = ol > hist ? emul_adler32(buf + hist, ol - hist) : 1u;
     if (seg_stride && seg_crc && ol > hist) {
         uint32_t pos = hist, n = 0;
         const uint32_t first = seg_first < ol - hist ? seg_first : ol - hist;
@@ -71,6 +72,13 @@ MOCK_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_le
         }
     }
     return st;
+}
+MOCK_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                               const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                               uint32_t *in_used, uint32_t *crc, uint32_t seg_first, uint32_t seg_stride,
+                                               uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
+    return mzhip_inflate_resume_host_seg2(in, in_len, buf, buf_cap, state_in, state_out, out_len, in_used, crc, nullptr, seg_first, seg_stride,
+                                          seg_crc, seg_cap, nseg);
 }
 MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
                                     uint32_t *in_used, uint32_t *crc) {
@@ -133,9 +141,11 @@ MOCK_API int mzmock_par_blocks(void) { return g_mock_par_blocks; }
 MOCK_API int mzmock_par_calls(void) { return g_mock_par_calls; }
 MOCK_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                              const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
-                                             uint32_t *blocks, uint32_t *ended, uint32_t seg_first, uint32_t seg_stride,
-                                             uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
+                                             uint32_t *blocks, uint32_t *ended, uint32_t *crc, uint32_t *adler, uint32_t seg_first,
+                                             uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
     const uint32_t hist = state_in ? state_in->out_pos : 0u;
+    if (crc) *crc = 0u;
+    if (adler) *adler = 1u;
     const uint32_t start = state_in && (state_in->flags & 1u) ? state_in->hdr_bit : 0u;
     if (nseg) *nseg = 0;
     if (blocks) *blocks = 0;
@@ -162,6 +172,8 @@ MOCK_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len,
         state_out->flags = 1u;
     }
     const uint32_t ol = w.total;
+    if (crc && ol > hist) *crc = emul_crc32(buf + hist, ol - hist);
+    if (adler && ol > hist) *adler = emul_adler32(buf + hist, ol - hist);
     if (seg_stride && seg_crc && ol > hist) {
         uint32_t pos = hist, n = 0;
         const uint32_t first = seg_first < ol - hist ? seg_first : ol - hist;

@@ -67,6 +67,48 @@ def test_wrapped_read_parity(libs):
                 assert a["out"] == d and a["total_in"] == len(z)
 
 
+def test_wrappers_in_window_mode(libs):
+    """The zlib and gzip wrappers of a READ stream in window mode (round 4: they used to hold the whole entry): the header is
+    parsed once, the DEFLATE payload goes through the same windows as a raw stream -- serial ones with a 192 KiB window, a
+    wave per block with a 3 MiB one -- and the trailer is checked against the Adler-32 / CRC-32 + ISIZE combined from the
+    device's per-window values.  Same read() sequence, bytes, TOTAL_IN / TOTAL_OUT, close() and error() as the reference
+    for whole streams, streams with bytes behind them, every cut of the trailer, a wrong checksum and a wrong length."""
+    hip, ref = libs
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    c = synth.bench_corpus()[0]
+
+    def flip(z, i, m=1):
+        b = bytearray(z)
+        b[i] ^= m
+        return bytes(b)
+
+    try:
+        for window, gulp, d in ((192 << 10, 48 << 10, c[:450000] + bytes(300000) + c[1000:200000]),
+                                (3 << 20, 512 << 10, c * 9 + bytes(1500000) + c[::-1] * 5)):
+            L.mzhip_set_stream_window(window, gulp)
+            for wb_stream, wb_open in ((31, 31), (15, 15), (31, 47), (15, 47)):
+                z = _wrap(d, wb_stream)
+                for chunk, extra in ((65535, b""), (30000, b"\x00" * 100), (len(d) // 3, z[:5000])):
+                    a = hip.stream_decode(8, z + extra, len(d) + 64, chunk=chunk, window_bits=wb_open)
+                    b = ref.stream_decode(8, z + extra, len(d) + 64, chunk=chunk, window_bits=wb_open)
+                    assert {k: a[k] for k in KEYS} == {k: b[k] for k in KEYS}, (window, wb_stream, wb_open, chunk, {k: (a[k], b[k]) for k in KEYS if k != "out" and a[k] != b[k]})
+                    assert a["out"] == d and a["total_in"] == len(z)
+                if wb_open == 47:
+                    continue
+                tl = 8 if wb_stream == 31 else 4
+                bad = [("cut %d" % k, z[:len(z) - k]) for k in range(1, tl + 2)] + [("cut mid", z[:len(z) // 2])]
+                bad += [("trailer byte %d" % k, flip(z, -k)) for k in range(1, tl + 1)]
+                for name, data in bad:
+                    a = hip.stream_decode(8, data, len(d) + 70000, window_bits=wb_open)
+                    b = ref.stream_decode(8, data, len(d) + 70000, window_bits=wb_open)
+                    assert {k: a[k] for k in KEYS} == {k: b[k] for k in KEYS}, (window, wb_stream, name, {k: (a[k], b[k]) for k in KEYS if k != "out" and a[k] != b[k]})
+                    assert b["error"] != 0, name
+    finally:
+        L.mzhip_set_stream_window(0, 0)
+
+
 def test_gzip_optional_header_fields(libs):
     hip, ref = libs
     d = synth.corpus()[:70000]

@@ -76,6 +76,10 @@ def test_wrapped_read_parity(libs):
     W.test_wrapped_read_parity(libs)
 
 
+def test_wrappers_in_window_mode(libs):
+    W.test_wrappers_in_window_mode(libs)
+
+
 def test_gzip_optional_header_fields(libs):
     W.test_gzip_optional_header_fields(libs)
 
