@@ -122,6 +122,13 @@ MZHIP_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len
                                               uint32_t seg_first, uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap,
                                               uint32_t *nseg);
 
+/* ONE large raw-DEFLATE entry, device-resident, decoded by a wave per DEFLATE block window after window (the batch
+ * kernel gives an entry one wave: 0.1 - 0.2 GB/s; this: several GB/s): d_in / d_out are device pointers, the four results
+ * host pointers (any may be NULL), status as mzhip_inflate_batch's per-entry status.  Synchronous on `stream`.  What
+ * mzhip_prime_* routes entries of 4 MiB and more of compressed bytes through. */
+MZHIP_API int32_t mzhip_inflate_large(const void *d_in, uint32_t in_len, void *d_out, uint32_t out_cap, uint32_t *out_len,
+                                      uint32_t *in_used, uint32_t *crc, int32_t *status, void *stream);
+
 /* mzhip_inflate_resume_host_seg plus the Adler-32 of the new bytes (NULL: not wanted) */
 MZHIP_API int32_t mzhip_inflate_resume_host_seg2(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                                  const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,

@@ -103,6 +103,9 @@ def gather_results(results, world, group=None):
     return torch.cat([p[: int(c.item())] for p, c in zip(parts, counts)], dim=0)
 
 
+LARGE_ENTRY = 4 << 20   # compressed bytes from which a DEFLATE entry is decoded by a wave per block (as mzhip_prime_* does)
+
+
 class DeviceArchive:
     """A ZIP archive resident in HBM, decoded shard-wise by the batch kernels."""
 
@@ -153,8 +156,25 @@ class DeviceArchive:
             return torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(dev)
 
         with torch.cuda.device(dev):
+            # DEFLATE entries of LARGE_ENTRY compressed bytes and more: one wave per entry is 0.1 - 0.2 GB/s, so each of them
+            # is decoded by a wave per DEFLATE block (mzhip_inflate_large, csrc/inflate_parallel.inc), one call per entry
+            large = np.nonzero((t[:, COL_METHOD] == 8) & ((t[:, COL_FLAG] & 1) == 0) & (t[:, COL_CSIZE] >= LARGE_ENTRY))[0]
+            if len(large) and ((t[large, COL_CSIZE] >= 2**32) | (usize[large] >= 2**32)).any():
+                raise _mz.MzHipError("entries >= 4 GiB are outside the batch path")
+            L.mzhip_inflate_large.restype = C.c_int32
+            L.mzhip_inflate_large.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
+            for e in large:
+                ol, iu, ck, st1 = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int32()
+                rc = L.mzhip_inflate_large(self.d_file.data_ptr() + int(t[e, COL_PAYLOAD]), int(t[e, COL_CSIZE]),
+                                           d_out.data_ptr() + int(out_off[e]), int(usize[e]), C.byref(ol), C.byref(iu), C.byref(ck),
+                                           C.byref(st1), stream)
+                if rc != 0:
+                    raise _mz.MzHipError("mzhip_inflate_large failed: %d %s" % (rc, L.mzhip_last_error().decode()))
+                crc[e], out_len[e] = ck.value, ol.value
+                status[e] = MZ_CRC_ERROR if (st1.value == 0 and iu.value == t[e, COL_CSIZE] and ck.value != np.uint32(t[e, COL_CRC])) else st1.value
             for method in (8, 14, 95, 0):
-                sel = np.nonzero((t[:, COL_METHOD] == method) & ((t[:, COL_FLAG] & 1) == 0))[0]
+                sel = np.nonzero((t[:, COL_METHOD] == method) & ((t[:, COL_FLAG] & 1) == 0) &
+                                 ~((t[:, COL_METHOD] == 8) & (t[:, COL_CSIZE] >= LARGE_ENTRY)))[0]
                 if len(sel) == 0:
                     continue
                 k = len(sel)

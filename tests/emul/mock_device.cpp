@@ -87,6 +87,11 @@ MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t 
 
 // one window of one large entry, every block by a "wave" of its own (inflate_parallel.inc): the same orchestration as the
 // device's, its three steps as loops over the emulated device functions
+#ifndef MZ_LARGE_WINDOW
+#define MZ_LARGE_WINDOW (2u << 20)
+#define MZ_LARGE_SHOW_MAX (1u << 20)
+#define MZ_LARGE_MIN_ROOM (128u << 10)
+#endif
 #include "inflate_parallel.inc"
 namespace {
 struct MockParBackend {
@@ -136,6 +141,51 @@ MOCK_API void *mzhip_window_alloc(size_t bytes, size_t *cap) {
     return getenv("MZMOCK_NO_PINNED") ? nullptr : malloc(bytes);
 }
 MOCK_API void mzhip_window_free(void *p, size_t) { free(p); }
+// one large entry where it lies ("device-resident": the mock's device memory is host memory), inflate_parallel.inc's
+// mz_large_entry over the emulated device functions; MZMOCK_LARGE_WINDOW / _SHOW shrink the windows for the tests
+namespace {
+struct MockLargeBackend {
+    const uint8_t *in;
+    uint8_t *out;
+    int32_t window(uint32_t vbyte, uint32_t vlen, uint32_t obase, uint32_t buf_cap, uint32_t start_bit, uint32_t hist, MzParWindow *w) {
+        MockParBackend be;
+        be.in = in + vbyte;
+        be.in_len = vlen;
+        be.buf = out + obase;
+        be.ptr.assign((size_t)buf_cap + 64, 0u);
+        return mz_parallel_window(be, vlen, buf_cap, start_bit, hist, w);
+    }
+    int32_t serial(uint32_t vbyte, uint32_t vlen, uint32_t obase, uint32_t buf_cap, uint32_t hdr_bit, uint32_t bit, uint32_t hist, uint32_t flags,
+                   MzSerialResult *o) {
+        uint32_t a[4] = {hdr_bit, bit, hist, flags}, b[4] = {0, 0, 0, 0}, crc = 0;
+        o->status = emul_inflate_resume(in + vbyte, vlen, out + obase, buf_cap, a, b, &o->out_len, &o->in_used, &crc);
+        o->hdr_bit = b[0];
+        o->bit = b[1];
+        o->out_pos = b[2];
+        o->ok = b[3] & 1u;
+        return 0;
+    }
+};
+} // namespace
+static uint32_t g_mock_large[3];
+MOCK_API void mzmock_large_stats(uint32_t *v) { memcpy(v, g_mock_large, sizeof(g_mock_large)); }
+MOCK_API int32_t mzhip_inflate_large(const void *d_in, uint32_t in_len, void *d_out, uint32_t out_cap, uint32_t *out_len, uint32_t *in_used,
+                                     uint32_t *crc, int32_t *status, void *) {
+    MockLargeBackend be;
+    be.in = (const uint8_t *)d_in;
+    be.out = (uint8_t *)d_out;
+    MzLargeResult r;
+    const int32_t rc = mz_large_entry(be, in_len, out_cap, &r);
+    if (rc) return rc;
+    g_mock_large[0] = r.par_windows;
+    g_mock_large[1] = r.par_blocks;
+    g_mock_large[2] = r.serial_calls;
+    if (out_len) *out_len = r.out_len;
+    if (in_used) *in_used = r.in_used;
+    if (crc) *crc = emul_crc32(be.out, r.out_len);
+    if (status) *status = r.status;
+    return 0;
+}
 static int g_mock_par_blocks = 0, g_mock_par_calls = 0;
 MOCK_API int mzmock_par_blocks(void) { return g_mock_par_blocks; }
 MOCK_API int mzmock_par_calls(void) { return g_mock_par_calls; }

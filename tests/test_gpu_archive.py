@@ -205,3 +205,23 @@ def test_store_entry_with_disagreeing_sizes_is_refused():
         for i in (0, 1, 3, 4, 5):
             assert r["status"][i] == 0 and r["ok"][i]
             assert h[r["out_off"][i]:r["out_off"][i] + len(datas[i])].tobytes() == datas[i]
+
+
+def test_archive_with_large_entries(env):
+    """A few large DEFLATE entries between small ones: DeviceArchive.decode gives every entry of 4 MiB and more of compressed
+    bytes to mzhip_inflate_large (a wave per DEFLATE block) and the rest to the batch launch; CRCs against the central
+    directory, bytes against the reference reader."""
+    archive, ref = env
+    text = synth.bench_corpus()[0]
+    datas = [text[:70000], (text + text[::-1][:50000]) * 60, text[1000:300000], text * 100, text[:5], bytes(8 << 20)]
+    blob = np.frombuffer(b"".join(datas), dtype=np.uint8)
+    lens = np.array([len(d) for d in datas], dtype=np.int32)
+    offs = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "large.zip")
+        ref.zip_write(path, blob, offs, lens, method=8, level=6)
+        da, r = _check(archive, ref, path, lens.astype(np.int64))
+        assert (da.table[:, archive.COL_CSIZE] >= archive.LARGE_ENTRY).sum() == 2
+        h = r["out"].cpu().numpy()
+        for i in (1, 3):                                                   # the large ones byte for byte
+            assert h[r["out_off"][i]:r["out_off"][i] + lens[i]].tobytes() == datas[i]

@@ -389,3 +389,61 @@ def test_two_primed_archives_that_agree_in_what_a_stream_presents():
         L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
         assert hits.value == 10 and miss.value == 2   # the ambiguous entry of either archive took the ordinary path
         L.mzhip_prime_clear()
+
+
+def test_prime_routes_large_entries_through_many_waves():
+    """An archive with two large DEFLATE entries (12 and 30 MB of compressed text) between small ones: mzhip_prime_file takes
+    entries of 4 MiB and more of compressed bytes out of the batch launch and decodes each by a wave per block
+    (mzhip_inflate_large); the unmodified reader loop is then served the same bytes, sizes and CRC verdicts as the
+    all-reference reader, and as the same prime with MZHIP_PRIME_LARGE=0 in a child process (one wave per entry)."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    hip, ref = oracle.MzDriver(DROP), oracle.ref()
+    L = mz.lib()
+    L.mzhip_prime_file.restype = C.c_int64
+    L.mzhip_prime_file.argtypes = [C.c_char_p]
+    text = synth.bench_corpus()[0]
+    big1, big2 = (text + text[::-1][:50000]) * 70, text * 170
+    datas = [text[:70000], big1, text[1000:300000], bytes(100), big2, text[:5]]
+    blob = np.frombuffer(b"".join(datas), dtype=np.uint8)
+    lens = np.array([len(d) for d in datas], dtype=np.int32)
+    offs = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "large.zip")
+        ref.zip_write(path, blob, offs, lens, method=8, level=6)
+        table = ref.zip_index(path)
+        assert (table[:, 3] >= (4 << 20)).sum() == 2
+        cd = table[:, 6].copy()
+        o_ref = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        t_ref, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_ref, out_off=offs)
+        assert (st_r == 0).all() and o_ref[:-1].tobytes() == blob.tobytes()
+        L.mzhip_prime_clear()
+        L.mzhip_prime_file(path.encode())                                   # (first call: runtime start-up, page-locking)
+        L.mzhip_prime_clear()
+        t0 = time.time()
+        cached = L.mzhip_prime_file(path.encode())
+        t_prime = time.time() - t0
+        assert cached == len(datas)
+        t_hip, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_hip, out_off=offs)
+        assert (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all() and (o_hip == o_ref).all()
+        L.mzhip_prime_clear()
+        prog = ("import sys, time, json, ctypes as C, importlib\\nsys.path.insert(0, %r)\\nmz = importlib.import_module('minizip-ng_amd')\\n"
+                "L = mz.lib()\\nL.mzhip_prime_file.restype = C.c_int64\\nL.mzhip_prime_file.argtypes = [C.c_char_p]\\n"
+                "L.mzhip_prime_file(%r)\\nL.mzhip_prime_clear()\\nt0 = time.time()\\nn = L.mzhip_prime_file(%r)\\n"
+                "print(json.dumps(dict(n=int(n), sec=time.time() - t0)))\\n" % (ROOT, path.encode(), path.encode()))
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                           env=dict(os.environ, MZHIP_PRIME_LARGE="0"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        one = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert one["n"] == len(datas)
+        print("prime of %.0f MB (two large entries): %.3f s with a wave per block, %.3f s with a wave per entry; reference reader %.3f s"
+              % (lens.sum() / 1e6, t_prime, one["sec"], t_ref))
+        assert t_prime * 3 < one["sec"]

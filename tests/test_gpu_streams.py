@@ -240,3 +240,63 @@ def test_written_entry_larger_than_any_segment_bounded_memory(tmp_path):
     print("3 GiB entry written through the drop-in: %.1f s, %.2f GiB/s, archive %.1f MiB, peak RSS %.0f MiB (a 70 KB entry: %.0f MiB)"
           % (got["sec"], total / 2**30 / got["sec"], os.path.getsize(path) / 2**20, got["rss_kib"] / 1024, base["rss_kib"] / 1024))
     assert got["rss_kib"] - base["rss_kib"] < 512 * 1024
+
+
+def test_large_entry_device_resident(gpu):
+    """mzhip_inflate_large: one large entry where it lies in HBM, a wave per DEFLATE block window after window, against the
+    batch kernel's one wave for the same entry (mzhip_inflate_batch): the four result words agree for a whole stream, for
+    a buffer that is too small, a truncated and a corrupted stream; bytes against zlib; both are timed."""
+    import time
+
+    import torch
+
+    L = gpu.mz.lib()
+    L.mzhip_inflate_large.restype = C.c_int32
+    L.mzhip_inflate_large.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
+    L.mzhip_inflate_batch.restype = C.c_int32
+    L.mzhip_inflate_batch.argtypes = [C.c_void_p] * 6 + [C.c_uint32] + [C.c_void_p] * 5
+    text, _ = synth.bench_corpus()
+    dev = torch.device("cuda", 0)
+
+    def both(z, cap):
+        d_in = torch.from_numpy(np.frombuffer(z + bytes(64), dtype=np.uint8).copy()).to(dev)
+        outs = []
+        for which in ("large", "batch"):
+            d_out = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            if which == "large":
+                ol, iu, ck, st = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int32()
+                assert L.mzhip_inflate_large(d_in.data_ptr(), len(z), d_out.data_ptr(), cap, C.byref(ol), C.byref(iu), C.byref(ck), C.byref(st), None) == 0
+                torch.cuda.synchronize()
+                r = (st.value, ol.value, iu.value, ck.value)
+            else:
+                m64 = torch.tensor([0, 0], dtype=torch.int64, device=dev)
+                m32 = torch.tensor([len(z), cap, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+                p = m32.data_ptr()
+                assert L.mzhip_inflate_batch(d_in.data_ptr(), m64.data_ptr(), p, d_out.data_ptr(), m64.data_ptr() + 8, p + 4, 1, p + 8, p + 12, p + 16, p + 20, None) == 0
+                torch.cuda.synchronize()
+                v = m32.cpu().numpy()
+                r = (int(v[5]), int(np.uint32(v[2])), int(np.uint32(v[3])), int(np.uint32(v[4])))
+            outs.append((r, time.time() - t0, d_out[:r[1]].cpu().numpy().tobytes()))
+        return outs
+
+    d = (text + text[::-1][:100000]) * 60 + bytes(5000000) + text * 10               # ~43 MB
+    for lvl in (6, 1):
+        z = synth.deflate_raw(d, lvl)
+        both(z[:200000], 1 << 20)                                                      # (warm both paths up)
+        (ra, ta, oa), (rb, tb, ob) = both(z, len(d))
+        assert ra == rb == (0, len(d), len(z), zlib.crc32(d)) and oa == d, (lvl, ra, rb)
+        print("level %d: %d -> %d bytes; a wave per block %.1f ms (%.2f GB/s), one wave %.1f ms (%.2f GB/s)"
+              % (lvl, len(z), len(d), ta * 1e3, len(d) / ta / 1e9, tb * 1e3, len(d) / tb / 1e9))
+        assert ta * 5 < tb
+        (ra, _, oa), (rb, _, ob) = both(z, len(d) - 1000)
+        assert ra[0] == rb[0] == -200 and oa == d[:ra[1]], (ra, rb)
+        (ra, _, oa), (rb, _, ob) = both(z[:len(z) // 2], len(d))
+        assert ra[0] == rb[0] == -5 and oa == d[:ra[1]] and ob == d[:rb[1]], (ra, rb)
+        zz = bytearray(z)
+        zz[len(z) // 3] ^= 0x10
+        (ra, _, oa), (rb, _, ob) = both(bytes(zz), 2 * len(d))
+        assert ra[0] == rb[0], (ra, rb)
+        if ra[0] == 0:
+            assert ra == rb and oa == ob

@@ -272,3 +272,66 @@ def test_window_mode_many_waves():
     assert ref.stream_decode(8, z, len(d) + 10) == hip.stream_decode(8, z, len(d) + 10)
     assert L.mzmock_par_blocks() == b0
     L.mzhip_set_stream_parallel(1)
+
+
+def test_large_entry_where_it_lies():
+    """mz_large_entry (csrc/inflate_parallel.inc): one large device-resident entry window after window -- many-wave windows
+    where a window starts at a block header, the serial kernel with "stop at the next block header" where not -- on the
+    mock (2 MiB windows, the emulated device functions): bytes, consumed count, CRC and status against zlib for streams of
+    dynamic, fixed and stored blocks; a buffer that is too small, a truncated and a corrupted stream."""
+    import ctypes as C
+    import random
+    import zlib
+
+    import numpy as np
+
+    from tests import synth
+
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul")], check=True, capture_output=True)
+    L = C.CDLL(os.path.join(ROOT, "tests", "emul", "_build", "libmockdrop.so"))
+    L.mzhip_inflate_large.restype = C.c_int32
+    L.mzhip_inflate_large.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
+    text = synth.bench_corpus()[0]
+    rnd = random.Random(5)
+    noise = bytes(rnd.getrandbits(8) for _ in range(150000))
+
+    def blocks_of(parts):
+        out = b""
+        for i, (data, lvl, strat) in enumerate(parts):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+            out += co.compress(data) + (co.flush(zlib.Z_FULL_FLUSH) if i + 1 < len(parts) else co.flush())
+        return out
+
+    def run(z, cap):
+        zin = np.frombuffer(z + bytes(64), dtype=np.uint8).copy()
+        out = np.zeros(cap + 64, dtype=np.uint8)
+        ol, iu, crc, st = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int32()
+        assert L.mzhip_inflate_large(zin.ctypes.data, len(z), out.ctypes.data, cap, C.byref(ol), C.byref(iu), C.byref(crc), C.byref(st), None) == 0
+        s = (C.c_uint32 * 3)()
+        L.mzmock_large_stats(s)
+        return st.value, ol.value, iu.value, crc.value, out[:ol.value].tobytes(), list(s)
+
+    big = text * 7 + bytes(2000000) + text[::-1] * 2
+    cases = [("dynamic", blocks_of([(big, 6, 0)])), ("level 1", blocks_of([(big, 1, 0)])),
+             ("mixed", blocks_of([(text * 3, 6, 0), (text, 6, zlib.Z_FIXED), (noise, 0, 0), (text * 4, 9, 0), (noise[:70000], 6, 0),
+                                  (text * 2, 6, zlib.Z_FIXED), (text * 3, 6, 0)])),
+             ("fixed", blocks_of([(text * 2, 6, zlib.Z_FIXED)] * 3)), ("stored", blocks_of([(noise * 8, 0, 0)]))]
+    for name, z in cases:
+        d = zlib.decompress(z, -15)
+        st, ol, iu, crc, got, s = run(z, len(d))
+        assert (st, ol, iu, crc) == (0, len(d), len(z), zlib.crc32(d)) and got == d, name
+        print("%s: %d -> %d bytes; many-wave windows %d (%d blocks), serial calls %d" % (name, len(z), len(d), s[0], s[1], s[2]))
+        if name != "fixed":
+            assert s[1] >= 10, (name, s)
+        st, ol, _, _, got, _ = run(z, len(d) - 1000)                      # the entry is larger than it says
+        assert st == -200 and got == d[:ol] and ol <= len(d) - 1000, name
+        st, ol, iu, _, got, _ = run(z[:len(z) // 2], len(d))               # the stream ends short
+        assert st == -5 and got == d[:ol], name
+        zz = bytearray(z)
+        zz[len(z) // 3] ^= 0x10
+        st, ol, _, crc, got, _ = run(bytes(zz), 2 * len(d) + 100000)
+        try:
+            want = zlib.decompressobj(-15).decompress(bytes(zz))
+            assert st == 0 and got == want and crc == zlib.crc32(want), name
+        except zlib.error:
+            assert st == -3, (name, st)
