@@ -42,7 +42,10 @@ Besides the contract fields the JSON line carries
                  roofline {achieved, frac, traffic, traffic_source} and cpu_baseline;
   legs         : (config 2, N = 1) SURVEY 8(d) i-iii: kernel only / H2D of the compressed bytes + kernel + D2H of
                  {crc, len, status} from pinned host memory / the reference's unmodified mz_zip_reader loop on the
-                 drop-in library (prime + vtbl shims) into host buffers, GiB/s of decompressed bytes each.
+                 drop-in library (prime + vtbl shims) into host buffers, GiB/s of decompressed bytes each; and ONE large entry
+                 (512 MiB of the corpus at level 1) through the same reader loop, per entry (`one_large_entry_vtbl`: window
+                 mode, a wave per DEFLATE block) and primed (`one_large_entry_primed`), with the reference's one thread on the
+                 same archive as `cpu_baseline.one_large_entry`.
 """
 import argparse
 import ctypes as C
@@ -468,6 +471,58 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
     return out
 
 
+def large_entry_leg(c, mib, with_reference):
+    """ONE large DEFLATE entry (mib MiB of the corpus, zlib level 1, ZIP64) through the unmodified mz_zip_reader on the drop-in:
+    per entry (the READ stream's window mode: a wave per DEFLATE block) and under the prime (the same
+    kernels where the entry lies in HBM).  -> (legs dict, cpu_baseline dict or None): decompressed GiB/s, one reader thread."""
+    import zipfile
+
+    drop = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+    if not os.path.exists(drop):
+        return {}, None
+    D = C.CDLL(drop)
+    if not hasattr(D, "mzdrop_extract_all"):
+        return {}, None
+    D.mzdrop_extract_all.restype = C.c_double
+    D.mzdrop_extract_all.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_int32)]
+    tmp = tempfile.mkdtemp(prefix="mzhip_large_")
+    path = os.path.join(tmp, "large.zip")
+    total, piece = mib << 20, bytes(c) * 2
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as zf:
+        with zf.open("large.bin", "w", force_zip64=True) as f:
+            left = total
+            while left > 0:
+                k = min(left, len(piece))
+                f.write(piece[:k])
+                left -= k
+    legs, cb = {}, None
+    what = "one %d MiB entry (the corpus repeated, zlib level 1, ratio %.2f)" % (mib, os.path.getsize(path) / total)
+    for key, prime, how in (("one_large_entry_vtbl", 0, "per entry: mz_stream_zlib READ in window mode, every window by a wave per DEFLATE block"),
+                            ("one_large_entry_primed", 2, "under mzhip_prime_mem_begin: the entry decoded where it lies in HBM (mzhip_inflate_large), every byte copied back")):
+        best = None
+        for _ in range(3):
+            ne, nb, tp, fe = C.c_int64(0), C.c_int64(0), C.c_double(0), C.c_int32(0)
+            sec = D.mzdrop_extract_all(path.encode(), 1, prime, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
+            if sec > 0 and fe.value == 0 and nb.value == total and (best is None or sec < best):
+                best = sec
+        legs[key] = round(total / 2**30 / best, 3) if best else None
+        legs[key + "_sample"] = "%s through the unmodified mz_zip_reader on libmzhipdrop.so, one reader thread, CRC verified, %s; best of 3" % (what, how)
+    if with_reference:
+        import oracle
+
+        if oracle.have_ref():
+            ref = oracle.ref()
+            table = ref.zip_index(path)
+            sec, _, ulen, st = ref.zip_read_all(path, table[:, 6].copy(), nthreads=1, own_crc=False)
+            if (st == 0).all() and int(ulen[0]) == total:
+                cb = dict(value=round(total / 2**30 / sec, 3), unit="GiB/s", cores=1, kind="reference",
+                          sample=what + ": mz_zip_entry_read (zlib 1.2.11 inflate + crc32 + CRC verify) on one thread -- one entry is one inflate() state")
+    os.remove(path)
+    os.rmdir(tmp)
+    return legs, cb
+
+
 def other_configs(args):
     """`python bench.py --config 3|4|5` (one GPU) as child processes of the default run, condensed: the driver sees the four
     configurations of BASELINE.json that run on a GPU in ONE line.  A step of config 4 takes a second, so the children run
@@ -841,6 +896,11 @@ def main():
                 legs_zip = os.path.join(tempfile.mkdtemp(prefix="mzhip_legs_"), "legs.zip")
                 write_stream_zip(legs_zip, [pays[i] for i in pick[:k_leg]], want_crc_np[:k_leg], size)
             line["legs"] = legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, value, legs_zip)
+            if not (args.entries or args.entry_size or args.unique):
+                ll, lcb = large_entry_leg(c, 512, not args.no_cpu_baseline)
+                line["legs"].update(ll)
+                if lcb and "cpu_baseline" in line:
+                    line["cpu_baseline"]["one_large_entry"] = lcb
             if legs_zip != sample_zip and legs_zip:
                 os.remove(legs_zip)
                 os.rmdir(os.path.dirname(legs_zip))
