@@ -272,7 +272,11 @@ MZHIP_API uint32_t mzhip_lzma_model_bytes(void);
  * the coder in state_out (sixteen words: flags -- in: bit 0 go on from state_in, else a fresh stream whose header comes
  * first --, the range coder with its held-back byte, the packet state, the four repeat distances) and the adaptive model in
  * `model` (mzhip_lzma_model_bytes(), the caller's); last != 0 writes the end marker and flushes the coder.  The bytes of
- * the segments, in order, are the payload.  No CRC is computed. */
+ * the segments, in order, are the payload.  No CRC is computed.  A caller that keeps
+ * min(everything coded so far, mzhip_lzma_encode_history_bytes()) bytes in front of every segment gets the bytes the
+ * one-shot coder makes of the whole stream: the encoder's matches reach back that far (8 MiB, liblzma's preset 6:
+ * mz_strm_lzma.c:81) and no further. */
+MZHIP_API uint32_t mzhip_lzma_encode_history_bytes(void);
 /* A ZIP method-95 payload (.xz) written block by block in bounded memory: every call codes one block of independent
  * LZMA2 chunks -- behind the stream header when first != 0 -- and reports the block's unpadded size; when the entry is
  * complete mzhip_xz_encode_finish_host writes the index over all blocks and the stream footer.  liblzma's

@@ -122,7 +122,7 @@ typedef struct mz_lzma_result {
 
 #define LZ_NORM()                                                                       \
     do {                                                                                \
-        if (range < (1u << 24)) {                                                       \
+        if (LZ_UBR(range < (1u << 24))) {                                               \
             uint32_t _nb;                                                               \
             LZ_NEXT_BYTE(_nb);                                                          \
             range <<= 8;                                                                \
@@ -135,9 +135,9 @@ typedef struct mz_lzma_result {
     do {                                                                                \
         LZ_NORM();                                                                      \
         uint32_t _pi = (idx);                                                           \
-        uint32_t _p = LZ_U(pr[_pi]);                                                    \
+        uint32_t _p = LZ_PU(LZ_U(pr[_pi]));                                             \
         uint32_t _bound = (range >> 11) * _p;                                           \
-        if (code < _bound) {                                                            \
+        if (LZ_UBR(code < _bound)) {                                                            \
             range = _bound;                                                             \
             _p += (2048u - _p) >> 5;                                                    \
             (bit) = 0;                                                                  \
@@ -159,7 +159,7 @@ typedef struct mz_lzma_result {
         uint32_t _pi = (idx) - LZ_NUM_PROBS;                                            \
         uint32_t _p = LZ_U(prx[_pi]);                                                   \
         uint32_t _bound = (range >> 11) * _p;                                           \
-        if (code < _bound) {                                                            \
+        if (LZ_UBR(code < _bound)) {                                                            \
             range = _bound;                                                             \
             _p += (2048u - _p) >> 5;                                                    \
             (bit) = 0;                                                                  \
@@ -463,23 +463,45 @@ typedef struct mz_lzma_result {
  *                    vector ports of the four SIMDs, only the uniform branches remain scalar.
  * Measured for one full round of 2304 resident 1 MiB entries: scalar 480 ms, vector see DESIGN.md K3.  The kernel
  * runs MZ_LZMA_VPORT_OF_8 of every 8 workgroups on the vector build.  The host emulation builds the first only. */
+/* A decision on a lane-invariant value that sits in a VGPR (the vector-port builds): asked through a ballot, the
+ * compiler knows the branch is uniform -- one side is executed (s_cbranch) instead of both under exec masks, and what
+ * hangs on the decided bit (the symbol, the next probability's index, the state) moves to the scalar unit by itself. */
+#ifndef MZ_LZMA_UBR
+#define MZ_LZMA_UBR 1
+#endif
+#if MZ_LZMA_UBR && !defined(MZHIP_HOST_EMUL)
+#define MZ_VEC_UBR(c) (__ballot(c) != 0ull)
+#else
+#define MZ_VEC_UBR(c) (c)
+#endif
+/* MZ_LZMA_UBR == 2 (measurement): the probability itself goes to the scalar unit as well (its update is three scalar
+ * instructions instead of three to five vector ones); range and code stay in VGPRs */
+#if MZ_LZMA_UBR == 2 && !defined(MZHIP_HOST_EMUL)
+#define LZ_PU(x) MZ_UNIFORM(x)
+#else
+#define LZ_PU(x) (x)
+#endif
 #define LZ_LITERAL_SITE(sym) LZ_LITERAL_SITE_FULL(sym)
 #define LZ_LDS_T mz_lzma_lds
 #define LZ_ENTRY_PROBS LZ_NUM_PROBS
 #define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_UBR(c) (c)
 #define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
 #define LZ_ENTRY_NAME mz_lzma_entry
 #include "lzma_entry.inc"
 #undef LZ_U
+#undef LZ_UBR
 #undef LZ_WIN_DW
 #undef LZ_ENTRY_NAME
 
 #if !defined(MZHIP_HOST_EMUL)
 #define LZ_U(x) (x)
+#define LZ_UBR(c) MZ_VEC_UBR(c)
 #define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
 #define LZ_ENTRY_NAME mz_lzma_entry_v
 #include "lzma_entry.inc"
 #undef LZ_U
+#undef LZ_UBR
 #undef LZ_WIN_DW
 #undef LZ_ENTRY_NAME
 #endif
@@ -494,14 +516,17 @@ typedef struct mz_lzma_result {
 #define LZ_SLOTS_BUILD 1
 #if defined(MZHIP_HOST_EMUL)
 #define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_UBR(c) (c)
 #define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
 #else
 #define LZ_U(x) (x)
+#define LZ_UBR(c) MZ_VEC_UBR(c)
 #define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
 #endif
 #define LZ_ENTRY_NAME mz_lzma_entry_s
 #include "lzma_entry.inc"
 #undef LZ_U
+#undef LZ_UBR
 #undef LZ_WIN_DW
 #undef LZ_ENTRY_NAME
 #undef LZ_SLOTS_BUILD
@@ -514,9 +539,11 @@ typedef struct mz_lzma_result {
  * packet when the output buffer or -- unless it is the stream's last -- the input runs low */
 #if defined(MZHIP_HOST_EMUL)
 #define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_UBR(c) (c)
 #define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
 #else
 #define LZ_U(x) (x)
+#define LZ_UBR(c) MZ_VEC_UBR(c)
 #define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
 #endif
 #define LZ_LDS_T mz_lzma_lds
@@ -539,6 +566,7 @@ typedef struct mz_lzma_result {
 #define LZ_RESUME_CHECK() ((void)0)
 #undef LZ_RESUME_BUILD
 #undef LZ_U
+#undef LZ_UBR
 #undef LZ_WIN_DW
 #undef LZ_LDS_T
 #undef LZ_ENTRY_PROBS
@@ -546,9 +574,11 @@ typedef struct mz_lzma_result {
 /* for code that expands the coder macros outside the two entry builds (xz_core.h): vector-port forms on the device */
 #if defined(MZHIP_HOST_EMUL)
 #define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_UBR(c) (c)
 #define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
 #else
 #define LZ_U(x) (x)
+#define LZ_UBR(c) MZ_VEC_UBR(c)
 #define LZ_WIN_DW(idx) ((uint32_t)__builtin_amdgcn_ds_bpermute((int)((idx) << 2), (int)win))
 #endif
 

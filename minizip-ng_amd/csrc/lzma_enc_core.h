@@ -27,20 +27,100 @@
 #define MZ_LZE_LC 3u
 #define MZ_LZE_PB 2u
 #define MZ_LZE_PROPS 0x5Du /* (pb * 5 + lp) * 9 + lc */
-#define MZ_LZE_DICT 0x10000u
+#define MZ_LZE_DICT 0x10000u /* a stream of one block: every distance is below 64 KiB */
+/* Streams of more than one block look back over MZ_LZE_FAR_DICT bytes (liblzma's preset 6, mz_strm_lzma.c:81, has 8 MiB):
+ * the chain pass below leaves every position its nearest earlier occurrence, the block parse tries it beside the
+ * candidates of its own hash table.  A token's distance field has 23 bits. */
+#ifndef MZ_LZE_FAR_DICT
+#define MZ_LZE_FAR_DICT 0x800000u
+#endif
+#define MZ_LZE_FAR_MAXDIST (MZ_LZE_FAR_DICT - 1u)
+#ifndef MZ_LZE_FAR_HBITS
+#define MZ_LZE_FAR_HBITS 18u /* the chain pass's table: 1 MiB per resident wave.  One size for every stream: the links of a
+                                stream written in segments are then the links of the same bytes coded in one piece */
+#endif
+#define MZ_LZE_MAXMATCH 273u /* the longest match LZMA codes (2 + 16 + 255) */
+#define MZ_LZE_CHAIN_WAVES 1024u /* resident waves of the chain pass (1 MiB of table each) */
+#ifndef MZ_LZE_FAR_MINLEN
+#define MZ_LZE_FAR_MINLEN 5u /* a far match shorter than this costs more than the literals it replaces */
+#endif
 
+#ifndef MZ_LZE_FAR_GAIN
+#define MZ_LZE_FAR_GAIN 0u /* bytes a far match must be longer than a near one that is already there */
+#endif
+#ifndef MZ_LZE_FAR_NGRAM
+#define MZ_LZE_FAR_NGRAM 7u /* bytes the chain pass hashes: the nearest earlier occurrence of that many bytes */
+#endif
+#ifndef MZ_LZE_FAR_DEPTH
+#define MZ_LZE_FAR_DEPTH 4u /* links of the chain the block parse follows from a position (presets 4-9; 1 for the fast class) */
+#endif
 typedef struct mz_lz_tok_lds {
     uint16_t head[1 << MZ_DEF_HBITS];
 } mz_lz_tok_lds;
 
+#if defined(MZHIP_HOST_EMUL)
+#define MZ_GLB_ATOMIC_MAX(ptr, v) (*(ptr) = (*(ptr) > (v)) ? *(ptr) : (v))
+#define MZ_GLB_LOAD_DEV(ptr) (*(ptr))
+#define MZ_VM_DRAIN() ((void)0)
+#else
+#define MZ_GLB_ATOMIC_MAX(ptr, v) atomicMax((ptr), (v))
+/* read where the device-scope atomics of earlier steps landed (L2), not a line the vector L1 may still hold */
+#define MZ_GLB_LOAD_DEV(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+/* every vector-memory operation of this wave has completed (loads returned) before the next one is issued */
+#define MZ_VM_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
+/* The chain pass: ONE wave walks a whole stream, 64 positions per step, and leaves in links[p] the position + 1 of the
+ * nearest position of an earlier step whose MZ_LZE_FAR_NGRAM bytes hash like those at p (0 = none) -- a hash chain over the
+ * whole stream, which is what lets the block parse (one wave per 64 KiB block, in any order) reach back further than
+ * the history it can hash itself: it follows links[p], links[links[p] - 1], ... MZ_LZE_FAR_DEPTH deep.  head[]:
+ * 1 << MZ_LZE_FAR_HBITS words of global scratch.  Occurrences inside the same step of 64 positions are the block
+ * parse's own business (its table sees them).  Deterministic: the table takes positions by atomic maximum, and is read
+ * where the atomics land. */
+MZ_DEV void mz_lz_chain(const uint8_t *in, uint32_t in_len, uint32_t *links, uint32_t *head) {
+    MZ_LANE_DECL
+    const uint32_t hb = MZ_LZE_FAR_HBITS;
+    MZ_LANES {
+        for (uint32_t i = (uint32_t)lane; i < (1u << hb); i += 64u) head[i] = 0u;
+    }
+    MZ_WAVE_SYNC();
+    MZ_VM_DRAIN();
+    for (uint32_t p = 0; p < in_len; p += 64u) {
+        PV(uint32_t, hh);
+        PV(uint32_t, old);
+        MZ_LANES {
+            const uint32_t pos = p + (uint32_t)lane;
+            /* (the last seven positions of a 64 KiB block stay out: a stream written in segments of whole blocks then has
+             * the links of the same stream coded in one piece) */
+            const uint32_t bend = (pos | (MZ_DEF_BLOCK - 1u)) + 1u;
+            const uint32_t ok = (pos + 8u <= in_len && pos + 8u <= bend) ? 1u : 0u;
+            uint32_t h = 0;
+            if (ok) {
+                const uint64_t v = (uint64_t)mz_load_u32(in + pos) | ((uint64_t)mz_load_u32(in + pos + 4u) << 32);
+                h = (uint32_t)(((v << (64u - 8u * MZ_LZE_FAR_NGRAM)) * 0x9E3779B185EBCA87ull) >> (64u - hb));
+            }
+            P(hh) = ok ? h : 0xFFFFFFFFu;
+            P(old) = ok ? MZ_GLB_LOAD_DEV(head + h) : 0u;
+        }
+        MZ_WAVE_SYNC();
+        MZ_VM_DRAIN(); /* the table as the steps before left it: this step's positions go in behind the reads */
+        MZ_LANES {
+            const uint32_t pos = p + (uint32_t)lane;
+            if (pos < in_len) links[pos] = P(old);
+            if (P(hh) != 0xFFFFFFFFu) MZ_GLB_ATOMIC_MAX(head + P(hh), pos + 1u);
+        }
+        MZ_WAVE_SYNC();
+    }
+}
+
 /* LZ77 parse of in[blk, blk_end) (blk_end - blk <= MZ_DEF_BLOCK) of the stream in[0..); matches may start up to 32 KiB
- * before blk.  Returns the
- * number of tokens written to tok[]: [8:0] match length (0 = literal), [24:9] distance | literal byte.
+ * before blk -- and, with links (the chain pass's array for the whole stream, or null), wherever those point.  Returns the
+ * number of tokens written to tok[]: [8:0] match length (0 = literal), [31:9] distance | literal byte.
  * ways / xhead: as in K4 (deflate_core.h) -- the `ways` most recent positions of every hash bucket are tried and the
  * longest match wins; 1 = the fast class (presets 0-3), MZ_DEF_WAYS_BEST = presets 4-9 and the default
  * (mz_strm_lzma.c:81 hands the level to lzma_lzma_preset).  xhead: (ways - 1) more tables behind the wave's LDS. */
 MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end, uint32_t *tok, mz_lz_tok_lds *L,
-                               uint32_t ways, uint16_t *xhead) {
+                               uint32_t ways, uint16_t *xhead, const uint32_t *links) {
     MZ_LANE_DECL
     MZ_LANES {
         for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->head)[i] = 0u;
@@ -84,9 +164,11 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
         PV(uint32_t, hh);
         PV(uint32_t, cand);
         PV2(uint32_t, candx, MZ_DEF_WAYS_BEST - 1u);
+        PV(uint32_t, fcand); /* the chain pass's link for this position (position + 1, 0 = none) */
         MZ_LANES {
             const uint32_t pos = p + (uint32_t)lane;
             const uint32_t have4 = (pos + 4u <= blk_end) ? 1u : 0u;
+            P(fcand) = (links && have4) ? links[pos] : 0u;
             const uint32_t v = P(vnx);
             P(vnx) = (pos + 68u <= blk_end) ? mz_load_u32(in + pos + 64u) : 0u;
             const uint32_t h = (v * 2654435761u) >> (32 - MZ_DEF_HBITS);
@@ -111,7 +193,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
             const uint32_t pos = p + (uint32_t)lane;
             uint32_t mlen = 0, dist = 0;
             if ((uint32_t)lane < nv && P(hh) != 0xFFFFFFFFu) {
-                const uint32_t maxl = (blk_end - pos < MZ_DEF_MAXMATCH) ? (blk_end - pos) : MZ_DEF_MAXMATCH;
+                const uint32_t maxl = (blk_end - pos < MZ_LZE_MAXMATCH) ? (blk_end - pos) : MZ_LZE_MAXMATCH;
                 for (uint32_t w = 0; w < MZ_DEF_WAYS_BEST; w++) { /* most recent first: a tie keeps the shorter distance */
                     if (w >= ways) break;
                     const uint32_t d = (pos - (w ? P(candx)[w - 1u] : P(cand))) & 0xFFFFu;
@@ -121,6 +203,21 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
                             mlen = l;
                             dist = d;
                         }
+                    }
+                }
+                {
+                    uint32_t fc = P(fcand);
+                    for (uint32_t dep = 0; fc && dep < (ways > 1u ? MZ_LZE_FAR_DEPTH : 1u); dep++) {
+                        const uint32_t d = pos + 1u - fc;
+                        if (d > MZ_LZE_FAR_MAXDIST) break;
+                        if (d != dist) {
+                            const uint32_t l = mz_match_len(in + pos, in + (pos - d), maxl);
+                            if (l >= MZ_DEF_MINMATCH && l > mlen + ((mlen && d > 32768u) ? MZ_LZE_FAR_GAIN : 0u) && (d <= 32768u || l >= MZ_LZE_FAR_MINLEN)) {
+                                mlen = l;
+                                dist = d;
+                            }
+                        }
+                        fc = (dep + 1u < (ways > 1u ? MZ_LZE_FAR_DEPTH : 1u)) ? links[fc - 1u] : 0u;
                     }
                 }
             }
@@ -402,11 +499,14 @@ MZ_DEV void mz_lzma_rc_encode_x(const uint8_t *in, uint32_t in_len, const uint32
         LZE_OUT_BYTE(20u);
         LZE_OUT_BYTE(5u);
         LZE_OUT_BYTE(0u);
+        /* the dictionary the distances may need: a stream of more than one block (and every stream written in segments)
+         * was parsed with the chain pass's links */
+        const uint32_t dictv = (in_len > MZ_DEF_BLOCK || rs) ? MZ_LZE_FAR_DICT : MZ_LZE_DICT;
         LZE_OUT_BYTE(MZ_LZE_PROPS);
-        LZE_OUT_BYTE(MZ_LZE_DICT & 0xFFu);
-        LZE_OUT_BYTE((MZ_LZE_DICT >> 8) & 0xFFu);
-        LZE_OUT_BYTE((MZ_LZE_DICT >> 16) & 0xFFu);
-        LZE_OUT_BYTE((MZ_LZE_DICT >> 24) & 0xFFu);
+        LZE_OUT_BYTE(dictv & 0xFFu);
+        LZE_OUT_BYTE((dictv >> 8) & 0xFFu);
+        LZE_OUT_BYTE((dictv >> 16) & 0xFFu);
+        LZE_OUT_BYTE((dictv >> 24) & 0xFFu);
     }
     {
         const uint32_t nblocks = (in_len + MZ_DEF_BLOCK - 1u) / MZ_DEF_BLOCK;

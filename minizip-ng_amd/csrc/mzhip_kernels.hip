@@ -435,7 +435,25 @@ struct LzmaEncArgs {
     int32_t *status;
     uint32_t *counter;
     const mzhip_crc_tables *tabs;
+    uint32_t *links;       // chain pass: 4 bytes per input position, laid out like tok; null = no stream of more than one block
+    uint32_t *chain_head;  // chain pass: 1 << MZ_LZE_FAR_HBITS words per resident wave of k_lz_chain_batch
+    uint32_t skip_blocks;  // blocks in front of every entry that are history only (a stream written in segments): not parsed
 };
+
+// LZMA encode, pass 0: the chain pass, one wave per method-14 stream of more than one block (lzma_enc_core.h mz_lz_chain)
+__global__ __launch_bounds__(64) void k_lz_chain_batch(LzmaEncArgs a) {
+    MZ_LANE_DECL
+    for (;;) {
+        uint32_t e;
+        MZ_WAVE_FETCH_ADD(e, a.counter + 2);
+        if (e >= a.n) break;
+        const uint32_t len = MZ_UNIFORM(a.in_len[e]);
+        if (len <= MZ_DEF_BLOCK || (a.mode && MZ_UNIFORM((uint32_t)a.mode[e]) != 0u)) continue;
+        const uint64_t io = a.in_off[e];
+        const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
+        mz_lz_chain(in, len, a.links + (size_t)e * a.maxb * MZ_DEF_BLOCK, a.chain_head + ((size_t)blockIdx.x << MZ_LZE_FAR_HBITS));
+    }
+}
 
 // LZMA encode, pass 1: the LZ77 parse, one wave per 64 KiB block of any entry (work item = entry * maxb + block).
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(LzmaEncArgs a) {
@@ -453,11 +471,12 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(Lzma
         const uint32_t len = MZ_UNIFORM(a.in_len[e]);
         const uint32_t lo = b * MZ_DEF_BLOCK;
         uint32_t nt = 0;
-        if (lo < len) {
+        if (lo < len && b >= a.skip_blocks) {
             const uint64_t io = a.in_off[e];
             const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
+            const uint32_t far = (a.links && len > MZ_DEF_BLOCK && !(a.mode && MZ_UNIFORM((uint32_t)a.mode[e]) != 0u)) ? 1u : 0u;
             nt = mz_lz_tokenize(in, lo, (len - lo < MZ_DEF_BLOCK) ? len : lo + MZ_DEF_BLOCK, a.tok + (size_t)w * MZ_DEF_BLOCK, L,
-                                MZ_UNIFORM(a.ways), xhead);
+                                MZ_UNIFORM(a.ways), xhead, far ? a.links + (size_t)e * a.maxb * MZ_DEF_BLOCK : (const uint32_t *)nullptr);
         }
         a.ntok[w] = nt; // uniform store
     }

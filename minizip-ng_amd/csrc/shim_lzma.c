@@ -78,7 +78,7 @@ typedef struct mzhip_lzma_s {
     /* write side, method 14, entries larger than one segment: coded segment by segment (mzhip_lzma_encode_resume_host), wbuf[]
      * then holds [the previous segment's last 64 KiB | bytes not coded yet] */
     int32_t w_segments;    /* segments coded so far */
-    int64_t w_hist;        /* bytes at the front of wbuf[] that are history (0 or 65536) */
+    int64_t w_hist;        /* bytes at the front of wbuf[] that are history (whole blocks, at most mzhip_lzma_encode_history_bytes()) */
     mzhip_lzma_enc_state west;
     /* ... and method 95: one .xz block per segment; the index at close() wants every block's sizes */
     uint64_t *xz_unpadded, *xz_usize;
@@ -524,7 +524,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
     return n;
 }
 
-#define LZ_WRITE_BLOCK 65536 /* the tokenizer's block: segments are multiples of it, one block of history goes along */
+#define LZ_WRITE_BLOCK 65536 /* the tokenizer's block: segments are multiples of it */
 
 static int32_t base_write(mzhip_stream *base, const void *buf, int32_t size);
 
@@ -540,8 +540,9 @@ static int64_t lz_write_segment(void) {
 
 /* Method 14 in bounded memory (mz_strm_lzma.c:244-332 stages any entry through 32 767 bytes): a segment of whole blocks is
  * coded with the range coder's state and the adaptive model carried over (the same tokens and the same bytes as the
- * one-shot coder would make: the LZ77 parse sees the same 32 KiB of history either way), its output goes to base, its last
- * 64 KiB stay in front of wbuf[] as match sources and contexts for the next one. */
+ * one-shot coder would make: the LZ77 parse sees the same history either way -- the encoder's matches reach back
+ * mzhip_lzma_encode_history_bytes() = 8 MiB), its output goes to base, and the last 8 MiB coded so far stay in front of
+ * wbuf[] as match sources and contexts for the next one. */
 static int32_t lz_write_segment_out(mzhip_lzma *z, int32_t last) {
     const int64_t fresh = z->wlen - z->w_hist;
     int64_t take = fresh;
@@ -586,11 +587,16 @@ static int32_t lz_write_segment_out(mzhip_lzma *z, int32_t last) {
     z->w_segments++;
     if (!last) {
         z->west = sout;
-        /* the coded bytes go, but for their last block; what was not coded moves up behind it */
-        memmove(z->wbuf, z->wbuf + in_len - LZ_WRITE_BLOCK, (size_t)LZ_WRITE_BLOCK);
-        memmove(z->wbuf + LZ_WRITE_BLOCK, z->wbuf + in_len, (size_t)(z->wlen - in_len));
-        z->wlen = LZ_WRITE_BLOCK + (z->wlen - in_len);
-        z->w_hist = LZ_WRITE_BLOCK;
+        /* the coded bytes go, but for the history the encoder looks back over (whole blocks); what was not coded moves up
+         * behind it */
+        int64_t keep = (int64_t)(mzhip_lzma_encode_history_bytes() & ~(uint32_t)(LZ_WRITE_BLOCK - 1));
+        if (keep < LZ_WRITE_BLOCK)
+            keep = LZ_WRITE_BLOCK;
+        if (keep > in_len)
+            keep = in_len;
+        memmove(z->wbuf, z->wbuf + in_len - keep, (size_t)(keep + (z->wlen - in_len)));
+        z->wlen = keep + (z->wlen - in_len);
+        z->w_hist = keep;
     }
     return MZH_OK;
 }

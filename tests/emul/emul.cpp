@@ -201,13 +201,23 @@ extern "C" int32_t emul_lzma_encode_ways(const uint8_t *in, uint32_t in_len, uin
     mz_lz_tok_lds *T = (mz_lz_tok_lds *)malloc(sizeof(mz_lz_tok_lds));
     const size_t xbytes = (MZ_DEF_WAYS_BEST - 1u) * (sizeof(uint16_t) << MZ_DEF_HBITS);
     uint16_t *xhead = (uint16_t *)malloc(xbytes);
+    uint32_t *links = (uint32_t *)0;
+    if ((mode == 0u && in_len > MZ_DEF_BLOCK)) { /* the chain pass (k_lz_chain_batch): one wave over the whole stream */
+        uint32_t *head = (uint32_t *)malloc(sizeof(uint32_t) << MZ_LZE_FAR_HBITS);
+        links = (uint32_t *)malloc((size_t)nblocks * MZ_DEF_BLOCK * sizeof(uint32_t));
+        memset(head, 0xA5, sizeof(uint32_t) << MZ_LZE_FAR_HBITS);
+        memset(links, 0xA5, (size_t)nblocks * MZ_DEF_BLOCK * sizeof(uint32_t));
+        mz_lz_chain(in, in_len, links, head);
+        free(head);
+    }
     for (uint32_t b = 0; b < nblocks; b++) {
         memset(T, 0xA5, sizeof(*T));
         memset(xhead, 0xA5, xbytes);
         const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
-        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0);
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links);
     }
     free(xhead);
+    free(links);
     mz_lzma_lds *L = (mz_lzma_lds *)malloc(sizeof(mz_lzma_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_lzma_enc_result r;
@@ -233,13 +243,23 @@ extern "C" int32_t emul_lzma_encode_resume(const uint8_t *in, uint32_t in_len, u
     mz_lz_tok_lds *T = (mz_lz_tok_lds *)malloc(sizeof(mz_lz_tok_lds));
     const size_t xbytes = (MZ_DEF_WAYS_BEST - 1u) * (sizeof(uint16_t) << MZ_DEF_HBITS);
     uint16_t *xhead = (uint16_t *)malloc(xbytes);
-    for (uint32_t b = 0; b < nblocks; b++) {
+    uint32_t *links = (uint32_t *)0;
+    if ((in_len > MZ_DEF_BLOCK)) { /* the chain pass (k_lz_chain_batch): one wave over the whole stream */
+        uint32_t *head = (uint32_t *)malloc(sizeof(uint32_t) << MZ_LZE_FAR_HBITS);
+        links = (uint32_t *)malloc((size_t)nblocks * MZ_DEF_BLOCK * sizeof(uint32_t));
+        memset(head, 0xA5, sizeof(uint32_t) << MZ_LZE_FAR_HBITS);
+        memset(links, 0xA5, (size_t)nblocks * MZ_DEF_BLOCK * sizeof(uint32_t));
+        mz_lz_chain(in, in_len, links, head);
+        free(head);
+    }
+    for (uint32_t b = skip_blocks; b < nblocks; b++) { /* (the history blocks are linked, not parsed) */
         memset(T, 0xA5, sizeof(*T));
         memset(xhead, 0xA5, xbytes);
         const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
-        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0);
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links);
     }
     free(xhead);
+    free(links);
     mz_lzma_lds *L = (mz_lzma_lds *)malloc(sizeof(mz_lzma_lds));
     memset(L, 0xA5, sizeof(*L));
     mz_lzma_enc_state a, b;
@@ -318,6 +338,7 @@ extern "C" int32_t emul_lzma_slots(const uint8_t *in, uint32_t in_len, uint8_t *
 }
 /* the resumable build: state = 16 words (mz_lzma_state), model = MZ_LZMA_MODEL_U16 probabilities, both owned by the caller */
 extern "C" uint32_t emul_lzma_model_u16(void) { return MZ_LZMA_MODEL_U16; }
+extern "C" uint32_t emul_lzma_encode_history_bytes(void) { return MZ_LZE_FAR_DICT; }
 extern "C" int32_t emul_lzma_resume(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap, const uint32_t *st_in,
                                     uint32_t *st_out, uint16_t *model, uint32_t *out_len, uint32_t *in_used) {
     ready();

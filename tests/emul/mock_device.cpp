@@ -285,6 +285,7 @@ MOCK_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *ou
     return st;
 }
 MOCK_API uint32_t mzhip_lzma_model_bytes(void) { return emul_lzma_model_u16() * 2u; }
+MOCK_API uint32_t mzhip_lzma_encode_history_bytes(void) { return emul_lzma_encode_history_bytes(); }
 static int g_mock_lzma_windows = 0;
 MOCK_API int mzmock_lzma_windows(void) { return g_mock_lzma_windows; }
 MOCK_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,

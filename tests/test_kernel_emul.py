@@ -427,6 +427,33 @@ def _lzma_encode(emu, d, mode=0):
     return st, out[:ol.value].tobytes(), crc.value
 
 
+def test_lzma_encode_long_history(emu):
+    """K6's chain pass (lzma_enc_core.h mz_lz_chain + the links the block parse follows): matches reach back 8 MiB like
+    liblzma's preset 6 (mz_strm_lzma.c:81).  Ratio bar of VERDICT r3 item 8 on config-4 entries (<= 0.30; round 3: 0.42),
+    distances beyond one block really occur, liblzma and the oracle decode the streams."""
+    import lzma as pylzma
+
+    emu.emul_lzma_encode_ways.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    datas = synth.markov_entries(2, 1 << 20, 77, synth.bench_corpus()[0])
+    tin = tout = 0
+    for d in datas + [synth.corpus()[:200000] + synth.corpus()[:200000]]:
+        a = np.frombuffer(d, dtype=np.uint8).copy()
+        out = np.zeros(len(d) + len(d) // 8 + 4096, dtype=np.uint8)
+        ol, crc = C.c_uint32(), C.c_uint32()
+        assert emu.emul_lzma_encode_ways(C.cast(a.ctypes.data, _u8p), len(d), 0, 4, C.cast(out.ctypes.data, _u8p), len(out), C.byref(ol), C.byref(crc)) == 0
+        z = out[:ol.value].tobytes()
+        assert crc.value == zlib.crc32(d)
+        assert z[:9] == bytes([9, 20, 5, 0, 0x5D, 0, 0, 0x80, 0])
+        assert pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == d
+        assert oracle.lzma_zip_decode(z, len(d) + 64, -1) == (0, len(z), d)
+        if len(d) == 1 << 20:
+            tin += len(d)
+            tout += len(z)
+        else:
+            assert len(z) < 0.62 * len(pylzma.compress(d[:200000], format=pylzma.FORMAT_RAW, filters=[{"id": pylzma.FILTER_LZMA1, "preset": 6}])) * 2  # the second copy costs next to nothing: it lies 200 000 bytes back
+    assert tout <= 0.30 * tin, (tout, tin)
+
+
 def test_lzma_encode_roundtrip(emu):
     """LZMA encode parity = valid streams that the reference side decodes back to the input: ZIP method-14 payloads
     through the oracle restatement, liblzma (Python's lzma) and -- where built -- the compiled reference; LZMA2 chunk
@@ -440,7 +467,8 @@ def test_lzma_encode_roundtrip(emu):
     for d in cases:
         st, z, crc = _lzma_encode(emu, d)
         assert st == 0 and crc == zlib.crc32(d), len(d)
-        assert z[:9] == bytes([9, 20, 5, 0, 0x5D, 0, 0, 1, 0])
+        # the header's dictionary: 64 KiB for a stream of one block, 8 MiB (the reach of the chain pass's links) beyond
+        assert z[:9] == bytes([9, 20, 5, 0, 0x5D]) + (bytes([0, 0, 1, 0]) if len(d) <= 65536 else bytes([0, 0, 0x80, 0]))
         so, used, out = oracle.lzma_zip_decode(z, len(d) + 64, -1)
         assert (so, used, out) == (0, len(z), d), len(d)
         assert pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == d
