@@ -41,8 +41,9 @@
 #define LZ_IS_REP_G2 (LZ_IS_REP_G1 + 12)   /* [12] */
 #define LZ_IS_REP0_LONG (LZ_IS_REP_G2 + 12) /* [12][16] */
 #define LZ_POS_SLOT (LZ_IS_REP0_LONG + 192) /* [4][64] */
-#define LZ_POS_DEC (LZ_POS_SLOT + 256)     /* [115] */
-#define LZ_ALIGN (LZ_POS_DEC + 115)        /* [16] */
+#define LZ_POS_DEC (LZ_POS_SLOT + 256)     /* [115] + 1 unused: every bit tree below starts on an even index, so the two
+                                              children of a node are one aligned 32-bit word (LZ_BITTREE_PF) */
+#define LZ_ALIGN (LZ_POS_DEC + 116)        /* [16] */
 #define LZ_LEN (LZ_ALIGN + 16)             /* choice, choice2, low[16][8], mid[16][8], high[256] = 514 */
 #define LZ_REP_LEN (LZ_LEN + 514)
 #define LZ_LIT (LZ_REP_LEN + 514)
@@ -196,19 +197,135 @@ typedef struct mz_lzma_result {
         (sym) = _s;                                                                     \
     } while (0)
 
+/* ---- the same trees with the LDS round trip off the decision chain (MZ_LZMA_PAIRS, default on) ----
+ * K3 is one chain of dependent instructions per decision; the read of the next node's probability was on it: the bit
+ * decides the index, the index the address, the address the read.  The two children of node m are the nodes 2m and
+ * 2m + 1 -- neighbours, and with every tree on an even index one aligned word: that word is fetched BEFORE node m is decided
+ * and the bit only picks the half.  (Round 2 measured a form of this as slower on the scalar-port build at 10 waves per CU;
+ * with the decisions on uniform branches and 16 waves per CU the chain is what is left: profiles/r4/ab_k3_pairs.log.) */
+#ifndef MZ_LZMA_PAIRS
+#define MZ_LZMA_PAIRS 1
+#endif
+MZ_DEV uint32_t mz_prob_pair(const uint16_t *pr, uint32_t idx) { /* idx even */
+    uint32_t v;
+    __builtin_memcpy(&v, pr + idx, 4);
+    return v;
+}
+MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 4)) & 0xFFFFu; }
+/* one bit with the probability already in hand (pv); its update goes to probs[idx] */
+#define LZ_BIT_P(bit, idx, pv)                                                          \
+    do {                                                                                \
+        LZ_NORM();                                                                      \
+        uint32_t _pi = (idx);                                                           \
+        uint32_t _p = (pv);                                                             \
+        uint32_t _bound = (range >> 11) * _p;                                           \
+        if (LZ_UBR(code < _bound)) {                                                    \
+            range = _bound;                                                             \
+            _p += (2048u - _p) >> 5;                                                    \
+            (bit) = 0;                                                                  \
+        } else {                                                                        \
+            range -= _bound;                                                            \
+            code -= _bound;                                                             \
+            _p -= _p >> 5;                                                              \
+            (bit) = 1;                                                                  \
+        }                                                                               \
+        MZ_LANES { pr[_pi] = (uint16_t)_p; } /* uniform store, no lane-0 branch */      \
+        MZ_WAVE_SYNC();                                                                 \
+    } while (0)
+#if MZ_LZMA_PAIRS
+#define LZ_BITTREE_PF(sym, base, nbits)                                                 \
+    do {                                                                                \
+        uint32_t _m = 1;                                                                \
+        uint32_t _pv = LZ_U(pr[(base) + 1u]);                                           \
+        for (int _i = 0; _i < (nbits); _i++) {                                          \
+            uint32_t _pair = 0;                                                         \
+            if (_i + 1 < (nbits)) _pair = LZ_U(mz_prob_pair(pr, (base) + 2u * _m));     \
+            uint32_t _b;                                                                \
+            LZ_BIT_P(_b, (base) + _m, _pv);                                             \
+            _m = (_m << 1) + _b;                                                        \
+            _pv = mz_prob_half(_pair, _b);                                           \
+        }                                                                               \
+        (sym) = _m - (1u << (nbits));                                                   \
+    } while (0)
+#define LZ_BITTREE_REV_PF(sym, base, nbits)                                             \
+    do {                                                                                \
+        uint32_t _m = 1, _s = 0;                                                        \
+        uint32_t _pv = LZ_U(pr[(base) + 1u]);                                           \
+        for (int _i = 0; _i < (int)(nbits); _i++) {                                     \
+            uint32_t _pair = 0;                                                         \
+            if (_i + 1 < (int)(nbits)) _pair = LZ_U(mz_prob_pair(pr, (base) + 2u * _m)); \
+            uint32_t _b;                                                                \
+            LZ_BIT_P(_b, (base) + _m, _pv);                                             \
+            _m = (_m << 1) + _b;                                                        \
+            _s |= _b << _i;                                                             \
+            _pv = mz_prob_half(_pair, _b);                                           \
+        }                                                                               \
+        (sym) = _s;                                                                     \
+    } while (0)
+/* a literal out of the LDS model: while the bits follow the match byte the children under the NEXT match bit and the
+ * children in the plain tree are both on their way */
+#define LZ_LITERAL_PF()                                                                 \
+    do {                                                                                \
+        uint32_t _pv;                                                                   \
+        uint32_t _plain = 1;                                                            \
+        if (state >= 7) {                                                               \
+            uint32_t mb = match_byte;                                                   \
+            uint32_t mbit = (mb >> 7) & 1u;                                             \
+            mb <<= 1;                                                                   \
+            _pv = LZ_U(pr[lbase + ((1u + mbit) << 8) + sym]);                           \
+            _plain = 0;                                                                 \
+            for (;;) {                                                                  \
+                const uint32_t mbit2 = (mb >> 7) & 1u;                                  \
+                uint32_t _pm = 0, _pp = 0;                                              \
+                if (sym < 0x80u) {                                                      \
+                    _pm = LZ_U(mz_prob_pair(pr, lbase + ((1u + mbit2) << 8) + 2u * sym)); \
+                    _pp = LZ_U(mz_prob_pair(pr, lbase + 2u * sym));                     \
+                }                                                                       \
+                uint32_t b;                                                             \
+                LZ_BIT_P(b, lbase + ((1u + mbit) << 8) + sym, _pv);                     \
+                sym = (sym << 1) | b;                                                   \
+                if (sym >= 0x100u) break;                                               \
+                if (mbit != b) {                                                        \
+                    _pv = mz_prob_half(_pp, b);                                      \
+                    _plain = 2;                                                         \
+                    break;                                                              \
+                }                                                                       \
+                _pv = mz_prob_half(_pm, b);                                          \
+                mbit = mbit2;                                                           \
+                mb <<= 1;                                                               \
+            }                                                                           \
+        }                                                                               \
+        if (sym < 0x100u) {                                                             \
+            if (_plain == 1) _pv = LZ_U(pr[lbase + sym]);                               \
+            while (sym < 0x100u) {                                                      \
+                uint32_t _pair = 0;                                                     \
+                if (sym < 0x80u) _pair = LZ_U(mz_prob_pair(pr, lbase + 2u * sym));      \
+                uint32_t b;                                                             \
+                LZ_BIT_P(b, lbase + sym, _pv);                                          \
+                sym = (sym << 1) | b;                                                   \
+                _pv = mz_prob_half(_pair, b);                                        \
+            }                                                                           \
+        }                                                                               \
+    } while (0)
+#else
+#define LZ_BITTREE_PF(sym, base, nbits) LZ_BITTREE(sym, base, nbits)
+#define LZ_BITTREE_REV_PF(sym, base, nbits) LZ_BITTREE_REV(sym, base, nbits)
+#define LZ_LITERAL_PF() LZ_LITERAL(LZ_BIT)
+#endif
+
 #define LZ_LEN_DECODE(len, lbase, ps)                                                   \
     do {                                                                                \
         uint32_t _c;                                                                    \
         LZ_BIT(_c, (lbase));                                                            \
         if (!_c) {                                                                      \
-            LZ_BITTREE(len, (lbase) + 2 + (ps) * 8, 3);                                 \
+            LZ_BITTREE_PF(len, (lbase) + 2 + (ps) * 8, 3);                                 \
         } else {                                                                        \
             LZ_BIT(_c, (lbase) + 1);                                                    \
             if (!_c) {                                                                  \
-                LZ_BITTREE(len, (lbase) + 2 + 128 + (ps) * 8, 3);                       \
+                LZ_BITTREE_PF(len, (lbase) + 2 + 128 + (ps) * 8, 3);                       \
                 (len) += 8;                                                             \
             } else {                                                                    \
-                LZ_BITTREE(len, (lbase) + 2 + 256, 8);                                  \
+                LZ_BITTREE_PF(len, (lbase) + 2 + 256, 8);                                  \
                 (len) += 16;                                                            \
             }                                                                           \
         }                                                                               \
@@ -241,7 +358,7 @@ typedef struct mz_lzma_result {
     do {                                                                                                              \
         const uint32_t lbase = LZ_LIT + 0x300u * (((opos & lp_mask) << lc) + (prev_byte >> (8 - lc)));                \
         if (lbase < LZ_NUM_PROBS) {                                                                                   \
-            LZ_LITERAL(LZ_BIT);                                                                                       \
+            LZ_LITERAL_PF();                                                                                          \
         } else { /* lc + lp = 4, upper half of the literal model */                                                   \
             LZ_LITERAL(LZ_BIT_X);                                                                                     \
         }                                                                                                             \
@@ -303,7 +420,7 @@ typedef struct mz_lzma_result {
         _Pragma("unroll") for (uint32_t k_ = 0; k_ < MZ_LZMA_SLOTS; k_++)                                             \
             if (k_ == sl_) sage[k_] = opos + 1u; /* (0 = never used) */                                               \
         const uint32_t lbase = LZ_LIT + 0x300u * sl_;                                                                 \
-        LZ_LITERAL(LZ_BIT);                                                                                           \
+        LZ_LITERAL_PF();                                                                                              \
     } while (0)
 
 /* The packet loop, shared by K3 (LZMA1 to the end marker: lzma2 = 0, dict_start = 0) and the .xz kernel
@@ -387,7 +504,7 @@ typedef struct mz_lzma_result {
             LZ_LEN_DECODE(len, LZ_LEN, ps);                                                                           \
             state = state < 7 ? 7 : 10;                                                                               \
             uint32_t slot;                                                                                            \
-            LZ_BITTREE(slot, LZ_POS_SLOT + (len < 4 ? len : 3u) * 64, 6);                                             \
+            LZ_BITTREE_PF(slot, LZ_POS_SLOT + (len < 4 ? len : 3u) * 64, 6);                                             \
             if (slot < 4) {                                                                                           \
                 rep0 = slot;                                                                                          \
             } else {                                                                                                  \
@@ -408,7 +525,7 @@ typedef struct mz_lzma_result {
                         direct = (direct << 1) + (t + 1);                                                             \
                     }                                                                                                 \
                     rep0 += direct << 4;                                                                              \
-                    LZ_BITTREE_REV(low, LZ_ALIGN, 4);                                                                 \
+                    LZ_BITTREE_REV_PF(low, LZ_ALIGN, 4);                                                                 \
                     rep0 += low;                                                                                      \
                 }                                                                                                     \
             }                                                                                                         \
@@ -529,6 +646,19 @@ typedef struct mz_lzma_result {
 #undef LZ_UBR
 #undef LZ_WIN_DW
 #undef LZ_ENTRY_NAME
+#if !defined(MZHIP_HOST_EMUL) && defined(MZ_LZMA_SLOT_SPORT_OF_4)
+/* measurement builds: the slot build in the scalar-port form as well -- MZ_LZMA_SLOT_SPORT_OF_4 of every four waves of a
+ * SIMD run it, so that the vector and the scalar port of a CU both carry decisions (profiles/r4/ab_k3_ports.log) */
+#define LZ_U(x) MZ_UNIFORM(x)
+#define LZ_UBR(c) (c)
+#define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
+#define LZ_ENTRY_NAME mz_lzma_entry_ss
+#include "lzma_entry.inc"
+#undef LZ_U
+#undef LZ_UBR
+#undef LZ_WIN_DW
+#undef LZ_ENTRY_NAME
+#endif
 #undef LZ_SLOTS_BUILD
 #undef LZ_LITERAL_SITE
 #undef LZ_LDS_T

@@ -279,6 +279,15 @@ __global__ __launch_bounds__(256, 4) void k_lzma_slot_batch(LzmaArgs a) {
         MZ_WAVE_FETCH_ADD(e, a.counter);
         if (e >= a.n) break;
         mz_lzma_result r;
+#ifdef MZ_LZMA_SLOT_SPORT_OF_4
+        // (measurement builds) wave w of a workgroup sits on SIMD w; the workgroups that share a CU differ in blockIdx.x & 3
+        // or in blockIdx.x >> 8, whichever way the dispatcher lays them out: every SIMD gets the same mix of the two forms
+        if (((wave + blockIdx.x + (blockIdx.x >> 8)) & 3u) < MZ_LZMA_SLOT_SPORT_OF_4)
+            mz_lzma_entry_ss(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
+                             a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
+                             a.sprobs + wave_id * MZ_LZMA_SPROBS, &r);
+        else
+#endif
         mz_lzma_entry_s(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
                         a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
                         a.sprobs + wave_id * MZ_LZMA_SPROBS, &r);
