@@ -866,12 +866,14 @@ def main():
         if cfg["codec"] == "inflate":
             geo = (C.c_uint32(), C.c_uint32(), C.c_uint32())
             L.mzhip_inflate_launch_geometry(n, *(C.byref(g) for g in geo))
+            launched = geo[0].value * geo[1].value  # what this shard's launch starts (every resident slot once it has that many entries)
+            L.mzhip_inflate_launch_geometry(0x7FFFFFFF, *(C.byref(g) for g in geo))
             resident = geo[0].value * geo[1].value
             # one wave decodes one entry and the waves of a launch are persistent: a shard of E equal entries takes
             # ceil(E / resident waves) rounds, so a shard that is not a multiple of the resident waves pays for a last,
             # partly empty round (at N = 8, 12 500 entries over 4096 waves = 3.05 -> 4 rounds)
             rounds = [e / max(resident, 1) for e in rank_entries]
-            line["config"]["launch"] = {"workgroups": geo[0].value, "waves_per_wg": geo[1].value, "lds_bytes_per_wg": geo[2].value,
+            line["config"]["launch"] = {"workgroups": launched // max(geo[1].value, 1), "waves_per_wg": geo[1].value, "lds_bytes_per_wg": geo[2].value,
                                         "resident_waves": resident, "entries_per_rank": rank_entries,
                                         "rounds_per_rank": [round(r, 3) for r in rounds],
                                         "predicted_quantisation_efficiency": round(min(r / max(1.0, float(np.ceil(r))) for r in rounds), 3)}

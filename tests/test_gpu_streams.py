@@ -113,17 +113,19 @@ def test_one_window_on_many_waves(gpu):
     seg = (C.c_uint32 * 2048)()
     L.mzhip_inflate_parallel_host.restype = C.c_int32
     L.mzhip_inflate_parallel_host.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                              C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    wcrc, wadl = C.c_uint32(), C.c_uint32()   # CRC-32 / Adler-32 of the window's bytes (what the gzip / zlib trailers run over)
     best = 1e9
     for _ in range(3):
         t0 = time.time()
         rc = L.mzhip_inflate_parallel_host(zin.ctypes.data, zin.size, buf.ctypes.data, cap, None, C.byref(st), C.byref(ol), C.byref(nb),
-                                           C.byref(ended), 0, 65535, seg, 2048, C.byref(nseg))
+                                           C.byref(ended), C.byref(wcrc), C.byref(wadl), 0, 65535, seg, 2048, C.byref(nseg))
         best = min(best, time.time() - t0)
         assert rc == 0, rc
     print("one window: %d blocks, %d bytes, ended %d, %.1f ms host to host (%.2f GB/s)" % (nb.value, ol.value, ended.value, best * 1e3, ol.value / best / 1e9))
     assert nb.value >= 100 and ol.value <= len(d)
     assert buf[:ol.value].tobytes() == d[:ol.value]
+    assert wcrc.value == zlib.crc32(d[:ol.value]) and wadl.value == zlib.adler32(d[:ol.value])
     if ended.value:
         assert ol.value == len(d) and (st[1] + 7) // 8 == len(z)
     else:                                                                   # the chain stopped (the last bits of the stream are the serial kernel's)
