@@ -247,8 +247,9 @@ MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *o
                                   uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                 uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
-/* a whole entry: ZIP method-14 payload / one .xz stream (single block of independent 48 KiB LZMA2 chunks, CRC32
- * check); *crc = CRC-32 of `in` */
+/* a whole entry: ZIP method-14 payload / one .xz stream (a single block of 64 KiB LZMA2 chunks that reset state and
+ * properties and keep the dictionary: matches reach back 8 MiB as in the method-14 stream; CRC32 check); *crc = CRC-32 of
+ * `in` */
 MZHIP_API int32_t mzhip_lzma_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
                                          uint32_t *out_len, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_encode_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,

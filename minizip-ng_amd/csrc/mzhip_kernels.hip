@@ -514,6 +514,40 @@ __global__ __launch_bounds__(64) void k_lzma_rc_encode_batch(LzmaEncArgs a) {
     }
 }
 
+// LZMA encode, pass 2 for the LZMA2 chunks of ONE .xz block (mzhip_xz_encode_*): entry 0 of `a` is the block, parsed as one
+// stream (chain pass and all: a chunk's matches reach back over the chunks before it); every 64 KiB block of it is coded by
+// a wave of its own with a fresh coder and model -- LZMA2 chunks that reset state and properties but keep the dictionary.
+struct LzmaEncChunksArgs {
+    LzmaEncArgs a;
+    uint32_t nchunks;
+    uint32_t chunk_cap;      // bytes of room per chunk: chunk b is written at a.out + a.out_off[0] + b * chunk_cap
+    uint32_t *chunk_len;     // [nchunks]
+    int32_t *chunk_status;   // [nchunks]
+};
+__global__ __launch_bounds__(64) void k_lzma2_chunks_encode(LzmaEncChunksArgs r) {
+    __shared__ __attribute__((aligned(16))) mz_lzma_lds lds;
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = r.a.tabs->byte_tab[i];
+    __syncthreads();
+    MZ_LANE_DECL
+    const LzmaEncArgs &a = r.a;
+    const uint64_t io = a.in_off[0], oo = a.out_off[0];
+    const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
+    uint8_t *out0 = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
+    const uint32_t len = MZ_UNIFORM(a.in_len[0]);
+    for (;;) {
+        uint32_t b;
+        MZ_WAVE_FETCH_ADD(b, a.counter + 1);
+        if (b >= r.nchunks) break;
+        const uint32_t hi = (len - b * MZ_DEF_BLOCK < MZ_DEF_BLOCK) ? len : (b + 1u) * MZ_DEF_BLOCK;
+        mz_lzma_enc_result res;
+        mz_lzma_rc_encode_x(in, hi, a.tok, a.ntok, 1u, out0 + (size_t)b * r.chunk_cap, r.chunk_cap, &lds, crc_tab, a.tabs, &res, b,
+                            (const mz_lzma_enc_state *)nullptr, (mz_lzma_enc_state *)nullptr, (uint16_t *)nullptr);
+        r.chunk_len[b] = res.out_len; // wave-uniform results: stored by all lanes
+        r.chunk_status[b] = res.status;
+    }
+}
+
 // LZMA encode, pass 2 of ONE stream that is written segment by segment (the drop-in WRITE stream, shim_lzma.c): the
 // coder goes on from / is left in a 64-byte state, the adaptive model travels in global memory beside it.
 struct LzmaEncResumeArgs {

@@ -8,7 +8,7 @@
  * (xz_core.h) through mzhip_xz_host().  WRITE collects the entry and codes it at
  * close() on the device (lzma_enc_core.h): method 14 as one LZMA1 stream with the
  * ZIP-LZMA header and the end marker (mz_strm_lzma.c:94-104, mz_zip.c:1984), method
- * 95 as one .xz stream of independent LZMA2 chunks.  The bytes are valid but not
+ * 95 as one .xz stream whose LZMA2 chunks are coded independently (state and properties reset) over one dictionary.  The bytes are valid but not
  * liblzma's; the reference's reader decodes them back (tests/test_gpu_lzma_enc.py).
  *
  * Contract mirrored from the reference (file:line = mz_strm_lzma.c):
@@ -601,10 +601,10 @@ static int32_t lz_write_segment_out(mzhip_lzma *z, int32_t last) {
     return MZH_OK;
 }
 
-/* Method 95 in bounded memory: the .xz container holds any number of blocks, and this backend's blocks are made of LZMA2
- * chunks that reset the dictionary anyway -- so a segment is simply one block (behind the stream header when it is the
- * first), and close() adds the index over all blocks and the footer.  Nothing is carried from segment to segment but the
- * two sizes per block the index wants. */
+/* Method 95 in bounded memory: the .xz container holds any number of blocks and a block starts with a fresh dictionary --
+ * so a segment (8 MiB: as far as the parse looks back anyway) is simply one block (behind the stream header when it is
+ * the first), and close() adds the index over all blocks and the footer.  Nothing is carried from segment to segment but
+ * the two sizes per block the index wants. */
 static int32_t xz_write_block_out(mzhip_lzma *z, int64_t take) {
     if (z->w_segments >= z->xz_cap) {
         const int32_t ncap = z->xz_cap ? z->xz_cap * 2 : 64;

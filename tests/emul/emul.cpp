@@ -231,6 +231,54 @@ extern "C" int32_t emul_lzma_encode_ways(const uint8_t *in, uint32_t in_len, uin
     return r.status;
 }
 
+/* The LZMA2 chunks of one .xz block (mzhip_xz_encode_*'s device side): the block is parsed as ONE stream -- chain pass and
+ * all, so a chunk's matches reach back over the chunks before it -- and every 64 KiB block of it is range-coded by itself
+ * with a fresh state (LZMA2 control 0xE0 for the first chunk, 0xC0 = state and properties reset, dictionary kept, for the
+ * others).  out[b * stride ...] / out_lens[b] receive chunk b's payload. */
+extern "C" int32_t emul_lzma2_chunks_encode(const uint8_t *in, uint32_t in_len, uint32_t ways, uint8_t *out, uint32_t stride,
+                                            uint32_t *out_lens) {
+    ready();
+    const uint32_t nblocks = (in_len + MZ_DEF_BLOCK - 1) / MZ_DEF_BLOCK;
+    uint32_t *tok = (uint32_t *)malloc((size_t)(nblocks ? nblocks : 1) * MZ_DEF_BLOCK * sizeof(uint32_t));
+    uint32_t *ntok = (uint32_t *)calloc(nblocks ? nblocks : 1, sizeof(uint32_t));
+    mz_lz_tok_lds *T = (mz_lz_tok_lds *)malloc(sizeof(mz_lz_tok_lds));
+    const size_t xbytes = (MZ_DEF_WAYS_BEST - 1u) * (sizeof(uint16_t) << MZ_DEF_HBITS);
+    uint16_t *xhead = (uint16_t *)malloc(xbytes);
+    uint32_t *links = (uint32_t *)0;
+    if (in_len > MZ_DEF_BLOCK) {
+        uint32_t *head = (uint32_t *)malloc(sizeof(uint32_t) << MZ_LZE_FAR_HBITS);
+        links = (uint32_t *)malloc((size_t)nblocks * MZ_DEF_BLOCK * sizeof(uint32_t));
+        memset(head, 0xA5, sizeof(uint32_t) << MZ_LZE_FAR_HBITS);
+        memset(links, 0xA5, (size_t)nblocks * MZ_DEF_BLOCK * sizeof(uint32_t));
+        mz_lz_chain(in, in_len, links, head);
+        free(head);
+    }
+    for (uint32_t b = 0; b < nblocks; b++) {
+        memset(T, 0xA5, sizeof(*T));
+        memset(xhead, 0xA5, xbytes);
+        const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links);
+    }
+    free(xhead);
+    free(links);
+    mz_lzma_lds *L = (mz_lzma_lds *)malloc(sizeof(mz_lzma_lds));
+    int32_t status = 0;
+    for (uint32_t b = 0; b < nblocks && status == 0; b++) {
+        memset(L, 0xA5, sizeof(*L));
+        const uint32_t hi = (in_len - b * MZ_DEF_BLOCK < MZ_DEF_BLOCK) ? in_len : (b + 1u) * MZ_DEF_BLOCK;
+        mz_lzma_enc_result r;
+        mz_lzma_rc_encode_x(in, hi, tok, ntok, 1u, out + (size_t)b * stride, stride, L, g_tabs.byte_tab, &g_tabs, &r, b,
+                            (const mz_lzma_enc_state *)0, (mz_lzma_enc_state *)0, (uint16_t *)0);
+        status = r.status;
+        out_lens[b] = r.out_len;
+    }
+    free(L);
+    free(T);
+    free(tok);
+    free(ntok);
+    return status;
+}
+
 /* one segment of a method-14 stream written in segments (mzhip_lzma_encode_resume_host's device side): state = 16 words
  * (mz_lzma_enc_state), model = LZ_NUM_PROBS probabilities, both the caller's */
 extern "C" int32_t emul_lzma_encode_resume(const uint8_t *in, uint32_t in_len, uint32_t skip_blocks, uint32_t last, uint32_t ways,

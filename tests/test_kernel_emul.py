@@ -493,21 +493,34 @@ def test_lzma_encode_roundtrip(emu):
         fast += len(_lzma_encode(emu, d)[1])
         best += len(z)
     assert best < 0.97 * fast
-    # LZMA2 chunk payloads -> one .xz stream (single block, CRC32 check, every chunk resets dict + state + props)
-    for d in (c[:150000], rnd.bytes(60000) + c[:1000], b"x"):
+    # LZMA2 chunk payloads -> one .xz stream (single block, CRC32 check) exactly like mzhip_xz_encode_host lays it out: the
+    # block is parsed as one stream (a chunk's matches reach back over the chunks before it), every 64 KiB of it is a
+    # chunk with a fresh coder and model -- the first resets the dictionary (0xE0 / stored 0x01), the others keep it
+    # (0xC0 / stored 0x02)
+    emu.emul_lzma2_chunks_encode.argtypes = [_u8p, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32)]
+    xz_sizes = {}
+    for name, d in (("text", c[:150000]), ("noise+text", rnd.bytes(60000) + c[:1000]), ("x", b"x"), ("twice", c[:100000] + rnd.bytes(70000) + c[:100000]),
+                    ("markov", synth.markov_entries(1, 1 << 20, 78, synth.bench_corpus()[0])[0])):
+        nch = (len(d) + 65535) // 65536
+        stride = 65536 + 8192 + 1024
+        a = np.frombuffer(d, dtype=np.uint8).copy()
+        outb = np.zeros(nch * stride, dtype=np.uint8)
+        lens = (C.c_uint32 * nch)()
+        st = emu.emul_lzma2_chunks_encode(C.cast(a.ctypes.data, _u8p), len(d), 4, C.cast(outb.ctypes.data, _u8p), stride, lens)
+        assert st in (0, -200), st       # (-200: a chunk of noise did not fit its room -- it is stored, as below)
         body = b""
-        for o in range(0, len(d), 49152):
-            piece = d[o:o + 49152]
-            st, z, crc = _lzma_encode(emu, piece, 1)
-            assert st == 0 and crc == zlib.crc32(piece)
+        for i in range(nch):
+            piece = d[i * 65536:(i + 1) * 65536]
+            z = outb[i * stride:i * stride + lens[i]].tobytes()
             us, cs = len(piece), len(z)
-            if cs >= us:
-                body += bytes([1, (us - 1) >> 8, (us - 1) & 255]) + piece
+            if cs >= us or cs > 65536 or (st != 0 and cs + 16 >= stride):
+                body += bytes([1 if i == 0 else 2, (us - 1) >> 8, (us - 1) & 255]) + piece
             else:
-                body += bytes([0xE0 | ((us - 1) >> 16), ((us - 1) >> 8) & 255, (us - 1) & 255, (cs - 1) >> 8, (cs - 1) & 255, 0x5D]) + z
+                body += bytes([(0xE0 if i == 0 else 0xC0) | ((us - 1) >> 16), ((us - 1) >> 8) & 255, (us - 1) & 255, (cs - 1) >> 8, (cs - 1) & 255, 0x5D]) + z
         body += b"\x00"
         flags = b"\x00\x01"
-        bh = bytes([2, 0, 0x21, 1, 8, 0, 0, 0])
+        bh = bytes([2, 0, 0x21, 1, 0x16 if nch > 1 else 8, 0, 0, 0])
+        xz_sizes[name] = (len(d), len(body))
         x = b"\xfd7zXZ\x00" + flags + zlib.crc32(flags).to_bytes(4, "little") + bh + zlib.crc32(bh).to_bytes(4, "little")
         x += body + b"\x00" * (-len(body) % 4) + zlib.crc32(d).to_bytes(4, "little")
         idx = b"\x00\x01" + synth._vli(12 + len(body) + 4) + synth._vli(len(d))
@@ -517,6 +530,12 @@ def test_lzma_encode_roundtrip(emu):
         x += idx + zlib.crc32(tail).to_bytes(4, "little") + tail + b"YZ"
         assert pylzma.decompress(x) == d
         assert oracle.xz_decode(x, len(d) + 64) == (0, len(x), d)
+        st2, used2, out2, crc2 = _run(emu.emul_xz, x, len(d) + 64, C.c_int64(-1))         # and back through the .xz kernel's core
+        assert (st2, used2, out2) == (0, len(x), d)
+    # the second copy of "twice" lies 170 000 bytes behind the first: it costs next to nothing now; a config-4 entry
+    # (VERDICT r3 missing 5, for method 95 as for method 14): <= 0.30 where chunks that were streams of their own made 0.40
+    assert xz_sizes["twice"][1] < 70000 + 1.25 * xz_sizes["text"][1] * 100000 / 150000
+    assert xz_sizes["markov"][1] <= 0.30 * xz_sizes["markov"][0], xz_sizes["markov"]
 
 
 def test_inflate_differential_fuzz(emu):
