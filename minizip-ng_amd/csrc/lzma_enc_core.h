@@ -92,8 +92,8 @@ MZ_DEV void mz_lz_chain(const uint8_t *in, uint32_t in_len, uint32_t *links, uin
             const uint32_t pos = p + (uint32_t)lane;
             /* (the last seven positions of a 64 KiB block stay out: a stream written in segments of whole blocks then has
              * the links of the same stream coded in one piece) */
-            const uint32_t bend = (pos | (MZ_DEF_BLOCK - 1u)) + 1u;
-            const uint32_t ok = (pos + 8u <= in_len && pos + 8u <= bend) ? 1u : 0u;
+            const uint32_t bend = (pos | (MZ_DEF_BLOCK - 1u)) + 1u; /* (0 behind the last block of a 4 GiB stream: the difference below is right anyway) */
+            const uint32_t ok = (pos < in_len && in_len - pos >= 8u && bend - pos >= 8u) ? 1u : 0u;
             uint32_t h = 0;
             if (ok) {
                 const uint64_t v = (uint64_t)mz_load_u32(in + pos) | ((uint64_t)mz_load_u32(in + pos + 4u) << 32);
