@@ -131,6 +131,14 @@ typedef struct mz_lzma_result {
         }                                                                               \
     } while (0)
 
+#ifndef MZ_LZMA_BORROW
+#define MZ_LZMA_BORROW 1
+#endif
+#if MZ_LZMA_BORROW
+#define LZ_BORROW(a, b, d) ((uint32_t)__builtin_sub_overflow((uint32_t)(a), (uint32_t)(b), (d)))
+#else
+#define LZ_BORROW(a, b, d) (*(d) = (a) - (b), (uint32_t)((a) < (b)))
+#endif
 /* decode one bit with the adaptive model at probs[idx]; result in `bit` */
 #define LZ_BIT(bit, idx)                                                                \
     do {                                                                                \
@@ -138,13 +146,15 @@ typedef struct mz_lzma_result {
         uint32_t _pi = (idx);                                                           \
         uint32_t _p = LZ_PU(LZ_U(pr[_pi]));                                             \
         uint32_t _bound = (range >> 11) * _p;                                           \
-        if (LZ_UBR(code < _bound)) {                                                            \
+        uint32_t _diff;                                                                 \
+        const uint32_t _lt = LZ_BORROW(code, _bound, &_diff);                           \
+        if (LZ_UBR(_lt != 0u)) {                                                        \
             range = _bound;                                                             \
             _p += (2048u - _p) >> 5;                                                    \
             (bit) = 0;                                                                  \
         } else {                                                                        \
             range -= _bound;                                                            \
-            code -= _bound;                                                             \
+            code = _diff;                                                               \
             _p -= _p >> 5;                                                              \
             (bit) = 1;                                                                  \
         }                                                                               \
@@ -160,13 +170,15 @@ typedef struct mz_lzma_result {
         uint32_t _pi = (idx) - LZ_NUM_PROBS;                                            \
         uint32_t _p = LZ_U(prx[_pi]);                                                   \
         uint32_t _bound = (range >> 11) * _p;                                           \
-        if (LZ_UBR(code < _bound)) {                                                            \
+        uint32_t _diff;                                                                 \
+        const uint32_t _lt = LZ_BORROW(code, _bound, &_diff);                           \
+        if (LZ_UBR(_lt != 0u)) {                                                        \
             range = _bound;                                                             \
             _p += (2048u - _p) >> 5;                                                    \
             (bit) = 0;                                                                  \
         } else {                                                                        \
             range -= _bound;                                                            \
-            code -= _bound;                                                             \
+            code = _diff;                                                               \
             _p -= _p >> 5;                                                              \
             (bit) = 1;                                                                  \
         }                                                                               \
@@ -219,13 +231,15 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
         uint32_t _pi = (idx);                                                           \
         uint32_t _p = (pv);                                                             \
         uint32_t _bound = (range >> 11) * _p;                                           \
-        if (LZ_UBR(code < _bound)) {                                                    \
+        uint32_t _diff;                                                                 \
+        const uint32_t _lt = LZ_BORROW(code, _bound, &_diff); /* code < bound and code - bound from one subtraction */ \
+        if (LZ_UBR(_lt != 0u)) {                                                        \
             range = _bound;                                                             \
             _p += (2048u - _p) >> 5;                                                    \
             (bit) = 0;                                                                  \
         } else {                                                                        \
             range -= _bound;                                                            \
-            code -= _bound;                                                             \
+            code = _diff;                                                               \
             _p -= _p >> 5;                                                              \
             (bit) = 1;                                                                  \
         }                                                                               \

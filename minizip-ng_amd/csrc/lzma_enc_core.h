@@ -346,10 +346,17 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
         cache_size++;                                                                    \
         low = (uint64_t)((uint32_t)low & 0x00FFFFFFu) << 8;                              \
     } while (0)
-#define LZE_BIT(idx, bitv)                                                               \
+/* The coder knows every bit before it codes it, so the probabilities of a whole symbol's path are read up front
+ * (MZ_LZE_PRELOAD: eight independent LDS reads for a literal, then eight codings that wait for nothing) instead of one
+ * LDS round trip on the range's dependency chain per bit.  LZE_BIT_P codes one bit with the probability in hand. */
+#ifndef MZ_LZE_PRELOAD
+#define MZ_LZE_PRELOAD 1
+#endif
+#define LZE_BIT(idx, bitv) LZE_BIT_P(idx, bitv, LZE_U(pr[(idx)]))
+#define LZE_BIT_P(idx, bitv, pv)                                                         \
     do {                                                                                 \
         const uint32_t _pi = (idx);                                                      \
-        uint32_t _p = LZE_U(pr[_pi]);                                                    \
+        uint32_t _p = (pv);                                                              \
         const uint32_t _bound = (range >> 11) * _p;                                      \
         if (!(bitv)) {                                                                   \
             range = _bound;                                                              \
@@ -377,6 +384,45 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
             }                                                                            \
         }                                                                                \
     } while (0)
+#if MZ_LZE_PRELOAD
+#define LZE_BITTREE(base, nbits, sym)                                                    \
+    do {                                                                                 \
+        uint32_t _pp[8];                                                                 \
+        {                                                                                \
+            uint32_t _m = 1;                                                             \
+            _Pragma("unroll") for (int _k = 0; _k < (int)(nbits); _k++) {                \
+                _pp[_k] = LZE_U(pr[(base) + _m]);                                        \
+                _m = (_m << 1) | (((sym) >> ((int)(nbits) - 1 - _k)) & 1u);              \
+            }                                                                            \
+        }                                                                                \
+        uint32_t _m = 1;                                                                 \
+        _Pragma("unroll") for (int _k = 0; _k < (int)(nbits); _k++) {                    \
+            const uint32_t _b = ((sym) >> ((int)(nbits) - 1 - _k)) & 1u;                 \
+            LZE_BIT_P((base) + _m, _b, _pp[_k]);                                         \
+            _m = (_m << 1) | _b;                                                         \
+        }                                                                                \
+    } while (0)
+/* nbits <= 5 here (the distance's low bits below slot 14, the four aligned bits) */
+#define LZE_BITTREE_REV(base, nbits, sym)                                                \
+    do {                                                                                 \
+        uint32_t _pp[5];                                                                 \
+        {                                                                                \
+            uint32_t _m = 1;                                                             \
+            _Pragma("unroll") for (int _k = 0; _k < 5; _k++) {                           \
+                _pp[_k] = (_k < (int)(nbits)) ? LZE_U(pr[(base) + _m]) : 0u;             \
+                _m = (_m << 1) | (((sym) >> _k) & 1u);                                   \
+            }                                                                            \
+        }                                                                                \
+        uint32_t _m = 1;                                                                 \
+        _Pragma("unroll") for (int _k = 0; _k < 5; _k++) {                               \
+            if (_k < (int)(nbits)) {                                                     \
+                const uint32_t _b = ((sym) >> _k) & 1u;                                  \
+                LZE_BIT_P((base) + _m, _b, _pp[_k]);                                     \
+                _m = (_m << 1) | _b;                                                     \
+            }                                                                            \
+        }                                                                                \
+    } while (0)
+#else
 #define LZE_BITTREE(base, nbits, sym)                                                    \
     do {                                                                                 \
         uint32_t _m = 1;                                                                 \
@@ -395,6 +441,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
             _m = (_m << 1) | _b;                                                         \
         }                                                                                \
     } while (0)
+#endif
 #define LZE_LEN(lbase, l, ps)                                                            \
     do {                                                                                 \
         if ((l) < 8u) {                                                                  \
@@ -547,6 +594,23 @@ MZ_DEV void mz_lzma_rc_encode_x(const uint8_t *in, uint32_t in_len, const uint32
                         const uint32_t sym = (t >> 9) & 0xFFu;
                         LZE_BIT(LZ_IS_MATCH + state * 16 + ps, 0u);
                         const uint32_t lbase = LZ_LIT + 0x300u * ((ctx & 0xFFu) >> (8u - MZ_LZE_LC));
+#if MZ_LZE_PRELOAD
+                        {
+                            /* the eight nodes of this literal's path -- in the matched trees while its bits follow the match
+                             * byte, in the plain tree from the first difference on -- and their probabilities, up front */
+                            uint32_t li[8], lp[8];
+                            uint32_t m = 1, matching = (state >= 7u) ? 1u : 0u, mbyte = (ctx >> 8) & 0xFFu;
+                            _Pragma("unroll") for (int j = 0; j < 8; j++) {
+                                const uint32_t bb = (sym >> (7 - j)) & 1u, mbit = (mbyte >> 7) & 1u;
+                                mbyte <<= 1;
+                                li[j] = lbase + (matching ? ((1u + mbit) << 8) : 0u) + m;
+                                lp[j] = LZE_U(pr[li[j]]);
+                                if (mbit != bb) matching = 0u;
+                                m = (m << 1) | bb;
+                            }
+                            _Pragma("unroll") for (int j = 0; j < 8; j++) LZE_BIT_P(li[j], (sym >> (7 - j)) & 1u, lp[j]);
+                        }
+#else
                         uint32_t m = 1;
                         int k = 7;
                         if (state >= 7u) {
@@ -567,6 +631,7 @@ MZ_DEV void mz_lzma_rc_encode_x(const uint8_t *in, uint32_t in_len, const uint32
                             LZE_BIT(lbase + m, bb);
                             m = (m << 1) | bb;
                         }
+#endif
                         state = state < 4u ? 0u : (state < 10u ? state - 3u : state - 6u);
                         pos += 1u;
                     } else {
