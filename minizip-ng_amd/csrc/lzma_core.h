@@ -131,8 +131,11 @@ typedef struct mz_lzma_result {
         }                                                                               \
     } while (0)
 
+/* MZ_LZMA_BORROW (measurement): `code < bound` and `code - bound` from ONE subtraction with borrow -- a vector instruction
+ * less on the path of a 1 bit, and slower all the same (config 4 10.35 -> 10.19 GiB/s, profiles/r4/ab_k3_borrow.log: the
+ * compare's result is wanted first, and v_sub_co delivers it with the difference) */
 #ifndef MZ_LZMA_BORROW
-#define MZ_LZMA_BORROW 1
+#define MZ_LZMA_BORROW 0
 #endif
 #if MZ_LZMA_BORROW
 #define LZ_BORROW(a, b, d) ((uint32_t)__builtin_sub_overflow((uint32_t)(a), (uint32_t)(b), (d)))
