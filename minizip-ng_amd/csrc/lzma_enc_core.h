@@ -51,9 +51,11 @@
 #ifndef MZ_LZE_FAR_NGRAM
 #define MZ_LZE_FAR_NGRAM 7u /* bytes the chain pass hashes: the nearest earlier occurrence of that many bytes */
 #endif
-#ifndef MZ_LZE_FAR_DEPTH
-#define MZ_LZE_FAR_DEPTH 4u /* links of the chain the block parse follows from a position (presets 4-9; 1 for the fast class) */
-#endif
+/* links of the chain the block parse follows from a position, by liblzma preset (mz_strm_lzma.c:81 hands COMPRESS_LEVEL to
+ * lzma_lzma_preset, whose presets search deeper as they go up): config-4 entries 0.276 at 4 links, 0.269 at 8, 0.265 at 16
+ * (liblzma's own fast mode over a hash chain: 0.338 / 0.301 / 0.276 at depth 4 / 16 / 64; its preset 6 -- a binary tree and
+ * a priced parse -- 0.245) */
+#define MZ_LZE_DEPTH_FOR_PRESET(p) (((p) >= 0 && (p) <= 3) ? 1u : ((p) == 4 || (p) == 5) ? 4u : ((p) >= 7) ? 16u : 8u)
 typedef struct mz_lz_tok_lds {
     uint16_t head[1 << MZ_DEF_HBITS];
 } mz_lz_tok_lds;
@@ -73,7 +75,7 @@ typedef struct mz_lz_tok_lds {
 /* The chain pass: ONE wave walks a whole stream, 64 positions per step, and leaves in links[p] the position + 1 of the
  * nearest position of an earlier step whose MZ_LZE_FAR_NGRAM bytes hash like those at p (0 = none) -- a hash chain over the
  * whole stream, which is what lets the block parse (one wave per 64 KiB block, in any order) reach back further than
- * the history it can hash itself: it follows links[p], links[links[p] - 1], ... MZ_LZE_FAR_DEPTH deep.  head[]:
+ * the history it can hash itself: it follows links[p], links[links[p] - 1], ... far_depth deep.  head[]:
  * 1 << MZ_LZE_FAR_HBITS words of global scratch.  Occurrences inside the same step of 64 positions are the block
  * parse's own business (its table sees them).  Deterministic: the table takes positions by atomic maximum, and is read
  * where the atomics land. */
@@ -118,9 +120,10 @@ MZ_DEV void mz_lz_chain(const uint8_t *in, uint32_t in_len, uint32_t *links, uin
  * number of tokens written to tok[]: [8:0] match length (0 = literal), [31:9] distance | literal byte.
  * ways / xhead: as in K4 (deflate_core.h) -- the `ways` most recent positions of every hash bucket are tried and the
  * longest match wins; 1 = the fast class (presets 0-3), MZ_DEF_WAYS_BEST = presets 4-9 and the default
- * (mz_strm_lzma.c:81 hands the level to lzma_lzma_preset).  xhead: (ways - 1) more tables behind the wave's LDS. */
+ * (mz_strm_lzma.c:81 hands the level to lzma_lzma_preset).  xhead: (ways - 1) more tables behind the wave's LDS.
+ * far_depth: links of the chain followed per position (MZ_LZE_DEPTH_FOR_PRESET). */
 MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end, uint32_t *tok, mz_lz_tok_lds *L,
-                               uint32_t ways, uint16_t *xhead, const uint32_t *links) {
+                               uint32_t ways, uint16_t *xhead, const uint32_t *links, uint32_t far_depth) {
     MZ_LANE_DECL
     MZ_LANES {
         for (uint32_t i = (uint32_t)lane; i < (1u << MZ_DEF_HBITS) / 2u; i += 64u) ((uint32_t *)L->head)[i] = 0u;
@@ -207,7 +210,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
                 }
                 {
                     uint32_t fc = P(fcand);
-                    for (uint32_t dep = 0; fc && dep < (ways > 1u ? MZ_LZE_FAR_DEPTH : 1u); dep++) {
+                    for (uint32_t dep = 0; fc && dep < far_depth; dep++) {
                         const uint32_t d = pos + 1u - fc;
                         if (d > MZ_LZE_FAR_MAXDIST) break;
                         if (d != dist) {
@@ -217,7 +220,7 @@ MZ_DEV uint32_t mz_lz_tokenize(const uint8_t *in, uint32_t blk, uint32_t blk_end
                                 dist = d;
                             }
                         }
-                        fc = (dep + 1u < (ways > 1u ? MZ_LZE_FAR_DEPTH : 1u)) ? links[fc - 1u] : 0u;
+                        fc = (dep + 1u < far_depth) ? links[fc - 1u] : 0u;
                     }
                 }
             }

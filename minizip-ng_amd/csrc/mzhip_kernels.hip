@@ -447,6 +447,7 @@ struct LzmaEncArgs {
     uint32_t *links;       // chain pass: 4 bytes per input position, laid out like tok; null = no stream of more than one block
     uint32_t *chain_head;  // chain pass: 1 << MZ_LZE_FAR_HBITS words per resident wave of k_lz_chain_batch
     uint32_t skip_blocks;  // blocks in front of every entry that are history only (a stream written in segments): not parsed
+    uint32_t far_depth;    // links of the chain the block parse follows per position (MZ_LZE_DEPTH_FOR_PRESET)
 };
 
 // LZMA encode, pass 0: the chain pass, one wave per method-14 stream of more than one block (lzma_enc_core.h mz_lz_chain)
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(Lzma
             const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
             const uint32_t far = (a.links && len > MZ_DEF_BLOCK && !(a.mode && MZ_UNIFORM((uint32_t)a.mode[e]) != 0u)) ? 1u : 0u;
             nt = mz_lz_tokenize(in, lo, (len - lo < MZ_DEF_BLOCK) ? len : lo + MZ_DEF_BLOCK, a.tok + (size_t)w * MZ_DEF_BLOCK, L,
-                                MZ_UNIFORM(a.ways), xhead, far ? a.links + (size_t)e * a.maxb * MZ_DEF_BLOCK : (const uint32_t *)nullptr);
+                                MZ_UNIFORM(a.ways), xhead, far ? a.links + (size_t)e * a.maxb * MZ_DEF_BLOCK : (const uint32_t *)nullptr,
+                                MZ_UNIFORM(a.far_depth));
         }
         a.ntok[w] = nt; // uniform store
     }

@@ -184,6 +184,12 @@ extern "C" uint32_t emul_xz_lds_bytes(void) { return (uint32_t)sizeof(mz_xz_lds)
 
 #include "lzma_enc_core.h"
 
+/* links of the chain the block parse follows (MZ_LZE_DEPTH_FOR_PRESET of the preset the caller means; 0 = by the class:
+ * the default preset's for four ways, one link for the fast class) */
+static uint32_t g_far_depth = 0;
+extern "C" void emul_set_far_depth(uint32_t d) { g_far_depth = d; }
+static uint32_t far_depth_for(uint32_t ways) { return g_far_depth ? g_far_depth : (ways > 1u ? MZ_LZE_DEPTH_FOR_PRESET(6) : 1u); }
+
 /* mode 0: ZIP method-14 payload; mode 1: raw LZMA2 chunk payload */
 extern "C" int32_t emul_lzma_encode_ways(const uint8_t *in, uint32_t in_len, uint32_t mode, uint32_t ways, uint8_t *out,
                                          uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
@@ -214,7 +220,7 @@ extern "C" int32_t emul_lzma_encode_ways(const uint8_t *in, uint32_t in_len, uin
         memset(T, 0xA5, sizeof(*T));
         memset(xhead, 0xA5, xbytes);
         const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
-        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links);
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links, far_depth_for(ways));
     }
     free(xhead);
     free(links);
@@ -257,7 +263,7 @@ extern "C" int32_t emul_lzma2_chunks_encode(const uint8_t *in, uint32_t in_len, 
         memset(T, 0xA5, sizeof(*T));
         memset(xhead, 0xA5, xbytes);
         const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
-        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links);
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links, far_depth_for(ways));
     }
     free(xhead);
     free(links);
@@ -304,7 +310,7 @@ extern "C" int32_t emul_lzma_encode_resume(const uint8_t *in, uint32_t in_len, u
         memset(T, 0xA5, sizeof(*T));
         memset(xhead, 0xA5, xbytes);
         const uint32_t lo = b * MZ_DEF_BLOCK, hi = (in_len - lo < MZ_DEF_BLOCK) ? in_len : lo + MZ_DEF_BLOCK;
-        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links);
+        ntok[b] = mz_lz_tokenize(in, lo, hi, tok + (size_t)b * MZ_DEF_BLOCK, T, ways, ways > 1u ? xhead : (uint16_t *)0, links, far_depth_for(ways));
     }
     free(xhead);
     free(links);

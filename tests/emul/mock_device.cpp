@@ -306,6 +306,7 @@ MOCK_API int32_t mzhip_lzma_encode_resume_host(const uint8_t *in, uint32_t in_le
                                                uint8_t *out, uint32_t out_cap, uint32_t *out_len) {
     uint32_t ol = 0;
     g_mock_lzma_segments++;
+    emul_set_far_depth(MZ_LZE_DEPTH_FOR_PRESET(preset));
     const int32_t st = emul_lzma_encode_resume(in, in_len, skip_blocks, last, (preset >= 0 && preset <= 3) ? 1u : MZ_DEF_WAYS_BEST,
                                                (const uint32_t *)state_in, (uint32_t *)state_out, (uint16_t *)model, out, out_cap, &ol);
     if (out_len) *out_len = ol;
@@ -331,6 +332,7 @@ MOCK_API int32_t mzhip_xz_encode_host(const uint8_t *, uint32_t, uint8_t *, uint
 MOCK_API int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out, uint32_t out_cap,
                                                uint32_t *out_len, uint32_t *crc) {
     const uint8_t dummy = 0;
+    emul_set_far_depth(MZ_LZE_DEPTH_FOR_PRESET(preset));
     return emul_lzma_encode_ways(in ? in : &dummy, in_len, 0u, (preset >= 0 && preset <= 3) ? 1u : MZ_DEF_WAYS_BEST, out, out_cap, out_len,
                                  crc);
 }

@@ -180,7 +180,13 @@ if which in ("lzmaenc", "all"):
 
     L.mzhip_lzma_encode_batch.restype = C.c_int32
     L.mzhip_lzma_encode_batch.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 4
+    L.mzhip_lzma_encode_batch_preset.restype = C.c_int32
+    L.mzhip_lzma_encode_batch_preset.argtypes = [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 4 + [C.c_uint32, C.c_int32] + [C.c_void_p] * 4
+    import os
+    preset = int(os.environ.get("LZMA_PRESET", "1"))  # 1 = the fast class (what mzhip_lzma_encode_batch runs); 4 / 6 / 9: four candidates, 4 / 8 / 16 links
     for n_unique, n_total, size, tag in ((512, 18432, 65536, "64 KiB entries"), (16, 2304, 1 << 20, "1 MiB entries")):
+        if preset != 1 and size == 65536:
+            continue
         if size == 65536:
             datas = synth.slices(n_unique, size, 1234)
         else:
@@ -192,9 +198,9 @@ if which in ("lzmaenc", "all"):
         out_len, crc, status = (torch.empty(n_total, dtype=torch.int32, device=dev) for _ in range(3))
 
         def run5():
-            assert L.mzhip_lzma_encode_batch(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(), size,
-                                             b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None,
-                                             n_total, out_len.data_ptr(), crc.data_ptr(), status.data_ptr(), None) == 0
+            assert L.mzhip_lzma_encode_batch_preset(b["d_in"].data_ptr(), b["in_off"].data_ptr(), b["in_len"].data_ptr(), size,
+                                                    b["d_out"].data_ptr(), b["out_off"].data_ptr(), b["out_cap"].data_ptr(), None,
+                                                    n_total, preset, out_len.data_ptr(), crc.data_ptr(), status.data_ptr(), None) == 0
         ms = timed(run5, 2)
         want = np.array([zlib.crc32(d) for d in datas], dtype=np.uint32)[idx]
         ol = out_len.cpu().numpy()
@@ -203,8 +209,8 @@ if which in ("lzmaenc", "all"):
         for i in range(0, n_total, 1777):
             z = gpu_util.entry_bytes(b, h, i, int(ol[i]))
             ok = ok and pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == datas[idx[i]]
-        print("LZMA encode (%s): %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.3f  ok=%s" % (
-            tag, n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), ok), flush=True)
+        print("LZMA encode (%s, preset %d): %d x %d B: %.1f ms  %.2f GiB/s in  ratio %.3f  ok=%s" % (
+            tag, preset, n_total, size, ms, n_total * size / 2**30 / (ms / 1e3), ol.sum() / (n_total * size), ok), flush=True)
 
 if which in ("crc", "all"):
     n_total, size = 65536, 65536           # STORE entries: CRC-32 only (mz_crypt_crc32_update over the raw stream)

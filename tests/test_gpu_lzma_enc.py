@@ -94,7 +94,8 @@ def test_host_entry_points(gpu):
 
 def test_preset_selects_the_parse_class(gpu):
     """COMPRESS_LEVEL reaches the encoder as liblzma's preset (mz_strm_lzma.c:81): presets 0-3 = the one-candidate parse,
-    4-9 and the default four candidates + lazy rule -- every stream decodes with liblzma, the default class is smaller."""
+    4-9 and the default four candidates + lazy rule, the chain followed deeper as the preset goes up -- every stream decodes
+    with liblzma, the default class is smaller."""
     L = gpu.mz.lib()
     for f in (L.mzhip_lzma_encode_host_preset, L.mzhip_xz_encode_host_preset):
         f.restype = C.c_int32
@@ -117,7 +118,9 @@ def test_preset_selects_the_parse_class(gpu):
                     assert lzma.decompress(z, format=lzma.FORMAT_XZ) == d
                 tot += len(z)
         sizes[preset] = tot
-    assert sizes[0] == sizes[3] and sizes[4] == sizes[6] == sizes[9] == sizes[-1]
+    # the classes: 0-3 one candidate and one link of the chain; 4-5 four candidates + 4 links, 6 (= the default) 8 links, 7-9 16
+    # links (MZ_LZE_DEPTH_FOR_PRESET) -- the chain only matters for the streams of more than one block (one case of four)
+    assert sizes[0] == sizes[3] and sizes[6] == sizes[-1] and sizes[9] <= sizes[6] <= sizes[4]
     assert sizes[6] < 0.95 * sizes[3]
     # ratio bars against liblzma itself at preset 6.  One 64 KiB piece: the same history for both,
     # what differs is the parse (liblzma prices every choice; K6 = four hash candidates + inheritance + lazy rule).
