@@ -454,6 +454,78 @@ def test_lzma_encode_long_history(emu):
     assert tout <= 0.30 * tin, (tout, tin)
 
 
+def test_lzma_encode_far_fuzz(emu):
+    """Seeded structure fuzz of K6's long-range path (chain pass, links followed 1 / 4 / 8 / 16 deep, 273-byte matches,
+    LZMA2 chunks over one dictionary): inputs made of segments copied from anywhere earlier -- across block boundaries, a few
+    bytes and megabytes back, overlapping themselves -- between runs of text and noise, at sizes around multiples of the
+    64 KiB block.  Every stream must decode with liblzma (method 14 as .lzma, the chunks framed as .xz) to the input."""
+    import lzma as pylzma
+    import random
+
+    emu.emul_lzma_encode_ways.argtypes = [_u8p, C.c_uint32, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    emu.emul_lzma2_chunks_encode.argtypes = [_u8p, C.c_uint32, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32)]
+    emu.emul_set_far_depth.argtypes = [C.c_uint32]
+    text = synth.corpus()
+    rnd = random.Random(41)
+    sizes = [65536, 65537, 131072, 131071, 200000, 3 * 65536 + 5, 1 << 20, (1 << 20) + 70001, 2500000]
+    try:
+        for case, size in enumerate(sizes):
+            buf = bytearray()
+            while len(buf) < size:
+                k = rnd.random()
+                if k < 0.25 or len(buf) < 100:
+                    o = rnd.randrange(len(text) - 3000)
+                    buf += text[o:o + rnd.randrange(1, 3000)]
+                elif k < 0.35:
+                    buf += rnd.randbytes(rnd.randrange(1, 400))
+                elif k < 0.45:
+                    buf += bytes([rnd.randrange(256)]) * rnd.randrange(1, 700)
+                else:                       # a copy from anywhere earlier (it may run into itself: distance < length)
+                    d = rnd.choice([1, 2, 3, 7, 8, 9, 63, 64, 65, 4096, 32768, 32769, 65535, 65536, 65537, 100000, 1 << 20, (1 << 20) + 1,
+                                    rnd.randrange(1, len(buf) + 1)])
+                    d = min(d, len(buf))
+                    n = rnd.choice([2, 3, 4, 5, 7, 8, 16, 64, 272, 273, 274, 600, 5000, rnd.randrange(1, 90000)])
+                    for i in range(n):
+                        buf.append(buf[len(buf) - d])
+            data = bytes(buf[:size])
+            a = np.frombuffer(data, dtype=np.uint8).copy()
+            for ways, depth in ((1, 1), (4, 4), (4, 8), (4, 16)):
+                if size > (1 << 20) and depth not in (1, 8):
+                    continue
+                emu.emul_set_far_depth(depth)
+                out = np.zeros(size + size // 8 + 4096, dtype=np.uint8)
+                ol, crc = C.c_uint32(), C.c_uint32()
+                assert emu.emul_lzma_encode_ways(C.cast(a.ctypes.data, _u8p), size, 0, ways, C.cast(out.ctypes.data, _u8p), len(out), C.byref(ol), C.byref(crc)) == 0
+                z = out[:ol.value].tobytes()
+                assert crc.value == zlib.crc32(data)
+                assert pylzma.decompress(z[4:9] + b"\xff" * 8 + z[9:], format=pylzma.FORMAT_ALONE) == data, (case, size, ways, depth)
+                if depth == 8:
+                    st2, used2, out2, crc2 = _run(emu.emul_lzma, z, size + 64, C.c_int64(-1))          # K3's core on K6's stream
+                    assert (st2, used2, out2) == (0, len(z), data), (case, size)
+            # the same bytes as the LZMA2 chunks of one .xz block
+            emu.emul_set_far_depth(8)
+            nch = (size + 65535) // 65536
+            stride = 65536 + 8192 + 1024
+            outb = np.zeros(nch * stride, dtype=np.uint8)
+            lens = (C.c_uint32 * nch)()
+            st = emu.emul_lzma2_chunks_encode(C.cast(a.ctypes.data, _u8p), size, 4, C.cast(outb.ctypes.data, _u8p), stride, lens)
+            assert st in (0, -200), st
+            body = b""
+            for i in range(nch):
+                piece = data[i * 65536:(i + 1) * 65536]
+                zc = outb[i * stride:i * stride + lens[i]].tobytes()
+                us, cs = len(piece), len(zc)
+                if cs >= us or cs > 65536 or (st != 0 and cs + 16 >= stride):
+                    body += bytes([1 if i == 0 else 2, (us - 1) >> 8, (us - 1) & 255]) + piece
+                else:
+                    body += bytes([(0xE0 if i == 0 else 0xC0) | ((us - 1) >> 16), ((us - 1) >> 8) & 255, (us - 1) & 255, (cs - 1) >> 8, (cs - 1) & 255, 0x5D]) + zc
+            body += b"\x00"
+            filt = [{"id": pylzma.FILTER_LZMA2, "dict_size": 8 << 20}]
+            assert pylzma.decompress(body, format=pylzma.FORMAT_RAW, filters=filt) == data, (case, size)
+    finally:
+        emu.emul_set_far_depth(0)
+
+
 def test_lzma_encode_roundtrip(emu):
     """LZMA encode parity = valid streams that the reference side decodes back to the input: ZIP method-14 payloads
     through the oracle restatement, liblzma (Python's lzma) and -- where built -- the compiled reference; LZMA2 chunk
