@@ -132,7 +132,7 @@ MZ_DEV uint32_t mz_brev32(uint32_t v) {
 /* a function that is NOT inlined gets generic pointers and would address LDS and global memory through flat
  * instructions; so pointers cross the call as integers and are re-made inside in their real address space
  * (infer-address-spaces then rewrites every use) */
-#define MZ_DEV_NOINLINE __device__ __attribute__((noinline))
+#define MZ_DEV_NOINLINE static __device__ __attribute__((noinline))
 #define PVIN(type, name) type name
 typedef uint32_t mz_lds_handle; /* an LDS address is 32 bits */
 typedef uint64_t mz_glb_handle;
