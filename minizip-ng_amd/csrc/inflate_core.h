@@ -6,9 +6,9 @@
  * mz_crypt_crc32_update (mz_zip.c:2049).  Format: doc/zip/appnote.txt:2030-2166.
  *
  * MI355X mapping (not a port of zlib's byte-serial state machine):
- *   - Huffman tables are built by the whole wave (histogram -> canonical first
- *     codes -> ranked symbols -> LDS lookup tables whose 32-bit entries are
- *     ready-made tokens / operand descriptors), see MZ_BUILD_HUFF.
+ *   - Huffman tables are built by the whole wave from code lengths held in registers (a ballot per length gives every
+ *     symbol its rank, two wave scans the first codes -> LDS lookup tables whose 32-bit entries are ready-made tokens /
+ *     operand descriptors), see inflate_tables.inc.
  *   - Two decode front ends:
  *       CHASE WINDOW (inflate_chase.inc = inflate_walk.inc + the chain + inflate_emit.inc; the default for all but what
  *       needs a verdict): the rest of the stream is cut into <= 64 spans of up to 3072 bits, one per lane.  Pass 1: every
@@ -122,7 +122,21 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #endif
 #define MZ_REC_AREA(cap_) (((cap_) / 4u) * 1024u) /* records: 4 bytes a step, four steps of a lane = one 16-byte quad, [quad][lane] (inflate_chase.inc MZ_REC_ADDR) */
 #define MZ_REC_BYTES (MZ_REC_AREA(MZ_REC_CAP1) + MZ_REC_AREA(MZ_REC_CAP2) + 64u * MZ_REC_CAP1 + 64u * MZ_REC_CAP2 + 1024u) /* HBM scratch per wave: records + a byte per step */
-#define MZ_REC_ADDR(quad_, lane_) ((((quad_) * 64u) + (lane_)) << 4) /* where the quad lives inside its area */
+#ifndef MZ_REC_LAYOUT
+#define MZ_REC_LAYOUT 0 /* where quad q (steps 4q .. 4q + 3) of lane l lives inside its area.  0: [quad][lane], a store of the wave is 1 KiB
+                           contiguous, the emit's two 16-byte loads of a group use an eighth of the two 128-byte lines they fetch;
+                           1: a row per lane (the emit's 32 bytes are contiguous and four neighbouring lanes share a line; a store
+                           touches 64 lines); 2 / 3: [pair of quads][lane] / [four quads][lane] */
+#endif
+#if MZ_REC_LAYOUT == 0
+#define MZ_REC_ADDR(cap_, quad_, lane_) ((((quad_) * 64u) + (lane_)) << 4)
+#elif MZ_REC_LAYOUT == 1
+#define MZ_REC_ADDR(cap_, quad_, lane_) ((lane_) * ((cap_) * 4u) + ((quad_) << 4))
+#elif MZ_REC_LAYOUT == 2
+#define MZ_REC_ADDR(cap_, quad_, lane_) ((((((quad_) >> 1) * 64u) + (lane_)) << 5) + (((quad_) & 1u) << 4))
+#else
+#define MZ_REC_ADDR(cap_, quad_, lane_) ((((((quad_) >> 2) * 64u) + (lane_)) << 6) + (((quad_) & 3u) << 4))
+#endif
 #define MZ_CRING_DW 16u /* a power of two: the slot of a stream dword is its index & 15, nothing to keep track of */
 #define MZ_CRING_RS 19u /* row stride: 16 + 2 mirrored, odd */
 #ifndef MZ_EMIT_GROUP
@@ -244,14 +258,9 @@ MZ_DEV uint32_t mz_clc_ent(uint32_t s) { return s << 4; }
 MZ_DEV uint32_t mz_fin_ent(uint32_t e, uint32_t len) { return (e & MZ_E_BAD) ? (len << 16) : e + len; }
 
 /* per-wave LDS scratch */
-typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed and tables are built */
-    uint16_t clc_fast[1 << MZ_CROOT];
-    uint32_t clc_ent[20];
-    uint16_t first[16], count[16], offs[16]; /* canonical first code / population / rank offset per length */
-    uint16_t rank_base[16];
-    uint32_t hist[16];
-    uint8_t cl[320];     /* code lengths of the current block (nlen + ndist <= 316; fixed: 288 + 32) */
-    uint8_t clc_len[20]; /* lengths of the code-length code */
+typedef struct mz_inflate_hdr_scratch { /* live while a block header is parsed (the tables themselves are built from registers: inflate_tables.inc) */
+    uint16_t clc_fast[1 << MZ_CROOT]; /* the code-length code: symbol << 4 | bits at every 7-bit index */
+    uint8_t cl[320];     /* code lengths of the current dynamic block (nlen + ndist <= 316), as the run-length decode leaves them */
 } mz_inflate_hdr_scratch;
 
 typedef struct mz_inflate_body_scratch { /* live while the block body is decoded */
@@ -367,7 +376,7 @@ MZ_DEV uint64_t mz_bits_at(const uint8_t *in, uint32_t in_len, uint32_t bitpos) 
     return w;
 }
 
-/* Branch-free search for a code longer than `root` bits.  With lim[L] = (first[L] + count[L]) << (15 - L)
+/* Branch-free search for a code longer than `root` bits (tables: inflate_tables.inc).  With lim[L] = (first[L] + count[L]) << (15 - L)
  * a 15-bit left-justified stream value v carries a code of length L iff lim[L-1] <= v < lim[L]; its
  * descriptor is ent[delta[L] + (v >> (15 - L))].  Returns descriptor + length, or 0 when no code matches
  * (an unused code of an incomplete set). */
@@ -382,164 +391,6 @@ MZ_DEV uint32_t mz_long_code(uint32_t lo, int root, const uint16_t *lim, const i
     const uint32_t e = ent[ok ? idx : 0u];
     return ok ? e + len : 0u;
 }
-
-/* Build one Huffman decoding table from code lengths cl[0..n) with the whole wave: fast_[] gets
- * ENT_(symbol) + length at every index whose low bits are the (bit-reversed) code, ent_[] gets ENT_(symbol)
- * in canonical order.  Returns (wave-uniform) the number of unused codes `left` (>0 incomplete, <0
- * over-subscribed) and the longest length.  lim_/delta_ (may be NULL) receive the long-code search limits. */
-#define MZ_BUILD_HUFF(left_out, maxlen_out, L_, cl_, n_, fast_, root_, ent_, ENT_, lim_, delta_)               \
-    do {                                                                                                       \
-        mz_inflate_hdr_scratch *_H = &(L_)->u.h;                                                               \
-        uint16_t *_lim = (lim_);                                                                               \
-        int16_t *_dlt = (delta_);                                                                              \
-        MZ_LANES {                                                                                             \
-            if (lane < 16) { _H->hist[lane] = 0; _H->rank_base[lane] = 0; }                                    \
-            for (int _k = lane; _k < (1 << (root_)); _k += 64) (fast_)[_k] = 0;                                \
-        }                                                                                                      \
-        MZ_WAVE_SYNC();                                                                                        \
-        MZ_LANES {                                                                                             \
-            for (int _s = lane; _s < (int)(n_); _s += 64) {                                                    \
-                uint32_t _l = (cl_)[_s];                                                                       \
-                if (_l) MZ_LDS_ATOMIC_INC(&_H->hist[_l]);                                                      \
-            }                                                                                                  \
-        }                                                                                                      \
-        MZ_WAVE_SYNC();                                                                                        \
-        int32_t _left = 1, _over = 0;                                                                          \
-        uint32_t _code = 0, _off = 0, _max = 0;                                                                \
-        for (int _l = 1; _l <= 15; _l++) {                                                                     \
-            uint32_t _c = MZ_UNIFORM(_H->hist[_l]);                                                            \
-            _left = (_left << 1) - (int32_t)_c;                                                                \
-            if (_left < 0) _over = 1;                                                                          \
-            MZ_LANES { /* uniform stores: every lane writes the same value (no lane-0 branch) */              \
-                _H->first[_l] = (uint16_t)_code;                                                               \
-                _H->count[_l] = (uint16_t)_c;                                                                  \
-                _H->offs[_l] = (uint16_t)_off;                                                                 \
-                if (_lim) {                                                                                    \
-                    _lim[_l] = (uint16_t)((_code + _c) << (15 - _l));                                          \
-                    _dlt[_l] = (int16_t)((int32_t)_off - (int32_t)_code);                                      \
-                }                                                                                              \
-            }                                                                                                  \
-            _code = (_code + _c) << 1;                                                                         \
-            _off += _c;                                                                                        \
-            if (_c) _max = (uint32_t)_l;                                                                       \
-        }                                                                                                      \
-        MZ_WAVE_SYNC();                                                                                        \
-        if (!_over) {                                                                                          \
-            for (int _base = 0; _base < (int)(n_); _base += 64) {                                              \
-                PV(uint32_t, _len);                                                                            \
-                PV(uint32_t, _rank);                                                                           \
-                MZ_LANES {                                                                                     \
-                    int _s = _base + lane;                                                                     \
-                    P(_len) = (_s < (int)(n_)) ? (cl_)[_s] : 0u;                                               \
-                    P(_rank) = 0;                                                                              \
-                }                                                                                              \
-                uint64_t _pending;                                                                             \
-                MZ_BALLOT(_pending, P(_len) != 0);                                                             \
-                while (_pending) {                                                                             \
-                    uint32_t _t = mz_ctz64(_pending);                                                          \
-                    uint32_t _lt = MZ_READLANE(_len, _t);                                                      \
-                    uint64_t _m;                                                                               \
-                    MZ_BALLOT(_m, P(_len) == _lt);                                                             \
-                    uint32_t _rb = MZ_UNIFORM(_H->rank_base[_lt]);                                             \
-                    MZ_LANES {                                                                                 \
-                        if (P(_len) == _lt) P(_rank) = _rb + mz_popc64(_m & ((1ull << lane) - 1));            \
-                        _H->rank_base[_lt] = (uint16_t)(_rb + mz_popc64(_m)); /* uniform store */              \
-                    }                                                                                          \
-                    MZ_WAVE_SYNC();                                                                            \
-                    _pending &= ~_m;                                                                           \
-                }                                                                                              \
-                MZ_LANES {                                                                                     \
-                    uint32_t _l = P(_len);                                                                     \
-                    if (_l) {                                                                                  \
-                        uint32_t _s = (uint32_t)(_base + lane);                                                \
-                        uint32_t _cd = (uint32_t)_H->first[_l] + P(_rank);                                     \
-                        uint32_t _e = ENT_(_s);                                                                \
-                        (ent_)[_H->offs[_l] + P(_rank)] = _e;                                                  \
-                        if (_l <= (uint32_t)(root_)) {                                                         \
-                            uint32_t _rv = mz_brev32(_cd) >> (32 - _l);                                        \
-                            for (uint32_t _k = _rv; _k < (1u << (root_)); _k += (1u << _l)) (fast_)[_k] = mz_fin_ent(_e, _l); \
-                        }                                                                                      \
-                    }                                                                                          \
-                }                                                                                              \
-            }                                                                                                  \
-        }                                                                                                      \
-        MZ_WAVE_SYNC();                                                                                        \
-        (left_out) = _over ? -1 : _left;                                                                       \
-        (maxlen_out) = _max;                                                                                   \
-    } while (0)
-
-/* Second-level tables for the literal/length codes longer than MZ_LROOT bits (after MZ_BUILD_HUFF, which left
- * the descriptors in canonical order in lit_sub[] and first/count/offs in the header scratch).  Every root index
- * that is the prefix of long codes gets a sub-table of 2^(longest code in the group - root) entries:
- *   A  long symbols (<= 5 per lane, kept in registers) atomicMax their length into the root entry;
- *   B  a prefix sum over the 512 root entries hands out sub-table offsets, root entry <- MZ_E_SUB | off | bits;
- *   C  the sub-tables are filled (shorter codes of a group replicated). */
-#define MZ_BUILD_LIT_SUB(err_out, used_out, L_)                                                                         \
-    do {                                                                                                       \
-        mz_inflate_hdr_scratch *_H = &(L_)->u.h;                                                               \
-        const uint32_t _lo = MZ_UNIFORM(_H->offs[MZ_LROOT + 1]);                                               \
-        const uint32_t _hi = MZ_UNIFORM((uint32_t)_H->offs[15] + _H->count[15]);                               \
-        PV2(uint32_t, _e5, 5);                                                                                 \
-        PV2(uint32_t, _r5, 5); /* bit-reversed code | length << 16; 0 = none */                                \
-        MZ_LANES {                                                                                             \
-            for (int _j = 0; _j < 5; _j++) {                                                                   \
-                const uint32_t _i = _lo + (uint32_t)lane + 64u * (uint32_t)_j;                                 \
-                uint32_t _rv = 0, _e = 0;                                                                      \
-                if (_i < _hi) {                                                                                \
-                    uint32_t _l = MZ_LROOT + 1;                                                                \
-                    for (int _k = MZ_LROOT + 2; _k <= 15; _k++) _l += (_i >= _H->offs[_k]) ? 1u : 0u;          \
-                    const uint32_t _cd = (uint32_t)_H->first[_l] + (_i - _H->offs[_l]);                        \
-                    _rv = (mz_brev32(_cd) >> (32u - _l)) | (_l << 16);                                         \
-                    _e = (L_)->lit_sub[_i];                                                                    \
-                    MZ_LDS_ATOMIC_MAX(&(L_)->lit_fast[_rv & ((1u << MZ_LROOT) - 1)], _l);                      \
-                }                                                                                              \
-                P(_e5)[_j] = _e;                                                                               \
-                P(_r5)[_j] = _rv;                                                                              \
-            }                                                                                                  \
-        }                                                                                                      \
-        MZ_WAVE_SYNC();                                                                                        \
-        PV(uint32_t, _sz);                                                                                     \
-        PV(uint32_t, _szend);                                                                                  \
-        MZ_LANES {                                                                                             \
-            uint32_t _t = 0;                                                                                   \
-            for (int _j = 0; _j < (1 << MZ_LROOT) / 64; _j++) {                                                \
-                const uint32_t _v = (L_)->lit_fast[((1 << MZ_LROOT) / 64) * lane + _j];                        \
-                _t += (_v > MZ_LROOT && _v <= 15u) ? (1u << (_v - MZ_LROOT)) : 0u;                             \
-            }                                                                                                  \
-            P(_sz) = _t;                                                                                       \
-        }                                                                                                      \
-        MZ_INCL_SCAN(_szend, _sz);                                                                             \
-        const uint32_t _total = MZ_READLANE(_szend, 63);                                                       \
-        (err_out) = (_total > MZ_LIT_SUB_ENTRIES) ? 1 : 0;                                                     \
-        (used_out) = _total;                                                                                   \
-        if (!(err_out)) {                                                                                      \
-            MZ_LANES {                                                                                         \
-                for (int _j = lane; _j < MZ_LIT_SUB_ENTRIES; _j += 64) (L_)->lit_sub[_j] = 0u;                 \
-                uint32_t _off = P(_szend) - P(_sz);                                                            \
-                for (int _j = 0; _j < (1 << MZ_LROOT) / 64; _j++) {                                            \
-                    const uint32_t _ix = ((1 << MZ_LROOT) / 64) * lane + _j;                                   \
-                    const uint32_t _v = (L_)->lit_fast[_ix];                                                   \
-                    if (_v > MZ_LROOT && _v <= 15u) {                                                          \
-                        (L_)->lit_fast[_ix] = MZ_E_SUB | (_off << 8) | (_v - MZ_LROOT);                        \
-                        _off += 1u << (_v - MZ_LROOT);                                                         \
-                    }                                                                                          \
-                }                                                                                              \
-            }                                                                                                  \
-            MZ_WAVE_SYNC();                                                                                    \
-            MZ_LANES {                                                                                         \
-                for (int _j = 0; _j < 5; _j++) {                                                               \
-                    const uint32_t _rv = P(_r5)[_j] & 0xFFFFu, _l = P(_r5)[_j] >> 16;                          \
-                    if (_l) {                                                                                  \
-                        const uint32_t _re = (L_)->lit_fast[_rv & ((1u << MZ_LROOT) - 1)];                     \
-                        const uint32_t _of = (_re >> 8) & 0x1FFu, _kb = _re & 7u;                              \
-                        for (uint32_t _t = _rv >> MZ_LROOT; _t < (1u << _kb); _t += 1u << (_l - MZ_LROOT))     \
-                            (L_)->lit_sub[_of + _t] = mz_fin_ent(P(_e5)[_j], _l);                              \
-                    }                                                                                          \
-                }                                                                                              \
-            }                                                                                                  \
-        }                                                                                                      \
-        MZ_WAVE_SYNC();                                                                                        \
-    } while (0)
 
 /* 64 bits of the stream at (uniform) bit position pos_: from the header window hwin (dword hw0 + lane of the stream,
  * bytes outside the input already zero) when the three dwords lie inside it, else from memory -- same value either way */
@@ -1019,30 +870,28 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
             goto finish;
         }
 
-        int32_t left;
-        uint32_t maxlen;
         uint32_t sub_used = MZ_LIT_SUB_ENTRIES; /* second-level entries this block's literal/length code occupies */
+        /* Round 5: the code lengths of the block live in registers from the moment they are known -- P(lr)[k] = the length
+         * of literal/length symbol 64 k + lane, P(dl) = the length of distance symbol `lane` -- and inflate_tables.inc
+         * builds the tables from there (ballots and two wave scans; no histogram, no rank loop through LDS). */
+        PV2(uint32_t, lr, 5);
+        PV(uint32_t, dl);
         if (btype == 1) {
-            /* fixed code, appnote.txt:2050-2059 */
+            /* fixed code, appnote.txt:2050-2059 (286 / 287 and the distance symbols 30 / 31 take part in the code and are
+             * refused when they are met: mz_lit_ent / mz_dist_ent) */
             MZ_LANES {
-                for (int s = lane; s < 288 + 32; s += 64)
-                    L->u.h.cl[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t s = 64u * (uint32_t)k + (uint32_t)lane;
+                    P(lr)[k] = s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 0u;
+                }
+                P(dl) = lane < 32 ? 5u : 0u;
             }
-            MZ_WAVE_SYNC();
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, 288, L->lit_fast, MZ_LROOT, L->lit_sub, mz_lit_ent, (uint16_t *)0,
-                          (int16_t *)0);
-            {
-                int suberr;
-                MZ_BUILD_LIT_SUB(suberr, sub_used, L);
-                (void)suberr; /* the fixed code has no literal/length code longer than 9 bits */
-            }
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + 288, 32, L->dist_fast, MZ_DROOT, L->dist_ent, mz_dist_ent,
-                          L->dist_lim, L->dist_delta);
         } else {
             /* dynamic code, appnote.txt:2060-2106 */
             uint32_t h;
             MZ_HDR_BITS(h, 14);
-            uint32_t nlen = (h & 31u) + 257, ndist = ((h >> 5) & 31u) + 1, ncode = (h >> 10) + 4;
+            const uint32_t nlen = (h & 31u) + 257, ndist = ((h >> 5) & 31u) + 1, ncode = (h >> 10) + 4;
             if (nlen > 286 || ndist > 30) {
                 status = MZHIP_DATA_ERROR; /* too many length or distance symbols */
                 goto finish;
@@ -1051,30 +900,62 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                 status = MZHIP_BUF_ERROR;
                 goto finish;
             }
-            MZ_LANES {
-                if (lane < 19) L->u.h.clc_len[lane] = 0;
-            }
-            MZ_WAVE_SYNC();
-            MZ_LANES {
-                if ((uint32_t)lane < ncode) {
-                    uint64_t w = mz_bits_at(in, in_len, bitpos + 3u * (uint32_t)lane);
-                    L->u.h.clc_len[mz_k_order[lane]] = (uint8_t)((uint32_t)w & 7u);
+            /* the code-length code: lane s < 19 takes the 3-bit field of symbol s out of the (uniform) 57 bits; where a
+             * symbol stands in the transmission order (appnote.txt:2083-2090) is a packed constant, 5 bits a symbol */
+            PV(uint32_t, cl19);
+            {
+                uint64_t w;
+                MZ_HDR_WIN_BITS(w, bitpos);
+                const uint32_t wlo = MZ_UNIFORM((uint32_t)w), whi = MZ_UNIFORM((uint32_t)(w >> 32));
+                const uint64_t wu = ((uint64_t)whi << 32) | wlo;
+                MZ_LANES {
+                    /* position of symbol s in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 */
+                    const uint64_t inv_lo = 3ull | 17ull << 5 | 15ull << 10 | 13ull << 15 | 11ull << 20 | 9ull << 25 | 7ull << 30 | 5ull << 35 |
+                                            4ull << 40 | 6ull << 45 | 8ull << 50 | 10ull << 55;
+                    const uint64_t inv_hi = 12ull | 14ull << 5 | 16ull << 10 | 18ull << 15 | 0ull << 20 | 1ull << 25 | 2ull << 30;
+                    const uint32_t s = (uint32_t)lane;
+                    const uint32_t pos = (uint32_t)((s < 12u ? inv_lo >> (5u * s) : inv_hi >> (5u * ((s - 12u) & 7u)))) & 31u;
+                    P(cl19) = (s < 19u && pos < ncode) ? (uint32_t)(wu >> (3u * (pos & 31u))) & 7u : 0u;
                 }
             }
             bitpos += 3u * ncode;
-            MZ_WAVE_SYNC();
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.clc_len, 19, L->u.h.clc_fast, MZ_CROOT, L->u.h.clc_ent, mz_clc_ent,
-                          (uint16_t *)0, (int16_t *)0);
-            if (left != 0) {
-                status = MZHIP_DATA_ERROR; /* invalid code lengths set */
-                goto finish;
+            PV(uint32_t, clcreg); /* the 128-entry table of the code-length code: entry i in lane i & 63, half i >> 6 (symbol << 4 | bits) */
+            {
+                PV(uint32_t, ccnt);
+                PV(uint32_t, crk);
+                MZ_LANES { P(ccnt) = P(crk) = 0u; }
+#pragma unroll
+                for (uint32_t lg = 1; lg <= 7u; lg++) {
+                    uint64_t m;
+                    MZ_BALLOT(m, P(cl19) == lg);
+                    MZ_LANES {
+                        if (P(cl19) == lg) P(crk) = MZ_RANK_BELOW(m);
+                    }
+                    MZ_WRITELANE_S(ccnt, lg, mz_popc64(m));
+                }
+                PV(uint32_t, cx);
+                PV(uint32_t, clim);
+                PV(uint32_t, cfirst);
+                MZ_LANES { P(cx) = (lane >= 1 && lane <= 7) ? P(ccnt) << (7 - lane) : 0u; }
+                MZ_INCL_SCAN(clim, cx);
+                if (MZ_READLANE(clim, 7) != 128u) {
+                    status = MZHIP_DATA_ERROR; /* invalid code lengths set: over-subscribed or incomplete */
+                    goto finish;
+                }
+                MZ_LANES { P(cfirst) = (P(clim) - P(cx)) >> ((7u - (uint32_t)lane) & 7u); }
+                PV(uint32_t, cf);
+                MZ_GATHER4(cf, cfirst, 4u * P(cl19));
+                MZ_LANES {
+                    const uint32_t l = P(cl19);
+                    if (l) {
+                        const uint32_t rv = mz_brev32(P(cf) + P(crk)) >> (32u - l);
+                        for (uint32_t q = rv; q < (1u << MZ_CROOT); q += 1u << l) L->u.h.clc_fast[q] = (uint16_t)(((uint32_t)lane << 4) | l);
+                    }
+                }
+                MZ_WAVE_SYNC();
+                MZ_LANES { P(clcreg) = (uint32_t)L->u.h.clc_fast[lane] | ((uint32_t)L->u.h.clc_fast[lane + 64] << 16); }
             }
-            /* code lengths: serial by nature (run-length coded), wave-uniform loop
-             * consuming a 64-bit window at a time; the 128-entry code-length-code table sits in a register pair of
-             * halves per lane (entry i in lane i & 63, half i >> 6), so a lookup is a v_readlane, not an LDS round trip */
             MZ_PROF_MARK(0); /* block header up to the code-length code */
-            PV(uint32_t, clcreg);
-            MZ_LANES { P(clcreg) = (uint32_t)L->u.h.clc_fast[lane] | ((uint32_t)L->u.h.clc_fast[lane + 64] << 16); }
             uint32_t idx = 0, prev = 0;
             const uint32_t ntot = nlen + ndist;
 #if MZ_CL_PARALLEL
@@ -1216,30 +1097,16 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                 status = MZHIP_DATA_ERROR; /* invalid code -- missing end-of-block */
                 goto finish;
             }
-            /* incomplete sets are accepted only when the longest code is 1 bit (zlib 1.2.11 inftrees.c);
-             * the distance set may also be empty */
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl, nlen, L->lit_fast, MZ_LROOT, L->lit_sub, mz_lit_ent, (uint16_t *)0,
-                          (int16_t *)0);
-            if (left < 0 || (left > 0 && maxlen != 1)) {
-                status = MZHIP_DATA_ERROR; /* invalid literal/lengths set */
-                goto finish;
-            }
-            {
-                int suberr;
-                MZ_BUILD_LIT_SUB(suberr, sub_used, L);
-                if (suberr) { /* cannot happen for a complete code (zlib enough.c bound) */
-                    status = MZHIP_DATA_ERROR;
-                    goto finish;
+            MZ_LANES {
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t s = 64u * (uint32_t)k + (uint32_t)lane;
+                    P(lr)[k] = s < nlen ? (uint32_t)L->u.h.cl[s] : 0u;
                 }
-            }
-            MZ_BUILD_HUFF(left, maxlen, L, L->u.h.cl + nlen, ndist, L->dist_fast, MZ_DROOT, L->dist_ent, mz_dist_ent,
-                          L->dist_lim, L->dist_delta);
-            if (left < 0 || (left > 0 && maxlen > 1)) {
-                status = MZHIP_DATA_ERROR; /* invalid distances set */
-                goto finish;
+                P(dl) = (uint32_t)lane < ndist ? (uint32_t)L->u.h.cl[nlen + (uint32_t)lane] : 0u;
             }
         }
-
+#include "inflate_tables.inc"
         MZ_PROF_MARK(2); /* decode tables */
         in_header = 0;
         if (resume_at != 0xFFFFFFFFu) { /* taken up inside this block: the tables are back, on to the next token */

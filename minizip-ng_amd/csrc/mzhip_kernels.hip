@@ -53,6 +53,12 @@ extern "C" __attribute__((visibility("default"))) int mzhip_prof_read(unsigned l
     return 0;
 }
 #endif
+/* MZ_WAVE_INDEX.  threadIdx.x >> 6 is the same in all 64 lanes, but to the compiler it is a per-lane value, and so is
+ * everything computed from it: the wave's LDS slice, its record scratch -- and `rec != null`, which K1 asks before every
+ * window.  That one "divergent" branch joined the window path and the step loop at the bottom of the block loop, so every
+ * loop-carried value of mz_inflate_entry (bit cursor, output position, block state) lived in vector registers and all of its
+ * wave-uniform control ran on the vector unit under exec masks (rounds 1 - 4; found with opt -passes='print<uniformity>',
+ * profiles/r5).  Reading the index back through v_readfirstlane keeps that state on the scalar unit. */
 #define MZ_CRC_TAB_BYTES 1024
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const int wave = threadIdx.x >> 6;
+    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX below */
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
     uint8_t *const rec = a.rec ? a.rec + ((size_t)blockIdx.x * MZ_WAVES_PER_WG + (size_t)wave) * MZ_REC_BYTES : nullptr;
     for (;;) {
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256, 4) void k_lzma_slot_batch(LzmaArgs a) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = MZ_UNIFORM(threadIdx.x >> 6); /* see MZ_WAVE_INDEX */
     mz_lzma_lds_s &lds = lds4[wave];
     const size_t wave_id = (size_t)blockIdx.x * 4u + wave;
     for (;;) {
@@ -401,7 +407,7 @@ __device__ __forceinline__ void deflate_batch_body(const DeflateArgs &a) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const int wave = threadIdx.x >> 6;
+    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX below */
     mz_deflate_lds *L = (mz_deflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_DEF_LDS_STRIDE);
     uint16_t *xhead = a.ways > 1u ? (uint16_t *)(smem + MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE + wave * MZ_DEF_XHEAD_BYTES)
                                   : nullptr;
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(64) void k_lz_chain_batch(LzmaEncArgs a) {
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(LzmaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; /* one head table per wave, then (ways - 1) more each */
     MZ_LANE_DECL
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = MZ_UNIFORM(threadIdx.x >> 6); /* see MZ_WAVE_INDEX */
     mz_lz_tok_lds *L = (mz_lz_tok_lds *)smem + wave;
     uint16_t *xhead = a.ways > 1u ? (uint16_t *)(smem + MZ_WAVES_PER_WG * sizeof(mz_lz_tok_lds) + wave * MZ_DEF_XHEAD_BYTES) : (uint16_t *)nullptr;
     const uint32_t items = a.n * a.maxb;
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const int wave = threadIdx.x >> 6;
+    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX below */
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
     uint8_t *const rec = a.rec + ((size_t)blockIdx.x * MZ_WAVES_PER_WG + (size_t)wave) * MZ_REC_BYTES;
     for (;;) {

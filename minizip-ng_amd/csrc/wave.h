@@ -44,7 +44,10 @@ typedef uintptr_t mz_glb_handle;
 #define P(name) name[lane]
 #define MZ_READLANE(name, idx) (name[(idx)])
 #define MZ_WRITELANE(name, idx, val) (name[(idx)] = (val)) /* one wave-uniform value into lane idx */
+#define MZ_WRITELANE_S(name, idx, val) (name[(idx)] = (val)) /* the same where idx and val are known to live in scalar registers */
+#define MZ_RANK_BELOW(m) ((uint32_t)__builtin_popcountll((uint64_t)(m) & ((1ull << lane) - 1ull))) /* set bits of the wave-uniform mask m below this lane (v_mbcnt) */
 #define MZ_UNIFORM(x) (x)
+#define MZ_UNIFORM64(x) (x)
 #define MZ_WAVE_SYNC() ((void)0)
 #define MZ_CHASE_FENCE() ((void)0)
 #define MZ_BALLOT(dst, cond)                         \
@@ -138,11 +141,18 @@ typedef uint32_t mz_lds_handle; /* an LDS address is 32 bits */
 typedef uint64_t mz_glb_handle;
 #define MZ_LDS_HANDLE(p) ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(p))
 #define MZ_GLB_HANDLE(p) ((uint64_t)(uintptr_t)(p))
-#define MZ_LDS_FROM(T, h) ((T *)(__attribute__((address_space(3))) T *)(uintptr_t)(h))
-#define MZ_GLB_FROM(T, h) ((T *)(__attribute__((address_space(1))) T *)(h))
+/* (arguments reach a function that is not inlined in VECTOR registers, and so do its results: to the compiler they differ from
+ * lane to lane, and everything computed from them -- loop counters, branch conditions, base addresses -- would run on the
+ * vector unit under exec masks.  Handles and wave-uniform scalars are therefore read back to scalar registers
+ * (MZ_UNIFORM / MZ_UNIFORM64) on the callee's first line and on the caller's side of the return.) */
+#define MZ_UNIFORM64(x) (((uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)(x) >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x)))
+#define MZ_LDS_FROM(T, h) ((T *)(__attribute__((address_space(3))) T *)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(h)))
+#define MZ_GLB_FROM(T, h) ((T *)(__attribute__((address_space(1))) T *)MZ_UNIFORM64(h))
 #define P(name) name
 #define MZ_READLANE(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
 #define MZ_WRITELANE(name, idx, val) ((name) = ((uint32_t)lane == (uint32_t)(idx)) ? (uint32_t)(val) : (name)) /* a select, not a branch */
+#define MZ_WRITELANE_S(name, idx, val) MZ_WRITELANE(name, idx, val) /* (this clang has no v_writelane builtin: a compare and a select, as above) */
+#define MZ_RANK_BELOW(m) ((uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)((uint64_t)(m) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m), 0u)))
 #define MZ_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 /* orders this wave's memory operations for the compiler; the hardware already
  * executes one wave's LDS (and vector-memory) instructions in issue order. */
