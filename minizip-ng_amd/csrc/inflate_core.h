@@ -122,21 +122,9 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #endif
 #define MZ_REC_AREA(cap_) (((cap_) / 4u) * 1024u) /* records: 4 bytes a step, four steps of a lane = one 16-byte quad, [quad][lane] (inflate_chase.inc MZ_REC_ADDR) */
 #define MZ_REC_BYTES (MZ_REC_AREA(MZ_REC_CAP1) + MZ_REC_AREA(MZ_REC_CAP2) + 64u * MZ_REC_CAP1 + 64u * MZ_REC_CAP2 + 1024u) /* HBM scratch per wave: records + a byte per step */
-#ifndef MZ_REC_LAYOUT
-#define MZ_REC_LAYOUT 0 /* where quad q (steps 4q .. 4q + 3) of lane l lives inside its area.  0: [quad][lane], a store of the wave is 1 KiB
-                           contiguous, the emit's two 16-byte loads of a group use an eighth of the two 128-byte lines they fetch;
-                           1: a row per lane (the emit's 32 bytes are contiguous and four neighbouring lanes share a line; a store
-                           touches 64 lines); 2 / 3: [pair of quads][lane] / [four quads][lane] */
-#endif
-#if MZ_REC_LAYOUT == 0
-#define MZ_REC_ADDR(cap_, quad_, lane_) ((((quad_) * 64u) + (lane_)) << 4)
-#elif MZ_REC_LAYOUT == 1
-#define MZ_REC_ADDR(cap_, quad_, lane_) ((lane_) * ((cap_) * 4u) + ((quad_) << 4))
-#elif MZ_REC_LAYOUT == 2
-#define MZ_REC_ADDR(cap_, quad_, lane_) ((((((quad_) >> 1) * 64u) + (lane_)) << 5) + (((quad_) & 1u) << 4))
-#else
-#define MZ_REC_ADDR(cap_, quad_, lane_) ((((((quad_) >> 2) * 64u) + (lane_)) << 6) + (((quad_) & 3u) << 4))
-#endif
+#define MZ_REC_ADDR(quad_, lane_) ((((quad_) * 64u) + (lane_)) << 4) /* where the quad lives inside its area: [quad][lane], a store of the wave is 1 KiB
+                                                                     contiguous.  (Round 5 timed a row per lane and [2 / 4 quads][lane]: the L2's memory-side
+                                                                     reads fall 7 - 11 %, its writes grow 40 - 60 %, the probe is 0.3 - 7 % slower: profiles/r5/call4_probe.log) */
 #define MZ_CRING_DW 16u /* a power of two: the slot of a stream dword is its index & 15, nothing to keep track of */
 #define MZ_CRING_RS 19u /* row stride: 16 + 2 mirrored, odd */
 #ifndef MZ_EMIT_GROUP

@@ -58,7 +58,10 @@ extern "C" __attribute__((visibility("default"))) int mzhip_prof_read(unsigned l
  * window.  That one "divergent" branch joined the window path and the step loop at the bottom of the block loop, so every
  * loop-carried value of mz_inflate_entry (bit cursor, output position, block state) lived in vector registers and all of its
  * wave-uniform control ran on the vector unit under exec masks (rounds 1 - 4; found with opt -passes='print<uniformity>',
- * profiles/r5).  Reading the index back through v_readfirstlane keeps that state on the scalar unit. */
+ * profiles/r5).  Reading the index back through v_readfirstlane keeps that state on the scalar unit: K1 on 8 KiB entries
+ * +6.5 %, on 64 KiB entries +0.4 %.  Only K1 and its one-block twin do it: the LZMA slot kernel LOSES 6.7 % with a uniform wave
+ * index (config 4 10.38 -> 9.69 GiB/s on one box, profiles/r5/call6_probe.log -- its decisions then go through the CU's one
+ * scalar unit, which round 4 measured as the slower port for it), the DEFLATE encoder does not move. */
 #define MZ_CRC_TAB_BYTES 1024
 #define MZ_LDS_STRIDE ((sizeof(mz_inflate_lds) + 15) & ~(size_t)15)
 #define MZ_NUM_COUNTERS 64
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX below */
+    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX above */
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
     uint8_t *const rec = a.rec ? a.rec + ((size_t)blockIdx.x * MZ_WAVES_PER_WG + (size_t)wave) * MZ_REC_BYTES : nullptr;
     for (;;) {
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, 4) void k_lzma_slot_batch(LzmaArgs a) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const uint32_t wave = MZ_UNIFORM(threadIdx.x >> 6); /* see MZ_WAVE_INDEX */
+    const uint32_t wave = threadIdx.x >> 6; /* (per-lane to the compiler, on purpose: MZ_WAVE_INDEX) */
     mz_lzma_lds_s &lds = lds4[wave];
     const size_t wave_id = (size_t)blockIdx.x * 4u + wave;
     for (;;) {
@@ -407,7 +410,7 @@ __device__ __forceinline__ void deflate_batch_body(const DeflateArgs &a) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX below */
+    const int wave = threadIdx.x >> 6; /* (per-lane to the compiler, on purpose: MZ_WAVE_INDEX) */
     mz_deflate_lds *L = (mz_deflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_DEF_LDS_STRIDE);
     uint16_t *xhead = a.ways > 1u ? (uint16_t *)(smem + MZ_CRC_TAB_BYTES + MZ_WAVES_PER_WG * MZ_DEF_LDS_STRIDE + wave * MZ_DEF_XHEAD_BYTES)
                                   : nullptr;
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(64) void k_lz_chain_batch(LzmaEncArgs a) {
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64) void k_lz_tokenize_batch(LzmaEncArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[]; /* one head table per wave, then (ways - 1) more each */
     MZ_LANE_DECL
-    const uint32_t wave = MZ_UNIFORM(threadIdx.x >> 6); /* see MZ_WAVE_INDEX */
+    const uint32_t wave = threadIdx.x >> 6; /* (per-lane to the compiler, on purpose: MZ_WAVE_INDEX) */
     mz_lz_tok_lds *L = (mz_lz_tok_lds *)smem + wave;
     uint16_t *xhead = a.ways > 1u ? (uint16_t *)(smem + MZ_WAVES_PER_WG * sizeof(mz_lz_tok_lds) + wave * MZ_DEF_XHEAD_BYTES) : (uint16_t *)nullptr;
     const uint32_t items = a.n * a.maxb;
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
     for (int i = threadIdx.x; i < 256; i += blockDim.x) crc_tab[i] = a.tabs->byte_tab[i];
     __syncthreads();
     MZ_LANE_DECL
-    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX below */
+    const int wave = (int)MZ_UNIFORM(threadIdx.x >> 6); /* wave-uniform, and known to be: MZ_WAVE_INDEX above */
     mz_inflate_lds *L = (mz_inflate_lds *)(smem + MZ_CRC_TAB_BYTES + wave * MZ_LDS_STRIDE);
     uint8_t *const rec = a.rec + ((size_t)blockIdx.x * MZ_WAVES_PER_WG + (size_t)wave) * MZ_REC_BYTES;
     for (;;) {
