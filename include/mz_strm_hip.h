@@ -114,6 +114,7 @@ MZHIP_API void mz_crypt_sha_delete(void **handle);
 #define MZH_INTERNAL_ERROR (-104) /* mz.h:33 */
 #define MZH_EXIST_ERROR (-107) /* mz.h:36 */
 #define MZH_SUPPORT_ERROR (-109) /* mz.h:38 */
+#define MZH_HASH_ERROR (-110)    /* mz.h:39 */
 #define MZH_OPEN_ERROR (-111)  /* mz.h:40 */
 #define MZH_CLOSE_ERROR (-112) /* mz.h:41 */
 #define MZH_SEEK_ERROR (-113)  /* mz.h:42 */

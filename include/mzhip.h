@@ -372,6 +372,10 @@ MZHIP_API void mzhip_prime_clear(void);
  * MZHIP_STREAM_GULP in the environment); floors 128 KiB / 32 KiB; 0 = back to the default.  Applies to streams opened
  * afterwards. */
 MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes);
+/* bytes of an entry that mz_stream_lzma WRITE codes per launch once the entry is larger than that (whole 64 KiB blocks, at
+ * least two, at most the default: 8 MiB; 0 = the default, or MZHIP_WRITE_SEGMENT in the environment).  Independent of the READ
+ * window above: what a written stream looks like never depends on a read-side setting. */
+MZHIP_API void mzhip_set_write_segment(int64_t segment_bytes);
 /* Window mode of mz_stream_zlib READ offers every window that starts at a block header to mzhip_inflate_parallel_host first
  * (a wave per DEFLATE block); 0 turns that off (MZHIP_STREAM_PARALLEL=0 in the environment does the same). */
 MZHIP_API void mzhip_set_stream_parallel(int32_t on);

@@ -25,7 +25,7 @@ BATCH_SYMBOLS = [
     "mzhip_prime_mem_multi", "mzhip_shard_bounds", "mzhip_deflate_batch_level", "mzhip_deflate_host_level",
     "mzhip_lzma_encode_batch", "mzhip_lzma_encode_batch_preset", "mzhip_lzma_encode_host_preset", "mzhip_xz_encode_host_preset",
     "mzhip_inflate_resume_batch", "mzhip_inflate_resume_host", "mzhip_inflate_resume_host_seg", "mzhip_inflate_resume_host_seg2", "mzhip_inflate_parallel_host", "mzhip_inflate_large",
-    "mzhip_set_stream_window", "mzhip_set_stream_parallel", "mzhip_window_alloc", "mzhip_window_free", "mzhip_lzma_resume_host", "mzhip_lzma_model_bytes", "mzhip_lzma_encode_resume_host", "mzhip_xz_encode_block_host", "mzhip_xz_encode_finish_host",
+    "mzhip_set_stream_window", "mzhip_set_write_segment", "mzhip_set_stream_parallel", "mzhip_window_alloc", "mzhip_window_free", "mzhip_lzma_resume_host", "mzhip_lzma_model_bytes", "mzhip_lzma_encode_resume_host", "mzhip_xz_encode_block_host", "mzhip_xz_encode_finish_host",
 ]
 
 _u64p, _u32p, _i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)

@@ -284,6 +284,11 @@ static int32_t lz_stream_start(mzhip_lzma *z) {
     uint64_t dict = (uint64_t)z->in[5] | ((uint64_t)z->in[6] << 8) | ((uint64_t)z->in[7] << 16) | ((uint64_t)z->in[8] << 24);
     if (dict < 4096)
         dict = 4096;
+    /* the header's dictionary size is untrusted; no match can reach back further than the entry is long, so an entry of
+     * known size (MZ_STREAM_PROP_TOTAL_OUT_MAX, what mz_zip.c hands every LZMA entry) never keeps more than that: a small
+     * entry that declares 1 GiB costs its own size, not the gigabyte */
+    if (z->max_total_out >= 0 && (uint64_t)z->max_total_out < dict)
+        dict = (uint64_t)z->max_total_out < 4096 ? 4096 : (uint64_t)z->max_total_out;
     dict = (dict + 15) & ~(uint64_t)15;
     if (dict > ((uint64_t)1 << 30))
         return MZH_MEM_ERROR; /* (a dictionary beyond 1 GiB: liblzma would allocate it; this backend does not) */
@@ -369,6 +374,10 @@ static int32_t lz_stream_next(mzhip_lzma *z) {
             if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof) {
                 want_in = z->in_len + mzh_stream_gulp(); /* not one packet's worth of input: more, then again */
                 continue;
+            }
+            if (st == MZHIP_STATUS_BUF_ERROR) { /* the input ended inside a packet: truncation, not corruption (LZMA_BUF_ERROR) */
+                z->s_err = MZHIP_STATUS_BUF_ERROR;
+                return MZH_OK;
             }
             /* no room for one packet in a window: cannot happen (a window is >= 128 KiB) */
             z->s_err = MZHIP_STATUS_DATA_ERROR;
@@ -528,9 +537,23 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
 
 static int32_t base_write(mzhip_stream *base, const void *buf, int32_t size);
 
-/* bytes coded per launch once an entry is larger than that: an eighth of the READ window (8 MiB by default), whole blocks */
+/* bytes coded per launch once an entry is larger than that: 8 MiB by default, whole blocks (mzhip_set_write_segment /
+ * MZHIP_WRITE_SEGMENT; its own knob -- round 4 derived it from the READ window, so a read-side setting changed the bytes a
+ * method-95 stream was written as) */
+static int64_t lz_wseg_bytes; /* 0 = not decided yet; read and written with atomics: streams of several threads ask */
+MZHIP_API void mzhip_set_write_segment(int64_t segment_bytes) {
+    __atomic_store_n(&lz_wseg_bytes, segment_bytes > 0 ? segment_bytes : 0, __ATOMIC_RELAXED);
+}
 static int64_t lz_write_segment(void) {
-    int64_t sgm = (mzh_stream_window() / 8) & ~(int64_t)(LZ_WRITE_BLOCK - 1);
+    int64_t sgm = __atomic_load_n(&lz_wseg_bytes, __ATOMIC_RELAXED);
+    if (!sgm) {
+        const char *e = getenv("MZHIP_WRITE_SEGMENT");
+        sgm = e ? strtoll(e, NULL, 0) : 0;
+        if (sgm <= 0)
+            sgm = 8 << 20;
+        __atomic_store_n(&lz_wseg_bytes, sgm, __ATOMIC_RELAXED);
+    }
+    sgm &= ~(int64_t)(LZ_WRITE_BLOCK - 1);
     if (sgm < 2 * LZ_WRITE_BLOCK)
         sgm = 2 * LZ_WRITE_BLOCK;
     if (sgm > (8 << 20))

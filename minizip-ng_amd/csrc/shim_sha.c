@@ -49,7 +49,12 @@ typedef struct mzhip_sha_s {
     int8_t begun;
     int8_t on_ref;       /* the reference context holds everything presented so far */
     /* while every update() so far was the next piece of one primed entry: */
-    const uint8_t *ent_base, *ent_digest;
+    const uint8_t *ent_base; /* the primed bytes: only read while the slot's epoch is the one recorded below (to_ref) */
+    uint8_t ent_digest[32];  /* the device's digest of the entry, COPIED when the first piece went by: the primed
+                                generation may be gone by the time end() is called (a stream closed early, mzhip_prime_clear,
+                                a caller-owned context), the digest of the bytes that were presented stays what it is */
+    int8_t have_digest;
+    uint32_t ent_slot, ent_epoch; /* the stream slot whose buffers ent_base points into, and its epoch then */
     int64_t ent_usize, ent_seen;
     uint16_t ent_alg;
 } mzhip_sha;
@@ -72,6 +77,9 @@ static int32_t to_ref(mzhip_sha *s) {
         return MZH_OK;
     if (!s->ref)
         return MZH_SUPPORT_ERROR; /* no reference implementation linked in: only primed digests can be answered */
+    /* the primed bytes are only there while the stream that served them has not given its buffers back */
+    if (s->ent_seen > 0 && (!s->ent_base || s->ent_epoch != __atomic_load_n(&mzhip_stream_epoch[s->ent_slot], __ATOMIC_ACQUIRE)))
+        return MZH_HASH_ERROR; /* the bytes that went by cannot be hashed again: the message is lost to this context */
     int64_t pos = 0;
     while (pos < s->ent_seen) {
         const int32_t n = (int32_t)(s->ent_seen - pos < (1 << 20) ? s->ent_seen - pos : (1 << 20));
@@ -81,7 +89,8 @@ static int32_t to_ref(mzhip_sha *s) {
         pos += n;
     }
     s->on_ref = 1;
-    s->ent_base = s->ent_digest = NULL;
+    s->ent_base = NULL;
+    s->have_digest = 0;
     s->ent_seen = 0;
     return MZH_OK;
 }
@@ -94,7 +103,8 @@ void mz_crypt_sha_reset(void *handle) {
         mz_ref_crypt_sha_reset(s->ref);
     s->begun = 0;
     s->on_ref = 0;
-    s->ent_base = s->ent_digest = NULL;
+    s->ent_base = NULL;
+    s->have_digest = 0;
     s->ent_seen = s->ent_usize = 0;
 }
 
@@ -124,7 +134,12 @@ int32_t mz_crypt_sha_update(void *handle, const void *buf, int32_t size) {
         /* the next piece of a primed entry, unchanged since it was served: hashed on the device already */
         h->valid_sha = 0;
         s->ent_base = h->ent_base;
-        s->ent_digest = h->ent_digest;
+        s->ent_slot = h->slot;
+        s->ent_epoch = h->epoch;
+        if (!s->have_digest) {
+            memcpy(s->ent_digest, h->ent_digest, sizeof(s->ent_digest));
+            s->have_digest = 1;
+        }
         s->ent_usize = h->ent_usize;
         s->ent_alg = h->ent_alg;
         s->ent_seen += size;
@@ -143,7 +158,7 @@ int32_t mz_crypt_sha_end(void *handle, uint8_t *digest, int32_t digest_size) {
         return MZH_PARAM_ERROR;
     if (digest_size < digest_bytes(s->algorithm))
         return MZH_PARAM_ERROR; /* mz_crypt_openssl.c:207-208 */
-    if (!s->on_ref && s->ent_seen > 0 && s->ent_seen == s->ent_usize && s->ent_alg == s->algorithm && s->ent_digest) {
+    if (!s->on_ref && s->ent_seen > 0 && s->ent_seen == s->ent_usize && s->ent_alg == s->algorithm && s->have_digest) {
         memcpy(digest, s->ent_digest, (size_t)digest_bytes(s->algorithm)); /* SHA-1: 20, SHA-256: 32 of the 32 kept */
         (void)__atomic_add_fetch(&g_sha_primed_digests, 1, __ATOMIC_RELAXED);
         return MZH_OK;

@@ -470,18 +470,25 @@ static int64_t mzh_env_bytes(const char *name, int64_t dflt, int64_t floor) {
 }
 MZHIP_API void mzhip_set_stream_window(int64_t window_bytes, int64_t gulp_bytes) {
     /* a window holds at least the 32 KiB history plus something to decode into; 0 = back to the default / environment */
-    mzh_win_bytes = window_bytes > 0 ? (window_bytes < (128 << 10) ? (128 << 10) : window_bytes) : 0;
-    mzh_gulp_bytes = gulp_bytes > 0 ? (gulp_bytes < (32 << 10) ? (32 << 10) : gulp_bytes) : 0;
+    __atomic_store_n(&mzh_win_bytes, window_bytes > 0 ? (window_bytes < (128 << 10) ? (128 << 10) : window_bytes) : 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&mzh_gulp_bytes, gulp_bytes > 0 ? (gulp_bytes < (32 << 10) ? (32 << 10) : gulp_bytes) : 0, __ATOMIC_RELAXED);
 }
+/* (decided lazily by whichever thread asks first; every thread computes the same value, the loads and stores are atomic) */
 int64_t mzh_stream_window(void) {
-    if (!mzh_win_bytes)
-        mzh_win_bytes = mzh_env_bytes("MZHIP_STREAM_WINDOW", MZH_STREAM_WINDOW, 128 << 10);
-    return mzh_win_bytes > 0x7FFFFFFF ? 0x7FFFFFFF : mzh_win_bytes;
+    int64_t v = __atomic_load_n(&mzh_win_bytes, __ATOMIC_RELAXED);
+    if (!v) {
+        v = mzh_env_bytes("MZHIP_STREAM_WINDOW", MZH_STREAM_WINDOW, 128 << 10);
+        __atomic_store_n(&mzh_win_bytes, v, __ATOMIC_RELAXED);
+    }
+    return v > 0x7FFFFFFF ? 0x7FFFFFFF : v;
 }
 int64_t mzh_stream_gulp(void) {
-    if (!mzh_gulp_bytes)
-        mzh_gulp_bytes = mzh_env_bytes("MZHIP_STREAM_GULP", MZH_STREAM_GULP, 32 << 10);
-    return mzh_gulp_bytes;
+    int64_t v = __atomic_load_n(&mzh_gulp_bytes, __ATOMIC_RELAXED);
+    if (!v) {
+        v = mzh_env_bytes("MZHIP_STREAM_GULP", MZH_STREAM_GULP, 32 << 10);
+        __atomic_store_n(&mzh_gulp_bytes, v, __ATOMIC_RELAXED);
+    }
+    return v;
 }
 
 /* One inflate() state per entry is the reference's model and one wave per entry is this backend's; an entry that needs

@@ -316,22 +316,22 @@ def test_lzma_write_in_segments(libs):
 
     hip, ref = libs
     L = hip.L
-    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
-    L.mzhip_set_stream_window.restype = None
+    L.mzhip_set_write_segment.argtypes = [C.c_int64]
+    L.mzhip_set_write_segment.restype = None
     text, _ = synth.bench_corpus()
     d = (text[:450000] + bytes(100000) + text[:300000]) * 2 + bytes(range(256)) * 100
     try:
         for lvl in (1, 6):
-            L.mzhip_set_stream_window(0, 0)
+            L.mzhip_set_write_segment(0)
             z0, i0 = hip.stream_encode(14, d, level=lvl)              # one launch (the entry is smaller than 8 MiB)
-            L.mzhip_set_stream_window(1 << 20, 48 << 10)              # segments of 128 KiB
+            L.mzhip_set_write_segment(128 << 10)                      # segments of 128 KiB
             for chunk in (65535, 1000, 400000):
                 z1, i1 = hip.stream_encode(14, d, level=lvl, chunk=chunk)
                 assert z1 == z0 and i1 == i0, (lvl, chunk, len(z0), len(z1))
             b = ref.stream_decode(14, z1, len(d) + 64, max_in=len(z1), max_out=len(d))
             assert b["out"] == d and b["close"] == 0 and b["error"] == 0, lvl
     finally:
-        L.mzhip_set_stream_window(0, 0)
+        L.mzhip_set_write_segment(0)
 
 
 def test_lzma_stream_parity(libs):

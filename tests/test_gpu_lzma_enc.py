@@ -294,12 +294,12 @@ def test_xz_write_in_blocks_is_read_by_the_reference(gpu):
         pytest.skip("drop-in / reference libraries missing")
     hip, ref = oracle.MzDriver(DROP), oracle.ref()
     L = hip.L
-    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
-    L.mzhip_set_stream_window.restype = None
+    L.mzhip_set_write_segment.argtypes = [C.c_int64]
+    L.mzhip_set_write_segment.restype = None
     text, _ = synth.bench_corpus()
     d = (text[:450000] + bytes(100000) + text[:300000]) * 2 + bytes(range(256)) * 100
     try:
-        L.mzhip_set_stream_window(1 << 20, 48 << 10)                  # segments of 128 KiB: 14 blocks
+        L.mzhip_set_write_segment(128 << 10)                          # segments of 128 KiB: 14 blocks
         for lvl, chunk in ((1, 65535), (6, 1000), (6, 400000)):
             z, info = hip.stream_encode(95, d, level=lvl, chunk=chunk)
             assert info["close"] == 0 and info["total_in"] == len(d) and info["total_out"] == len(z)
@@ -309,4 +309,4 @@ def test_xz_write_in_blocks_is_read_by_the_reference(gpu):
             a = hip.stream_decode(95, z, len(d) + 64)                 # ... and the .xz kernel of this backend
             assert a["out"] == d and a["close"] == 0 and a["error"] == 0
     finally:
-        L.mzhip_set_stream_window(0, 0)
+        L.mzhip_set_write_segment(0)
