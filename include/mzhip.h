@@ -93,27 +93,41 @@ MZHIP_API int32_t mzhip_inflate_resume_batch(const void *d_in, const uint64_t *d
                                              const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,
                                              uint32_t *d_out_len, uint32_t *d_in_used, uint32_t *d_crc, int32_t *d_status,
                                              const mzhip_inflate_state *d_resume, mzhip_inflate_state *d_stop, void *stream);
-/* one window of one stream through host buffers: buf[0 .. state_in->out_pos) = history, new bytes behind it, buf_cap
- * bytes in all; *out_len = bytes valid in buf, *crc = CRC-32 of the NEW bytes.  Returns the device verdict. */
-MZHIP_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
-                                            const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
-                                            uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
-/* ... and the CRC-32 of the new bytes in the pieces a caller hands on to a checksum (mz_zip_entry_read ->
- * mz_crypt_crc32_update, 65 535 bytes per call, mz_zip_rw.c:55): the first seg_first new bytes (what completes the piece
- * the previous window left open; 0 = none), then seg_stride at a time, then the rest.  seg_crc[0 .. *nseg) from the
- * device's copy of the window, one launch; *nseg = 0 when seg_cap is too small (the window itself is still valid). */
-MZHIP_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
-                                                const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
-                                                uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t seg_first,
-                                                uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg);
+/* ---- ONE raw-DEFLATE entry, or one window of it, through host buffers (H2D + kernel + D2H, synchronous): what the
+ * mz_stream_zlib READ shim calls.  One entry point with an args struct: `size` = sizeof(mzhip_inflate_host_args) as the
+ * caller was compiled, so fields can be appended without a new symbol.  (Round 5 folded mzhip_inflate_host, _host2,
+ * _resume_host, _resume_host_seg and _resume_host_seg2 into this one.)
+ *   whole entry   state_in = state_out = NULL: in[0 .. in_len) is the stream, buf[0 .. buf_cap) takes its bytes;
+ *   one window    state_out != NULL (state_in = NULL or flags bit 0 clear: the start of the stream): buf[0 ..
+ *                 state_in->out_pos) is the history the caller kept (the last 32 KiB it was given), the new bytes land
+ *                 behind it, buf_cap bytes in all; the verdict is MZHIP_STATUS_OK (stream end), _OUT_FULL (call again with
+ *                 state_out and the tail of buf as history), _BUF_ERROR (more input from state_out's block header on) or a
+ *                 data error.
+ * Results (any pointer may be NULL): *out_len = bytes valid in buf (history included), *in_used, *crc / *adler = CRC-32 /
+ * Adler-32 of the NEW bytes; and the CRC-32 of the new bytes in the pieces a caller hands on to a checksum
+ * (mz_zip_entry_read -> mz_crypt_crc32_update, 65 535 bytes per call, mz_zip_rw.c:55): the first seg_first new bytes (what
+ * completes the piece the previous window left open; 0 = none), then seg_stride at a time, then the rest -- seg_crc[0 ..
+ * *nseg) from the device's copy of the window; *nseg = 0 when seg_cap is too small (the window itself is still valid).
+ * Returns the device verdict (or an MZ_* error of the runtime). */
+typedef struct mzhip_inflate_host_args {
+    uint32_t size;
+    uint32_t in_len, buf_cap;
+    uint32_t seg_first, seg_stride, seg_cap;
+    const uint8_t *in;
+    uint8_t *buf;
+    const mzhip_inflate_state *state_in;
+    mzhip_inflate_state *state_out;
+    uint32_t *out_len, *in_used, *crc, *adler, *seg_crc, *nseg;
+} mzhip_inflate_host_args;
+MZHIP_API int32_t mzhip_inflate_host(const mzhip_inflate_host_args *a);
 
 /* One window of ONE large entry decoded by as many waves as it holds blocks (replaces the single inflate() state the
  * reference streams an entry of any size through, mz_strm_zlib.c:116-193, where that state is the bottleneck): block
  * headers are searched for at every bit offset, every candidate is parsed by a wave of its own, the chain of blocks that
  * starts at state_in's header is believed, its bytes are produced as a source map and resolved by pointer jumping
- * (csrc/inflate_parallel.inc).  Same buffers as mzhip_inflate_resume_host_seg; state_in must stand at a block header
+ * (csrc/inflate_parallel.inc).  Same buffers as a window of mzhip_inflate_host; state_in must stand at a block header
  * (bit == hdr_bit; NULL = the start of the stream).  Returns 0 with *blocks = blocks decoded (0: nothing a wave of its own
- * could take -- go on with mzhip_inflate_resume_host_seg, flags bit 1 makes it stop at the next block header), *out_len =
+ * could take -- go on with mzhip_inflate_host, flags bit 1 makes it stop at the next block header), *out_len =
  * bytes valid in buf, *ended = the final block was among them, state_out = the header of the first block not decoded;
  * *crc / *adler (either may be NULL) = CRC-32 / Adler-32 of the new bytes (what the gzip / zlib trailers run over). */
 MZHIP_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
@@ -128,13 +142,6 @@ MZHIP_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len
  * mzhip_prime_* routes entries of 4 MiB and more of compressed bytes through. */
 MZHIP_API int32_t mzhip_inflate_large(const void *d_in, uint32_t in_len, void *d_out, uint32_t out_cap, uint32_t *out_len,
                                       uint32_t *in_used, uint32_t *crc, int32_t *status, void *stream);
-
-/* mzhip_inflate_resume_host_seg plus the Adler-32 of the new bytes (NULL: not wanted) */
-MZHIP_API int32_t mzhip_inflate_resume_host_seg2(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
-                                                 const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out,
-                                                 uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t *adler,
-                                                 uint32_t seg_first, uint32_t seg_stride, uint32_t *seg_crc, uint32_t seg_cap,
-                                                 uint32_t *nseg);
 
 MZHIP_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *d_in_off, const uint32_t *d_in_len,
                                       void *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap, uint32_t n,
@@ -240,9 +247,7 @@ MZHIP_API int32_t mzhip_lzma_encode_batch_preset(const void *d_in, const uint64_
                                                  uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream);
 
 /* Host-buffer conveniences (H2D + kernel + D2H, synchronous); these are what the
- * vtbl shim uses for one-entry-at-a-time callers. */
-MZHIP_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
-                                     uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
+ * vtbl shims use for one-entry-at-a-time callers (raw DEFLATE: mzhip_inflate_host / mzhip_deflate_host above / below). */
 MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                   uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
@@ -302,17 +307,20 @@ MZHIP_API int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_l
                                                 uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out,
                                               uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
-/* one segment of a stream: 64 KiB pieces, the last one final iff `final`; *crc = CRC-32 of `in` */
-MZHIP_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
-                                     uint32_t out_cap, uint32_t *out_len, uint32_t *crc);
-/* the same two with the Adler-32 (of the decoded bytes / of `in`) the zlib wrapper needs; adler may be NULL */
-MZHIP_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap,
-                                      uint32_t *out_len, uint32_t *in_used, uint32_t *crc, uint32_t *adler);
-MZHIP_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out,
-                                      uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler);
-/* ... at a compression level (see mzhip_deflate_batch_level); what mz_stream_zlib_write / _close use */
-MZHIP_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level,
-                                           int32_t window_log2, uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler);
+/* ONE segment of a raw-DEFLATE stream through host buffers (what mz_stream_zlib_write / _close call): 64 KiB pieces, one
+ * wave each, every piece but the last closed on a byte boundary, the last one final iff `final`; `level` / `window_log2` as
+ * mzhip_deflate_batch_level (COMPRESS_LEVEL, mz_strm_zlib.c:87,339-343: levels 0 .. 3 are one class; window_log2 0 = 15); *crc / *adler (either
+ * may be NULL) = CRC-32 / Adler-32 of `in`.  `size` = sizeof(mzhip_deflate_host_args) as the caller was compiled.  (Round 5
+ * folded mzhip_deflate_host, _host2 and _host_level into this one.) */
+typedef struct mzhip_deflate_host_args {
+    uint32_t size;
+    uint32_t in_len, final, out_cap;
+    int32_t level, window_log2;
+    const uint8_t *in;
+    uint8_t *out;
+    uint32_t *out_len, *crc, *adler;
+} mzhip_deflate_host_args;
+MZHIP_API int32_t mzhip_deflate_host(const mzhip_deflate_host_args *a);
 /* mz_crypt_crc32_update on a host buffer (mz_crypt.c:35-92: chaining value in, chaining value out).  Buffers of
  * MZHIP_CRC_HOST_BELOW bytes or more are reduced on the device (K2); smaller ones -- the reference calls the symbol
  * per byte from mz_strm_pkcrypt.c:79,86 -- are folded on the host with the same generated tables.  Never aborts: if

@@ -14,21 +14,74 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MZHIP_LIB") or os.path.join(_HERE, "_build", "libmzhip.so")  # env: tuning builds only
 
-# symbols include/mzhip.h and include/mz_strm_hip.h declare (checked by tests/test_abi.py)
-BATCH_SYMBOLS = [
-    "mzhip_device_count", "mzhip_init", "mzhip_last_error", "mzhip_version", "mzhip_inflate_batch",
-    "mzhip_crc32_batch", "mzhip_adler32_batch", "mzhip_lzma_batch", "mzhip_xz_batch", "mzhip_deflate_batch",
-    "mzhip_sha_batch", "mzhip_inflate_host", "mzhip_inflate_host2", "mzhip_lzma_host", "mzhip_xz_host",
-    "mzhip_deflate_host", "mzhip_deflate_host2", "mzhip_crc32_host", "mzhip_inflate_launch_geometry",
-    "mzhip_zip_index_mem", "mzhip_prime_file", "mzhip_prime_mem", "mzhip_prime_mem_begin", "mzhip_prime_wait", "mzhip_device_local_cpus", "mzhip_bind_thread_near_device", "mzhip_prime_clear", "mzhip_prime_stats",
-    "mzhip_prime_write", "mzhip_prime_write_clear", "mzhip_prime_write_stats", "mzhip_prime_file_multi",
-    "mzhip_prime_mem_multi", "mzhip_shard_bounds", "mzhip_deflate_batch_level", "mzhip_deflate_host_level",
-    "mzhip_lzma_encode_batch", "mzhip_lzma_encode_batch_preset", "mzhip_lzma_encode_host_preset", "mzhip_xz_encode_host_preset",
-    "mzhip_inflate_resume_batch", "mzhip_inflate_resume_host", "mzhip_inflate_resume_host_seg", "mzhip_inflate_resume_host_seg2", "mzhip_inflate_parallel_host", "mzhip_inflate_large",
-    "mzhip_set_stream_window", "mzhip_set_write_segment", "mzhip_set_stream_parallel", "mzhip_window_alloc", "mzhip_window_free", "mzhip_lzma_resume_host", "mzhip_lzma_model_bytes", "mzhip_lzma_encode_resume_host", "mzhip_xz_encode_block_host", "mzhip_xz_encode_finish_host",
-]
 
 _u64p, _u32p, _i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "mzhip.h")
+
+
+class InflateState(C.Structure):
+    """include/mzhip.h mzhip_inflate_state"""
+    _fields_ = [("hdr_bit", C.c_uint32), ("bit", C.c_uint32), ("out_pos", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class InflateHostArgs(C.Structure):
+    """include/mzhip.h mzhip_inflate_host_args (tests/test_abi.py checks the layout against the header's text)"""
+    _fields_ = [("size", C.c_uint32), ("in_len", C.c_uint32), ("buf_cap", C.c_uint32), ("seg_first", C.c_uint32),
+                ("seg_stride", C.c_uint32), ("seg_cap", C.c_uint32), ("in_", C.c_void_p), ("buf", C.c_void_p),
+                ("state_in", C.c_void_p), ("state_out", C.c_void_p), ("out_len", C.c_void_p), ("in_used", C.c_void_p),
+                ("crc", C.c_void_p), ("adler", C.c_void_p), ("seg_crc", C.c_void_p), ("nseg", C.c_void_p)]
+
+
+class DeflateHostArgs(C.Structure):
+    """include/mzhip.h mzhip_deflate_host_args"""
+    _fields_ = [("size", C.c_uint32), ("in_len", C.c_uint32), ("final", C.c_uint32), ("out_cap", C.c_uint32),
+                ("level", C.c_int32), ("window_log2", C.c_int32), ("in_", C.c_void_p), ("out", C.c_void_p),
+                ("out_len", C.c_void_p), ("crc", C.c_void_p), ("adler", C.c_void_p)]
+
+
+_SCALARS = {"int32_t": C.c_int32, "uint32_t": C.c_uint32, "int64_t": C.c_int64, "uint64_t": C.c_uint64, "size_t": C.c_size_t,
+            "int": C.c_int, "uint16_t": C.c_uint16, "uint8_t": C.c_uint8}
+
+
+def header_prototypes(path=None):
+    """{name: (restype, [argtypes])} of every MZHIP_API function include/mzhip.h declares -- the ONE source of the ctypes
+    signatures (round 4 lost a GPU suite to a hand-written argtypes list that lagged the header by two arguments).  Every
+    pointer becomes c_void_p (bytes, integers, byref() and ctypes arrays all pass), every scalar its fixed-width type."""
+    import re
+
+    text = open(path or HEADER).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"MZHIP_API\s+([^;{}()]+?)\b(mzhip_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+
+        def ctype(decl, is_ret=False):
+            decl = decl.strip()
+            if "*" in decl:
+                return C.c_char_p if is_ret and "char" in decl else C.c_void_p
+            words = [w for w in decl.replace("const", " ").split() if w]
+            base = words[0] if is_ret or len(words) == 1 else words[-2] if len(words) >= 2 else words[0]
+            if base == "void":
+                return None
+            return _SCALARS[base]
+
+        argt = [] if args in ("", "void") else [ctype(a) for a in args.split(",")]
+        out[name] = (ctype(ret, True), argt)
+    return out
+
+
+# every function include/mzhip.h declares (tests/test_abi.py checks that the library exports them all)
+BATCH_SYMBOLS = sorted(header_prototypes())
+
+
+def bind(L, path=None):
+    """restype / argtypes of every function the header declares, on a loaded library (libmzhip.so, the drop-in, the mock)"""
+    for name, (ret, argt) in header_prototypes(path).items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.restype = ret
+            fn.argtypes = argt
+    return L
 
 
 class MzHipError(RuntimeError):
@@ -54,23 +107,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MzHipError("%s missing: run __graft_entry__.build() / make -C minizip-ng_amd/csrc" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
-        L.mzhip_last_error.restype = C.c_char_p
-        L.mzhip_version.restype = C.c_char_p
-        L.mzhip_inflate_batch.restype = C.c_int32
-        L.mzhip_inflate_batch.argtypes = [C.c_void_p] * 11 + [C.c_void_p]
-        L.mzhip_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.mzhip_crc32_batch.restype = C.c_int32
-        L.mzhip_crc32_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
-                                        C.c_void_p]
-        L.mzhip_inflate_host.restype = C.c_int32
-        L.mzhip_inflate_host.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint32, _u32p, _u32p, _u32p]
-        L.mzhip_crc32_host.restype = C.c_uint32
-        L.mzhip_crc32_host.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]
-        L.mzhip_inflate_launch_geometry.restype = None
-        L.mzhip_inflate_launch_geometry.argtypes = [C.c_uint32, _u32p, _u32p, _u32p]
-        _lib = L
+        _lib = bind(C.CDLL(LIB_PATH))  # every signature from include/mzhip.h
     return _lib
 
 
@@ -138,8 +175,11 @@ def inflate_host(data, out_cap):
     """One entry through the host-buffer convenience entry point -> (status, in_used, out bytes, crc)."""
     require_gpu()
     out = C.create_string_buffer(max(out_cap, 1))
+    src = C.create_string_buffer(bytes(data), max(len(data), 1))
     ol, iu, crc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
-    st = lib().mzhip_inflate_host(bytes(data), len(data), out, out_cap, C.byref(ol), C.byref(iu), C.byref(crc))
+    a = InflateHostArgs(size=C.sizeof(InflateHostArgs), in_len=len(data), buf_cap=out_cap, in_=C.addressof(src), buf=C.addressof(out),
+                        out_len=C.addressof(ol), in_used=C.addressof(iu), crc=C.addressof(crc))
+    st = lib().mzhip_inflate_host(C.byref(a))
     return int(st), int(iu.value), out.raw[: ol.value], int(crc.value)
 
 

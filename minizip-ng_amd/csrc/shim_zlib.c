@@ -531,7 +531,7 @@ static int32_t stream_drop_input(mzhip_zlib *z) {
     return 0;
 }
 
-/* the pieces of one decode call: the same cut as mzhip_inflate_resume_host_seg makes (first, stride ..., rest) */
+/* the pieces of one decode call: the same cut as a window of mzhip_inflate_host makes (first, stride ..., rest) */
 static void stream_pieces_add(mzhip_zlib *z, int64_t g, int64_t nbytes, uint32_t first, uint32_t stride, uint32_t nseg) {
     if (nbytes <= 0 || !stride)
         return;
@@ -743,9 +743,25 @@ static int32_t stream_next(mzhip_zlib *z) {
             z->sst.flags |= 2u; /* stop at the next block header: the many-wave decode goes on from there */
         const double ts0 = mzh_now();
         uint32_t adler = 1;
-        int32_t st = mzhip_inflate_resume_host_seg2(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, &nst, &out_len,
-                                                    &in_used, &crc, z->wrap == 1 ? &adler : NULL, seg_first, z->pc_tmp_cap ? stride : 0u,
-                                                    z->pc_tmp, (uint32_t)z->pc_tmp_cap, &nseg);
+        mzhip_inflate_host_args wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.size = (uint32_t)sizeof(wa);
+        wa.in = z->in;
+        wa.in_len = (uint32_t)z->in_len;
+        wa.buf = z->out;
+        wa.buf_cap = (uint32_t)z->out_cap;
+        wa.state_in = &z->sst;
+        wa.state_out = &nst;
+        wa.out_len = &out_len;
+        wa.in_used = &in_used;
+        wa.crc = &crc;
+        wa.adler = z->wrap == 1 ? &adler : NULL;
+        wa.seg_first = seg_first;
+        wa.seg_stride = z->pc_tmp_cap ? stride : 0u;
+        wa.seg_crc = z->pc_tmp;
+        wa.seg_cap = (uint32_t)z->pc_tmp_cap;
+        wa.nseg = &nseg;
+        int32_t st = mzhip_inflate_host(&wa);
         z->t_serial += mzh_now() - ts0;
         z->n_serial++;
         if (out_len > (uint32_t)z->out_len) {
@@ -765,8 +781,11 @@ static int32_t stream_next(mzhip_zlib *z) {
                 return 0; /* serve first; the next call slides the window and comes back here */
             z->sst.out_pos = (uint32_t)z->out_len;
             z->sst.flags = 1;
-            st = mzhip_inflate_resume_host_seg2(z->in, (uint32_t)z->in_len, z->out, (uint32_t)z->out_cap, &z->sst, NULL, &out_len,
-                                                &in_used, &crc, z->wrap == 1 ? &adler : NULL, 0, 0, NULL, 0, NULL);
+            wa.in_len = (uint32_t)z->in_len; /* (stream_drop_input moved the input) */
+            wa.state_out = NULL;
+            wa.seg_first = wa.seg_stride = wa.seg_cap = 0;
+            wa.seg_crc = wa.nseg = NULL;
+            st = mzhip_inflate_host(&wa);
             if (st == MZHIP_STATUS_OK || st == MZHIP_STATUS_BUF_ERROR || st == MZHIP_STATUS_DATA_ERROR) {
                 stream_sum(z, (int64_t)out_len - z->out_len, crc, adler);
                 z->out_len = out_len;
@@ -839,9 +858,18 @@ static int32_t attempt_decode(mzhip_zlib *z) {
                 return MZH_MEM_ERROR;
         }
         uint32_t out_len = 0, in_used = 0;
-        int32_t st = mzhip_inflate_host2(z->in + z->hdr_len, (uint32_t)(z->in_len - z->hdr_len), z->out,
-                                         (uint32_t)z->out_cap, &out_len, &in_used, &z->out_crc,
-                                         z->wrap == 1 ? &z->out_adler : NULL);
+        mzhip_inflate_host_args ea; /* the whole entry at once: no states */
+        memset(&ea, 0, sizeof(ea));
+        ea.size = (uint32_t)sizeof(ea);
+        ea.in = z->in + z->hdr_len;
+        ea.in_len = (uint32_t)(z->in_len - z->hdr_len);
+        ea.buf = z->out;
+        ea.buf_cap = (uint32_t)z->out_cap;
+        ea.out_len = &out_len;
+        ea.in_used = &in_used;
+        ea.crc = &z->out_crc;
+        ea.adler = z->wrap == 1 ? &z->out_adler : NULL;
+        int32_t st = mzhip_inflate_host(&ea);
         int32_t early = 0;
         const int64_t early_out = MZH_STREAM_EARLY_OUT < mzh_stream_window() ? MZH_STREAM_EARLY_OUT : mzh_stream_window();
         if (mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
@@ -1114,8 +1142,20 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
     if (!out)
         return MZH_MEM_ERROR;
     uint32_t out_len = 0, crc = 0, adler = 1;
-    int32_t st = mzhip_deflate_host_level(z->wbuf, (uint32_t)z->wlen, (uint32_t)final, z->level, z->wlog, out, cap, &out_len,
-                                          &crc, z->wrap == 1 ? &adler : NULL); /* level and window as mz_strm_zlib.c:87 hands them on */
+    mzhip_deflate_host_args da; /* level and window as mz_strm_zlib.c:87 hands them on */
+    memset(&da, 0, sizeof(da));
+    da.size = (uint32_t)sizeof(da);
+    da.in = z->wbuf;
+    da.in_len = (uint32_t)z->wlen;
+    da.final = (uint32_t)final;
+    da.level = z->level;
+    da.window_log2 = z->wlog;
+    da.out = out;
+    da.out_cap = cap;
+    da.out_len = &out_len;
+    da.crc = &crc;
+    da.adler = z->wrap == 1 ? &adler : NULL;
+    int32_t st = mzhip_deflate_host(&da);
     if (st != 0) {
         free(out);
         z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */

@@ -17,8 +17,8 @@ MOCK_API int32_t mzhip_init(int32_t) { return 0; }
 MOCK_API const char *mzhip_last_error(void) { return ""; }
 MOCK_API const char *mzhip_version(void) { return "mock (host emulation of the device cores)"; }
 
-MOCK_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
-                                     uint32_t *in_used, uint32_t *crc, uint32_t *adler) {
+static int32_t mock_inflate_whole(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
+                                  uint32_t *in_used, uint32_t *crc, uint32_t *adler) {
     uint32_t ol = 0, iu = 0, k = 0;
     const uint8_t dummy = 0;
     const int32_t st = emul_inflate(in ? in : &dummy, in_len, out, out_cap, &ol, &iu, &k);
@@ -28,9 +28,9 @@ MOCK_API int32_t mzhip_inflate_host2(const uint8_t *in, uint32_t in_len, uint8_t
     if (adler) *adler = emul_adler32(out, ol);
     return st;
 }
-MOCK_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
-                                           const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
-                                           uint32_t *in_used, uint32_t *crc) {
+static int32_t mock_inflate_resume(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                   const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                   uint32_t *in_used, uint32_t *crc) {
     uint32_t ol = 0, iu = 0, k = 0;
     const uint8_t dummy = 0;
     const int32_t st = emul_inflate_resume(in ? in : &dummy, in_len, buf, buf_cap, (const uint32_t *)state_in, (uint32_t *)state_out, &ol,
@@ -43,13 +43,13 @@ MOCK_API int32_t mzhip_inflate_resume_host(const uint8_t *in, uint32_t in_len, u
 // ... with the CRCs of the new bytes in the caller's pieces (the device does this with one k_crc32_batch launch)
 static int g_mock_seg_calls = 0;
 MOCK_API int mzmock_seg_calls(void) { return g_mock_seg_calls; }
-MOCK_API int32_t mzhip_inflate_resume_host_seg2(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
-                                                const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
-                                                uint32_t *in_used, uint32_t *crc, uint32_t *adler, uint32_t seg_first, uint32_t seg_stride,
-                                                uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
+static int32_t mock_inflate_window(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
+                                   const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
+                                   uint32_t *in_used, uint32_t *crc, uint32_t *adler, uint32_t seg_first, uint32_t seg_stride,
+                                   uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
     const uint32_t hist = state_in ? state_in->out_pos : 0u;
     uint32_t ol = 0;
-    const int32_t st = mzhip_inflate_resume_host(in, in_len, buf, buf_cap, state_in, state_out, &ol, in_used, crc);
+    const int32_t st = mock_inflate_resume(in, in_len, buf, buf_cap, state_in, state_out, &ol, in_used, crc);
     if (out_len) *out_len = ol;
     if (nseg) *nseg = 0;
     if (adler) *adler = ol > hist ? emul_adler32(buf + hist, ol - hist) : 1u;
@@ -73,16 +73,18 @@ MOCK_API int32_t mzhip_inflate_resume_host_seg2(const uint8_t *in, uint32_t in_l
     }
     return st;
 }
-MOCK_API int32_t mzhip_inflate_resume_host_seg(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
-                                               const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
-                                               uint32_t *in_used, uint32_t *crc, uint32_t seg_first, uint32_t seg_stride,
-                                               uint32_t *seg_crc, uint32_t seg_cap, uint32_t *nseg) {
-    return mzhip_inflate_resume_host_seg2(in, in_len, buf, buf_cap, state_in, state_out, out_len, in_used, crc, nullptr, seg_first, seg_stride,
-                                          seg_crc, seg_cap, nseg);
-}
-MOCK_API int32_t mzhip_inflate_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,
-                                    uint32_t *in_used, uint32_t *crc) {
-    return mzhip_inflate_host2(in, in_len, out, out_cap, out_len, in_used, crc, nullptr);
+// include/mzhip.h: a whole entry (no states) or one window of it, one entry point
+MOCK_API int32_t mzhip_inflate_host(const mzhip_inflate_host_args *ap) {
+    if (!ap || ap->size < offsetof(mzhip_inflate_host_args, buf) + sizeof(void *)) return -102;
+    mzhip_inflate_host_args a;
+    memset(&a, 0, sizeof(a));
+    memcpy(&a, ap, ap->size < sizeof(a) ? ap->size : sizeof(a));
+    if (!a.state_in && !a.state_out) {
+        if (a.nseg) *a.nseg = 0;
+        return mock_inflate_whole(a.in, a.in_len, a.buf, a.buf_cap, a.out_len, a.in_used, a.crc, a.adler);
+    }
+    return mock_inflate_window(a.in, a.in_len, a.buf, a.buf_cap, a.state_in, a.state_out, a.out_len, a.in_used, a.crc, a.adler, a.seg_first,
+                               a.seg_stride, a.seg_crc, a.seg_cap, a.nseg);
 }
 
 // one window of one large entry, every block by a "wave" of its own (inflate_parallel.inc): the same orchestration as the
@@ -244,9 +246,9 @@ MOCK_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len,
     return 0;
 }
 
-// one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host2 does)
-MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, int32_t window_log2,
-                                          uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
+// one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host does)
+static int32_t mock_deflate_segment(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, int32_t window_log2,
+                                    uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
     const uint32_t piece = 64u << 10;
     const uint32_t np = in_len ? (in_len + piece - 1) / piece : 1u;
     uint32_t total = 0, k = 0, ad = 1;
@@ -266,13 +268,12 @@ MOCK_API int32_t mzhip_deflate_host_level(const uint8_t *in, uint32_t in_len, ui
     if (adler) *adler = ad;
     return 0;
 }
-MOCK_API int32_t mzhip_deflate_host2(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
-                                     uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
-    return mzhip_deflate_host_level(in, in_len, final, 1, 15, out, out_cap, out_len, crc, adler);
-}
-MOCK_API int32_t mzhip_deflate_host(const uint8_t *in, uint32_t in_len, uint32_t final, uint8_t *out, uint32_t out_cap,
-                                    uint32_t *out_len, uint32_t *crc) {
-    return mzhip_deflate_host2(in, in_len, final, out, out_cap, out_len, crc, nullptr);
+MOCK_API int32_t mzhip_deflate_host(const mzhip_deflate_host_args *ap) {
+    if (!ap || ap->size < offsetof(mzhip_deflate_host_args, out) + sizeof(void *)) return -102;
+    mzhip_deflate_host_args a;
+    memset(&a, 0, sizeof(a));
+    memcpy(&a, ap, ap->size < sizeof(a) ? ap->size : sizeof(a));
+    return mock_deflate_segment(a.in, a.in_len, a.final, a.level, a.window_log2 ? a.window_log2 : 15, a.out, a.out_cap, a.out_len, a.crc, a.adler);
 }
 
 MOCK_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,

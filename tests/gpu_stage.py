@@ -20,8 +20,11 @@ cases = {n: (d, z) for n, d, z in synth.edge_payloads()}
 def inflate(name, extra=b""):
     d, z = cases[name]
     out = C.create_string_buffer(len(d) + 16)
+    src = C.create_string_buffer(z + extra, len(z) + len(extra) + 1)
     ol, iu, crc = C.c_uint32(), C.c_uint32(), C.c_uint32()
-    st = L.mzhip_inflate_host(z + extra, len(z) + len(extra), out, len(d) + 8, C.byref(ol), C.byref(iu), C.byref(crc))
+    a = mz.InflateHostArgs(size=C.sizeof(mz.InflateHostArgs), in_len=len(z) + len(extra), buf_cap=len(d) + 8, in_=C.addressof(src),
+                           buf=C.addressof(out), out_len=C.addressof(ol), in_used=C.addressof(iu), crc=C.addressof(crc))
+    st = L.mzhip_inflate_host(C.byref(a))
     ok = st == 0 and out.raw[:ol.value] == d and crc.value == zlib.crc32(d) and iu.value == len(z)
     print(name, "status", st, "out", ol.value, "/", len(d), "used", iu.value, "/", len(z), "crc_ok",
           crc.value == zlib.crc32(d), "OK" if ok else "FAIL", "err=", L.mzhip_last_error(), flush=True)

@@ -40,6 +40,37 @@ def test_every_declared_symbol_is_exported(lib):
         assert n in names
 
 
+def test_ctypes_signatures_come_from_the_header(lib):
+    """Every MZHIP_API function gets its restype / argtypes from include/mzhip.h (minizip-ng_amd.header_prototypes): a change
+    of a signature cannot leave a hand-written list behind (round 4: test_one_window_on_many_waves crashed the GPU suite that
+    way).  The two args structs of the host entry points are restated in Python; their field lists are checked against the
+    header's text, and the retired suffix-versioned entry points are gone."""
+    protos = mz.header_prototypes()
+    assert set(protos) == set(declared_symbols()) - {n for n in declared_symbols() if not n.startswith("mzhip_")}
+    for name, (ret, argt) in protos.items():
+        fn = getattr(lib, name)
+        assert fn.restype == ret and list(fn.argtypes) == argt, name
+    assert len(protos["mzhip_inflate_parallel_host"][1]) == 16 and len(protos["mzhip_inflate_batch"][1]) == 12
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mzhip.h")).read(), flags=re.S)
+    for cls, cname in ((mz.InflateHostArgs, "mzhip_inflate_host_args"), (mz.DeflateHostArgs, "mzhip_deflate_host_args"),
+                       (mz.InflateState, "mzhip_inflate_state")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ptr = "*" in decl
+            names = [w.strip(" *") for w in decl.replace("*", " * ").split(",")]
+            names[0] = names[0].split()[-1]
+            fields += [(n.split()[-1].strip("*"), ptr) for n in names]
+        got = [(n.rstrip("_"), t is C.c_void_p) for n, t in cls._fields_]
+        assert got == fields, (cname, got, fields)
+    for gone in ("mzhip_inflate_host2", "mzhip_inflate_resume_host", "mzhip_inflate_resume_host_seg", "mzhip_inflate_resume_host_seg2",
+                 "mzhip_deflate_host2", "mzhip_deflate_host_level"):
+        assert not hasattr(lib, gone), gone
+
+
 def test_dropin_symbol_set_matches_reference_headers(lib):
     """exactly the 13 functions mz_strm_zlib.h:20-35 / mz_strm_lzma.h:20-35 declare, plus the CRC"""
     per_stream = ["open", "is_open", "read", "write", "tell", "seek", "close", "error", "get_prop_int64",

@@ -375,3 +375,18 @@ def test_archives_through_unmodified_mz_zip(libs):
             assert (crc_r == crc_h).all() and (ulen_r == ulen_h).all() and (ulen_h == lens).all()
             assert (crc_h == t_ref[:, 2].astype(np.uint32)).all()      # == the central directory's CRCs
             assert (o_ref == o_hip).all()
+
+
+def test_window_mode_differential_fuzz(libs):
+    """A short seed of tests/fuzz_gpu_windows.py in the suite (the fuzz was a script the driver never ran): random
+    streams of 1 - 6 MB -- text, noise, runs, mixtures; levels 0 - 9; dynamic, fixed and stored blocks with flush points; raw,
+    zlib and gzip framing -- through the drop-in's READ stream with a 3 MiB window and 512 KiB gulps (many-wave and serial
+    windows both happen) and through the all-reference build: whole, cut at a random byte, with a random bit flipped.  Every
+    return value, byte, total and verdict agrees; the ONE tolerated difference is TOTAL_IN at a DATA error, by at most
+    TOTAL_IN_SLACK = 2 bytes (where inflate()'s bit buffer stood: SURVEY appendix B calls that field best effort)."""
+    from tests import fuzz_gpu_windows as F
+
+    hip, ref = libs
+    cases, mism, soft, worst = F.run(8, 21, hip=hip, ref=ref, verbose=True)
+    assert cases == 24 and mism == 0, (cases, mism, soft, worst)
+    assert worst <= F.TOTAL_IN_SLACK, worst
