@@ -20,8 +20,6 @@
  *       buffer, near ones copied LDS to LDS in dependency order, then one coalesced 16-byte store per lane.  Every token
  *       is Huffman-decoded once (+ the resynchronisation tail of a span).  The two halves are functions of their own
  *       (mz_chase_walk, mz_chase_emit: not inlined, their own register allocations).
- *       (inflate_window.inc, MZ_WINDOW_CHASE = 0, is the round-2 window kept as an A/B build: 256-bit spans re-walked until
- *       the starts stop moving.)
  *       STEP LOOP (the last bits of a stream, hand-backs, and every error verdict): lane l decodes the complete token
  *       that would start at bit cursor+l, for all 64 bit offsets at once; which candidates are real is
  *       decided without a serial walk: f(l) = l + bits(l) is squared with cross-lane gathers and lane i
@@ -91,26 +89,11 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_DROOT 8 /* distance fast-table index bits        */
 #endif
 #define MZ_CROOT 7 /* code-length-code table bits (== max)  */
-#ifndef MZ_WINDOW_CHASE
-#define MZ_WINDOW_CHASE 1 /* span path, round 3 (inflate_chase.inc): every lane decodes its span ONCE and records its steps in
-                             a per-wave HBM scratch, then keeps walking into the next span until it stands on a token start the
-                             next lane also recorded ("chase"); bytes are made from the records.  0: the round-2 window
-                             (inflate_window.inc: passes re-decode until the starts stop moving) */
-#endif
-#ifndef MZ_SPAN_DW
-#define MZ_SPAN_DW 8 /* span-parallel decode (see mz_span_token): dwords of compressed stream per lane (4 or 8), 0 = off */
-#endif
-#if MZ_SPAN_DW != 0 && MZ_SPAN_DW != 4 && MZ_SPAN_DW != 8
-#error "MZ_SPAN_DW must be 0, 4 or 8 (the span size of a window is 32 << shift bits, shift <= log2(MZ_SPAN_DW))"
-#endif
-#define MZ_SPAN_SH (MZ_SPAN_DW == 8 ? 3u : 2u)
-#define MZ_SPAN_RS (MZ_SPAN_DW + 3) /* LDS row stride of one span: its dwords + the next span's first three (odd) */
-#define MZ_SPAN_MAX_PASS 6u
-/* ---- chase window (MZ_WINDOW_CHASE): spans of up to MZ_CHASE_SMAX bits, one per lane; the stream reaches a lane through
+/* ---- chase window: spans of up to MZ_CHASE_SMAX bits, one per lane; the stream reaches a lane through
  * its own ring of MZ_CRING_DW dwords in LDS (+ 2 that mirror the first two, so dword a, a + 1, a + 2 are one address),
  * topped up 4 dwords at a time every second step from a prefetch register; a step record is two dwords
- * (token, leading literal: exactly what mz_span_token returns), two records per 16-byte store, row-major
- * [pair of steps][lane] so that the wave's stores of one pair are 1 KiB contiguous. */
+ * (mz_chase_step), four records per 16-byte store, row-major [quad of steps][lane] so that the wave's stores of one quad are
+ * 1 KiB contiguous. */
 #ifndef MZ_CHASE_SMAX
 #define MZ_CHASE_SMAX 3072u /* bits per span at most: ~170 steps on text, under the record cap below */
 #endif
@@ -131,21 +114,10 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_EMIT_GROUP 8u /* records one lane turns into bytes per emit round (4 or 8: records are stored in quads) */
 #endif
 #ifndef MZ_POOL_BYTES
-#if MZ_WINDOW_CHASE
-#define MZ_POOL_BYTES 1264u /* what the rings leave of the 9984 bytes a wave may have at 16 waves per CU */
-#else
-#define MZ_POOL_BYTES 3264u
-#endif
-#endif
-#ifndef MZ_POOL_BYTES
-#define MZ_POOL_BYTES 3264u /* span path: LDS pool of one window chunk = staging bytes of its output (from the front,
-                               at most 4 KiB), a pending bit per byte, its back-reference list, 4 bytes each (from the back) */
-#endif
-#ifndef MZ_EMIT_MIN_LANES
-#define MZ_EMIT_MIN_LANES 12u /* span path: verified lanes worth a commit while other lanes are still converging */
-#endif
-#ifndef MZ_NEAR_SLOTS
-#define MZ_NEAR_SLOTS 1 /* span path: pieces per lane in one batch of the near pass (1 or 2) */
+#define MZ_POOL_BYTES 1264u /* LDS pool of one emit round = staging bytes of its output (from the front, at most 4 KiB), a pending
+                               bit per byte, its back-reference list, 4 bytes each (from the back): what the rings leave of the
+                               9984 bytes a wave may have at 16 waves per CU (it runs on through the dead rings while a window is
+                               emitted; 768 bytes less changed nothing on the probe: profiles/r5/call6_probe.log) */
 #endif
 #ifndef MZ_LDS_PAD
 #define MZ_LDS_PAD 0
@@ -154,35 +126,8 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_VIEW_MAX 0x0FFFFFFFu   /* bytes of the stream the 32-bit bit cursor can address at a time (see mz_inflate_entry) */
 #define MZ_REBASE_BITS (1u << 30) /* the view moves when the cursor is this far into it */
 #endif
-#ifndef MZ_FUSED_EMIT
-#define MZ_FUSED_EMIT (!MZ_SUBSPAN_EMIT) /* 1: a chunk of >= MZ_EMIT_MIN_LANES verified lanes is emitted on a pass the other lanes still
-                                         count on (one lane per span); 0: every emit waits for convergence and uses three lanes per span.
-                                         Same step count either way (tests/study/k1_steps.py); 0 is less code and fewer registers */
-#endif
-#if !MZ_SUBSPAN_EMIT && !MZ_FUSED_EMIT
-#error "MZ_SUBSPAN_EMIT = 0 needs MZ_FUSED_EMIT = 1: nothing else would emit"
-#endif
-#ifndef MZ_NEAR_FRONTIER
-#define MZ_NEAR_FRONTIER 0 /* near copies: 0 = a pending bit per byte (24 rounds per text window), 1 = "source ends below the first
-                              unfinished destination" (one comparison per round, but 56 rounds: measured in tests/study/k1_steps.py) */
-#endif
-#ifndef MZ_SUBSPAN_EMIT
-#define MZ_SUBSPAN_EMIT 1 /* a pass that only emits splits every span of the chunk over three lanes (0: one lane per span) */
-#endif
-#define MZ_SPAN_LANES (MZ_SUBSPAN_EMIT ? 63u : 64u) /* spans per window: 63 = three chunks of 21, each emitted by 63 lanes */
 #ifndef MZ_CL_PARALLEL
 #define MZ_CL_PARALLEL 1 /* dynamic block headers: code lengths decoded 64 bits at a time (0: one symbol at a time) */
-#endif
-#ifndef MZ_FAR_SLOTS
-#define MZ_FAR_SLOTS 1 /* far pieces per lane whose global loads are in flight together (1 or 2) */
-#endif
-#ifndef MZ_NEAR_BATCHED
-#define MZ_NEAR_BATCHED 0 /* near copies whose source ends in front of the destination issue all loads first */
-#endif
-#ifndef MZ_SPAN_PRELIT
-#define MZ_SPAN_PRELIT 1 /* a walk step takes a leading literal and the token behind it (0: one token per step; 2: up to two
-                           leading literals -- chase window only: 160 -> 128 steps for the slowest lane of a 64 KiB entry's
-                           window, and 2 % slower on the GPU, profiles/r3/ab_token_variants.log) */
 #endif
 #ifndef MZ_ABLATE
 #define MZ_ABLATE 0 /* measurement builds only (wrong output): 1 no match copies, 2 no far loads, 4 no CRC, 8 no store */
@@ -258,21 +203,13 @@ typedef struct mz_inflate_body_scratch { /* live while the block body is decoded
                                    entries 128, 129 mirror 0, 1 so that a window read is one address plus constant offsets */
             uint16_t mslot[64]; /* step-loop flush: 4 * lane id of this step's match tokens, compacted */
         } s;
-#if MZ_SPAN_DW
         uint32_t pool[MZ_POOL_BYTES / 4]; /* span path (never live together with the step loop's ring) */
-#endif
     } x;
-#if MZ_SPAN_DW && MZ_WINDOW_CHASE
     uint32_t win[64 * MZ_CRING_RS]; /* chase window: one ring row per lane while the lanes walk; the chain's per-lane tables
                                        (steps, entry points, group counts) while the records become bytes */
-#elif MZ_SPAN_DW
-    uint32_t win[65 * MZ_SPAN_RS]; /* span path: dword d of a window of (1 << ssh)-dword spans at win[(d >> ssh) * MZ_SPAN_RS + (d & ((1 << ssh) - 1))], and the first three dwords of row r + 1 again behind row r */
-#endif
 } mz_inflate_body_scratch;
-#if MZ_SPAN_DW
 typedef char mz_pool_is_16_byte_granular[(MZ_POOL_BYTES % 16u == 0u && MZ_POOL_BYTES < 65536u && (MZ_LIT_SUB_ENTRIES % 4) == 0 &&
                                           ((1 << MZ_LROOT) % 4) == 0) ? 1 : -1];
-#endif
 #define MZ_L_WIN(L_) ((L_)->u.b.win)
 #define MZ_L_RING(L_) ((L_)->u.b.x.s.ring)
 #define MZ_L_MSLOT(L_) ((L_)->u.b.x.s.mslot)
@@ -429,7 +366,6 @@ __device__ static const uint8_t mz_k_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10,
 #endif
 
 
-#if MZ_SPAN_DW
 /* bits [sh, sh + n) of a 64-bit window as two words, 0 <= sh <= 31, 1 <= n <= 32 (the pending bits of one piece) */
 MZ_DEV void mz_bitrange(uint32_t sh, uint32_t n, uint32_t *m0, uint32_t *m1) {
     const uint32_t full = 0xFFFFFFFFu >> (32u - n);
@@ -480,126 +416,12 @@ MZ_DEV void mz_copy32_seq(uint8_t *dst, const uint8_t *src, uint32_t n) {
     if (n & 1u) dst[n - 1u] = src[n - 1u];
 }
 
-/* Span-parallel decode.  A DEFLATE token walk started at an arbitrary bit falls in step with the true token
- * sequence after 8.5 tokens on average (text at zlib level 6: 88 % of the walks within 256 bits, 98 % within 512,
- * profiles/r1/side_measurements.log), so instead of decoding 64 candidate offsets of ONE 64-bit window per step the
- * wave gives every lane its own span of 32 * MZ_SPAN_DW bits and lets all lanes walk token by token:
- *   pass 1    lane i walks from the first bit of span i until it crosses into span i + 1 (lane 0 starts at the true
- *             cursor);
- *   pass 2..  lane i restarts from where lane i - 1 crossed; when no start moves any more the walks are the true parse;
- *   emit      the lanes of a chunk walk once more and write bytes / back-reference pieces into the LDS pool
- *             (inflate_window.inc has the whole window logic).
- * Every lane does useful work in the final walks, where the step loop keeps ~5 of 64 candidates.  Anything unusual
- * -- an invalid code on the true path, the end of the input closer than a span -- stays with the step loop, which
- * owns the exact error verdicts: the span path only ever commits a prefix of verified tokens.
- *
- * One step of a walk at window-relative bit `rel` (the same table walk as phase 1 of the step loop): the token that
- * starts there, or, when that is a literal of fewer than `room` bits, the literal (*pre = its table entry, else 0) and
- * the token behind it. */
-/* bytes in front of a step's token: what its leading literal(s) produce (`pre` as mz_span_token3 returns it) */
-#define MZ_PRE_COUNT(pr) ((pr) ? 1u + ((MZ_SPAN_PRELIT >= 2) ? (((pr) >> 6) & 1u) : 0u) : 0u)
-#ifndef MZ_TOKEN_SELECT
-#define MZ_TOKEN_SELECT 0 /* 1: the measurement variant below (selects instead of branches): no gain on the GPU, profiles/r3/ab_token_variants.log */
-#endif
-MZ_DEV uint32_t mz_span_token3(const mz_inflate_lds *L, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t rel, uint32_t room,
-                               uint32_t *pre) {
-    /* d0, d1, d2 = the stream dword that holds bit `rel` (only rel & 31 is looked at) and the two behind it */
-    uint32_t w0 = mz_funnel(d1, d0, rel), w1 = mz_funnel(d2, d1, rel);
-#if MZ_TOKEN_SELECT && MZ_SPAN_PRELIT < 2
-    /* The same decode with SELECTS where the version below branches: with 64 lanes in a step, some lane takes every
-     * path of it almost every time, so the wave runs all of them anyway -- and pays 14 divergent branches per step for
-     * the privilege (285 instructions per step in the compiled walk loop, 57 s_cbranch_execz per trip of four steps;
-     * DESIGN 9).  Both table levels are read whether needed or not (index 0 of the second level when not), the second
-     * token is looked up whether the first was a literal or not (with nothing shifted out it is the first one again),
-     * the distance part is computed for every lane and kept for those that have a length.  Only the long distance
-     * codes (rare) stay behind a branch.  Two more LDS reads per step. */
-    {
-        const uint32_t m = (1u << MZ_LROOT) - 1u;
-        uint32_t e = L->lit_fast[w0 & m];
-        {
-            const uint32_t sub = (e & MZ_E_SUB) ? 1u : 0u;
-            const uint32_t es = L->lit_sub[sub ? ((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u) : 0u];
-            e = sub ? es : e;
-        }
-        const uint32_t islit = (MZ_SPAN_PRELIT && (e & (MZ_E_LEN | 0x80u)) == 0x80u && (e & 63u) < room) ? 1u : 0u;
-        const uint32_t n1 = islit ? (e & 63u) : 0u;
-        *pre = islit ? e : 0u;
-        const uint32_t v0 = mz_funnel(w1, w0, n1), v1 = w1 >> n1;
-        uint32_t f = L->lit_fast[v0 & m];
-        {
-            const uint32_t sub = (f & MZ_E_SUB) ? 1u : 0u;
-            const uint32_t fs = L->lit_sub[sub ? ((f >> 8) & 0x1FFu) + mz_bfe(v0, MZ_LROOT, f & 7u) : 0u];
-            f = sub ? fs : f;
-        }
-        const uint32_t haslen = (f & MZ_E_LEN) ? 1u : 0u;
-        const uint32_t nb = f & 63u, ex = mz_bfe(f, 16, 4);
-        const uint32_t lenl = mz_bfe(f, 7, 9) + mz_bfe(mz_funnel(v1, v0, nb), 0, ex);
-        const uint32_t nb2 = nb + ex;
-        const uint32_t dl = mz_funnel(v1, v0, nb2);
-        uint32_t dd = L->dist_fast[dl & ((1u << MZ_DROOT) - 1u)];
-        MZ_STAT(19, haslen);
-        if (haslen && dd == 0u) {
-            MZ_STAT(20, 1);
-            dd = mz_long_code(dl, MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
-        }
-        const uint32_t dn = dd & 15u, dex = mz_bfe(dd, 4, 4);
-        const uint32_t dist = mz_bfe(dd, 8, 15) + mz_bfe(dl, dn, dex);
-        const uint32_t tok = ((int32_t)dd <= 0) ? 0u : ((nb2 + dn + dex) | (lenl << 7) | (dist << 16));
-        return haslen ? tok : f;
-    }
-#endif
-    uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
-    if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
-    /* A literal that does not end the lane's walk takes the token behind it along in the same step: the slowest
-     * lanes of a pass are the literal-dense ones (26.3 -> 16.1 steps for the slowest lane of a window on text,
-     * tests/study/span_multi.c).  The 64 bits loaded above still hold the longest second token (<= 48 bits) behind the
-     * longest literal code (<= 15 bits). */
-    uint32_t p = 0;
-    if (MZ_SPAN_PRELIT && (e & (MZ_E_LEN | 0x80u)) == 0x80u && (e & 63u) < room) {
-        p = e;
-        const uint32_t n1 = e & 63u;
-        w0 = mz_funnel(w1, w0, n1);
-        w1 >>= n1;
-        e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
-        if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
-#if MZ_SPAN_PRELIT >= 2
-        /* ... and a second one, when the two codes are 16 bits at most (the 64 bits then still hold the longest token
-         * behind them): *pre = bits of both | 0x80 | 0x40 | first byte << 16 | second byte << 24 (MZ_PRE_COUNT) */
-        if ((e & (MZ_E_LEN | 0x80u)) == 0x80u && n1 + (e & 63u) <= 16u && n1 + (e & 63u) < room) {
-            const uint32_t n2 = e & 63u;
-            p = (n1 + n2) | 0xC0u | (p & 0x00FF0000u) | ((e & 0x00FF0000u) << 8);
-            w0 = mz_funnel(w1, w0, n2);
-            w1 >>= n2;
-            e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
-            if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
-        }
-#endif
-    }
-    *pre = p;
-    if (!(e & MZ_E_LEN)) return e; /* literal, end of block, or an invalid code (0 bits) */
-    const uint32_t nb = e & 63u, ex = mz_bfe(e, 16, 4);
-    const uint32_t lenl = mz_bfe(e, 7, 9) + mz_bfe(mz_funnel(w1, w0, nb), 0, ex);
-    const uint32_t nb2 = nb + ex;
-    const uint32_t dl = mz_funnel(w1, w0, nb2);
-    uint32_t dd = L->dist_fast[dl & ((1u << MZ_DROOT) - 1u)];
-    MZ_STAT(19, 1);
-    if (dd == 0u) {
-        MZ_STAT(20, 1);
-        dd = mz_long_code(dl, MZ_DROOT, L->dist_lim, L->dist_delta, L->dist_ent, 32u);
-    }
-    if ((int32_t)dd <= 0) return 0u; /* unused / 30 / 31 distance code */
-    const uint32_t dn = dd & 15u, dex = mz_bfe(dd, 4, 4);
-    const uint32_t dist = mz_bfe(dd, 8, 15) + mz_bfe(dl, dn, dex);
-    return (nb2 + dn + dex) | (lenl << 7) | (dist << 16);
-}
-MZ_DEV uint32_t mz_span_token(const mz_inflate_lds *L, const uint32_t *wrow, uint32_t rel, uint32_t room, uint32_t *pre) {
-    /* wrow = the lane's row of the window, biased so that window dword d is wrow[d]: a walk stays inside its span
-     * (rel < the span's end), so everything it reads is the row's own dwords or the three copied behind them */
-    const uint32_t a = rel >> 5;
-    return mz_span_token3(L, wrow[a], wrow[a + 1u], wrow[a + 2u], rel, room, pre);
-}
-/* One step of a chase-window walk (inflate_chase.inc) as its RECORD: the same table walk as mz_span_token3 with one
- * leading literal, but what comes out is what the emit needs and nothing else, in five bytes instead of eight:
+/* One step of a chase-window walk (inflate_chase.inc) as its RECORD.  A DEFLATE token walk started at an arbitrary bit falls
+ * in step with the true token sequence after 8.5 tokens on average (text at zlib level 6: 88 % of the walks within 256 bits,
+ * 98 % within 512, profiles/r1/side_measurements.log), which is what lets 64 lanes walk 64 spans of one stream at once.
+ * The table walk of one step: the token that starts at bit `rel`, or, when that is a literal of fewer than `room` bits, the
+ * literal and the token behind it (the slowest lanes of a pass are the literal-dense ones: 26.3 -> 16.1 steps for the slowest
+ * lane of a window on text, tests/study/span_multi.c); what comes out is what the emit needs and nothing else, in five bytes:
  *   *rec  [7:0] the leading literal and [31] "there is one"; [15:8] the token's literal byte, or match length - 3;
  *         [30:16] match distance - 1
  *   K     (returned) [5:0] bits of the whole step, 1 .. 63 (leading literal <= 15, token <= 48); 0 = no valid step starts
@@ -658,13 +480,10 @@ MZ_DEV mz_dw4 mz_load_stream_dw4(const uint8_t *in_al, uint32_t in_mis, uint32_t
     }
     return r;
 }
-#endif
 
 
-#if MZ_SPAN_DW && MZ_WINDOW_CHASE
 #include "inflate_walk.inc"
 #include "inflate_emit.inc"
-#endif
 
 /* ONE block of a large entry, parsed by a wave of its own (mzhip_inflate_parallel_host: every block of a window at once).
  * The wave starts at the block's header (rs: hdr_bit = bit = the header, out_pos = where the block's bytes go), decodes that
@@ -745,16 +564,12 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
     /* the two groups of four stream dwords that do not lie entirely inside the input, masked (the chase window's refills,
      * inflate_walk.inc): lanes 0 .. 3 the group of dword 0, lanes 4 .. 7 the group with the last dword.  Once per view, so
      * that no window waits for these loads */
-#if MZ_SPAN_DW && MZ_WINDOW_CHASE
     PV(uint32_t, edge_ev);
 #define MZ_EDGE_GROUPS()                                                                               \
     MZ_LANES {                                                                                         \
         const uint32_t _gl4 = ((in_mis + in_len) >> 2) & ~3u;                                          \
         P(edge_ev) = (lane < 8) ? mz_load_stream_dword(in_al, in_mis, in_len, (lane < 4) ? (uint32_t)lane : _gl4 + ((uint32_t)lane & 3u)) : 0u; \
     }
-#else
-#define MZ_EDGE_GROUPS() ((void)0)
-#endif
     MZ_EDGE_GROUPS();
 #define MZ_REBASE(also)                                                \
     if (bitpos >= MZ_REBASE_BITS) {                                    \
@@ -772,9 +587,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
         }                                                              \
     }
     uint32_t out_pos = rs ? MZ_UNIFORM(rs->out_pos) : 0u; /* bytes [0, out_pos) of out[] are history (back-references may reach them) */
-#if MZ_SPAN_DW && MZ_WINDOW_CHASE
     uint32_t chase_smax = MZ_CHASE_SMAX; /* bits per span at most (inflate_chase.inc halves it when a window runs into a record cap) */
-#endif
     int32_t status = MZHIP_OK;
     uint32_t last = 0;
     PV(uint32_t, crc_acc);
@@ -1116,13 +929,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
             uint32_t qn = 0;
             MZ_LANES { P(tq) = 0u; }
 
-#if MZ_SPAN_DW
             uint32_t span_skip = 0;     /* the step loop takes the next step (it owns the exact verdicts) */
-            uint32_t span_on = (use_span && (!MZ_WINDOW_CHASE || rec)) ? 1u : 0u; /* cleared for the rest of the block when a window cannot be committed here */
-#endif
+            uint32_t span_on = (use_span && rec) ? 1u : 0u; /* cleared for the rest of the block when a window cannot be committed here */
             for (;;) {
                 MZ_REBASE(ring_valid = 0) /* the ring is indexed by the position inside the view */
-#if MZ_SPAN_DW && MZ_WINDOW_CHASE
                 {
                     const uint32_t remain = total_bits - bitpos;
                     /* worth a window: two spans of 128 bits and some */
@@ -1137,37 +947,6 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                     }
                     span_skip = 0;
                 }
-#elif MZ_SPAN_DW
-                {
-                    const uint32_t remain = total_bits - bitpos;
-                    /* span size of this window: 256 bits, or 128 when what is left of the stream fits 64 spans of 128
-                     * (the last window of a block / a small entry: twice the lanes busy, passes half as long) */
-                    const uint32_t ssh = (MZ_SPAN_SH > 2u && remain <= 64u * 128u + 64u) ? 2u : MZ_SPAN_SH;
-                    const uint32_t S = 32u << ssh;
-                    /* lanes whose every token lies inside the input (a token is at most 48 bits) */
-                    uint32_t nact = (remain > 64u) ? (remain - 64u) / S : 0u;
-                    if (nact > MZ_SPAN_LANES) nact = MZ_SPAN_LANES;
-                    if (span_on && qn == 0u && !span_skip && nact >= 2u) {
-                        uint32_t *win = MZ_L_WIN(L);
-                        const uint32_t wpos = bitpos + pbase;
-                        const uint32_t wb = wpos >> 5, woff = wpos & 31u;
-                        const uint32_t ndw = (nact << ssh) + 3u;
-                        MZ_LANES {
-                            for (uint32_t d = (uint32_t)lane; d < ndw; d += 64u) {
-                                const uint32_t v = mz_load_stream_dword(in_al, in_mis, in_len, wb + d);
-                                const uint32_t row = d >> ssh, k = d & ((1u << ssh) - 1u);
-                                win[row * MZ_SPAN_RS + k] = v;
-                                if (k < 3u && row > 0u) win[(row - 1u) * MZ_SPAN_RS + (1u << ssh) + k] = v;
-                            }
-                        }
-                        MZ_WAVE_SYNC();
-                        ring_valid = 0; /* the pool covers the ring's place */
-                        MZ_PROF_MARK(3); /* step loop (if any) + window load */
-#include "inflate_window.inc"
-                    }
-                    span_skip = 0;
-                }
-#endif
                 if (!ring_valid) {
                     const uint32_t blk = (bitpos + pbase) >> 11; /* 2048 bits per block */
                     MZ_LANES {

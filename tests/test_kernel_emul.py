@@ -661,22 +661,14 @@ def _build_variant(tag, flags):
 
 @pytest.fixture(scope="module")
 def emu_staged():
-    """Other K1 builds in the same emulation.  The round-2 window (MZ_WINDOW_CHASE=0, kept as the A/B baseline): 128-bit
-    spans with two pieces per lane in the near pass, pools so small that windows are cut short or handed back to the step
-    loop all the time, the knobs of profiles/ab_k1.sh.  The chase window (the default): see the list."""
-    r2 = ["-DMZ_WINDOW_CHASE=0", "-DMZ_POOL_BYTES=3264u"]
-    return [_build_variant("s4", r2 + ["-DMZ_SPAN_DW=4", "-DMZ_POOL_BYTES=4608u", "-DMZ_NEAR_SLOTS=2", "-DMZ_SPAN_PRELIT=0"]),
-            _build_variant("tiny", r2 + ["-DMZ_POOL_BYTES=2048u", "-DMZ_NEAR_SLOTS=1", "-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"]),
-            _build_variant("r2", r2),
-            _build_variant("fused", r2 + ["-DMZ_FUSED_EMIT=1", "-DMZ_EMIT_MIN_LANES=8u"]),
-            _build_variant("frontier", r2 + ["-DMZ_NEAR_FRONTIER=1", "-DMZ_CL_PARALLEL=0"]),
-            # the chase window (the default build is `emu` itself): record caps and span limits so low that every window
-            # runs into them, chases cross several spans and the span limit halves; 4 records per lane and emit round
-            # in a pool that cuts every round; the r2 knobs of the shared commit code
-            _build_variant("c_caps", ["-DMZ_REC_CAP1=16u", "-DMZ_REC_CAP2=8u", "-DMZ_CHASE_SMAX=512u"]),
+    """Other K1 builds in the same emulation (the default build is `emu` itself): record caps and span limits so low that
+    every window runs into them, chases cross several spans and the span limit halves; 4 records per lane and emit round in
+    a pool that cuts every round; the code-length decode without its 64-bit front end.  (The round-2 window and the knobs of
+    rounds 2 - 4 whose A/B is closed went with their code in round 5.)"""
+    return [_build_variant("c_caps", ["-DMZ_REC_CAP1=16u", "-DMZ_REC_CAP2=8u", "-DMZ_CHASE_SMAX=512u"]),
             _build_variant("c_short", ["-DMZ_CHASE_SMAX=128u", "-DMZ_REC_CAP2=4u", "-DMZ_EMIT_GROUP=4u"]),
-            _build_variant("c_pool", ["-DMZ_POOL_BYTES=656u", "-DMZ_EMIT_GROUP=4u", "-DMZ_FAR_SLOTS=2", "-DMZ_NEAR_BATCHED=1"]),
-            _build_variant("c_knobs", ["-DMZ_NEAR_SLOTS=2", "-DMZ_NEAR_FRONTIER=1", "-DMZ_CHASE_SMAX=1024u"])]
+            _build_variant("c_pool", ["-DMZ_POOL_BYTES=656u", "-DMZ_EMIT_GROUP=4u"]),
+            _build_variant("c_serial_cl", ["-DMZ_CL_PARALLEL=0", "-DMZ_CHASE_SMAX=1024u"])]
 
 
 def test_inflate_span_and_step_paths(emu, emu_staged):
