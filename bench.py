@@ -391,7 +391,12 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
                            thread) with the reference's unmodified reader loop on the drop-in library running under it, ONE
                            reader thread
       vtbl_end_to_end_T    the same with T = all host cores reader threads, one mz_zip_reader each
-                           (integration/extract_threads.c: the shape of the cpu_baseline leg)"""
+                           (integration/extract_threads.c: the shape of the cpu_baseline leg)
+      vtbl_unprimed_default  the application is only re-linked: the unmodified reader loop on the drop-in with NO prime call
+                           and nothing in the environment, one thread -- the first read() images the archive through the
+                           reader's own stream and primes it (shim_autoprime.c, on by default since round 5); beside it
+                           vtbl_unprimed_per_entry, the same loop with MZHIP_AUTOPRIME=0 (a launch and a PCIe round trip per
+                           entry, what rounds 1 - 4 did by default), on a quarter of the sample"""
     out = {"kernel": round(kernel_gib, 2)}
     # chunks of one launch round each: a launch keeps 4096 waves resident (16 per CU) and a wave decodes one entry, so a
     # chunk of 5000 entries would pay a second, 22 % full round
@@ -468,6 +473,28 @@ def legs_config2(torch, mz, dev, h_in, in_off, in_len, size, want_crc_np, kernel
                 if best:
                     out[key] = round(nbytes / 2**30 / best, 3)
                     out[key + "_sample"] = desc
+            # the re-linked application: no prime call, nothing in the environment (prime mode 0 of the same driver)
+            had = os.environ.pop("MZHIP_AUTOPRIME", None)
+            try:
+                L.mzhip_autoprime_count.restype = C.c_uint64
+                best = None
+                for _ in range(3):
+                    L.mzhip_prime_clear()
+                    a0 = L.mzhip_autoprime_count()
+                    ne, nb, tp, fe = C.c_int64(0), C.c_int64(0), C.c_double(0), C.c_int32(0)
+                    sec = D.mzdrop_extract_all(sample_zip.encode(), 1, 0, C.byref(ne), C.byref(nb), C.byref(tp), C.byref(fe))
+                    if sec > 0 and fe.value == 0 and ne.value > 0 and L.mzhip_autoprime_count() == a0 + 1 and (best is None or sec < best):
+                        best, nbytes, nent = sec, nb.value, ne.value
+                L.mzhip_prime_clear()
+                if best:
+                    out["vtbl_unprimed_default"] = round(nbytes / 2**30 / best, 3)
+                    out["vtbl_unprimed_default_sample"] = ("%d entries / %.0f MiB: the unmodified mz_zip_reader loop on libmzhipdrop.so, ONE thread, no "
+                                                           "mzhip_prime_* call, no environment variable: the first read() images the archive through the reader's own "
+                                                           "stream and primes it (shim_autoprime.c), mz_zip_entry_read in 65 535-byte calls + CRC verification; "
+                                                           "map + index + imaging + decode + every read inside the clock; best of 3" % (nent, nbytes / 2**20))
+            finally:
+                if had is not None:
+                    os.environ["MZHIP_AUTOPRIME"] = had
     return out
 
 

@@ -362,6 +362,8 @@ MZHIP_API int64_t mzhip_prime_mem(const uint8_t *zip, uint64_t zip_len);
  * the number of entries they primed (or the first error) -- or mzhip_prime_clear(), which waits too. */
 MZHIP_API int64_t mzhip_prime_mem_begin(const uint8_t *zip, uint64_t zip_len);
 MZHIP_API int64_t mzhip_prime_wait(void);
+/* archives the READ streams primed on their own (shim_autoprime.c: on by default, MZHIP_AUTOPRIME=0 turns it off) */
+MZHIP_API uint64_t mzhip_autoprime_count(void);
 /* The same over several devices of the node (the host side of the sharded path in C): the entries are
  * independent (mz_zip.c:1682-1863 builds a fresh codec per entry), so the entry table is cut into ndev contiguous
  * slices balanced by compressed + uncompressed bytes (mzhip_shard_bounds) and ONE HOST THREAD PER SLICE decodes it on

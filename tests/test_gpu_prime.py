@@ -114,24 +114,32 @@ def test_prime_lzma_and_xz_entries():
             L.mzhip_prime_clear()
 
 
-def test_autoprime_env(monkeypatch):
-    """MZHIP_AUTOPRIME: no call to mzhip_prime_* at all -- the first read() of the unmodified reader loop images the
-    archive through the reader's own stream, primes it and every entry is then served from the cache."""
+def test_autoprime_is_the_default(monkeypatch):
+    """No call to mzhip_prime_* and nothing in the environment (the un-primed drop-in was slower than the
+    reference): the first read() of the unmodified reader loop images the archive through the reader's own stream, primes it,
+    and every entry is then served from the cache -- bytes, CRCs, sizes and verdicts as the all-reference reader.
+    MZHIP_AUTOPRIME=<MiB> raises the archive limit, MZHIP_AUTOPRIME=0 turns it off (per-entry path: no cache hit), an archive
+    of fewer than eight entries is left to the per-entry path, and several readers of one file prime it once."""
     mz = importlib.import_module("minizip-ng_amd")
     mz.require_gpu()
     if not (os.path.exists(DROP) and oracle.have_ref()):
         pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
     hip, ref = oracle.MzDriver(DROP), oracle.ref()
     L = mz.lib()
-    L.mzhip_prime_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
     c = np.frombuffer(synth.corpus(), dtype=np.uint8)
     rnd = np.random.RandomState(26)
+
+    def stats():
+        ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+        return int(ent.value), int(hits.value), int(miss.value), int(L.mzhip_autoprime_count())
+
     with tempfile.TemporaryDirectory() as tmp:
-        for method, n, size in ((8, 300, 65536), (14, 20, 100000), (95, 20, 100000)):
+        for method, n, size, env in ((8, 300, 65536, None), (14, 20, 100000, None), (95, 20, 100000, "64"), (8, 40, 30000, "0"), (8, 5, 30000, None)):
             lens = rnd.randint(0, size + 1, size=n).astype(np.int32)
             lens[:2] = (1, size)
             offs = rnd.randint(0, len(c) - size, size=n).astype(np.int64)
-            path = os.path.join(tmp, "a%d.zip" % method)
+            path = os.path.join(tmp, "a%d_%d.zip" % (method, n))
             ref.zip_write(path, c, offs, lens, method=method, level=6)
             cd = ref.zip_index(path)[:, 6].copy()
             out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
@@ -139,14 +147,21 @@ def test_autoprime_env(monkeypatch):
             o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
             _, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_ref, out_off=out_off)
             L.mzhip_prime_clear()
-            monkeypatch.setenv("MZHIP_AUTOPRIME", "64")
-            _, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_hip, out_off=out_off)
-            monkeypatch.delenv("MZHIP_AUTOPRIME")
-            ent, hits, miss = C.c_uint64(), C.c_uint64(), C.c_uint64()
-            L.mzhip_prime_stats(C.byref(ent), C.byref(hits), C.byref(miss))
+            if env is None:
+                monkeypatch.delenv("MZHIP_AUTOPRIME", raising=False)
+            else:
+                monkeypatch.setenv("MZHIP_AUTOPRIME", env)
+            a0 = stats()[3]
+            nthreads = 4 if (method, n) == (8, 300) else 1  # several readers, one mz_zip_reader each over the same file
+            _, crc_h, ulen_h, st_h = hip.zip_read_all(path, cd, nthreads=nthreads, own_crc=False, out=o_hip, out_off=out_off)
+            monkeypatch.delenv("MZHIP_AUTOPRIME", raising=False)
+            ent, hits, miss, autos = stats()
             assert (st_r == 0).all() and (st_h == 0).all() and (crc_h == crc_r).all() and (ulen_h == ulen_r).all()
             assert (o_hip == o_ref).all()
-            assert ent.value >= n - 1 and hits.value >= n - 1, (method, ent.value, hits.value, miss.value)
+            if env == "0" or n < 8:
+                assert hits == 0 and autos == a0, (method, n, env, ent, hits, autos - a0)
+            else:
+                assert ent >= n - 1 and hits >= n - 1 and autos == a0 + 1, (method, n, env, ent, hits, miss, autos - a0)
             L.mzhip_prime_clear()
 
 
