@@ -32,9 +32,10 @@ Besides the contract fields the JSON line carries
   roofline     : the dominant kernel against the 8 TB/s HBM roofline; achieved = algorithmic bytes (compressed bytes
                  read once + decompressed bytes written once) / mean launch duration, measured with HIP
                  events on the launch stream inside the timed region (max over ranks).  `traffic` is NOT measured by this
-                 run (counters cannot be collected from inside a timed run): it is the FETCH_SIZE + WRITE_SIZE of the
-                 committed rocprofv3 --pmc passes named in `traffic_source`, and null when those were taken on another
-                 workload shape;
+                 run (counters cannot be collected from inside a timed run): it is the bytes of the L2's memory-side requests
+                 (size x count) of the committed rocprofv3 --pmc passes named in `traffic_source`, `traffic_raw` what
+                 FETCH_SIZE + WRITE_SIZE say of the same passes (gfx950 tallies 128-byte reads at 64), both null when the
+                 passes were taken on another workload shape;
   cpu_baseline : the UNMODIFIED reference path (oracle/_ref) on the host cores of the same box, on a bounded sample of
                  the same workload.  Rank 0, N = 1 only;
   other_configs: (the default run: config 2, N = 1) BASELINE.json configs[2], [3], [4] -- `--config 3`, `4`, `5` run as child
@@ -84,21 +85,30 @@ CONFIGS = {
 
 
 def measured_traffic(cfg, n, size):
-    """(HBM bytes per launch, where the number comes from): the committed PMC passes (profiles/r*/hbm_traffic*.json, newest
-    round first), only when they were taken on this very workload shape; counters cannot be collected from inside a timed
-    run, so this is a STATIC number and `traffic_source` says so."""
+    """(bytes the L2 moved to and from memory per launch, the raw FETCH_SIZE + WRITE_SIZE sum, where the numbers come from): the
+    committed PMC passes (profiles/r*/hbm_traffic*.json, newest round first), only when they were taken on this very workload
+    shape; counters cannot be collected from inside a timed run, so these are STATIC numbers and `traffic_source` says so.
+    Round 5 on: traffic = the L2's memory-side requests summed as size x count (TCC_EA0_RDREQ_{32B,64B,128B}, WRREQ): on gfx950
+    every read request of K1 is 128 bytes and FETCH_SIZE tallies those at 64, so the derived counters under-report by the
+    read half (profiles/r4/pmc_calibration.json); `traffic_raw` keeps what they say."""
     name = "hbm_traffic.json" if cfg == 2 else "hbm_traffic_cfg%d.json" % cfg
-    for rnd in ("r4", "r3", "r2"):
+    for rnd in ("r5", "r4", "r3", "r2"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
                 t = json.load(f)
             if n == t.get("entries", 100000) and size == t.get("entry_bytes", 65536):
-                return (t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"],
-                        "static: profiles/%s/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit %s), not measured by this run"
+                if "read_bytes_per_launch" in t:
+                    return (t["read_bytes_per_launch"] + t["write_bytes_per_launch"], t.get("traffic_raw"),
+                            "static: profiles/%s/%s (rocprofv3 --pmc passes of the L2's memory-side requests by size, bytes = size x count, commit %s), "
+                            "not measured by this run" % (rnd, name, t.get("commit", "unknown")))
+                raw = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                return (raw + t["fetch_bytes_per_launch"], raw,
+                        "static: profiles/%s/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit %s; traffic = 2 x FETCH + WRITE, the "
+                        "gfx950 correction of the guide: 128-byte read requests are tallied at 64), not measured by this run"
                         % (rnd, name, t.get("commit", "unknown")))
         except (OSError, ValueError, KeyError):
             pass
-    return None, None
+    return None, None, None
 
 
 def usable_cores():
@@ -577,7 +587,7 @@ def other_configs(args):
             "metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
             "warmup": j["warmup"], "crc32_match_rate": j["crc32_match_rate"], "bytes_spot_check": j["bytes_spot_check"],
             "data": j["data"], "unique_streams": j["config"].get("unique_streams"), "workload": j["config"]["workload"],
-            "roofline": {x: rf[x] for x in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel",
+            "roofline": {x: rf.get(x) for x in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw", "traffic_source", "kernel",
                                             "kernel_ms", "algorithmic_bytes_per_launch")},
             "cpu_baseline": j.get("cpu_baseline"), "wall_s": round(time.time() - t0, 1)}
     return out
@@ -864,7 +874,7 @@ def main():
         bytes_ok = int(s[3].item()) == world
 
     if rank == 0:
-        traffic, traffic_src = measured_traffic(args.config, n, size)
+        traffic, traffic_raw, traffic_src = measured_traffic(args.config, n, size)
         value = total_entries * size * args.steps / elapsed / 2**30
         achieved = algo_all / world / (kernel_ms / 1e3) / 1e9  # per GPU: the slowest rank's launch over an average shard
         line = {
@@ -886,7 +896,7 @@ def main():
                        "host_placement": ("process bound to %d CPUs of the GPU's NUMA node: %s" % (near, sorted(os.sched_getaffinity(0))[:1] + sorted(os.sched_getaffinity(0))[-1:])
                                           if near > 0 else "not bound (one NUMA node, or sysfs does not name the device's)")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_raw": traffic_raw, "traffic_source": traffic_src,
                          "kernel": cfg["kernel"], "kernel_ms": round(kernel_ms, 3), "kernel_ms_per_rank": rank_ms,
                          "algorithmic_bytes_per_launch": int(algo_all / world), "per_gpu": True},
         }

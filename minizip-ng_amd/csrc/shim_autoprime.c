@@ -19,7 +19,8 @@
  *     threads, one mz_zip_reader each over the same file, prime it once -- nor three times before (an application that
  *     alternates between archives entry by entry would otherwise re-image them for ever).
  * A new archive replaces the cache's previous generation (streams still reading from it keep it alive): one archive's
- * worth of decoded bytes at a time. */
+ * worth of decoded bytes at a time.  An application that calls mzhip_prime_* itself is left alone: while the cache holds
+ * generations this file did not make, nothing is cleared or added. */
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -46,6 +47,7 @@ static struct {
     const void *arch;
     int64_t size;
     uint32_t era;
+    int32_t any; /* whether the cache held anything then */
 } g_done[16]; /* archive streams that have been dealt with (primed, in the cache already, or not worth it) while the cache
                  was in the state it is in now: the call that every entry's first read() makes returns on these without I/O */
 static uint32_t g_done_next, g_era; /* era: moves on whenever the cache changes under this file's feet */
@@ -90,9 +92,15 @@ void mzhip_autoprime(mzhip_stream *codec_base) {
         uint8_t *buf = NULL;
         int64_t *table = NULL;
         int dealt_with = 0;
+        const int32_t any_now = mzhip_prime_any();
         for (int i = 0; i < 16; i++)
-            if (g_done[i].arch == (const void *)arch && g_done[i].size == size && g_done[i].era == g_era)
+            if (g_done[i].arch == (const void *)arch && g_done[i].size == size && g_done[i].era == g_era && g_done[i].any == any_now)
                 dealt_with = 1;
+        if (!dealt_with && g_cur_size < 0 && any_now) {
+            /* the cache holds generations this file did not make: the application primes for itself (mzhip_prime_file ...);
+             * nothing is cleared or added under its feet -- entries it did not prime take the per-entry path */
+            dealt_with = 2;
+        }
         if (!dealt_with && size >= 22 && size <= limit) {
             /* which image is this?  its size and the CRC of its tail (the end record and the central directory's end) */
             const int64_t tail = size < 65536 ? size : 65536;
@@ -145,10 +153,11 @@ void mzhip_autoprime(mzhip_stream *codec_base) {
                 }
             }
         }
-        if (!dealt_with) {
+        if (dealt_with != 1) {
             g_done[g_done_next % 16].arch = arch;
             g_done[g_done_next % 16].size = size;
             g_done[g_done_next % 16].era = g_era;
+            g_done[g_done_next % 16].any = mzhip_prime_any();
             g_done_next++;
         }
         free(table);

@@ -24,7 +24,7 @@ REFC = os.path.join(ROOT, "oracle", "_ref", "libmzref_crypto.so")
 # run in a process of its own: libmzhip.so binds the (weak) mz_ref_crypt_sha_* of the drop-in library when it is loaded,
 # so the drop-in has to be what loads it
 PROG = r"""
-import sys, json, ctypes as C
+import sys, os, json, ctypes as C
 sys.path.insert(0, %(root)r)
 import numpy as np, oracle
 hip = oracle.MzDriver(%(drop)r)
@@ -41,7 +41,9 @@ out = {}
 for name, path in (("good", %(good)r), ("bad", %(bad)r)):
     L.mzhip_prime_clear()
     s0 = stats()
+    os.environ["MZHIP_AUTOPRIME"] = "0"                      # (the reader would prime the archive itself: on by default since round 5)
     st, ul = hip.zip_reader_walk(path)                       # nothing primed: the reference's SHA behind the shim
+    del os.environ["MZHIP_AUTOPRIME"]
     s1 = stats()
     primed = L.mzhip_prime_file(path.encode())
     st2, ul2 = hip.zip_reader_walk(path)                     # primed: digests from the device
