@@ -21,8 +21,8 @@ scaling : strong by default, as north_star states it: ONE entry table (100 000 e
 data    : synthetic, SURVEY 8(d): entries are slices of C = appnote.txt || appnote.iz.txt || alice29.txt of the reference
           tree (oracle/_ref/corpus.bin, built by oracle/make_corpus.py; CPython's pydoc prose when it did not travel);
           config 4 uses the seeded order-2 word-Markov expansion of C.  Every entry of config 2 is its OWN stream
-          (100 000 unique slices, ~240 core-seconds of level-6 compression spread over all host cores; config 3: 131 072
-          unique, config 4: 1 024 unique 1 MiB streams), compressed with exactly the reference writer's parameters
+          (100 000 unique slices, ~240 core-seconds of level-6 compression spread over all host cores; config 3: 524 288
+          unique slices of the corpus + 4 MiB of its 4 KiB pieces in random order, config 4: 1 024 unique 1 MiB streams), compressed with exactly the reference writer's parameters
           (mz_strm_zlib.c:87: raw, 32 KiB window, memLevel 8 -- the cpu_baseline leg checks that the reference writer
           emits the same bytes).  Only when the host is too slow (--gen-seconds runs out) the streams made so far are
           tiled to the entry count, and `data` says how many were tiled; every entry has its own copy of its compressed
@@ -72,7 +72,7 @@ CONFIGS = {
     2: dict(entries=100000, size=65536, codec="inflate", kernel="k_inflate_batch", unique=100000,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 100k x 64KiB DEFLATE entries",
             workload="BASELINE.json configs[1]: DEFLATE level-6 %d x %d B entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
-    3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=131072,
+    3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=524288, extend_mib=4,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 1M x 8KiB DEFLATE entries",
             workload="BASELINE.json configs[2]: DEFLATE level-6 %d x %d B small entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
     4: dict(entries=10000, size=1 << 20, codec="lzma", kernel="k_lzma_slot_batch (+ k_lzma_batch over the streams it gives back)", unique=1024,
@@ -141,6 +141,7 @@ def corpus():
 
 _C = None
 _LEVEL = 6
+_TABLE_CACHE = None
 
 
 def _compress_one(off_size):
@@ -153,6 +154,35 @@ def _compress_one(off_size):
 def _pool_init(c, level):
     global _C, _LEVEL
     _C, _LEVEL = c, level
+
+
+def shared_unique_deflate(c, n_unique, size, seed, gen_seconds, world, local_rank, tag):
+    """make_unique_deflate() once per NODE when several ranks build the SAME table (strong scaling: same seed on every rank):
+    the rank with LOCAL_RANK 0 compresses with every host core and leaves the table in a file of the temp directory, the
+    others wait for it and load it -- instead of N ranks compressing the same 6 GiB at 1/N of the cores each, N times over
+    (keep the --gpus 2 / 4 / 8 lines cheap for the driver)."""
+    global _TABLE_CACHE
+    path = os.path.join(tempfile.gettempdir(), "mzhip_bench_%s_%d_%d_%d_%08x_%d.npz" % (tag, n_unique, size, seed, zlib.crc32(bytes(c[:1 << 20])) & 0xFFFFFFFF, len(c)))
+    if local_rank == 0:
+        _TABLE_CACHE = path  # removed by this rank when every rank has reported (main)
+        if os.path.exists(path):
+            os.remove(path)  # (a run that died: the others wait for THIS run's file... they may have loaded the old one, which holds the same streams)
+        offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, gen_seconds, 1)
+        lens = np.array([len(p) for p in pays], dtype=np.int64)
+        tmp = path + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, offs=np.array([o for o, _ in offs], dtype=np.int64), lens=lens, crcs=crcs, blob=np.frombuffer(b"".join(pays), dtype=np.uint8))
+        os.replace(tmp, path)
+        return offs, pays, crcs
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > 4 * gen_seconds + 600:
+            fail("rank with LOCAL_RANK %d: the table of LOCAL_RANK 0 (%s) did not appear" % (local_rank, path))
+        time.sleep(0.5)
+    z = np.load(path)
+    ends = np.cumsum(z["lens"])
+    blob = z["blob"].tobytes()
+    pays = [blob[int(e - l):int(e)] for e, l in zip(ends, z["lens"])]
+    return [(int(o), size) for o in z["offs"]], pays, z["crcs"]
 
 
 def make_unique_deflate(c, n_unique, size, seed, gen_seconds, world):
@@ -676,6 +706,15 @@ def main():
     n_unique = args.unique or cfg["unique"]
     strong = args.scaling == "strong"
     c, cdesc = corpus()
+    if cfg.get("extend_mib") and not args.unique:
+        # config 3 wants half a million UNIQUE 8 KiB streams and the corpus has 463 000 distinct 8 KiB slices: slices are taken
+        # from the corpus followed by 4 KiB pieces of it in a seeded random order (an 8 KiB slice of that part is natural text
+        # with one or two seams: level 6 makes 0.367 of it where a plain slice gives 0.347)
+        ernd = random.Random(777)
+        cb = bytes(c)
+        ext = b"".join(cb[p:p + 4096] for p in (ernd.randrange(len(cb) - 4096) for _ in range(cfg["extend_mib"] * 256)))
+        c = cb + ext
+        cdesc += " followed by %d MiB of 4 KiB pieces of it in a seeded random order" % cfg["extend_mib"]
     # the worker pool that compresses the synthetic slices forks: do it before this process creates its HIP context
     # and the RCCL threads.  Strong scaling: every rank derives the SAME table (same seeds); weak: its own.
     seed = 1234 if strong else 1234 + rank
@@ -683,7 +722,10 @@ def main():
     if cfg["codec"] == "lzma":
         datas, pays, crcs = make_markov_lzma(c, n_unique, size, seed, max(args.gen_seconds, 90.0), world)
     else:
-        offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world)
+        if strong and world > 1 and not os.environ.get("MZHIP_BENCH_NO_TABLE_CACHE"):
+            offs, pays, crcs = shared_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world, local, "c%d" % args.config)
+        else:
+            offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world)
     # MZHIP_BENCH_SHARE_GPU=1 (tests/test_gpu_bench_ranks.py, a box with ONE GPU): every rank uses device 0 and the
     # collectives go through gloo on host copies -- the N > 1 logic (sharding, gather, reductions) on real kernels
     # where RCCL cannot run (it refuses two ranks on one device).  Never set by the driver: the product path is RCCL.
@@ -954,6 +996,9 @@ def main():
             line["other_configs"] = other_configs(args)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()  # (every rank has loaded the shared table long ago: it can go)
+        if _TABLE_CACHE and os.path.exists(_TABLE_CACHE):
+            os.remove(_TABLE_CACHE)
         dist.destroy_process_group()
 
 

@@ -34,13 +34,16 @@ def _run(n, extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n,cfg,entries,unique", [(2, 2, 3001, 256), (3, 3, 20000, 512), (2, 4, 48, 6), (2, 5, 2000, 256)])
+@pytest.mark.parametrize("n,cfg,entries,unique", [(2, 2, 3001, 256), (4, 2, 5003, 256), (3, 3, 20000, 512), (4, 3, 30001, 512), (2, 4, 48, 6), (2, 5, 2000, 256)])
 def test_strong_scaling_line_accounts_for_every_entry(n, cfg, entries, unique):
     line = _run(n, ["--config", str(cfg), "--entries", str(entries), "--unique", str(unique)])
     assert line["n_gpus"] == n and line["scaling"] == "strong"
     assert line["config"]["entries_total"] == entries and 0 < line["config"]["entries_rank0"] < entries
     assert line["crc32_match_rate"] == 1.0 and line["bytes_spot_check"] is True
     assert line["value"] > 0 and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    # every rank reports its own launch, and the ranks built ONE table (LOCAL_RANK 0 compresses, the others load its file)
+    assert len(line["roofline"]["kernel_ms_per_rank"]) == n and all(x > 0 for x in line["roofline"]["kernel_ms_per_rank"])
+    assert sum(line["config"]["launch"]["entries_per_rank"]) == entries
 
 
 def test_weak_scaling_line():
