@@ -374,6 +374,14 @@ MZHIP_API int64_t mzhip_prime_file_multi(const char *path, const int32_t *device
 MZHIP_API int64_t mzhip_prime_mem_multi(const uint8_t *zip, uint64_t zip_len, const int32_t *devices, int32_t ndev);
 /* bounds[0 .. world]: slice r = entries [bounds[r], bounds[r+1]) of an mzhip_zip_index_mem table (8 x int64 per entry) */
 MZHIP_API void mzhip_shard_bounds(const int64_t *table, int64_t n, int32_t world, int64_t *bounds);
+/* The per-archive result gather of a sharded decode (north_star: "RCCL over xGMI only for the final per-archive CRC gather").
+ * Rank r decoded entries [bounds[r], bounds[r + 1]) of the table (mzhip_shard_bounds); d_crc / d_status = this rank's slice
+ * (device memory, bounds[rank + 1] - bounds[rank] words each).  Afterwards d_crc_all / d_status_all (bounds[world] words each,
+ * device memory) hold every entry's pair on every rank: ONE ncclAllGather of max-slice-sized {crc, status} blocks + a copy per
+ * rank, queued on `stream`.  comm = the job's ncclComm_t (RCCL is opened with dlopen() on first use: libmzhip.so does not link
+ * it); world == 1: comm may be NULL, the call is two copies.  Returns 0 or an MZ_* code (MZ_SUPPORT_ERROR: no librccl.so). */
+MZHIP_API int32_t mzhip_gather_results(void *comm, int32_t rank, int32_t world, const int64_t *bounds, const uint32_t *d_crc,
+                                       const int32_t *d_status, uint32_t *d_crc_all, int32_t *d_status_all, void *stream);
 MZHIP_API void mzhip_prime_clear(void);
 
 /* Memory bound of the drop-in READ streams (shim_zlib.c window mode; the reference stages any entry through 32 767 bytes,

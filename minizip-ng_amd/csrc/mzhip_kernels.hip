@@ -24,6 +24,7 @@
 #include <thread>
 #include <unordered_map>
 #include <vector>
+#include <dlfcn.h>
 #include <sched.h>
 #include <stdlib.h>
 #include <stdio.h>

