@@ -956,6 +956,8 @@ def main():
                                         "resident_waves": resident, "entries_per_rank": rank_entries,
                                         "rounds_per_rank": [round(r, 3) for r in rounds],
                                         "predicted_quantisation_efficiency": round(min(r / max(1.0, float(np.ceil(r))) for r in rounds), 3)}
+        else:
+            line["config"]["launch"] = {"entries_per_rank": rank_entries}
         sample_zip = None
         if world == 1 and not args.no_cpu_baseline:
             cores = usable_cores()  # threads the CPU baseline really gets (affinity and cgroup quota, not the CPU count)
