@@ -72,7 +72,7 @@ CONFIGS = {
     2: dict(entries=100000, size=65536, codec="inflate", kernel="k_inflate_batch", unique=100000,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 100k x 64KiB DEFLATE entries",
             workload="BASELINE.json configs[1]: DEFLATE level-6 %d x %d B entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
-    3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=524288, extend_mib=4,
+    3: dict(entries=1000000, size=8192, codec="inflate", kernel="k_inflate_batch", unique=524288, extend_mib=4, gen_scale=1.4,
             metric="decompressed GiB/s (whole node) + CRC32 match rate, 1M x 8KiB DEFLATE entries",
             workload="BASELINE.json configs[2]: DEFLATE level-6 %d x %d B small entries, inflate + fused CRC32 (mzhip_inflate_batch), device-resident"),
     4: dict(entries=10000, size=1 << 20, codec="lzma", kernel="k_lzma_slot_batch (+ k_lzma_batch over the streams it gives back)", unique=1024,
@@ -723,9 +723,9 @@ def main():
         datas, pays, crcs = make_markov_lzma(c, n_unique, size, seed, max(args.gen_seconds, 90.0), world)
     else:
         if strong and world > 1 and not os.environ.get("MZHIP_BENCH_NO_TABLE_CACHE"):
-            offs, pays, crcs = shared_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world, local, "c%d" % args.config)
+            offs, pays, crcs = shared_unique_deflate(c, n_unique, size, seed, args.gen_seconds * cfg.get("gen_scale", 1.0), world, local, "c%d" % args.config)
         else:
-            offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds, world)
+            offs, pays, crcs = make_unique_deflate(c, n_unique, size, seed, args.gen_seconds * cfg.get("gen_scale", 1.0), world)
     # MZHIP_BENCH_SHARE_GPU=1 (tests/test_gpu_bench_ranks.py, a box with ONE GPU): every rank uses device 0 and the
     # collectives go through gloo on host copies -- the N > 1 logic (sharding, gather, reductions) on real kernels
     # where RCCL cannot run (it refuses two ranks on one device).  Never set by the driver: the product path is RCCL.

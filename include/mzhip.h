@@ -302,6 +302,40 @@ MZHIP_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uin
                                          const mzhip_lzma_state *state_in, mzhip_lzma_state *state_out, void *model,
                                          uint32_t *out_len, uint32_t *in_used);
 
+/* Method 95 (.xz) in windows -- entries of any size in bounded memory, as the reference streams them through 32 767 bytes
+ * (mz_strm_lzma.c:127-128,147-241).  The caller walks the container (stream header, block headers, padding, check fields,
+ * index, footer); this call decodes ONE block's LZMA2 chunk sequence a window at a time: `in` starts at a chunk header or
+ * inside the chunk the call before stopped in, buf[0 .. state_in->out_pos) is the dictionary so far and the room behind it
+ * receives the window.  `state` is twenty words: flags (in: 1 the model is in `model`, else a fresh block whose first chunk
+ * resets everything; 2 the input given is the entry's last; 4 / 8 the next chunk must bring properties / reset the
+ * dictionary -- a fresh block is 4 | 8 --; 32 / 64 inside an uncompressed / LZMA chunk.  out: the same bits, 1 = the
+ * decoder stopped where it can go on from, 16 = the block's end byte has been consumed, 128 = a data error was met between
+ * chunks rather than inside a packet), the range coder, LZMA state and
+ * repeat distances, the properties, the block header's dictionary size, out_pos / in_pos as in mzhip_lzma_state, where the
+ * dictionary begins in buf (the caller subtracts what it drops, stopping at 0), what is left of a chunk in progress, and
+ * the block's check (id 0 none / 1 CRC-32 / 4 CRC-64; value of the block's bytes so far, 0 at the start of a block).  The
+ * decoder stops in front of a chunk, or of a packet, when fewer than 274 bytes of room or (bit 2 clear) fewer than 64 bytes
+ * of the chunk's input are left: MZHIP_STATUS_OUT_FULL / MZHIP_STATUS_BUF_ERROR with flags bit 0.  Between calls the caller
+ * keeps at least min(everything the stream produced, dictionary size) bytes in front of buf.  Returns the status. */
+typedef struct mzhip_lzma2_state {
+    uint32_t flags, range, code, state, rep0, rep1, rep2, rep3, props, dict, out_pos, in_pos;
+    uint32_t dict_start, chunk_usize_left, chunk_csize_left, check_id, check_lo, check_hi, pad[2];
+} mzhip_lzma2_state;
+typedef struct mzhip_lzma2_run_args {
+    uint32_t size; /* sizeof(mzhip_lzma2_run_args): fields added later are taken as 0 / NULL */
+    uint32_t in_len;
+    uint32_t buf_cap;
+    uint32_t reserved;
+    const uint8_t *in;
+    uint8_t *buf;
+    const mzhip_lzma2_state *state_in;
+    mzhip_lzma2_state *state_out;
+    void *model;       /* mzhip_lzma_model_bytes(), the caller's */
+    uint32_t *out_len; /* bytes valid in buf */
+    uint32_t *in_used; /* bytes of `in` that are done with */
+} mzhip_lzma2_run_args;
+MZHIP_API int32_t mzhip_lzma2_run_host(const mzhip_lzma2_run_args *args);
+
 /* ... at a preset (see mzhip_lzma_encode_batch_preset); what mz_stream_lzma_write / _close use */
 MZHIP_API int32_t mzhip_lzma_encode_host_preset(const uint8_t *in, uint32_t in_len, int32_t preset, uint8_t *out,
                                                 uint32_t out_cap, uint32_t *out_len, uint32_t *crc);

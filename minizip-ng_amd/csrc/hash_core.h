@@ -246,10 +246,13 @@ MZ_DEV uint64_t mz_gf2_mul64(uint64_t a, uint64_t b) {
 }
 
 /* result (uniform) = CRC-64/XZ of buf[0..n); tab64 = 256-entry table (LDS) */
-#define MZ_CRC64(result, buf, n, tab64)                                                                  \
+#define MZ_CRC64(result, buf, n, tab64) MZ_CRC64_FROM(result, 0ull, buf, n, tab64)
+/* ... taken up from `prev`, the CRC-64 of the bytes in front of buf (0 for none): the value of both together */
+#define MZ_CRC64_FROM(result, prev, buf, n, tab64)                                                       \
     do {                                                                                                 \
         const uint64_t _n = (n);                                                                         \
-        uint64_t _res = 0;                                                                               \
+        const uint64_t _init = ~(uint64_t)(prev); /* the raw register before byte 0 */                   \
+        uint64_t _res = (prev);                                                                          \
         if (_n != 0) {                                                                                   \
             const uint64_t _piece = (_n + 63) / 64;                                                      \
             PV(uint32_t, _lo);                                                                           \
@@ -260,7 +263,7 @@ MZ_DEV uint64_t mz_gf2_mul64(uint64_t a, uint64_t b) {
             MZ_LANES {                                                                                   \
                 const int64_t _s = (int64_t)_n - (int64_t)(64 - lane) * (int64_t)_piece;                 \
                 const int64_t _e = _s + (int64_t)_piece;                                                 \
-                uint64_t _r = (_s <= 0 && _e > 0) ? ~0ull : 0ull;                                        \
+                uint64_t _r = (_s <= 0 && _e > 0) ? _init : 0ull;                                        \
                 for (int64_t _i = _s < 0 ? 0 : _s; _i < _e; _i++)                                        \
                     _r = (tab64)[(uint8_t)_r ^ (buf)[_i]] ^ (_r >> 8);                                   \
                 P(_lo) = (uint32_t)_r;                                                                   \

@@ -339,6 +339,37 @@ __global__ __launch_bounds__(64, 2) void k_xz_batch(LzmaArgs a) {
     }
 }
 
+// .xz in windows: ONE block's LZMA2 chunk sequence taken up where the call before left it (mz_lzma2_run, xz_core.h; the
+// window mode of the drop-in READ stream for method 95, shim_lzma.c).  State record and model travel as in k_lzma_resume.
+struct Lzma2RunArgs {
+    const uint8_t *in;
+    uint32_t in_len;
+    uint8_t *buf; // [dictionary so far | room for this window]
+    uint32_t buf_cap;
+    const mz_lzma2_state *rs;
+    mz_lzma2_state *st;
+    uint16_t *model; // MZ_LZMA_MODEL_U16 probabilities, in and out
+    uint32_t *out_len;
+    uint32_t *in_used;
+    int32_t *status;
+    const mzhip_crc_tables *tabs;
+    const uint64_t *tab64;
+};
+__global__ __launch_bounds__(64) void k_lzma2_run(Lzma2RunArgs a) {
+    __shared__ __attribute__((aligned(16))) mz_xz_lds lds;
+    __shared__ uint32_t crc_tab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        crc_tab[i] = a.tabs->byte_tab[i];
+        lds.crc64_tab[i] = a.tab64[i];
+    }
+    __syncthreads();
+    mz_lzma_result r;
+    mz_lzma2_run(a.in, a.in_len, a.buf, a.buf_cap, &lds, crc_tab, a.tabs, a.model, a.rs, a.st, &r);
+    *a.out_len = r.out_len; // wave-uniform results: stored by all lanes
+    *a.in_used = r.in_used;
+    *a.status = r.status;
+}
+
 struct ShaArgs {
     const uint8_t *buf;
     const uint64_t *off;

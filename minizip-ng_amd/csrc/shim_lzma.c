@@ -75,6 +75,22 @@ typedef struct mzhip_lzma_s {
     int64_t out_abs;       /* position in the decoded stream of out[0] (a multiple of 16) */
     int64_t in_dropped;    /* compressed bytes consumed and dropped from the front of in[] */
     int64_t dict_keep;     /* dictionary bytes kept between windows */
+    /* read side, method 95 in window mode (streaming == 2): the container is walked here, a block's LZMA2 chunks are decoded
+     * window by window by mzhip_lzma2_run_host */
+    int8_t xz_phase;       /* XZP_* */
+    int8_t xz_no_stream;   /* this stream cannot be read in windows (filters, a SHA-256 check): the one-buffer path has it */
+    uint8_t xz_check;      /* the stream flags' check id (0 none, 1 CRC-32, 4 CRC-64) */
+    mzhip_lzma2_state xst;
+    uint64_t xz_blk_hsize, xz_blk_csize, xz_blk_usize; /* this block: header bytes, chunk bytes consumed, bytes decoded */
+    uint64_t xz_want_csize, xz_want_usize;             /* what the block header promises (~0: nothing) */
+    uint64_t xz_nblocks, xz_digest;                    /* blocks so far and a running hash of their (unpadded size, size) records */
+    uint64_t xz_index_size;
+    /* liblzma walks on through block padding, check, the next block header, index and footer in the lzma_code() call that
+     * made a block's last bytes -- as far as the 32 767 bytes staged at the time reach (mz_strm_lzma.c:170-210) -- so what it
+     * finds wrong there fails the read() that would have returned those bytes, and TOTAL_IN stands where the staging ends */
+    int8_t xz_err_eager;   /* s_err was met on that walk */
+    int8_t xz_tail_tried;  /* TOTAL_OUT_MAX reached, a later read() has walked the rest of the container */
+    int64_t xz_tin_hold;   /* >= 0: TOTAL_IN to report while the walk waits for the next staging buffer */
     /* write side, method 14, entries larger than one segment: coded segment by segment (mzhip_lzma_encode_resume_host), wbuf[]
      * then holds [the previous segment's last 64 KiB | bytes not coded yet] */
     int32_t w_segments;    /* segments coded so far */
@@ -143,6 +159,8 @@ int32_t mz_stream_lzma_open(void *stream, const char *path, int32_t mode) {
     z->streaming = z->resumed = z->stream_end = 0;
     z->s_err = 0;
     z->hist = z->out_abs = z->in_dropped = z->dict_keep = 0;
+    z->xz_phase = z->xz_no_stream = z->xz_err_eager = z->xz_tail_tried = 0;
+    z->xz_tin_hold = -1;
     free(z->model);
     z->model = NULL;
     z->w_segments = 0;
@@ -229,7 +247,9 @@ static int32_t pull_chunk(mzhip_lzma *z) {
     return rd;
 }
 
+#define LZ_START_STREAMING 2 /* attempt_decode(): the stream was (re)started in window mode */
 static int32_t lz_stream_start(mzhip_lzma *z);
+static int32_t xz_stream_start(mzhip_lzma *z);
 static int32_t attempt_decode(mzhip_lzma *z) {
     for (;;) {
         if (z->out_cap == 0) {
@@ -237,6 +257,14 @@ static int32_t attempt_decode(mzhip_lzma *z) {
             if (z->method == MZH_COMPRESS_METHOD_LZMA && z->out_cap > mzh_stream_window() && z->in_len >= LZMA_MAGIC_SIZE + 5) {
                 z->out_cap = 0;
                 return lz_stream_start(z); /* larger than a window: decoded window by window from the start */
+            }
+            if (z->method == MZH_COMPRESS_METHOD_XZ && z->out_cap > mzh_stream_window() && !z->xz_no_stream) {
+                const int64_t cap = z->out_cap;
+                z->out_cap = 0;
+                const int32_t r = xz_stream_start(z);
+                if (r != 0)
+                    return r; /* in windows from the start (LZ_START_STREAMING), more input first (1), or out of memory */
+                z->out_cap = cap; /* (filters, a SHA-256 check, a malformed header: the one-buffer path and its verdicts) */
             }
             z->out = (uint8_t *)malloc((size_t)z->out_cap);
             if (!z->out)
@@ -248,6 +276,12 @@ static int32_t attempt_decode(mzhip_lzma *z) {
         if (st == MZHIP_STATUS_OUT_FULL) {
             if (z->method == MZH_COMPRESS_METHOD_LZMA && z->out_cap >= mzh_stream_window())
                 return lz_stream_start(z); /* more than a window of output: once more, this time window by window */
+            if (z->method == MZH_COMPRESS_METHOD_XZ && z->out_cap >= mzh_stream_window() && !z->xz_no_stream) {
+                const int32_t r = xz_stream_start(z);
+                if (r == LZ_START_STREAMING || r < 0)
+                    return r;
+                /* (r == 1 cannot be: the one-shot decode has just read past the first block header) */
+            }
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
             int64_t ncap = z->out_cap * 4;
@@ -279,7 +313,6 @@ static int32_t attempt_decode(mzhip_lzma *z) {
  * model 28 KB of host memory, out[] = [the dictionary so far, at most what the header asks for | the window].  Memory:
  * dictionary + window + one gulp of input.  One stream is one wave (an LZMA stream is one serial chain): this is about
  * being able to read such an entry at all, not about speed. */
-#define LZ_START_STREAMING 2 /* attempt_decode(): the stream was (re)started in window mode */
 static int32_t lz_stream_start(mzhip_lzma *z) {
     uint64_t dict = (uint64_t)z->in[5] | ((uint64_t)z->in[6] << 8) | ((uint64_t)z->in[7] << 16) | ((uint64_t)z->in[8] << 24);
     if (dict < 4096)
@@ -388,6 +421,371 @@ static int32_t lz_stream_next(mzhip_lzma *z) {
     }
 }
 
+/* ---- window mode (method 95): .xz entries of any size in bounded memory -----------------------------------------------
+ * lzma_stream_decoder (mz_strm_lzma.c:127-128) streams an .xz entry through the same 32 767-byte staging buffer.  Here the
+ * container (.xz 1.0.4: stream header 2.1.1, block header 3.1, block padding and check 3.3 / 3.4, index 4, stream footer
+ * 2.1.2) is walked by this file -- a few dozen bytes per block -- and each block's LZMA2 chunk sequence is decoded by the
+ * device window by window (mzhip_lzma2_run_host: coder state a 80-byte record, the model 28 KB of host memory, out[] =
+ * [dictionary so far | window]), the block's CRC-32 / CRC-64 carried through the windows on the device.  Streams this does
+ * not take -- Delta / BCJ filters in front of LZMA2, a SHA-256 check, anything malformed in the first header -- stay with
+ * the one-buffer path (the reference reads those in bounded memory too: a limitation). */
+enum { XZP_BLOCK = 0, XZP_CHUNKS, XZP_BLOCK_END, XZP_INDEX, XZP_FOOTER };
+static uint32_t xz_le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint64_t xz_mix(uint64_t h, uint64_t v) {
+    h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    return h * 0xFF51AFD7ED558CCDull;
+}
+/* variable-length integer (1.2): 1 ok, 0 runs off `lim`, -1 malformed */
+static int xz_vli(const uint8_t *b, int64_t *p, int64_t lim, uint64_t *v) {
+    uint64_t r = 0;
+    for (int i = 0;; i++) {
+        if (i == 9)
+            return -1;
+        if (*p >= lim)
+            return 0;
+        const uint8_t c = b[(*p)++];
+        if (c == 0 && i != 0)
+            return -1;
+        r |= (uint64_t)(c & 0x7F) << (7 * i);
+        if (!(c & 0x80))
+            break;
+    }
+    *v = r;
+    return 1;
+}
+/* a block header of hsize bytes at b (3.1): 0 = LZMA2 alone and well-formed, 1 = anything else */
+static int xz_block_header(const uint8_t *b, int64_t hsize, uint64_t *want_c, uint64_t *want_u, uint32_t *dict) {
+    if (mzhip_crc32_host(0, b, (size_t)(hsize - 4)) != xz_le32(b + hsize - 4))
+        return 1;
+    const uint8_t fl = b[1];
+    if (fl & 0x3F) /* reserved bits; more filters than LZMA2 */
+        return 1;
+    int64_t p = 2;
+    const int64_t hend = hsize - 4;
+    *want_c = *want_u = ~0ull;
+    if ((fl & 0x40) && (xz_vli(b, &p, hend, want_c) != 1 || *want_c == 0))
+        return 1;
+    if ((fl & 0x80) && xz_vli(b, &p, hend, want_u) != 1)
+        return 1;
+    uint64_t id = 0, psize = 0;
+    if (xz_vli(b, &p, hend, &id) != 1 || xz_vli(b, &p, hend, &psize) != 1 || id != 0x21 || psize != 1 || p >= hend)
+        return 1;
+    const uint32_t db = b[p++];
+    if (db > 40)
+        return 1;
+    *dict = db == 40 ? 0xFFFFFFFFu : (uint32_t)(2u | (db & 1u)) << (db / 2u + 11u);
+    for (; p < hend; p++)
+        if (b[p] != 0)
+            return 1;
+    return 0;
+}
+static void xz_consume(mzhip_lzma *z, int64_t n) {
+    memmove(z->in, z->in + n, (size_t)(z->in_len - n));
+    z->in_len -= n;
+    z->in_dropped += n;
+}
+static void xz_fresh_block(mzhip_lzma *z, uint32_t dict) {
+    memset(&z->xst, 0, sizeof(z->xst));
+    z->xst.flags = 4u | 8u;
+    z->xst.dict = dict;
+    z->xst.check_id = z->xz_check;
+    z->xz_blk_csize = z->xz_blk_usize = 0;
+}
+
+/* 0: not in windows (the one-buffer path has this stream), 1: more input first, LZ_START_STREAMING, < 0: out of memory */
+static int32_t xz_stream_start(mzhip_lzma *z) {
+    static const uint8_t magic[6] = {0xFD, '7', 'z', 'X', 'Z', 0x00};
+    z->xz_no_stream = 1;
+    if (z->in_len < 13 || memcmp(z->in, magic, 6) != 0 || z->in[6] != 0 || (z->in[7] != 0 && z->in[7] != 1 && z->in[7] != 4) ||
+        mzhip_crc32_host(0, z->in + 6, 2) != xz_le32(z->in + 8) || z->in[12] == 0)
+        return 0;
+    const int64_t hsize = ((int64_t)z->in[12] + 1) * 4;
+    if (z->in_len < 12 + hsize) {
+        if (z->base_eof)
+            return 0;
+        z->xz_no_stream = 0;
+        return 1;
+    }
+    uint64_t wc, wu;
+    uint32_t dict32 = 0;
+    if (xz_block_header(z->in + 12, hsize, &wc, &wu, &dict32) != 0)
+        return 0;
+    uint64_t dict = dict32 < 4096 ? 4096 : dict32;
+    /* (no match reaches back further than the entry is long: see lz_stream_start) */
+    if (z->max_total_out >= 0 && (uint64_t)z->max_total_out < dict)
+        dict = (uint64_t)z->max_total_out < 4096 ? 4096 : (uint64_t)z->max_total_out;
+    dict = (dict + 15) & ~(uint64_t)15;
+    if (dict > ((uint64_t)1 << 30))
+        return MZH_MEM_ERROR; /* (a dictionary beyond 1 GiB: liblzma would allocate it; this backend does not) */
+    const int64_t cap = (int64_t)dict + mzh_stream_window() + 16;
+    if (cap > 0x7FFFFFFF)
+        return MZH_MEM_ERROR;
+    free(z->out);
+    z->out = (uint8_t *)malloc((size_t)cap);
+    if (!z->model)
+        z->model = malloc(mzhip_lzma_model_bytes());
+    if (!z->out || !z->model)
+        return MZH_MEM_ERROR;
+    z->out_cap = cap;
+    z->dict_keep = (int64_t)dict;
+    z->out_len = z->out_served = z->hist = z->out_abs = z->in_dropped = 0;
+    z->stream_end = 0;
+    z->s_err = 0;
+    z->xz_check = z->in[7];
+    z->xz_nblocks = z->xz_digest = z->xz_index_size = 0;
+    z->xz_blk_hsize = (uint64_t)hsize;
+    z->xz_want_csize = wc;
+    z->xz_want_usize = wu;
+    xz_fresh_block(z, dict32);
+    xz_consume(z, 12 + hsize);
+    z->xz_phase = XZP_CHUNKS;
+    z->xz_no_stream = 0;
+    z->streaming = 2;
+    z->decoded = 1; /* (the one-buffer loop is done with) */
+    return LZ_START_STREAMING;
+}
+
+/* the next window of a method-95 entry: new bytes in out[hist .. out_len), or the stream has ended / cannot go on */
+static int32_t xz_stream_next(mzhip_lzma *z) {
+    if (z->out_len > 0) { /* the dictionary moves to the front; a multiple of 16 goes (position contexts) */
+        int64_t keep = z->out_len < z->dict_keep ? z->out_len : z->dict_keep;
+        const int64_t drop = (z->out_len - keep) & ~(int64_t)15;
+        keep = z->out_len - drop;
+        if (drop > 0)
+            memmove(z->out, z->out + drop, (size_t)keep);
+        z->hist = keep;
+        z->out_abs += drop;
+        z->out_len = z->out_served = keep;
+        z->xst.dict_start = (int64_t)z->xst.dict_start > drop ? (uint32_t)(z->xst.dict_start - drop) : 0u;
+    }
+    const uint32_t check_size = z->xz_check == 0 ? 0u : z->xz_check == 1 ? 4u : 8u;
+    int64_t want_in = mzh_stream_gulp();
+    int eager = 0;         /* a block has just ended with bytes still to serve: the walk liblzma makes in the same call */
+    int64_t eager_lim = 0; /* ... reaches this far into the stream */
+    z->xz_tin_hold = -1;
+    z->xz_err_eager = 0;
+    for (;;) {
+        while (!z->base_eof && z->in_len < want_in) {
+            const int32_t rd = pull_chunk(z);
+            if (rd < 0) {
+                if (rd == MZH_MEM_ERROR)
+                    return rd;
+                z->base_err = rd; /* a failing base read ends the input; it is the result only if the stream needs more */
+                z->base_eof = 1;
+            }
+        }
+/* bytes [0, n) of in[] must be there: more input, or the stream ends short */
+#define XZ_WANT(n)                                                                      \
+    if (eager && z->in_dropped + (int64_t)(n) > eager_lim) {                            \
+        z->xz_tin_hold = eager_lim; /* the staging buffer ends here: the next call's */ \
+        return MZH_OK;                                                                  \
+    }                                                                                   \
+    if (z->in_len < (int64_t)(n)) {                                                     \
+        if (!z->base_eof) {                                                             \
+            want_in = z->in_len + mzh_stream_gulp();                                    \
+            continue;                                                                   \
+        }                                                                               \
+        if (eager) { /* (liblzma asks for more first: LZMA_BUF_ERROR is the next call's) */ \
+            z->xz_tin_hold = z->in_dropped + z->in_len;                                 \
+            return MZH_OK;                                                              \
+        }                                                                               \
+        z->s_err = MZHIP_STATUS_BUF_ERROR;                                              \
+        return MZH_OK;                                                                  \
+    }
+#define XZ_BAD()                                          \
+    do {                                                  \
+        z->s_err = MZHIP_STATUS_DATA_ERROR;               \
+        z->dev_in_used = 0;                               \
+        z->xz_err_eager = (int8_t)eager;                  \
+        return MZH_OK;                                    \
+    } while (0)
+        if (z->xz_phase == XZP_BLOCK) {
+            XZ_WANT(1);
+            if (z->in[0] == 0) {
+                z->xz_phase = XZP_INDEX;
+                continue;
+            }
+            const int64_t hsize = ((int64_t)z->in[0] + 1) * 4;
+            XZ_WANT(hsize);
+            uint32_t dict32 = 0;
+            if (xz_block_header(z->in, hsize, &z->xz_want_csize, &z->xz_want_usize, &dict32) != 0)
+                XZ_BAD(); /* (a block with filters behind one without: not read in windows) */
+            {
+                /* a block with a larger dictionary than the buffer was sized for: the buffer grows (bytes still to be
+                 * served stay where they are; the block's first chunk starts a new dictionary) */
+                uint64_t dict = dict32 < 4096 ? 4096 : dict32;
+                if (z->max_total_out >= 0 && (uint64_t)z->max_total_out < dict)
+                    dict = (uint64_t)z->max_total_out < 4096 ? 4096 : (uint64_t)z->max_total_out;
+                dict = (dict + 15) & ~(uint64_t)15;
+                if ((int64_t)dict > z->dict_keep) {
+                    const int64_t cap = (int64_t)dict + mzh_stream_window() + 16;
+                    uint8_t *nb = (dict > ((uint64_t)1 << 30) || cap > 0x7FFFFFFF) ? NULL : (uint8_t *)realloc(z->out, (size_t)cap);
+                    if (!nb)
+                        return MZH_MEM_ERROR;
+                    z->out = nb;
+                    z->out_cap = cap;
+                    z->dict_keep = (int64_t)dict;
+                }
+            }
+            z->xz_blk_hsize = (uint64_t)hsize;
+            xz_fresh_block(z, dict32);
+            z->xst.dict_start = (uint32_t)z->out_len; /* (the first chunk resets the dictionary anyway) */
+            xz_consume(z, hsize);
+            z->xz_phase = XZP_CHUNKS;
+            continue;
+        }
+        if (z->xz_phase == XZP_CHUNKS) {
+            if (eager)
+                return MZH_OK; /* the bytes in hand first */
+            mzhip_lzma2_state sin = z->xst, sout;
+            sin.flags = (sin.flags & ~(2u | 16u)) | (z->base_eof ? 2u : 0u);
+            sin.out_pos = (uint32_t)z->out_len;
+            memset(&sout, 0, sizeof(sout));
+            uint32_t ol = 0, iu = 0;
+            int64_t room = z->out_len + mzh_stream_window(); /* a window's worth behind what is there */
+            if (room > z->out_cap)
+                room = z->out_cap;
+            mzhip_lzma2_run_args a;
+            memset(&a, 0, sizeof(a));
+            a.size = (uint32_t)sizeof(a);
+            a.in = z->in;
+            a.in_len = (uint32_t)(z->in_len > 0x7FFFFFF0 ? 0x7FFFFFF0 : z->in_len);
+            a.buf = z->out;
+            a.buf_cap = (uint32_t)room;
+            a.state_in = &sin;
+            a.state_out = &sout;
+            a.model = z->model;
+            a.out_len = &ol;
+            a.in_used = &iu;
+            const int32_t st = mzhip_lzma2_run_host(&a);
+            if (st != 0 && st != MZHIP_STATUS_OUT_FULL && st != MZHIP_STATUS_BUF_ERROR && st != MZHIP_STATUS_DATA_ERROR) {
+                z->s_err = MZHIP_STATUS_DATA_ERROR; /* device failure: never substitute a CPU result */
+                z->error = MZH_STREAM_ERROR;
+                return MZH_OK;
+            }
+            if (iu > a.in_len)
+                iu = a.in_len;
+            if (ol < (uint32_t)z->out_len || ol > (uint32_t)room)
+                ol = (uint32_t)z->out_len;
+            const int64_t fresh = (int64_t)ol - z->out_len;
+            z->xz_blk_usize += (uint64_t)fresh;
+            z->out_len = ol;
+            if (st == 0 || (sout.flags & 1u)) { /* the consumed bytes are done with (a failed call keeps them: TOTAL_IN wants them) */
+                xz_consume(z, iu);
+                z->xz_blk_csize += iu;
+                z->xst = sout;
+                z->xst.flags = (sout.flags & ~(16u | 2u)) | ((sout.flags & 1u) ? 1u : 0u);
+            } else {
+                z->dev_in_used = iu;
+            }
+            if (st == 0) {
+                z->xz_phase = XZP_BLOCK_END;
+                if (z->out_len > z->out_served) {
+                    eager = 1;
+                    eager_lim = z->in_dropped > 0 ? ((z->in_dropped - 1) / MZH_STAGING_BYTES + 1) * MZH_STAGING_BYTES : 0;
+                    if (z->max_total_in > 0 && eager_lim > z->max_total_in)
+                        eager_lim = z->max_total_in;
+                }
+                continue;
+            }
+            if (sout.flags & 1u) {
+                if (fresh > 0)
+                    return MZH_OK; /* bytes to serve; the next window goes on from the state */
+                if (st == MZHIP_STATUS_BUF_ERROR && !z->base_eof) {
+                    want_in = z->in_len + mzh_stream_gulp(); /* not a chunk header's, or a packet's, worth of input: more, then again */
+                    continue;
+                }
+                if (st == MZHIP_STATUS_BUF_ERROR) { /* the input ended inside the block: truncation, not corruption (LZMA_BUF_ERROR) */
+                    z->s_err = MZHIP_STATUS_BUF_ERROR;
+                    return MZH_OK;
+                }
+                z->s_err = MZHIP_STATUS_DATA_ERROR; /* no room for one packet in a window: cannot happen (a window is >= 128 KiB) */
+                return MZH_OK;
+            }
+            z->s_err = st; /* the block ends short (BUF_ERROR) or is malformed: served once the bytes in front of it are */
+            if (st == MZHIP_STATUS_DATA_ERROR && (sout.flags & 128u))
+                z->xz_err_eager = 1; /* (between chunks: liblzma meets it in the call that made the bytes in front) */
+            return MZH_OK;
+        }
+        if (z->xz_phase == XZP_BLOCK_END) {
+            /* sizes, block padding, check (3.3, 3.4) */
+            const int64_t pad = (int64_t)((0 - z->xz_blk_csize) & 3u);
+            if ((z->xz_want_csize != ~0ull && z->xz_want_csize != z->xz_blk_csize) ||
+                (z->xz_want_usize != ~0ull && z->xz_want_usize != z->xz_blk_usize))
+                XZ_BAD();
+            XZ_WANT(pad + check_size);
+            for (int64_t i = 0; i < pad; i++)
+                if (z->in[i] != 0)
+                    XZ_BAD();
+            if (z->xz_check == 1 && xz_le32(z->in + pad) != z->xst.check_lo)
+                XZ_BAD();
+            if (z->xz_check == 4 && (xz_le32(z->in + pad) != z->xst.check_lo || xz_le32(z->in + pad + 4) != z->xst.check_hi))
+                XZ_BAD();
+            xz_consume(z, pad + check_size);
+            z->xz_nblocks++;
+            z->xz_digest = xz_mix(xz_mix(z->xz_digest, z->xz_blk_hsize + z->xz_blk_csize + check_size), z->xz_blk_usize);
+            z->xz_phase = XZP_BLOCK;
+            continue;
+        }
+        if (z->xz_phase == XZP_INDEX) {
+            /* index (4): indicator, record count, the records, padding, CRC-32 -- all of it in in[] before it is judged */
+            int64_t p = 1;
+            uint64_t count = 0, dig = 0;
+            int r = xz_vli(z->in, &p, z->in_len, &count);
+            if (r < 0 || (r == 1 && count != z->xz_nblocks))
+                XZ_BAD();
+            for (uint64_t i = 0; r == 1 && i < count; i++) {
+                uint64_t unpadded = 0, usz = 0;
+                r = xz_vli(z->in, &p, z->in_len, &unpadded);
+                if (r == 1)
+                    r = xz_vli(z->in, &p, z->in_len, &usz);
+                if (r < 0)
+                    XZ_BAD();
+                dig = xz_mix(xz_mix(dig, unpadded), usz);
+            }
+            if (r == 0) { /* the index runs on behind what there is */
+                XZ_WANT(z->in_len + 1);
+            }
+            if (dig != z->xz_digest)
+                XZ_BAD();
+            const int64_t isize = ((p + 3) & ~(int64_t)3) + 4;
+            XZ_WANT(isize);
+            for (int64_t i = p; i < isize - 4; i++)
+                if (z->in[i] != 0)
+                    XZ_BAD();
+            if (mzhip_crc32_host(0, z->in, (size_t)(isize - 4)) != xz_le32(z->in + isize - 4))
+                XZ_BAD();
+            z->xz_index_size = (uint64_t)isize;
+            xz_consume(z, isize);
+            z->xz_phase = XZP_FOOTER;
+            continue;
+        }
+        /* stream footer (2.1.2): CRC-32, backward size, stream flags, magic */
+        XZ_WANT(12);
+        if (z->in[10] != 'Y' || z->in[11] != 'Z' || mzhip_crc32_host(0, z->in + 4, 6) != xz_le32(z->in) || z->in[8] != 0 ||
+            z->in[9] != z->xz_check || ((uint64_t)xz_le32(z->in + 4) + 1u) * 4u != z->xz_index_size)
+            XZ_BAD();
+        xz_consume(z, 12);
+        z->stream_end = 1;
+        return MZH_OK;
+#undef XZ_WANT
+#undef XZ_BAD
+    }
+}
+
+/* liblzma failed inside this call: the reference returns the error, not the bytes of the call, and its totals count
+ * everything the decoder took and produced */
+static int32_t lz_stream_fail(mzhip_lzma *z) {
+    z->error = z->s_err == MZHIP_STATUS_BUF_ERROR ? 10 : 9; /* LZMA_BUF_ERROR : LZMA_DATA_ERROR */
+    z->total_out = z->out_abs + z->out_len;
+    if (z->max_total_out >= 0 && z->total_out > z->max_total_out)
+        z->total_out = z->max_total_out;
+    z->total_in = z->s_err == MZHIP_STATUS_BUF_ERROR ? z->in_dropped + z->in_len : z->in_dropped + z->dev_in_used;
+    if (z->base_err != 0 && z->s_err == MZHIP_STATUS_BUF_ERROR)
+        return z->base_err;
+    return MZH_DATA_ERROR;
+}
+
 static int32_t lz_stream_read(mzhip_lzma *z, void *buf, int32_t size) {
     int32_t got = 0;
     while (got < size) {
@@ -395,21 +793,23 @@ static int32_t lz_stream_read(mzhip_lzma *z, void *buf, int32_t size) {
         if (z->max_total_out >= 0 && z->total_out + avail > z->max_total_out)
             avail = z->max_total_out - z->total_out > 0 ? z->max_total_out - z->total_out : 0; /* mz_strm_lzma.c:214-215 */
         if (avail == 0) {
-            if (z->stream_end || (z->max_total_out >= 0 && z->total_out >= z->max_total_out))
+            if (z->stream_end)
                 break;
-            if (z->s_err != 0) {
-                /* liblzma failed inside this call: the reference returns the error, not the bytes of the call, and its
-                 * totals count everything the decoder took and produced */
-                z->error = z->s_err == MZHIP_STATUS_BUF_ERROR ? 10 : 9; /* LZMA_BUF_ERROR : LZMA_DATA_ERROR */
-                z->total_out = z->out_abs + z->out_len;
-                if (z->max_total_out >= 0 && z->total_out > z->max_total_out)
-                    z->total_out = z->max_total_out;
-                z->total_in = z->s_err == MZHIP_STATUS_BUF_ERROR ? z->in_dropped + z->in_len : z->in_dropped + z->dev_in_used;
-                if (z->base_err != 0 && z->s_err == MZHIP_STATUS_BUF_ERROR)
-                    return z->base_err;
-                return MZH_DATA_ERROR;
+            if (z->max_total_out >= 0 && z->total_out >= z->max_total_out) {
+                /* everything the caller may have has been served.  Method 95: the caller's buffer still has room, so the
+                 * reference goes on calling lzma_code (mz_strm_lzma.c:237): the rest of the container is walked, and judged,
+                 * in this call */
+                if (z->streaming != 2)
+                    break;
+                if (z->s_err != 0)
+                    return lz_stream_fail(z);
+                if (z->xz_tail_tried)
+                    break;
+                z->xz_tail_tried = 1;
+            } else if (z->s_err != 0) {
+                return lz_stream_fail(z);
             }
-            const int32_t rc = lz_stream_next(z);
+            const int32_t rc = z->streaming == 2 ? xz_stream_next(z) : lz_stream_next(z);
             if (rc != MZH_OK) {
                 z->error = 5; /* LZMA_MEM_ERROR */
                 return MZH_DATA_ERROR;
@@ -424,7 +824,11 @@ static int32_t lz_stream_read(mzhip_lzma *z, void *buf, int32_t size) {
         z->total_out += k;
         got += k;
     }
+    if (z->streaming == 2 && z->s_err != 0 && z->xz_err_eager && z->out_served == z->out_len)
+        return lz_stream_fail(z); /* met on the walk behind the block whose last bytes this call would have returned */
     z->total_in = z->in_dropped; /* exact once the end marker has been decoded (what mz_zip.c:2116 needs) */
+    if (z->streaming == 2 && z->xz_tin_hold >= 0 && z->out_served == z->out_len)
+        z->total_in = z->xz_tin_hold;
     return got;
 }
 

@@ -640,4 +640,319 @@ finish:
 #undef LZ_CRC_LIMIT
 #define LZ_CRC_LIMIT(o) (o)
 
+/* ---- LZMA2 in windows: method-95 entries of any size in bounded memory (shim_lzma.c) ----------------------------------
+ * The reference streams an .xz entry through 32 767 bytes (mz_strm_lzma.c:127-128,147-241: lzma_stream_decoder +
+ * lzma_code per staging buffer).  Here the container -- stream header, block headers, padding, check fields, index, footer:
+ * a few dozen bytes per block -- is walked by the shim, and a block's LZMA2 chunk sequence (.xz 1.0.4 section 5.3.1's
+ * filter, liblzma's lzma2_decoder.c) is decoded by this function one window at a time: `in` starts at a chunk header, or
+ * inside the chunk the call before stopped in; out[0 .. rs->out_pos) is the dictionary so far.  It stops (st->flags bit 0)
+ * in front of a chunk or in front of a packet when fewer than 274 bytes of room or (unless flags bit 1 says the input is
+ * the entry's last) fewer than 64 bytes of the chunk's input are left, and after the block's end byte (bit 4).  The block's
+ * check -- CRC-32 or CRC-64 of everything the block decodes to -- is carried through the windows in the state. */
+typedef struct mz_lzma2_state {
+    uint32_t flags;   /* in: 1 model in `model` (else a fresh block: the first chunk resets everything), 2 last input,
+                         4 the next LZMA chunk must bring properties, 8 the next chunk must reset the dictionary,
+                         32 inside an uncompressed chunk, 64 inside an LZMA chunk; out: the same, 1 = a state to go on
+                         from, 16 = the block's end byte has been consumed, 128 = the data error was met between chunks
+                         (control byte, chunk header, the coder's first bytes, its state at the chunk's end) and not
+                         inside a packet: liblzma meets those without room in the output */
+    uint32_t range, code, state;
+    uint32_t rep0, rep1, rep2, rep3;
+    uint32_t props;   /* lc | lp << 8 | pb << 16 */
+    uint32_t dict;    /* the block header's dictionary size */
+    uint32_t out_pos; /* in: bytes of dictionary in front of the room; out: bytes valid in the buffer */
+    uint32_t in_pos;  /* out: bytes of the given input that are done with */
+    uint32_t dict_start; /* where in the buffer the dictionary begins (0: further back than the buffer reaches) */
+    uint32_t chunk_usize_left, chunk_csize_left; /* inside a chunk: what is left of it */
+    uint32_t check_id; /* 0 none, 1 CRC-32, 4 CRC-64 */
+    uint32_t check_lo, check_hi; /* the check of the block's bytes so far */
+    uint32_t pad[2];
+} mz_lzma2_state;
+
+#undef LZ_RESUME_CHECK
+#define LZ_RESUME_CHECK()                                                                                   \
+    if (opos + 274u > out_cap || (rc_partial && in_pos + 64u > rc_len)) {                                   \
+        status = (opos + 274u > out_cap) ? MZHIP_OUT_FULL : MZHIP_BUF_ERROR;                                \
+        goto stop_in_chunk;                                                                                 \
+    }
+#undef LZ_CRC_LIMIT
+#define LZ_CRC_LIMIT(o) 0u /* no fused CRC: the block's check is folded when the window is done */
+MZ_DEV void mz_lzma2_run(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, mz_xz_lds *L,
+                         const uint32_t *crc_tab, const mzhip_crc_tables *tabs, uint16_t *model, const mz_lzma2_state *rs,
+                         mz_lzma2_state *st, mz_lzma_result *res) {
+    MZ_LANE_DECL
+    uint16_t *pr = L->lz.probs;
+    uint16_t *const prx = model + ((LZ_NUM_PROBS + 1u) & ~1u);
+    const uint64_t *tab64 = L->crc64_tab;
+    int32_t status = MZHIP_DATA_ERROR;
+    const uint32_t fin = MZ_UNIFORM(rs->flags);
+    const uint32_t last_input = (fin >> 1) & 1u;
+    uint32_t need_props = (fin >> 2) & 1u, need_dict_reset = (fin >> 3) & 1u;
+    uint32_t in_raw = (fin >> 5) & 1u, in_lz = (fin >> 6) & 1u;
+    uint32_t stopped = 0, ended = 0;
+    uint32_t front = 1; /* between packets of different chunks: control byte, chunk header, coder start and end */
+    uint32_t pos = 0; /* cursor in `in` */
+    uint32_t opos = MZ_UNIFORM(rs->out_pos);
+    const uint32_t start = opos;
+    const uint8_t *rc_in = in;
+    uint32_t rc_len = 0, in_pos = 0, in_base = 0, eof = 0, range = MZ_UNIFORM(rs->range), code = MZ_UNIFORM(rs->code);
+    const uint32_t lzma2 = 1;
+    uint32_t chunk_end = 0, dict_start = MZ_UNIFORM(rs->dict_start), rc_short = 0, rc_partial = 0;
+    uint32_t usize_left = MZ_UNIFORM(rs->chunk_usize_left), csize_left = MZ_UNIFORM(rs->chunk_csize_left), csize = 0;
+    uint64_t dict = MZ_UNIFORM(rs->dict);
+    uint32_t state = MZ_UNIFORM(rs->state), rep0 = MZ_UNIFORM(rs->rep0), rep1 = MZ_UNIFORM(rs->rep1), rep2 = MZ_UNIFORM(rs->rep2),
+             rep3 = MZ_UNIFORM(rs->rep3), prev_byte = 0, match_byte = 0;
+    const uint32_t pw = MZ_UNIFORM(rs->props);
+    uint32_t lc = pw & 0xFFu, lp_mask = (1u << ((pw >> 8) & 7u)) - 1u, pb_mask = (1u << ((pw >> 16) & 7u)) - 1u;
+    uint32_t lp_n = (pw >> 8) & 7u, pb_n = (pw >> 16) & 7u;
+    PV(uint32_t, win);
+    PV(uint32_t, crc_acc);
+    uint32_t crc_done = 0;
+    MZ_LANES {
+        P(crc_acc) = 0u;
+        P(win) = 0;
+    }
+    (void)crc_done;
+    if (dict < 4096) dict = 4096;
+    dict = (dict + 15) & ~(uint64_t)15;
+    if (opos > out_cap || state > 11u || dict_start > opos || lc + lp_n > 4u || pb_n > 4u || (in_raw && in_lz)) goto finish;
+    if (fin & 1u) {
+        MZ_LANES {
+            for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64) ((uint32_t *)pr)[i] = ((const uint32_t *)model)[i];
+        }
+        MZ_WAVE_SYNC();
+    } else if (in_lz || !need_props) {
+        goto finish; /* a chunk sequence in progress without its model */
+    }
+
+    for (;;) {
+        if (in_raw) {
+            /* ---- the rest of an uncompressed chunk ---- */
+            uint32_t n = usize_left, stop = 0;
+            if (n > in_len - pos) {
+                n = in_len - pos;
+                stop = MZHIP_BUF_ERROR;
+            }
+            if (n > out_cap - opos) {
+                n = out_cap - opos;
+                stop = MZHIP_OUT_FULL;
+            }
+            MZ_LANES {
+                for (uint32_t i = (uint32_t)lane; i < n; i += 64) out[opos + i] = in[pos + i];
+            }
+            MZ_WAVE_SYNC();
+            opos += n;
+            pos += n;
+            usize_left -= n;
+            if (usize_left != 0u) {
+                status = (int32_t)stop;
+                stopped = 1;
+                goto finish;
+            }
+            in_raw = 0;
+            continue;
+        }
+        if (!in_lz) {
+            /* ---- in front of a chunk ---- */
+            if (opos + 274u > out_cap) {
+                status = MZHIP_OUT_FULL;
+                stopped = 1;
+                goto finish;
+            }
+            if (pos >= in_len) {
+                status = MZHIP_BUF_ERROR;
+                stopped = 1;
+                goto finish;
+            }
+            const uint32_t ctl = XZ_BYTE(pos);
+            if (ctl == 0) {
+                pos++;
+                ended = 1;
+                status = MZHIP_OK;
+                goto finish;
+            }
+            const uint32_t resets_dict = (ctl >= 0xE0 || ctl == 1) ? 1u : 0u;
+            if (!resets_dict && need_dict_reset) goto finish;
+            if (ctl < 0x80) {
+                if (ctl > 2) goto finish;
+                if (in_len - pos < 3u) {
+                    status = MZHIP_BUF_ERROR;
+                    stopped = 1;
+                    goto finish;
+                }
+                usize_left = (XZ_BYTE(pos + 1) << 8) + XZ_BYTE(pos + 2) + 1u;
+                pos += 3;
+                if (resets_dict) {
+                    need_props = 1;
+                    need_dict_reset = 0;
+                    dict_start = opos;
+                }
+                in_raw = 1;
+                continue;
+            }
+            const uint32_t hl = ctl >= 0xC0 ? 6u : 5u;
+            if (in_len - pos < hl) {
+                status = MZHIP_BUF_ERROR;
+                stopped = 1;
+                goto finish;
+            }
+            usize_left = ((ctl & 0x1Fu) << 16) + (XZ_BYTE(pos + 1) << 8) + XZ_BYTE(pos + 2) + 1u;
+            csize = (XZ_BYTE(pos + 3) << 8) + XZ_BYTE(pos + 4) + 1u;
+            {
+                /* all of the chunk, or enough of it for the coder's five bytes and a packet: else more input first */
+                const uint32_t avail = in_len - pos - hl;
+                if (!last_input && avail < csize && avail < 128u) {
+                    status = MZHIP_BUF_ERROR;
+                    stopped = 1;
+                    goto finish;
+                }
+            }
+            if (resets_dict) {
+                need_props = 1;
+                need_dict_reset = 0;
+                dict_start = opos;
+            }
+            if (ctl >= 0xC0) {
+                uint32_t d = XZ_BYTE(pos + 5);
+                if (d > (4 * 5 + 4) * 9 + 8) goto finish;
+                const uint32_t nlc = d % 9;
+                d /= 9;
+                const uint32_t nlp = d % 5, npb = d / 5;
+                if (nlc + nlp > 4) goto finish;
+                lc = nlc;
+                lp_n = nlp;
+                pb_n = npb;
+                lp_mask = (1u << nlp) - 1;
+                pb_mask = (1u << npb) - 1;
+                need_props = 0;
+            } else if (need_props) {
+                goto finish;
+            }
+            pos += hl;
+            if (ctl >= 0xA0) {
+                MZ_LANES {
+                    for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64) ((uint32_t *)pr)[i] = 0x04000400u;
+                    for (uint32_t i = (uint32_t)lane; i < MZ_LZMA_XPROBS / 2; i += 64) ((uint32_t *)prx)[i] = 0x04000400u;
+                }
+                MZ_WAVE_SYNC();
+                state = 0;
+                rep0 = rep1 = rep2 = rep3 = 0;
+            }
+            /* the chunk's compressed bytes are one self-contained range-coder run */
+            rc_short = (in_len - pos) < csize;
+            rc_partial = rc_short && !last_input;
+            rc_in = in + pos;
+            rc_len = rc_short ? in_len - pos : csize;
+            in_pos = 0;
+            in_base = 0;
+            eof = 0;
+            range = 0xFFFFFFFFu;
+            code = 0;
+            if (rc_len > 0 && MZ_UNIFORM(rc_in[0]) != 0) goto finish; /* liblzma: first coder byte must be 0 */
+            LZ_REFILL();
+            for (int i = 0; i < 5; i++) {
+                uint32_t b;
+                LZ_NEXT_BYTE(b);
+                code = (code << 8) | b;
+            }
+        } else {
+            /* ---- inside the LZMA chunk the call before stopped in ---- */
+            in_lz = 0;
+            csize = csize_left;
+            rc_short = (in_len - pos) < csize;
+            rc_partial = rc_short && !last_input;
+            rc_in = in + pos;
+            rc_len = rc_short ? in_len - pos : csize;
+            in_pos = 0;
+            in_base = 0;
+            eof = 0;
+            LZ_REFILL();
+        }
+        chunk_end = opos + usize_left;
+        prev_byte = opos > dict_start ? MZ_UNIFORM(out[opos - 1]) : 0u;
+        match_byte = (state >= 7 && rep0 < opos - dict_start) ? MZ_UNIFORM(out[opos - rep0 - 1]) : 0u;
+        if (eof) goto finish;
+        front = 0;
+        LZ_PACKET_LOOP();
+        front = 1;
+        LZ_NORM(); /* liblzma normalises once more before it requires the coder to hold 0 */
+        if (eof) goto finish;
+        if (code != 0 || in_pos != csize) goto finish;
+        pos += csize;
+        in_pos = 0;
+        usize_left = 0;
+    }
+stop_in_chunk:
+    stopped = 1;
+    in_lz = 1;
+    usize_left = chunk_end - opos;
+    csize_left = csize - in_pos;
+    pos += in_pos;
+    in_pos = 0;
+    eof = 0;
+
+finish:
+    if (status == MZHIP_DATA_ERROR && eof && rc_short) {
+        status = MZHIP_BUF_ERROR; /* the coder ran off a chunk that the input does not hold completely: input ended early */
+        pos = in_len;
+    } else if (!stopped && !ended && in_pos != 0u) {
+        pos += in_pos > rc_len ? rc_len : in_pos; /* a failed chunk: as far as the coder had read */
+    }
+    {
+        /* the block's check over this window's bytes, taken up from the windows before */
+        const uint32_t cid = MZ_UNIFORM(rs->check_id);
+        uint32_t klo = MZ_UNIFORM(rs->check_lo), khi = MZ_UNIFORM(rs->check_hi);
+        const uint32_t fresh = opos > start ? opos - start : 0u;
+        if (cid == 1u && fresh) {
+            PV(uint32_t, _xa);
+            PV(uint32_t, _xt);
+            uint32_t _xd = 0;
+            MZ_LANES { P(_xa) = (lane == 0) ? ~klo : 0u; }
+            MZ_CRC_FOLD_TILES(_xa, _xd, out + start, fresh, crc_tab, tabs->kx);
+            MZ_CRC_FINISH_FROM(klo, _xa, _xt, _xd, out + start, fresh, crc_tab, tabs, ~klo);
+        } else if (cid == 4u && fresh) {
+            uint64_t k;
+            MZ_CRC64_FROM(k, ((uint64_t)khi << 32) | klo, out + start, (uint64_t)fresh, tab64);
+            klo = (uint32_t)k;
+            khi = (uint32_t)(k >> 32);
+        }
+        if (stopped) {
+            MZ_LANES {
+                for (uint32_t i = (uint32_t)lane; i < (LZ_NUM_PROBS + 1) / 2; i += 64) ((uint32_t *)model)[i] = ((const uint32_t *)pr)[i];
+            }
+        }
+        MZ_LANES { /* uniform stores */
+            st->flags = stopped | (need_props << 2) | (need_dict_reset << 3) | (ended << 4) | (in_raw << 5) | (in_lz << 6) |
+                        ((status == MZHIP_DATA_ERROR && front) ? 128u : 0u);
+            st->range = range;
+            st->code = code;
+            st->state = state;
+            st->rep0 = rep0;
+            st->rep1 = rep1;
+            st->rep2 = rep2;
+            st->rep3 = rep3;
+            st->props = lc | (lp_n << 8) | (pb_n << 16);
+            st->dict = MZ_UNIFORM(rs->dict);
+            st->out_pos = opos;
+            st->in_pos = pos > in_len ? in_len : pos;
+            st->dict_start = dict_start;
+            st->chunk_usize_left = usize_left;
+            st->chunk_csize_left = csize_left;
+            st->check_id = cid;
+            st->check_lo = klo;
+            st->check_hi = khi;
+            st->pad[0] = st->pad[1] = 0u;
+        }
+        MZ_WAVE_SYNC();
+        res->status = status;
+        res->out_len = opos;
+        res->in_used = pos > in_len ? in_len : pos;
+        res->crc = 0;
+    }
+}
+#undef LZ_RESUME_CHECK
+#define LZ_RESUME_CHECK() ((void)0)
+#undef LZ_CRC_LIMIT
+#define LZ_CRC_LIMIT(o) (o)
+
 #endif

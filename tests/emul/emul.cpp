@@ -181,6 +181,24 @@ extern "C" int32_t emul_xz(const uint8_t *in, uint32_t in_len, uint8_t *out, uin
 }
 
 extern "C" uint32_t emul_xz_lds_bytes(void) { return (uint32_t)sizeof(mz_xz_lds); }
+/* one window of one block's LZMA2 chunk sequence: state = 20 words (mz_lzma2_state), model as emul_lzma_resume */
+extern "C" int32_t emul_lzma2_run(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap, const uint32_t *st_in,
+                                  uint32_t *st_out, uint16_t *model, uint32_t *out_len, uint32_t *in_used) {
+    ready();
+    mz_xz_lds *L = (mz_xz_lds *)malloc(sizeof(mz_xz_lds));
+    memset(L, 0xA5, sizeof(*L));
+    mzhip_crc64_table_init(L->crc64_tab);
+    mz_lzma2_state a, b;
+    memcpy(&a, st_in, sizeof(a));
+    memset(&b, 0, sizeof(b));
+    mz_lzma_result r;
+    mz_lzma2_run(in, in_len, buf, buf_cap, L, g_tabs.byte_tab, &g_tabs, model, &a, &b, &r);
+    memcpy(st_out, &b, sizeof(b));
+    free(L);
+    *out_len = r.out_len;
+    *in_used = r.in_used;
+    return r.status;
+}
 
 #include "lzma_enc_core.h"
 

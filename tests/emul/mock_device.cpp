@@ -300,6 +300,23 @@ MOCK_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint
     if (in_used) *in_used = iu;
     return st;
 }
+static int g_mock_lzma2_windows = 0;
+MOCK_API int mzmock_lzma2_windows(void) { return g_mock_lzma2_windows; }
+MOCK_API int32_t mzhip_lzma2_run_host(const mzhip_lzma2_run_args *ap) {
+    if (!ap || ap->size < offsetof(mzhip_lzma2_run_args, in_used) + sizeof(void *)) return -102;
+    mzhip_lzma2_run_args a;
+    memset(&a, 0, sizeof(a));
+    memcpy(&a, ap, ap->size < sizeof(a) ? ap->size : sizeof(a));
+    if (!a.model || !a.state_in || !a.state_out || !a.buf || a.state_in->out_pos > a.buf_cap) return -102;
+    uint32_t ol = 0, iu = 0;
+    g_mock_lzma2_windows++;
+    const uint8_t dummy = 0;
+    const int32_t st = emul_lzma2_run(a.in ? a.in : &dummy, a.in_len, a.buf, a.buf_cap, (const uint32_t *)a.state_in, (uint32_t *)a.state_out,
+                                      (uint16_t *)a.model, &ol, &iu);
+    if (a.out_len) *a.out_len = ol;
+    if (a.in_used) *a.in_used = iu;
+    return st;
+}
 static int g_mock_lzma_segments = 0;
 MOCK_API int mzmock_lzma_segments(void) { return g_mock_lzma_segments; }
 MOCK_API int32_t mzhip_lzma_encode_resume_host(const uint8_t *in, uint32_t in_len, uint32_t skip_blocks, uint32_t last, int32_t preset,

@@ -307,6 +307,93 @@ def test_lzma_window_mode(libs):
         L.mzhip_set_stream_window(0, 0)
 
 
+def test_xz_window_mode(libs):
+    """mz_stream_lzma READ of method 95 in window mode (shim_lzma.c xz_stream_*: the container walked on the host side, each
+    block's LZMA2 chunks decoded window by window by mzhip_lzma2_run_host, the block check carried on the device): .xz
+    entries of many windows -- CRC-64 / CRC-32 / no check, dictionaries smaller than the entry and the default 8 MiB,
+    uncompressed chunks, several blocks in one stream -- whole, with and without the limits mz_zip sets, in small and large
+    read() calls, cut at several places (inside a chunk, a check field, the index, the footer), corrupted in the payload,
+    in a check field and in the index: every read() return value, byte, TOTAL_IN / TOTAL_OUT, close() and error() as the
+    all-reference build.  Streams window mode does not take (a BCJ filter, a SHA-256 check) still decode."""
+    import ctypes as C
+    import lzma as pylzma
+
+    hip, ref = libs
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    L.mzhip_set_stream_window(192 << 10, 48 << 10)
+    counter = getattr(L, "mzmock_lzma2_windows", None)  # (the mock counts the windows; the device library does not)
+    try:
+        text, _ = synth.bench_corpus()
+        rnd = np.random.RandomState(5)
+        d = text[:450000] + bytes(100000) + rnd.bytes(90000) + text[:300000] + bytes(range(256)) * 300
+        streams = [("crc64 preset 6", d, pylzma.compress(d, format=pylzma.FORMAT_XZ)),
+                   ("crc32 preset 0", d, pylzma.compress(d, format=pylzma.FORMAT_XZ, check=pylzma.CHECK_CRC32, preset=0)),
+                   ("no check, 64 KiB dictionary, lc0 lp2", d,
+                    pylzma.compress(d, format=pylzma.FORMAT_XZ, check=pylzma.CHECK_NONE,
+                                    filters=[dict(id=pylzma.FILTER_LZMA2, preset=4, dict_size=1 << 16, lc=0, lp=2, pb=0)]))]
+        parts = [text[:260000], rnd.bytes(70000), b"", text[260000:700000], bytes(200000)]
+        streams.append(("five blocks", b"".join(parts), synth.xz_join([pylzma.compress(p, format=pylzma.FORMAT_XZ, preset=1) for p in parts])))
+        for name, d, z in streams:
+            w0 = counter() if counter else 0
+            for kw in (dict(max_in=len(z), max_out=len(d)), dict(), dict(chunk=10000), dict(chunk=300000)):
+                a = hip.stream_decode(95, z, len(d) + 64, **kw)
+                b = ref.stream_decode(95, z, len(d) + 64, **kw)
+                assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (name, kw, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+                assert a["out"] == d and a["close"] == 0
+            if counter:
+                assert counter() - w0 >= 4 * (len(d) // (192 << 10)), (name, counter() - w0)
+            for cut in (len(z) // 5, len(z) // 2, len(z) - 40, len(z) - 13, len(z) - 5, len(z) - 1):
+                for how in ("eof", "max_in"):
+                    a = hip.stream_decode(95, z[:cut] if how == "eof" else z, len(d) + 64, max_in=cut if how == "max_in" else 0)
+                    b = ref.stream_decode(95, z[:cut] if how == "eof" else z, len(d) + 64, max_in=cut if how == "max_in" else 0)
+                    assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (name, cut - len(z), how, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+            for at in (len(z) * 2 // 3, len(z) - 30, len(z) - 14, len(z) - 3):   # payload, check field / index, footer
+                bad = z[:at] + bytes([z[at] ^ 0x55]) + z[at + 1:]
+                a = hip.stream_decode(95, bad, len(d) + 64)
+                b = ref.stream_decode(95, bad, len(d) + 64)
+                assert (a["rets"], a["out"], a["close"], a["error"] != 0) == (b["rets"], b["out"], b["close"], b["error"] != 0), (name, at - len(z), a["rets"][-3:], b["rets"][-3:])
+        # what window mode leaves to the one-buffer path
+        d = streams[0][1]
+        for name, z in (("x86 filter", pylzma.compress(d, format=pylzma.FORMAT_XZ, filters=[dict(id=pylzma.FILTER_X86), dict(id=pylzma.FILTER_LZMA2, preset=1)])),
+                        ("sha-256", pylzma.compress(d, format=pylzma.FORMAT_XZ, check=pylzma.CHECK_SHA256, preset=1))):
+            w0 = counter() if counter else 0
+            a = hip.stream_decode(95, z, len(d) + 64, max_in=len(z), max_out=len(d))
+            b = ref.stream_decode(95, z, len(d) + 64, max_in=len(z), max_out=len(d))
+            assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL} and a["out"] == d, name
+            assert not counter or counter() == w0
+        # through the zip layer: CRC verified by mz_zip_entry_read_close
+        import tempfile
+        datas = [streams[0][1], text[:300000] * 2]
+        blob = np.frombuffer(b"".join(datas), dtype=np.uint8)
+        lens = np.array([len(x) for x in datas], dtype=np.int32)
+        offs = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "x.zip")
+            ref.zip_write(path, blob, offs, lens, method=95, level=1)
+            table = ref.zip_index(path)
+            out = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+            _, crc, ulen, st = hip.zip_read_all(path, table[:, 6].copy(), nthreads=1, own_crc=False, out=out, out_off=offs)
+            assert (st == 0).all() and (ulen == lens).all() and out[:-1].tobytes() == blob.tobytes()
+    finally:
+        L.mzhip_set_stream_window(0, 0)
+
+
+def test_xz_window_mode_differential_fuzz(libs):
+    """tests/fuzz_xz_windows.py as a test: random .xz streams (presets, hand-set lc / lp / pb / dictionary, three check
+    kinds, one to four blocks) through the drop-in's method-95 READ in window mode and through the all-reference build --
+    whole, with mz_zip's limits, cut, bit-flipped anywhere.  No mismatch; a corrupted stream may be refused one read()
+    call apart (counted, bounded)."""
+    from tests import fuzz_xz_windows as F
+
+    hip, ref = libs
+    n = 40 if getattr(hip.L, "mzmock_lzma2_windows", None) else 6      # (the emulation decodes 80 MB/s, one wave 3)
+    cases, mism, soft = F.run(n, 31, hip=hip, ref=ref, verbose=True)
+    print("xz window fuzz: %d cases, %d mismatches, %d corrupted streams refused a read() call apart" % (cases, mism, soft))
+    assert mism == 0 and soft * 20 <= cases
+
+
 def test_lzma_write_in_segments(libs):
     """mz_stream_lzma WRITE in bounded memory (shim_lzma.c): an entry larger than one segment leaves in segments.  Method 14:
     the range coder's state and the adaptive model are carried from launch to launch, so the payload is byte for byte what

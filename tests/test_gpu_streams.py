@@ -198,6 +198,56 @@ def test_entry_larger_than_any_window_bounded_memory(tmp_path, kind):
     print("the all-reference reader: %.1f s" % sec_r)
 
 
+def test_xz_entry_larger_than_any_window_bounded_memory(tmp_path):
+    """Method 95 in bounded memory (mz_strm_lzma.c:127-128,147-241 streams an .xz entry through 32 767 bytes): a 3 GiB ZIP64
+    entry written by the ALL-REFERENCE writer as one .xz stream is extracted through the unmodified mz_zip reader on the
+    drop-in mz_stream_lzma READ stream -- the container walked by shim_lzma.c, the LZMA2 chunks decoded window by window by
+    k_lzma2_run, the block's CRC-64 carried on the device -- in a process whose peak RSS stays far below the entry: size,
+    CRC-32 and status (mz_zip_entry_read_close compares the CRC and, for a data descriptor, TOTAL_IN) as the all-reference
+    reader's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import oracle
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    DROP = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing")
+    path = str(tmp_path / "xbig.zip")
+    total = 3 * (1 << 30) + 54321
+    piece = (b"sparse " * 1024 + bytes(120000)) * 8 + synth.corpus()[:20000]      # ~1 MiB; one wave decodes long matches fast
+    ref = oracle.ref()
+    ref.zip_write_repeat(path, piece, total, method=95, level=1)
+    table = ref.zip_index(path)
+    assert len(table) == 2 and int(table[0, 4]) == total and int(table[0, 0]) == 95
+    cd = table[:, 6].copy()
+    sec_r, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False)
+    assert (st_r == 0).all() and int(ulen_r[0]) == total
+    prog = (
+        "import sys, json, resource\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np, oracle\n"
+        "hip = oracle.MzDriver(%r)\n"
+        "cd = np.array(%r, dtype=np.int64)\n"
+        "sec, crc, ulen, st = hip.zip_read_all(%r, cd, nthreads=1, own_crc=False)\n"
+        "print(json.dumps(dict(sec=sec, crc=[int(x) for x in crc], ulen=[int(x) for x in ulen], st=[int(x) for x in st],\n"
+        "                      rss_kib=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss)))\n" % (ROOT, DROP, [int(x) for x in cd], path))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert got["st"] == [0, 0] and got["ulen"] == [int(x) for x in ulen_r] and got["crc"] == [int(x) for x in crc_r]
+    prog0 = prog.replace(repr([int(x) for x in cd]), repr([int(cd[1])]))
+    r0 = subprocess.run([sys.executable, "-c", prog0], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    base = json.loads([l for l in r0.stdout.splitlines() if l.startswith("{")][-1])
+    print("3 GiB .xz entry (archive %.1f MiB) through the drop-in: %.1f s = %.3f GiB/s, peak RSS %.0f MiB (the same process reading a small entry: %.0f MiB); "
+          "the all-reference reader: %.1f s" % (os.path.getsize(path) / 2**20, got["sec"], total / got["sec"] / (1 << 30), got["rss_kib"] / 1024, base["rss_kib"] / 1024, sec_r))
+    assert got["rss_kib"] - base["rss_kib"] < 512 * 1024                  # dictionary + a 64 MiB window + 16 MiB of input, twice (staging): not the entry
+
+
 def test_written_entry_larger_than_any_segment_bounded_memory(tmp_path):
     """WRITE side of the same property (mz_strm_zlib.c:203-264 stages any entry through 32 767 bytes): a 3 GiB ZIP64 entry
     is written through the unmodified mz_zip_writer on the drop-in mz_stream_zlib WRITE stream -- 8 MiB segments, one K4

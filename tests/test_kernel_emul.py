@@ -321,6 +321,117 @@ def test_lzma_resumable_build(emu):
         assert rc == -5 and so < 0 and got == oo and d.startswith(got) and len(got) > 0, (rc, so, len(got), len(oo))
 
 
+def _lzma2_windows(emu, z, window, gulp, dict_size, check_id=4, keep_all=False):
+    """drive emul_lzma2_run as shim_lzma.c does: a sliding buffer [dictionary | window], input in gulps
+    -> (bytes, consumed, status, check value, windows)"""
+    emu.emul_lzma2_run.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    keep = (max(dict_size, 4096) + 15) & ~15
+    cap = keep + window + 16
+    buf = (C.c_uint8 * cap)()
+    model = (C.c_uint16 * emu.emul_lzma_model_u16())()
+    st_in = (C.c_uint32 * 20)()
+    st_out = (C.c_uint32 * 20)()
+    st_in[0] = 4 | 8
+    st_in[9] = dict_size
+    st_in[15] = check_id
+    got = bytearray()
+    hist = 0
+    pos = 0       # consumed input
+    have = min(len(z), gulp)
+    windows = 0
+    while True:
+        windows += 1
+        assert windows < 200000
+        last = have >= len(z)
+        st_in[0] = (st_in[0] & ~2) | (2 if last else 0)
+        st_in[10] = hist
+        chunk = z[pos:have]
+        src = (C.c_uint8 * max(len(chunk), 1)).from_buffer_copy(chunk or b"\0")
+        ol, iu = C.c_uint32(0), C.c_uint32(0)
+        room = min(cap, hist + window)
+        rc = emu.emul_lzma2_run(src, len(chunk), buf, room, st_in, st_out, model, C.byref(ol), C.byref(iu))
+        assert hist <= ol.value <= room and iu.value <= len(chunk)
+        got += bytes(buf[hist:ol.value])
+        f = st_out[0]
+        if rc == 0:
+            assert f & 16
+            return bytes(got), pos + iu.value, 0, st_out[16] | (st_out[17] << 32), windows
+        if not (f & 1):
+            return bytes(got), pos + iu.value, rc, 0, windows
+        pos += iu.value
+        if rc == -5:
+            if last and ol.value == hist:
+                return bytes(got), pos, rc, 0, windows
+            have = min(len(z), max(have, pos) + gulp)
+        else:
+            assert rc == -200
+        # slide: keep the dictionary
+        out_len = ol.value
+        k = out_len if keep_all else min(out_len, keep)
+        drop = (out_len - k) & ~15   # position contexts look at the low four bits of the position
+        k = out_len - drop
+        ds = st_out[12]
+        if drop:
+            C.memmove(buf, C.addressof(buf) + drop, k)
+        hist = k
+        for i in range(20):
+            st_in[i] = st_out[i]
+        st_in[12] = max(0, ds - drop)
+        st_in[0] = (st_out[0] & ~16) | 1
+
+
+def test_lzma2_windows(emu):
+    """mz_lzma2_run (xz_core.h; method 95 READ in window mode): a block's LZMA2 chunk sequence decoded in windows of 300 bytes
+    to 256 KiB from gulps of input down to 90 bytes gives the bytes and the CRC-64 / CRC-32 of the one-shot decode, for
+    every lc / lp / pb class, dictionaries smaller than the data (the buffer slides), uncompressed chunks (noise), chunks
+    that keep state and chunks that reset it; cut streams end with -5 and the bytes liblzma's decoder gives up to the cut;
+    corrupted ones never run away."""
+    import lzma as pylzma
+    import random
+    import binascii
+
+    def crc64(b):
+        # .xz's CRC-64 through liblzma itself: the check field of a one-block stream
+        x = pylzma.compress(b, format=pylzma.FORMAT_XZ, check=pylzma.CHECK_CRC64, preset=0)
+        return int.from_bytes(x[-12 - 8 - _index_len(x):][:8], "little")
+
+    def _index_len(x):
+        return (int.from_bytes(x[-8:-4], "little") + 1) * 4
+
+    rnd = random.Random(77)
+    c = synth.corpus()
+    noise = bytes(rnd.randrange(256) for _ in range(150000))
+    for lc, lp, pb, dsz, preset in ((3, 0, 2, 1 << 16, 6), (0, 2, 0, 1 << 12, 1), (4, 0, 4, 1 << 20, 6), (1, 3, 1, 1 << 13, 0), (0, 4, 2, 1 << 15, 9)):
+        d = c[rnd.randrange(1000):][:rnd.randrange(100000, 300000)] + noise[:rnd.randrange(70000, 150000)] + b"ab" * 50000 + c[:50000]
+        z = pylzma.compress(d, format=pylzma.FORMAT_RAW, filters=[dict(id=pylzma.FILTER_LZMA2, preset=preset, lc=lc, lp=lp, pb=pb, dict_size=dsz)])
+        want64 = crc64(d)
+        for window, gulp in ((300, 90), (4096, 700), (65536, 20000), (1000, 1 << 30), (262144, 70000)):
+            cid = 4 if window != 4096 else 1
+            got, used, rc, chk, nwin = _lzma2_windows(emu, z, window, gulp, dsz, cid)
+            assert rc == 0 and got == d and used == len(z), (lc, lp, pb, window, gulp, rc, len(got), len(d), used, len(z))
+            assert chk == (want64 if cid == 4 else zlib.crc32(d)), (window, cid, hex(chk))
+        cut = len(z) * 2 // 3
+        got, used, rc, _, _ = _lzma2_windows(emu, z[:cut], 4096, 1000, dsz)
+        dec = pylzma.LZMADecompressor(format=pylzma.FORMAT_RAW, filters=[dict(id=pylzma.FILTER_LZMA2, dict_size=dsz)])
+        ref = dec.decompress(z[:cut])
+        assert rc == -5 and got == ref and len(got) > 0, (rc, len(got), len(ref))
+        for it in range(12):
+            zz = bytearray(z)
+            zz[rnd.randrange(len(zz))] ^= 1 << rnd.randrange(8)
+            got, used, rc, _, _ = _lzma2_windows(emu, bytes(zz), 30000, 9000, dsz)
+            dec = pylzma.LZMADecompressor(format=pylzma.FORMAT_RAW, filters=[dict(id=pylzma.FILTER_LZMA2, dict_size=dsz)])
+            try:
+                ref = dec.decompress(bytes(zz))
+                ok = dec.eof
+            except pylzma.LZMAError:
+                ref, ok = None, False
+            if ok:
+                assert rc == 0 and got == ref
+            else:
+                assert rc != 0 or (ref is not None and got[:len(ref)] == ref), (it, rc)
+
+
 def test_lzma_fixture(emu, fixtures):
     for e in fixtures:
         if e["method"] != 14:

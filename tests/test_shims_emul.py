@@ -64,6 +64,14 @@ def test_lzma_window_mode(libs):
     D.test_lzma_window_mode(libs)
 
 
+def test_xz_window_mode(libs):
+    D.test_xz_window_mode(libs)
+
+
+def test_xz_window_mode_differential_fuzz(libs):
+    D.test_xz_window_mode_differential_fuzz(libs)
+
+
 def test_lzma_write_in_segments(libs):
     D.test_lzma_write_in_segments(libs)
 
