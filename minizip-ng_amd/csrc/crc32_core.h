@@ -16,6 +16,7 @@
 #ifndef MZHIP_CRC32_CORE_H
 #define MZHIP_CRC32_CORE_H
 
+#include <stddef.h>
 #include "wave.h"
 
 #define MZ_CRC_POLY 0xEDB88320u
@@ -168,15 +169,25 @@ MZ_DEV uint32_t mz_crc_dword4(uint32_t r, uint32_t d, const uint32_t *tab4) {
         }                                                                                  \
         (done) += MZ_CRC_SUPER;                                                            \
     }
+/* the advance of MZ_CRC_FOLD_SUPER_BT over the other lanes' 4032 bytes: four lookups in the bytewise advance tables where
+ * they lie in global memory (mzhip_crc_tables.mul4, 4 KiB, hot in the vector L1).  Rounds 3 - 4 multiplied by x^(8*4032)
+ * with 32 select-and-xor steps on constants in scalar registers: ~100 instructions per lane and super-tile where this is
+ * 15 and a memory round trip -- K1 is short of issue slots, not of latency: +3.5 % on 64 KiB entries, +1.3 % on 8 KiB
+ * (profiles/r5/call15_probe.log, call16).  The dword steps stay on the byte table in LDS: the slicing tables through global
+ * memory (four independent gathers per dword) measured 5 % slower. */
+#define MZ_CRC_ADVANCE_SUPER(r, kxp) mz_crc_advance_gm((r), (const uint32_t *)((const uint8_t *)(kxp) + (offsetof(mzhip_crc_tables, mul4) - offsetof(mzhip_crc_tables, kx4))))
+MZ_DEV uint32_t mz_crc_advance_gm(uint32_t r, const uint32_t *mul4) {
+    return mul4[r & 255u] ^ mul4[256u + ((r >> 8) & 255u)] ^ mul4[512u + ((r >> 16) & 255u)] ^ mul4[768u + (r >> 24)];
+}
 /* The same super-tiles with the byte table alone (no slicing / advance tables in LDS): K1's fused epilogue, where LDS
- * decides the occupancy.  The advance over the other lanes' 4032 bytes is one multiplication by x^(8*4032) (kx4[]),
- * paid once per 64 bytes of a lane instead of once per 16 as with the 1 KiB tiles. */
+ * decides the occupancy.  The advance over the other lanes' 4032 bytes (MZ_CRC_ADVANCE_SUPER; kx4 = &tabs->kx4[0], the
+ * tables are found from there) is paid once per 64 bytes of a lane instead of once per 16 as with the 1 KiB tiles. */
 #define MZ_CRC_FOLD_SUPER_BT(acc, done, buf, upto, tab, kx4)                               \
     while ((uint64_t)(done) + MZ_CRC_SUPER <= (uint64_t)(upto)) {                          \
         MZ_LANES {                                                                         \
             const uint8_t *_p = (buf) + (done) + 64u * (uint32_t)lane;                     \
             uint32_t _r = P(acc);                                                          \
-            if ((done) != 0) _r = mz_gf2_mul_kx(_r, (kx4));                                \
+            if ((done) != 0) _r = MZ_CRC_ADVANCE_SUPER(_r, (kx4));                         \
             for (int _k = 0; _k < 4; _k++) {                                               \
                 uint32_t _q[4];                                                            \
                 __builtin_memcpy(_q, _p + 16 * _k, 16); /* one 16-byte load */             \
