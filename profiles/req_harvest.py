@@ -15,7 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load(d, tag, kernel):
+    """kernel = a name prefix; with a trailing '+' the rows of every matching kernel are ADDED (one step of a workload that is
+    several launches: config 4 = k_lzma_slot_batch + k_lzma_batch over what it gives back), else they are averaged (the same
+    kernel launched several times)"""
     out = {}
+    add = kernel.endswith("+")
+    kernel = kernel.rstrip("+")
     for i in (1, 2):
         rows = [r for r in csv.DictReader(open(os.path.join(d, "req_%s_%d.csv" % (tag, i)))) if r["Kernel_Name"].startswith(kernel)]
         acc, dur = collections.defaultdict(list), {}
@@ -23,9 +28,9 @@ def load(d, tag, kernel):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
         for k, v in acc.items():
-            out[k] = sum(v) / len(v)
-        out["launches"] = len(dur)
-        out["kernel_ms_under_pmc"] = round(sum(dur.values()) / max(1, len(dur)), 3)
+            out[k] = sum(v) if add else sum(v) / len(v)
+        out["launches"] = 1 if add else len(dur)
+        out["kernel_ms_under_pmc"] = round(sum(dur.values()) / (1 if add else max(1, len(dur))), 3)
     n32, n64, n128 = out.get("TCC_EA0_RDREQ_32B_sum", 0), out.get("TCC_EA0_RDREQ_64B_sum", 0), out.get("TCC_EA0_RDREQ_128B_sum", 0)
     w, w64 = out.get("TCC_EA0_WRREQ_sum", 0), out.get("TCC_EA0_WRREQ_64B_sum", 0)
     rd = 32 * n32 + 64 * n64 + 128 * n128
