@@ -778,7 +778,10 @@ def main():
     if U >= n_table:
         pick_all = np.arange(n_table)  # every entry is its own stream
     else:
-        pick_all = rnd.randint(0, U, size=n_table)  # the generator ran out of time (or --unique asked for fewer): tiled
+        # fewer streams than entries (config 3's table is 524 288, or the generator ran out of time, or --unique asked for fewer):
+        # every stream is used once, the rest of the entries are repeats drawn at random, in a random order
+        pick_all = np.concatenate((np.arange(U), rnd.randint(0, U, size=n_table - U)))
+        rnd.shuffle(pick_all)
     tiled = n_table - len(np.unique(pick_all))
     plen = np.array([len(p) for p in pays], dtype=np.int64)
     lo, hi = 0, n_table
