@@ -832,6 +832,7 @@ def main():
     gathered = torch.empty(world * max_shard * 2, dtype=torch.int32, device=dev) if world > 1 else None
     mine = torch.zeros(max_shard * 2, dtype=torch.int32, device=dev) if world > 1 else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     stats = {}
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -859,8 +860,12 @@ def main():
         if i_timed is not None:
             ev[i_timed][1].record()
         if world > 1:
+            if i_timed is not None:
+                gev[i_timed][0].record()
             mine[:2 * n] = torch.stack((crc, status)).reshape(-1)
             all_gather_into(gathered, mine)
+            if i_timed is not None:
+                gev[i_timed][1].record()
         if True:  # every step, timed or not (the check stays inside the clock; a handful of elementwise launches, ~30 us)
             if cfg["codec"] == "deflate":
                 ok = (crc == want_crc) & (status == 0) & (out_len > 0)
@@ -884,6 +889,7 @@ def main():
     elapsed = time.perf_counter() - t0
     match = int(stats["match"].item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gev])) if world > 1 else 0.0  # the {crc, status} all-gather behind the launch
 
     # byte-exact spot check of the output buffer (outside the timed region)
     bytes_ok = True
@@ -910,8 +916,9 @@ def main():
         all_reduce(pr, dist.ReduceOp.SUM)
         rank_ms = [round(float(x), 3) for x in pr[0::2].tolist()]
         rank_entries = [int(x) for x in pr[1::2].tolist()]
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms, gather_ms], dtype=torch.float64, device=dev)
         all_reduce(t, dist.ReduceOp.MAX)
+        gather_ms = float(t[2].item())
         s = torch.tensor([float(match), float(n), float(algo_bytes), float(bytes_ok)], dtype=torch.float64, device=dev)
         all_reduce(s, dist.ReduceOp.SUM)
         elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
@@ -961,6 +968,8 @@ def main():
                                         "predicted_quantisation_efficiency": round(min(r / max(1.0, float(np.ceil(r))) for r in rounds), 3)}
         else:
             line["config"]["launch"] = {"entries_per_rank": rank_entries}
+        if world > 1:
+            line["config"]["launch"]["gather_ms"] = round(gather_ms, 3)  # slowest rank, mean of the timed steps (waits for the slowest rank's launch)
         sample_zip = None
         if world == 1 and not args.no_cpu_baseline:
             cores = usable_cores()  # threads the CPU baseline really gets (affinity and cgroup quota, not the CPU count)

@@ -43,7 +43,7 @@ def test_strong_scaling_line_accounts_for_every_entry(n, cfg, entries, unique):
     assert line["value"] > 0 and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
     # every rank reports its own launch, and the ranks built ONE table (LOCAL_RANK 0 compresses, the others load its file)
     assert len(line["roofline"]["kernel_ms_per_rank"]) == n and all(x > 0 for x in line["roofline"]["kernel_ms_per_rank"])
-    assert sum(line["config"]["launch"]["entries_per_rank"]) == entries
+    assert sum(line["config"]["launch"]["entries_per_rank"]) == entries and line["config"]["launch"]["gather_ms"] > 0
 
 
 def test_weak_scaling_line():
