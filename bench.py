@@ -332,7 +332,8 @@ def cpu_baseline_inflate(c, offs, size, pays, want_crc, cores, keep_path=None):
                        "%.3f GiB/s with the readers on mz_stream_mem over one shared mapping (%d passes); value = the better; "
                        "1-thread: %.3f GiB/s.  DEVIATION from BASELINE.md 3 (whole archive, median of 3): this is a SAMPLE of the "
                        "archive read repeatedly for ~3 s per mode (it stays in the page cache and the last-level cache), best of "
-                       "two ways to open it -- both choices favour the CPU" % (n, size, "identical to" if same else "DIFFER from", cores, rates[False][0],
+                       "two ways to open it -- both choices favour the CPU.  The codec under it is zlib 1.2.11, the slowest inflate the reference "
+                       "builds on: its CMakeLists prefers zlib-ng (absent here, no network), whose inflate is about 2 x this" % (n, size, "identical to" if same else "DIFFER from", cores, rates[False][0],
                                                  rates[False][1], rates[True][0], rates[True][1], k * size / 2**30 / sec1))
 
 
