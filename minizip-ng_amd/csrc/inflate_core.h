@@ -435,7 +435,7 @@ MZ_DEV uint32_t mz_chase_step(const mz_inflate_lds *L, uint32_t d0, uint32_t d1,
     uint32_t e = L->lit_fast[w0 & ((1u << MZ_LROOT) - 1u)];
     if (e & MZ_E_SUB) e = L->lit_sub[((e >> 8) & 0x1FFu) + mz_bfe(w0, MZ_LROOT, e & 7u)];
     uint32_t r = 0, pb = 0;
-    if ((e & (MZ_E_LEN | 0x80u)) == 0x80u && (e & 63u) < room) { /* a literal that does not end the lane's walk takes the token behind it along */
+    if ((((e & (MZ_E_LEN | 0x80u)) == 0x80u) & ((e & 63u) < room)) != 0) { /* a literal that does not end the lane's walk takes the token behind it along (one test, one exec bracket: `&&` made two) */
         pb = e & 63u;
         r = 0x80000000u | mz_bfe(e, 16, 8);
         w0 = mz_funnel(w1, w0, pb);
