@@ -529,6 +529,8 @@ MZ_DEV uint32_t mz_block_header_plausible(const uint8_t *in, uint32_t in_len, ui
     return kraft == 128u ? 1u : 0u;
 }
 
+#include "inflate_header.inc"
+
 /* Decode one raw-DEFLATE entry.  All arguments are wave-uniform. */
 MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out, uint32_t out_cap,
                              mz_inflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
@@ -671,244 +673,17 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
             goto finish;
         }
 
-        uint32_t sub_used = MZ_LIT_SUB_ENTRIES; /* second-level entries this block's literal/length code occupies */
-        /* Round 5: the code lengths of the block live in registers from the moment they are known -- P(lr)[k] = the length
-         * of literal/length symbol 64 k + lane, P(dl) = the length of distance symbol `lane` -- and inflate_tables.inc
-         * builds the tables from there (ballots and two wave scans; no histogram, no rank loop through LDS). */
-        PV2(uint32_t, lr, 5);
-        PV(uint32_t, dl);
-        if (btype == 1) {
-            /* fixed code, appnote.txt:2050-2059 (286 / 287 and the distance symbols 30 / 31 take part in the code and are
-             * refused when they are met: mz_lit_ent / mz_dist_ent) */
-            MZ_LANES {
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const uint32_t s = 64u * (uint32_t)k + (uint32_t)lane;
-                    P(lr)[k] = s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : s < 288u ? 8u : 0u;
-                }
-                P(dl) = lane < 32 ? 5u : 0u;
-            }
-        } else {
-            /* dynamic code, appnote.txt:2060-2106 */
-            uint32_t h;
-            MZ_HDR_BITS(h, 14);
-            const uint32_t nlen = (h & 31u) + 257, ndist = ((h >> 5) & 31u) + 1, ncode = (h >> 10) + 4;
-            if (nlen > 286 || ndist > 30) {
-                status = MZHIP_DATA_ERROR; /* too many length or distance symbols */
+        uint32_t sub_used; /* second-level entries this block's literal/length code occupies */
+        {
+            /* the block's code: code lengths -> decode tables in LDS (inflate_header.inc, a function of its own) */
+            const mz_code_result cr = mz_block_code(MZ_LDS_HANDLE(L), MZ_GLB_HANDLE(in), in_len, in_mis, total_bits, bitpos, hw0, btype, hwin MZ_PROF_ARGS);
+            sub_used = MZ_UNIFORM(cr.sub_used);
+            bitpos = MZ_UNIFORM(cr.bitpos);
+            if (MZ_UNIFORM(cr.status) != (uint32_t)MZHIP_OK) {
+                status = (int32_t)MZ_UNIFORM(cr.status);
                 goto finish;
-            }
-            if (bitpos + 3u * ncode > total_bits) {
-                status = MZHIP_BUF_ERROR;
-                goto finish;
-            }
-            /* the code-length code: lane s < 19 takes the 3-bit field of symbol s out of the (uniform) 57 bits; where a
-             * symbol stands in the transmission order (appnote.txt:2083-2090) is a packed constant, 5 bits a symbol */
-            PV(uint32_t, cl19);
-            {
-                uint64_t w;
-                MZ_HDR_WIN_BITS(w, bitpos);
-                const uint32_t wlo = MZ_UNIFORM((uint32_t)w), whi = MZ_UNIFORM((uint32_t)(w >> 32));
-                const uint64_t wu = ((uint64_t)whi << 32) | wlo;
-                MZ_LANES {
-                    /* position of symbol s in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 */
-                    const uint64_t inv_lo = 3ull | 17ull << 5 | 15ull << 10 | 13ull << 15 | 11ull << 20 | 9ull << 25 | 7ull << 30 | 5ull << 35 |
-                                            4ull << 40 | 6ull << 45 | 8ull << 50 | 10ull << 55;
-                    const uint64_t inv_hi = 12ull | 14ull << 5 | 16ull << 10 | 18ull << 15 | 0ull << 20 | 1ull << 25 | 2ull << 30;
-                    const uint32_t s = (uint32_t)lane;
-                    const uint32_t pos = (uint32_t)((s < 12u ? inv_lo >> (5u * s) : inv_hi >> (5u * ((s - 12u) & 7u)))) & 31u;
-                    P(cl19) = (s < 19u && pos < ncode) ? (uint32_t)(wu >> (3u * (pos & 31u))) & 7u : 0u;
-                }
-            }
-            bitpos += 3u * ncode;
-            PV(uint32_t, clcreg); /* the 128-entry table of the code-length code: entry i in lane i & 63, half i >> 6 (symbol << 4 | bits) */
-            {
-                PV(uint32_t, ccnt);
-                PV(uint32_t, crk);
-                MZ_LANES { P(ccnt) = P(crk) = 0u; }
-#pragma unroll
-                for (uint32_t lg = 1; lg <= 7u; lg++) {
-                    uint64_t m;
-                    MZ_BALLOT(m, P(cl19) == lg);
-                    MZ_LANES {
-                        if (P(cl19) == lg) P(crk) = MZ_RANK_BELOW(m);
-                    }
-                    MZ_WRITELANE_S(ccnt, lg, mz_popc64(m));
-                }
-                PV(uint32_t, cx);
-                PV(uint32_t, clim);
-                PV(uint32_t, cfirst);
-                MZ_LANES { P(cx) = (lane >= 1 && lane <= 7) ? P(ccnt) << (7 - lane) : 0u; }
-                MZ_INCL_SCAN(clim, cx);
-                if (MZ_READLANE(clim, 7) != 128u) {
-                    status = MZHIP_DATA_ERROR; /* invalid code lengths set: over-subscribed or incomplete */
-                    goto finish;
-                }
-                MZ_LANES { P(cfirst) = (P(clim) - P(cx)) >> ((7u - (uint32_t)lane) & 7u); }
-                PV(uint32_t, cf);
-                MZ_GATHER4(cf, cfirst, 4u * P(cl19));
-                MZ_LANES {
-                    const uint32_t l = P(cl19);
-                    if (l) {
-                        const uint32_t rv = mz_brev32(P(cf) + P(crk)) >> (32u - l);
-                        for (uint32_t q = rv; q < (1u << MZ_CROOT); q += 1u << l) L->u.h.clc_fast[q] = (uint16_t)(((uint32_t)lane << 4) | l);
-                    }
-                }
-                MZ_WAVE_SYNC();
-                MZ_LANES { P(clcreg) = (uint32_t)L->u.h.clc_fast[lane] | ((uint32_t)L->u.h.clc_fast[lane + 64] << 16); }
-            }
-            MZ_PROF_MARK(0); /* block header up to the code-length code */
-            uint32_t idx = 0, prev = 0;
-            const uint32_t ntot = nlen + ndist;
-#if MZ_CL_PARALLEL
-            /* Front end: 64 bits of the run-length coded lengths at a time.  Lane i decodes the symbol that would start
-             * at bit i of the window (one table lookup), a scalar walk picks the lanes that really are symbol starts, a
-             * prefix sum of their repeat counts places them, and every lane stores its own lengths (zeros are already
-             * there).  ~12 symbols per step instead of one.  It only ever consumes symbols that are certainly fine --
-             * inside the header window, far from the end of the input, not running over nlen + ndist -- and leaves
-             * anything else, with the cursor in front of it, to the serial loop below, which owns the verdicts. */
-            {
-                MZ_LANES {
-                    for (uint32_t k = (uint32_t)lane; k < 80u; k += 64u) mz_st4(L->u.h.cl + 4u * k, 0u);
-                }
-                MZ_WAVE_SYNC();
-                PV(uint32_t, tl); /* bits of the symbol at this lane's offset (0: no code) */
-                PV(uint32_t, tc); /* lengths it stands for */
-                PV(uint32_t, tv); /* their value; 16 = the value before */
-                PV(uint32_t, g0);
-                PV(uint32_t, g1);
-                PV(uint32_t, cm);
-                PV(uint32_t, cs);
-                PV(uint32_t, sl);
-                PV(uint32_t, rv);
-                PV(uint32_t, vr);
-                while (idx < ntot) {
-                    const uint32_t ab = bitpos + 8u * in_mis;
-                    const uint32_t j0 = (ab >> 5) - hw0;
-                    if (j0 + 3u >= 64u || bitpos + 64u + 14u > total_bits) break;
-                    MZ_GATHER4(g0, hwin, 4u * (j0 + (((ab & 31u) + (uint32_t)lane) >> 5)));
-                    MZ_GATHER4(g1, hwin, 4u * (j0 + (((ab & 31u) + (uint32_t)lane) >> 5) + 1u));
-                    MZ_LANES {
-                        const uint32_t w = mz_funnel(P(g1), P(g0), ab + (uint32_t)lane);
-                        const uint32_t e = L->u.h.clc_fast[w & ((1u << MZ_CROOT) - 1u)];
-                        const uint32_t nb = e & 15u, sym = e >> 4;
-                        const uint32_t ext = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
-                        const uint32_t xb = (w >> nb) & ((1u << ext) - 1u);
-                        P(tl) = nb ? nb + ext : 0u;
-                        P(tc) = sym < 16u ? 1u : sym == 18u ? 11u + xb : 3u + xb;
-                        P(tv) = sym < 16u ? sym : sym == 16u ? 16u : 0u;
-                    }
-                    uint64_t M = 0; /* lanes that are symbol starts and end inside the window */
-                    uint32_t cur = 0, stop = 0;
-                    while (cur < 64u) {
-                        const uint32_t l = MZ_READLANE(tl, cur);
-                        if (l == 0u) stop = 1; /* an invalid code (or garbage behind the last length): not ours */
-                        if (l == 0u || cur + l > 64u) break;
-                        M |= 1ull << cur;
-                        cur += l;
-                    }
-                    if (idx == 0u && MZ_READLANE(tv, 0) == 16u) break; /* a repeat with nothing before it */
-                    MZ_LANES { P(cm) = ((M >> lane) & 1ull) ? P(tc) : 0u; }
-                    MZ_INCL_SCAN(cs, cm);
-                    uint64_t F; /* symbols that do not end inside nlen + ndist: behind the last length, or an overrun */
-                    MZ_BALLOT(F, ((M >> lane) & 1ull) && idx + P(cs) > ntot);
-                    const uint32_t f = F ? mz_ctz64(F) : 64u;
-                    const uint64_t Pm = F ? (M & ((1ull << f) - 1ull)) : M;
-                    if (!Pm) break;
-                    uint64_t NC;
-                    MZ_BALLOT(NC, ((Pm >> lane) & 1ull) && P(tv) != 16u);
-                    MZ_LANES {
-                        const uint64_t below = NC & (((uint64_t)2 << lane) - 1ull);
-                        P(sl) = below ? 63u - mz_clz64(below) : 64u;
-                    }
-                    MZ_GATHER4(rv, tv, 4u * (P(sl) & 63u));
-                    MZ_LANES {
-                        const uint32_t v = (P(tv) != 16u) ? P(tv) : (P(sl) < 64u ? P(rv) : prev);
-                        P(vr) = v;
-                        if (((Pm >> lane) & 1ull) && v != 0u) {
-                            const uint32_t o = idx + P(cs) - P(cm);
-                            for (uint32_t k = 0; k < P(cm); k++) L->u.h.cl[o + k] = (uint8_t)v;
-                        }
-                    }
-                    const uint32_t lastl = 63u - mz_clz64(Pm);
-                    prev = MZ_READLANE(vr, lastl);
-                    idx += MZ_READLANE(cs, lastl);
-                    MZ_STAT(16, mz_popc64(Pm)); MZ_STAT(18, 1);
-                    bitpos += F ? f : cur;
-                    if (F || stop) break;
-                }
-                MZ_WAVE_SYNC();
-            }
-#endif
-            while (idx < ntot) {
-                uint64_t w;
-                MZ_HDR_WIN_BITS(w, bitpos);
-                uint32_t wlo = MZ_UNIFORM((uint32_t)w), whi = MZ_UNIFORM((uint32_t)(w >> 32));
-                uint64_t wu = ((uint64_t)whi << 32) | wlo;
-                uint32_t used = 0;
-                while (idx < ntot && used + 14 <= 64) {
-                    const uint32_t ci = (uint32_t)(wu >> used) & 127u;
-                    uint32_t e = (MZ_READLANE(clcreg, ci & 63u) >> ((ci >> 6) << 4)) & 0xFFFFu;
-                    uint32_t nb = e & 15u, sym = e >> 4;
-                    MZ_STAT(17, 1);
-                    if (nb == 0) {
-                        status = (bitpos + used + 7 > total_bits) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
-                        goto finish;
-                    }
-                    uint32_t ext = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
-                    if (bitpos + used + nb + ext > total_bits) {
-                        status = MZHIP_BUF_ERROR;
-                        goto finish;
-                    }
-                    uint32_t xb = (uint32_t)(wu >> (used + nb)) & ((1u << ext) - 1);
-                    used += nb + ext;
-                    if (sym < 16) {
-                        MZ_LANES { L->u.h.cl[idx] = (uint8_t)sym; } /* uniform store */
-                        prev = sym;
-                        idx++;
-                    } else {
-                        uint32_t rep, val = 0;
-                        if (sym == 16) {
-                            if (idx == 0) {
-                                status = MZHIP_DATA_ERROR; /* invalid bit length repeat */
-                                goto finish;
-                            }
-                            val = prev;
-                            rep = 3 + xb;
-                        } else if (sym == 17) {
-                            rep = 3 + xb;
-                        } else {
-                            rep = 11 + xb;
-                        }
-                        if (idx + rep > ntot) {
-                            status = MZHIP_DATA_ERROR; /* invalid bit length repeat */
-                            goto finish;
-                        }
-                        MZ_LANES {
-                            for (uint32_t k = (uint32_t)lane; k < rep; k += 64) L->u.h.cl[idx + k] = (uint8_t)val;
-                        }
-                        prev = val;
-                        idx += rep;
-                    }
-                }
-                bitpos += used;
-            }
-            MZ_WAVE_SYNC();
-            MZ_PROF_MARK(1); /* code lengths */
-            if (MZ_UNIFORM(L->u.h.cl[256]) == 0) {
-                status = MZHIP_DATA_ERROR; /* invalid code -- missing end-of-block */
-                goto finish;
-            }
-            MZ_LANES {
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const uint32_t s = 64u * (uint32_t)k + (uint32_t)lane;
-                    P(lr)[k] = s < nlen ? (uint32_t)L->u.h.cl[s] : 0u;
-                }
-                P(dl) = (uint32_t)lane < ndist ? (uint32_t)L->u.h.cl[nlen + (uint32_t)lane] : 0u;
             }
         }
-#include "inflate_tables.inc"
-        MZ_PROF_MARK(2); /* decode tables */
         in_header = 0;
         if (resume_at != 0xFFFFFFFFu) { /* taken up inside this block: the tables are back, on to the next token */
             if (resume_at > bitpos) bitpos = resume_at;

@@ -14,7 +14,7 @@ def main():
     floor = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     text = open(path).read().splitlines()
     start = next(i for i, l in enumerate(text) if re.match(r"^_ZL?\d+%s\w*:" % re.escape(fn), l))
-    end = next(i for i in range(start, len(text)) if re.search(r"s_endpgm|s_setpc_b64 s\[30:31\]", text[i]))
+    end = next(i for i in range(start, len(text)) if re.match(r"^\.Lfunc_end\d+:", text[i]))  # (a function may return in several places)
     body = text[start:end + 1]
     label_at = [i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
     loops = []
