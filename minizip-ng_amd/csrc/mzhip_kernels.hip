@@ -89,6 +89,11 @@ struct InflateArgs {
     mz_inflate_state *stop;         // per entry: where it can be taken up again, or null
 };
 
+// Two instantiations: RESUMABLE = false is the batch as mzhip_inflate_batch launches it (no entry is taken up or left in the
+// middle: a.resume and a.stop are null, and the compiler drops the resume bookkeeping -- which block the cursor is in, where the
+// step loop's unwritten tokens start, whether to stop at the next header -- from a function that already holds more uniform state
+// than a wave has scalar registers); true is the window-by-window decode of the drop-in streams (mzhip_inflate_host with a state).
+template <bool RESUMABLE>
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_batch(InflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t *crc_tab = (uint32_t *)smem;
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k
         const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
         mz_inflate_entry(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), L, crc_tab, a.tabs, 1u, rec,
-                         a.resume ? a.resume + e : nullptr, a.stop ? a.stop + e : nullptr, &r, nullptr);
+                         (RESUMABLE && a.resume) ? a.resume + e : nullptr, (RESUMABLE && a.stop) ? a.stop + e : nullptr, &r, nullptr);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round 5, call 25: k_inflate_batch<false>: the batch kernel without the resume bookkeeping (SGPR spills 190 -> 152) against HEAD
+set -u
+root=$PWD; out=$root/gpurun_out/c25; mkdir -p $out
+B=$root/minizip-ng_amd
+probe() { MZHIP_LIB=$B/_build_ab_$1/libmzhip.so timeout 120 python tests/perf_probe.py ${@:2} 2>&1 | grep -v '^rep [01]\|amdgpu.ids'; }
+{
+for t in plain; do echo "== $t parity"; MZHIP_LIB=$B/_build_ab_$t/libmzhip.so timeout 600 python -m pytest tests/test_gpu_inflate.py tests/test_gpu_streams.py -x -q -k "not bounded_memory" 2>&1 | tail -2; done
+for t in hdrfn plain hdrfn plain; do echo "== $t 64K"; probe $t; done
+for t in hdrfn plain hdrfn plain; do echo "== $t 8K"; probe $t 512 200000 8192; done
+} > $out/probe.log 2>&1
+cat $out/probe.log
