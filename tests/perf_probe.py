@@ -38,6 +38,11 @@ for rep in range(3):
 import ctypes  # noqa: E402
 
 lib = ctypes.CDLL(os.environ.get("MZHIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "minizip-ng_amd", "_build", "libmzhip.so"))
+if hasattr(lib, "mzhip_inflate_launch_geometry"):
+    geo = [ctypes.c_uint32() for _ in range(3)]
+    lib.mzhip_inflate_launch_geometry.restype = None
+    lib.mzhip_inflate_launch_geometry(ctypes.c_uint32(0x7FFFFFFF), *(ctypes.byref(g) for g in geo))
+    print("geometry: %d resident workgroups of %d waves, %d bytes of LDS each" % tuple(g.value for g in geo))
 if hasattr(lib, "mzhip_prof_read"):
     buf = (ctypes.c_ulonglong * 32)()
     lib.mzhip_prof_read(buf, 1)

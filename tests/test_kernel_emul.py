@@ -23,8 +23,8 @@ def emu():
     out = os.path.join(ROOT, "tests", "emul", "_build")
     os.makedirs(out, exist_ok=True)
     so = os.path.join(out, "libemul.so")
-    subprocess.run(["g++", "-O1", "-g", "-Wno-unknown-pragmas", "-DMZHIP_HOST_EMUL",
-                    "-I" + os.path.join(ROOT, "minizip-ng_amd", "csrc"), "-shared", "-fPIC",
+    subprocess.run(["g++", "-O1", "-g", "-Wno-unknown-pragmas", "-DMZHIP_HOST_EMUL"] + os.environ.get("MZ_EMUL_DEFS", "").split() +  # (build knobs of the device code, e.g. -DMZ_CRING_DW=8u)
+                   ["-I" + os.path.join(ROOT, "minizip-ng_amd", "csrc"), "-shared", "-fPIC",
                     os.path.join(ROOT, "tests", "emul", "emul.cpp"), "-o", so], check=True)
     L = C.CDLL(so)
     L.emul_inflate.argtypes = [_u8p, C.c_uint32, _u8p, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
