@@ -22,7 +22,7 @@ def load(d, tag, kernel):
     add = kernel.endswith("+")
     kernel = kernel.rstrip("+")
     for i in (1, 2):
-        rows = [r for r in csv.DictReader(open(os.path.join(d, "req_%s_%d.csv" % (tag, i)))) if r["Kernel_Name"].startswith(kernel)]
+        rows = [r for r in csv.DictReader(open(os.path.join(d, "req_%s_%d.csv" % (tag, i)))) if kernel in r["Kernel_Name"]]  # (a substring: k_inflate_batch is "void k_inflate_batch<false>(InflateArgs)" since it became a template)
         acc, dur = collections.defaultdict(list), {}
         for r in rows:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -29,7 +29,8 @@ def short(name):
     n = int(m.group(1))
     base, rest = name[m.end():m.end() + n], name[m.end() + n:]
     t = re.match(r"ILi(\d+)E", rest)
-    return base + ("<%s>" % t.group(1) if t else "")
+    b = re.match(r"ILb([01])E", rest)  # (k_inflate_batch<bool RESUMABLE>)
+    return base + ("<%s>" % t.group(1) if t else "<%s>" % ("true" if b.group(1) == "1" else "false") if b else "")
 
 
 def main():
