@@ -131,23 +131,15 @@ typedef struct mz_lzma_result {
         }                                                                               \
     } while (0)
 
-/* MZ_LZMA_BORROW (measurement): `code < bound` and `code - bound` from ONE subtraction with borrow -- a vector instruction
- * less on the path of a 1 bit, and slower all the same (config 4 10.35 -> 10.19 GiB/s, profiles/r4/ab_k3_borrow.log: the
- * compare's result is wanted first, and v_sub_co delivers it with the difference) */
-#ifndef MZ_LZMA_BORROW
-#define MZ_LZMA_BORROW 0
-#endif
-#if MZ_LZMA_BORROW
-#define LZ_BORROW(a, b, d) ((uint32_t)__builtin_sub_overflow((uint32_t)(a), (uint32_t)(b), (d)))
-#else
+/* `code < bound` and `code - bound` (one subtraction with borrow for both measured slower, round 4: config 4 10.35 -> 10.19
+ * GiB/s, profiles/r4/ab_k3_borrow.log) */
 #define LZ_BORROW(a, b, d) (*(d) = (a) - (b), (uint32_t)((a) < (b)))
-#endif
-/* decode one bit with the adaptive model at probs[idx]; result in `bit` */
+
 #define LZ_BIT(bit, idx)                                                                \
     do {                                                                                \
         LZ_NORM();                                                                      \
         uint32_t _pi = (idx);                                                           \
-        uint32_t _p = LZ_PU(LZ_U(pr[_pi]));                                             \
+        uint32_t _p = LZ_U(pr[_pi]);                                             \
         uint32_t _bound = (range >> 11) * _p;                                           \
         uint32_t _diff;                                                                 \
         const uint32_t _lt = LZ_BORROW(code, _bound, &_diff);                           \
@@ -595,8 +587,9 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
  *                    the CU's scalar port;
  *   mz_lzma_entry_v  LZ_U = identity: the same values stay in VGPRs (all lanes equal), the arithmetic issues on the
  *                    vector ports of the four SIMDs, only the uniform branches remain scalar.
- * Measured for one full round of 2304 resident 1 MiB entries: scalar 480 ms, vector see DESIGN.md K3.  The kernel
- * runs MZ_LZMA_VPORT_OF_8 of every 8 workgroups on the vector build.  The host emulation builds the first only. */
+ * Measured for one full round of 2304 resident 1 MiB entries: scalar 520 ms, 5 of 8 workgroups on the vector build 511 ms, all
+ * of them 469 ms (and mixes inside a SIMD 9.73 / 9.50 / 8.35 GiB/s against 10.34 on config 4, profiles/r4/ab_k3_ports.log): the
+ * kernels run the vector build.  The host emulation builds the first only. */
 /* A decision on a lane-invariant value that sits in a VGPR (the vector-port builds): asked through a ballot, the
  * compiler knows the branch is uniform -- one side is executed (s_cbranch) instead of both under exec masks, and what
  * hangs on the decided bit (the symbol, the next probability's index, the state) moves to the scalar unit by itself. */
@@ -608,13 +601,8 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
 #else
 #define MZ_VEC_UBR(c) (c)
 #endif
-/* MZ_LZMA_UBR == 2 (measurement): the probability itself goes to the scalar unit as well (its update is three scalar
- * instructions instead of three to five vector ones); range and code stay in VGPRs */
-#if MZ_LZMA_UBR == 2 && !defined(MZHIP_HOST_EMUL)
-#define LZ_PU(x) MZ_UNIFORM(x)
-#else
-#define LZ_PU(x) (x)
-#endif
+/* (With the probability on the scalar unit as well -- its update three scalar instructions instead of three to five vector
+ * ones -- config 4 ran at 9.26 GiB/s against 10.03: the transfers cost more than they save, profiles/r4/ab_k3_ubr.log.) */
 #define LZ_LITERAL_SITE(sym) LZ_LITERAL_SITE_FULL(sym)
 #define LZ_LDS_T mz_lzma_lds
 #define LZ_ENTRY_PROBS LZ_NUM_PROBS
@@ -663,19 +651,6 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
 #undef LZ_UBR
 #undef LZ_WIN_DW
 #undef LZ_ENTRY_NAME
-#if !defined(MZHIP_HOST_EMUL) && defined(MZ_LZMA_SLOT_SPORT_OF_4)
-/* measurement builds: the slot build in the scalar-port form as well -- MZ_LZMA_SLOT_SPORT_OF_4 of every four waves of a
- * SIMD run it, so that the vector and the scalar port of a CU both carry decisions (profiles/r4/ab_k3_ports.log) */
-#define LZ_U(x) MZ_UNIFORM(x)
-#define LZ_UBR(c) (c)
-#define LZ_WIN_DW(idx) MZ_READLANE(win, idx)
-#define LZ_ENTRY_NAME mz_lzma_entry_ss
-#include "lzma_entry.inc"
-#undef LZ_U
-#undef LZ_UBR
-#undef LZ_WIN_DW
-#undef LZ_ENTRY_NAME
-#endif
 #undef LZ_SLOTS_BUILD
 #undef LZ_LITERAL_SITE
 #undef LZ_LDS_T

@@ -208,10 +208,6 @@ struct LzmaArgs {
     uint32_t *retry_n;     // ... counted here; the full-model kernel then decodes exactly those (list != null: n = *retry_n)
 };
 
-#ifndef MZ_LZMA_VPORT_OF_8
-#define MZ_LZMA_VPORT_OF_8 8u
-#endif
-
 // K3: one wave per workgroup, the wave's whole probability model (15.6 KiB) in LDS -> 10 waves per CU.
 #ifdef MZ_LZMA_WAVES /* measurement builds (profiles/ab_k3.sh): waves per SIMD the register allocation is held to */
 __global__ __launch_bounds__(64, MZ_LZMA_WAVES) void k_lzma_batch(LzmaArgs a) {
@@ -230,16 +226,10 @@ __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {
         if (e >= n_here) break;
         if (a.retry_list) e = MZ_UNIFORM(a.retry_list[e]);
         mz_lzma_result r;
-        // how many of every 8 workgroups run the vector-port build of the decoder (measured: 0/8 520 ms, 5/8 511 ms,
-        // 8/8 469 ms for one full round of 2304 resident 1 MiB entries)
-        if ((blockIdx.x & 7u) < MZ_LZMA_VPORT_OF_8)
-            mz_lzma_entry_v(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
-                            a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
-                            a.xprobs + (size_t)blockIdx.x * MZ_LZMA_XPROBS, &r);
-        else
-            mz_lzma_entry(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
-                          a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
-                          a.xprobs + (size_t)blockIdx.x * MZ_LZMA_XPROBS, &r);
+        // the vector-port build of the decoder (lzma_core.h: the scalar-port form and every mix of the two measured slower)
+        mz_lzma_entry_v(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
+                        a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
+                        a.xprobs + (size_t)blockIdx.x * MZ_LZMA_XPROBS, &r);
         // wave-uniform results: stored by all lanes (same address, same value), see MZ_WAVE_FETCH_ADD
         a.out_len[e] = r.out_len;
         a.in_used[e] = r.in_used;
@@ -294,15 +284,6 @@ __global__ __launch_bounds__(256, 4) void k_lzma_slot_batch(LzmaArgs a) {
         MZ_WAVE_FETCH_ADD(e, a.counter);
         if (e >= a.n) break;
         mz_lzma_result r;
-#ifdef MZ_LZMA_SLOT_SPORT_OF_4
-        // (measurement builds) wave w of a workgroup sits on SIMD w; the workgroups that share a CU differ in blockIdx.x & 3
-        // or in blockIdx.x >> 8, whichever way the dispatcher lays them out: every SIMD gets the same mix of the two forms
-        if (((wave + blockIdx.x + (blockIdx.x >> 8)) & 3u) < MZ_LZMA_SLOT_SPORT_OF_4)
-            mz_lzma_entry_ss(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
-                             a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
-                             a.sprobs + wave_id * MZ_LZMA_SPROBS, &r);
-        else
-#endif
         mz_lzma_entry_s(a.in + a.in_off[e], a.in_len[e], a.out + a.out_off[e], a.out_cap[e],
                         a.max_out ? a.max_out[e] : (int64_t)-1, &lds, crc_tab, a.tabs,
                         a.sprobs + wave_id * MZ_LZMA_SPROBS, &r);
