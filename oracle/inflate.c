@@ -221,8 +221,20 @@ static int dynamic(st_t *s) {
             return s->err;
     }
     /* zlib 1.2.11 requires a COMPLETE code-length code (inftrees.c, type
-     * CODES); an all-zero set degenerates to "every length is 0", which then
-     * fails the end-of-block check below -- a data error either way. */
+     * CODES) -- except the set with no code at all: inflate_table() hands that
+     * back as a table of invalid one-bit entries ("no symbols, but wait for
+     * decoding to report error"), inflate()'s CODELENS state reads every one
+     * of the nlen + ndist lengths through it as a 0 of one bit, and the block
+     * then fails the end-of-block check.  A data error nlen + ndist bits later
+     * -- or "input exhausted" when the input ends inside those bits. */
+    if (max_len(lengths, 19) == 0) {
+        for (int i = 0; i < nlen + ndist; i++) {
+            (void)getbits(s, 1);
+            if (s->err)
+                return s->err;
+        }
+        return ORC_DATA_ERROR; /* invalid code -- missing end-of-block */
+    }
     if (build(&lc, lengths, 19) != 0)
         return ORC_DATA_ERROR; /* invalid code lengths set */
 

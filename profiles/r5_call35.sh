@@ -1,0 +1,11 @@
+#!/bin/bash
+# Round 5, call 35: the fuzz gate again with the oracle restating the empty code-length code as inflate() treats it (call 34's two
+# "mismatches" were the oracle's: -3 where the reference and the kernel say -5, the input ending inside the nlen + ndist bits)
+set -u
+root=$PWD; out=$root/gpurun_out/c35; mkdir -p $out
+{
+timeout 200 python tests/fuzz_gpu.py 6000 5 2>&1 | grep -v amdgpu.ids | tail -1
+timeout 300 python tests/fuzz_gpu.py 12000 7 2>&1 | grep -v amdgpu.ids | tail -1
+timeout 200 python -m pytest tests/test_gpu_dropin.py -x -q -k "code_length" 2>&1 | grep -v amdgpu.ids | tail -1
+} > $out/check.log 2>&1
+cat $out/check.log

@@ -103,6 +103,26 @@ def test_truncation_accounting_deflate(libs):
     _check_truncations_deflate(hip, ref, chunks=(65535, 16384, 1000))
 
 
+def test_code_length_code_without_a_code(libs):
+    """A dynamic block whose code-length code has no code at all (every HCLEN field 0).  zlib does not refuse it where it
+    stands: inflate_table() answers "no symbols" with a table of invalid one-bit entries, inflate()'s CODELENS state reads the
+    nlen + ndist lengths through it -- a 0 each, one bit each -- and then refuses the block for having no end-of-block code
+    (inflate.c: "invalid code -- missing end-of-block").  Same verdict, nlen + ndist bits later: every field, TOTAL_IN included,
+    as the all-reference build -- with the input ending inside those bits too (found by tests/fuzz_gpu_windows.py 1500 94)."""
+    hip, ref = libs
+    for hlit, hdist, hclen in ((0, 0, 0), (29, 29, 15), (7, 3, 2)):
+        # BFINAL = 1, BTYPE = 2, HLIT, HDIST, HCLEN, then (hclen + 4) x 3 zero bits and zeros on
+        hdr = 1 | (2 << 1) | (hlit << 3) | (hdist << 8) | (hclen << 13)
+        bits = 17 + 3 * (hclen + 4) + (hlit + 257) + (hdist + 1)
+        z = hdr.to_bytes(3, "little") + bytes(80)
+        for n in (3, (17 + 3 * (hclen + 4)) // 8 + 1, bits // 8, (bits + 7) // 8, (bits + 7) // 8 + 1, len(z)):
+            for chunk in (65535, 7):
+                a = hip.stream_decode(8, z[:n], 4096, chunk=chunk)
+                b = ref.stream_decode(8, z[:n], 4096, chunk=chunk)
+                assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (hlit, hdist, hclen, n, chunk, {k: (a[k], b[k]) for k in ALL if a[k] != b[k]})
+        assert b["error"] == -3 and b["total_in"] == (bits + 7) // 8, (b["error"], b["total_in"], bits)
+
+
 def test_bitflip_verdicts_deflate(libs):
     """One flipped bit anywhere: the same read() sequence, bytes, close() and error().  TOTAL_IN / TOTAL_OUT after a data
     error are zlib's internal detection point ("treat as best-effort"): compared, counted, not asserted."""

@@ -95,6 +95,23 @@ def test_inflate_status_parity_with_reference():
 
 
 @needs_ref
+def test_empty_code_length_code_status_with_reference():
+    """A dynamic block whose code-length code has no code at all: inflate() reads the nlen + ndist lengths as zeros of one bit
+    each before it refuses the block (-3), and asks for more input (-5) when the stream ends inside those bits.  The oracle's
+    verdict against the live reference at every cut."""
+    ref = oracle.ref()
+    for hlit, hdist, hclen in ((0, 0, 0), (29, 29, 15), (7, 3, 2)):
+        hdr = 1 | (2 << 1) | (hlit << 3) | (hdist << 8) | (hclen << 13)
+        bits = 17 + 3 * (hclen + 4) + (hlit + 257) + (hdist + 1)
+        z = hdr.to_bytes(3, "little") + bytes(80)
+        for n in range(3, (bits + 7) // 8 + 3):
+            r = ref.stream_decode(8, z[:n], 4096)
+            st, used, out = oracle.inflate_raw(z[:n], 4096)
+            assert st == r["rets"][-1], (hlit, hdist, hclen, n, st, r["rets"])
+            assert st == (-5 if 8 * n < bits else -3), (n, bits, st)
+
+
+@needs_ref
 def test_crc32_matches_reference():
     ref = oracle.ref()
     rnd = np.random.RandomState(5)

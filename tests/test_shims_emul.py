@@ -52,6 +52,10 @@ def test_bitflip_verdicts_deflate(libs):
     D.test_bitflip_verdicts_deflate(libs)
 
 
+def test_code_length_code_without_a_code(libs):
+    D.test_code_length_code_without_a_code(libs)
+
+
 def test_truncation_accounting_window_mode(libs):
     D.test_truncation_accounting_window_mode(libs)
 
