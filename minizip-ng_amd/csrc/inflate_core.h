@@ -805,15 +805,19 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                     const uint32_t t_match = (nb2 + dn + dex) | (P(lenl) << 7) | (dist << 16);
                     P(tk) = (e & MZ_E_LEN) ? (((int32_t)d > 0) ? t_match : 0u) : e;
                 }
-                if (avail < 64u + 48u) {
-                    MZ_LANES {
-                        const uint32_t e = P(le), d = P(de), nb2 = P(nb2l);
-                        const uint32_t t_badd = ((d == 0u) ? (nb2 + 15u) : (nb2 + (d & 15u))) << 16; /* invalid distance code */
-                        uint32_t t = P(tk);
-                        t = ((e & MZ_E_LEN) && (int32_t)d <= 0) ? t_badd : t;
-                        t = (e == 0u) ? (15u << 16) : t; /* no code within 15 bits */
-                        P(tk) = t;
-                    }
+                /* an invalid candidate carries the bits inflate() has dropped when it refuses it ([31:16], no bits in [5:0]): the
+                 * code's own for 286 / 287 and 30 / 31 (the tables say so), ONE for an unused code -- a set with unused codes
+                 * passes only when its longest code is one bit (inflate_table()), and the entry zlib leaves for the other
+                 * pattern is one bit wide.  That is what decides "data error" against "input exhausted" at the very end of the
+                 * input, and where TOTAL_IN stands after a data error (round 5: it stood at the token's first bit, 1 - 3 bytes
+                 * short in fixed-Huffman garbage: tests/fuzz_gpu_windows.py) */
+                MZ_LANES {
+                    const uint32_t e = P(le), d = P(de), nb2 = P(nb2l);
+                    const uint32_t t_badd = ((d == 0u) ? (nb2 + 1u) : (nb2 + (d & 15u))) << 16; /* invalid distance code */
+                    uint32_t t = P(tk);
+                    t = ((e & MZ_E_LEN) && (int32_t)d <= 0) ? t_badd : t;
+                    t = (e == 0u) ? (1u << 16) : t; /* an unused literal/length code */
+                    P(tk) = t;
                 }
                 MZ_LANES {
                     const uint32_t t = P(tk);
@@ -828,7 +832,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                  * interleaved, so it is five dependent ds_bpermute rounds, no scalar work, and the step's tokens
                  * come out COMPACTED (lane i holds token i).  Offsets are kept multiplied by 4 (the gather's byte
                  * address).  At most 15 tokens retire per step; lane 15 only supplies the continuation offset. */
-                uint32_t pos, eob = 0, ntok;
+                uint32_t pos, eob = 0, ntok, err_bits = 0;
                 int32_t chain_err = MZHIP_OK;
                 PV(uint32_t, cpos);
                 if (avail >= 64u + 48u) {
@@ -864,7 +868,10 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                     const uint32_t term = MZ_READLANE(cpos, ntok);
                     pos = (term >> 2) & 0xFFu;
                     eob = (term >> 10) & 1u;
-                    if (term & 0x800u) chain_err = MZHIP_DATA_ERROR;
+                    if (term & 0x800u) {
+                        chain_err = MZHIP_DATA_ERROR;
+                        err_bits = MZ_READLANE(tk, pos) >> 16;
+                    }
                 } else {
                     /* within 14 bytes of the end of input: serial walk that also polices every token's extent */
                     uint64_t sel = 0;
@@ -875,6 +882,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
                         const uint32_t nb = t & 63u;
                         if (nb == 0u) {
                             chain_err = (pos + (t >> 16) > avail) ? MZHIP_BUF_ERROR : MZHIP_DATA_ERROR;
+                            err_bits = t >> 16;
                             break;
                         }
                         if (pos + nb > avail) {
@@ -916,6 +924,7 @@ MZ_DEV void mz_inflate_entry(const uint8_t *in, uint32_t in_total, uint8_t *out,
 #include "inflate_flush.inc"
                 if (chain_err != MZHIP_OK) {
                     status = chain_err;
+                    if (chain_err == MZHIP_DATA_ERROR) bitpos += err_bits; /* (the bits of the code inflate() refuses are consumed: TOTAL_IN) */
                     goto finish;
                 }
                 if (eob) break;
