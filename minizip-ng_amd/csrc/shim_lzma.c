@@ -68,6 +68,7 @@ typedef struct mzhip_lzma_s {
     int8_t streaming;      /* window mode is on */
     int8_t resumed;        /* lst is a state to go on from */
     int8_t stream_end;     /* the end marker has been decoded */
+    int64_t ghost;         /* method 14 in windows: bytes behind TOTAL_OUT_MAX the reference has decoded into its callers' buffers by now */
     int32_t s_err;         /* the device's verdict once the stream cannot go on: served when the bytes in front of it are */
     mzhip_lzma_state lst;
     void *model;           /* mzhip_lzma_model_bytes(): the adaptive model between calls */
@@ -339,6 +340,7 @@ static int32_t lz_stream_start(mzhip_lzma *z) {
     z->out_len = z->out_served = z->hist = z->out_abs = z->in_dropped = 0;
     z->resumed = z->stream_end = 0;
     z->s_err = 0;
+    z->ghost = 0;
     memset(&z->lst, 0, sizeof(z->lst));
     z->streaming = 1;
     z->decoded = 1; /* (the one-buffer loop is done with) */
@@ -796,11 +798,39 @@ static int32_t lz_stream_read(mzhip_lzma *z, void *buf, int32_t size) {
             if (z->stream_end)
                 break;
             if (z->max_total_out >= 0 && z->total_out >= z->max_total_out) {
-                /* everything the caller may have has been served.  Method 95: the caller's buffer still has room, so the
-                 * reference goes on calling lzma_code (mz_strm_lzma.c:237): the rest of the container is walked, and judged,
-                 * in this call */
-                if (z->streaming != 2)
+                /* everything the caller may have has been served.  The caller's buffer still has room, so the reference goes
+                 * on calling lzma_code (mz_strm_lzma.c:237).  Method 14: liblzma decodes on into that room -- what it writes
+                 * there is not counted (mz_strm_lzma.c:214-215) -- until the room is full (the call returns what it had), the
+                 * end marker arrives (the same) or the stream fails: a stream cut inside its end marker is LZMA_BUF_ERROR
+                 * in the very call that would have returned the entry's last bytes (round 5, tests/fuzz_lzma_windows.py) */
+                if (z->streaming != 2) {
+                    int64_t room = size - got;
+                    int32_t rc14 = MZH_OK;
+                    for (;;) {
+                        const int64_t have = z->out_abs + z->out_len - z->max_total_out - z->ghost; /* decoded behind the limit, not yet "written" */
+                        if (have >= room) {
+                            z->ghost += room;
+                            room = 0;
+                            break;
+                        }
+                        z->ghost += have;
+                        room -= have;
+                        if (z->stream_end)
+                            break;
+                        if (z->s_err != 0)
+                            return lz_stream_fail(z);
+                        rc14 = lz_stream_next(z);
+                        if (rc14 != MZH_OK || z->error != 0)
+                            break;
+                    }
+                    if (rc14 != MZH_OK) {
+                        z->error = 5; /* LZMA_MEM_ERROR */
+                        return MZH_DATA_ERROR;
+                    }
+                    if (z->error != 0)
+                        return MZH_DATA_ERROR;
                     break;
+                }
                 if (z->s_err != 0)
                     return lz_stream_fail(z);
                 if (z->xz_tail_tried)
