@@ -79,8 +79,12 @@ def _run(n_streams, rnd, hip, ref, text, verbose):
             chunk = rnd.choice((65535, 65535, 1 << 20, 7777))
             if ONLY and it not in ONLY:
                 continue  # (MZ_FUZZ_ONLY=i,j,...: only these streams are decoded; the others are still generated, so that the random sequence is the same)
-            a = hip.stream_decode(8, data, 2 * cap, chunk=chunk, window_bits=wb)
-            b = ref.stream_decode(8, data, 2 * cap, chunk=chunk, window_bits=wb)
+            # TOTAL_IN_MAX as mz_zip sets it (the entry's compressed size) -- or, for a cut, the limit instead of the end of the file
+            lim = rnd.choice((0, 0, len(data)))
+            if name == "cut" and rnd.random() < 0.5:
+                lim, data = len(data), z
+            a = hip.stream_decode(8, data, 2 * cap, chunk=chunk, window_bits=wb, max_in=lim)
+            b = ref.stream_decode(8, data, 2 * cap, chunk=chunk, window_bits=wb, max_in=lim)
             cases += 1
             if name == "flip" and b["error"] != 0 and a["total_in"] != b["total_in"] and all(a[k] == b[k] for k in KEYS if k != "total_in"):
                 if verbose or abs(a["total_in"] - b["total_in"]) > TOTAL_IN_SLACK:
