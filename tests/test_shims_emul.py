@@ -56,6 +56,10 @@ def test_code_length_code_without_a_code(libs):
     D.test_code_length_code_without_a_code(libs)
 
 
+def test_crafted_deflate_corners(libs):
+    D.test_crafted_deflate_corners(libs)
+
+
 def test_truncation_accounting_window_mode(libs):
     D.test_truncation_accounting_window_mode(libs)
 
