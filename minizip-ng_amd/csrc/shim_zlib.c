@@ -622,8 +622,13 @@ static int32_t stream_finish(mzhip_zlib *z, int64_t used) {
             z->base_eof = 1;
         }
     }
-    if (z->in_len < lo + tl)
+    if (z->in_len < lo + tl) {
+        /* (a gzip trailer cut inside ISIZE: inflate() has checked the CRC field by then -- a wrong one is "incorrect data
+         * check" where it stands, not a request for more input; round 5, a wrapper fuzz on the emulation) */
+        if (z->wrap == 2 && z->in_len >= lo + 4 && le32(z->in + lo) != z->run_crc)
+            return verdict(z, MZHIP_STATUS_DATA_ERROR, used + 4);
         return verdict(z, MZHIP_STATUS_BUF_ERROR, z->in_dropped + z->in_len);
+    }
     const uint8_t *t = z->in + lo;
     if (z->wrap == 2) {
         if (le32(t) != z->run_crc) /* "incorrect data check": inflate() stops after the CRC field */
@@ -953,6 +958,8 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             z->next_attempt = z->dev_in_used + tl;
             return 1;
         }
+        if (z->wrap == 2 && z->in_len - z->dev_in_used >= 4 && le32(z->in + z->dev_in_used) != z->out_crc)
+            return verdict(z, MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 4); /* (cut inside ISIZE, the CRC field already wrong: stream_finish()) */
         return verdict(z, MZHIP_STATUS_BUF_ERROR, z->in_len);
     }
     const uint8_t *t = z->in + z->dev_in_used;

@@ -150,6 +150,9 @@ def test_wrapper_error_parity(libs):
              ("gz trunc 1", g[:1], 31, {}), ("gz trunc trailer", g[:-3], 31, {}), ("gz trunc mid", g[:len(g) // 2], 31, {}),
              ("zl trunc trailer", zl[:-1], 15, {}), ("zl trunc mid", zl[:len(zl) // 3], 15, {}),
              ("gz bad crc", flip(g, -8), 31, {}), ("gz bad isize", flip(g, -1), 31, {}),
+             # (cut inside ISIZE: a wrong CRC field has been judged by then -- -3 after it --, a right one waits for the rest: -5)
+             ("gz bad crc, isize cut", flip(g, -8)[:-2], 31, {}), ("gz bad crc, no isize", flip(g, -5)[:-4], 31, {}),
+             ("gz good crc, isize cut", g[:-2], 31, {}), ("gz crc cut", flip(g, -8)[:-5], 31, {}),
              ("zl bad adler", flip(zl, -1), 15, {}), ("zl bad adler hi", flip(zl, -4, 0x80), 15, {}),
              ("zl bad fcheck", flip(zl, 1), 15, {}), ("zl cm", flip(zl, 0, 1), 15, {}),
              ("zl cinfo 8", b"\x88" + bytes([31 - (0x8800 % 31)]) + zl[2:], 15, {}),
