@@ -89,6 +89,8 @@ typedef struct mzhip_zlib_s {
      * [history | the window's bytes]; the compressed bytes in front of the current block's header have been dropped */
     int8_t streaming;       /* window mode is on */
     int8_t stream_end;      /* the device has seen the end of the stream */
+    int8_t trailer_err;     /* the verdict is a trailer check that failed: inflate() gets there without needing room for output, so the call
+                             * that returns the payload's last byte reports it even when that byte fills the caller's buffer */
     mzhip_inflate_state sst; /* where the decode goes on (bit positions from in[0]) */
     int64_t in_dropped;     /* compressed bytes dropped from the front of in[] */
     /* ... and the device's CRC-32 of every window in the pieces the caller reads it in (the size of its read() calls:
@@ -247,6 +249,7 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->wp_off = 0;
     z->decoded = 0;
     z->streaming = z->stream_end = 0;
+    z->trailer_err = 0;
     z->t_par = z->t_serial = z->t_pull = 0.0;
     z->t_open = mzh_now();
     z->n_par = z->n_serial = 0;
@@ -370,6 +373,11 @@ static int32_t verdict(mzhip_zlib *z, int32_t status, int64_t in_used) {
     z->dev_in_used = in_used;
     z->decoded = 1;
     return 0;
+}
+/* a trailer check that failed ("incorrect data check" / "incorrect length check") */
+static int32_t trailer_verdict(mzhip_zlib *z, int64_t in_used) {
+    z->trailer_err = 1;
+    return verdict(z, MZHIP_STATUS_DATA_ERROR, in_used);
 }
 
 /* Wrapper header in front of the DEFLATE payload, field by field as zlib's inflate() HEAD..HCRC / DICTID
@@ -626,19 +634,19 @@ static int32_t stream_finish(mzhip_zlib *z, int64_t used) {
         /* (a gzip trailer cut inside ISIZE: inflate() has checked the CRC field by then -- a wrong one is "incorrect data
          * check" where it stands, not a request for more input; round 5, a wrapper fuzz on the emulation) */
         if (z->wrap == 2 && z->in_len >= lo + 4 && le32(z->in + lo) != z->run_crc)
-            return verdict(z, MZHIP_STATUS_DATA_ERROR, used + 4);
+            return trailer_verdict(z, used + 4);
         return verdict(z, MZHIP_STATUS_BUF_ERROR, z->in_dropped + z->in_len);
     }
     const uint8_t *t = z->in + lo;
     if (z->wrap == 2) {
         if (le32(t) != z->run_crc) /* "incorrect data check": inflate() stops after the CRC field */
-            return verdict(z, MZHIP_STATUS_DATA_ERROR, used + 4);
+            return trailer_verdict(z, used + 4);
         if (le32(t + 4) != (uint32_t)(z->g0 + z->out_len)) /* "incorrect length check" */
-            return verdict(z, MZHIP_STATUS_DATA_ERROR, used + 8);
+            return trailer_verdict(z, used + 8);
         return verdict(z, MZHIP_STATUS_OK, used + 8);
     }
     const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
-    return verdict(z, want == z->run_adler ? MZHIP_STATUS_OK : MZHIP_STATUS_DATA_ERROR, used + 4);
+    return want == z->run_adler ? verdict(z, MZHIP_STATUS_OK, used + 4) : trailer_verdict(z, used + 4);
 }
 
 /* window mode: make more decoded bytes available behind out_served.  Returns 0 (bytes, the stream end or a verdict are
@@ -959,19 +967,19 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             return 1;
         }
         if (z->wrap == 2 && z->in_len - z->dev_in_used >= 4 && le32(z->in + z->dev_in_used) != z->out_crc)
-            return verdict(z, MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 4); /* (cut inside ISIZE, the CRC field already wrong: stream_finish()) */
+            return trailer_verdict(z, z->dev_in_used + 4); /* (cut inside ISIZE, the CRC field already wrong: stream_finish()) */
         return verdict(z, MZHIP_STATUS_BUF_ERROR, z->in_len);
     }
     const uint8_t *t = z->in + z->dev_in_used;
     if (z->wrap == 2) {
         if (le32(t) != z->out_crc) /* "incorrect data check": inflate() stops after the CRC field */
-            return verdict(z, MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 4);
+            return trailer_verdict(z, z->dev_in_used + 4);
         if (le32(t + 4) != (uint32_t)z->out_len) /* "incorrect length check" */
-            return verdict(z, MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 8);
+            return trailer_verdict(z, z->dev_in_used + 8);
         return verdict(z, MZHIP_STATUS_OK, z->dev_in_used + 8);
     }
     const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
-    return verdict(z, want == z->out_adler ? MZHIP_STATUS_OK : MZHIP_STATUS_DATA_ERROR, z->dev_in_used + 4);
+    return want == z->out_adler ? verdict(z, MZHIP_STATUS_OK, z->dev_in_used + 4) : trailer_verdict(z, z->dev_in_used + 4);
 }
 
 int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
@@ -1054,7 +1062,16 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
                 return sr;
             }
         }
-        if (got < size && z->dev_status != 0) {
+        if (got == size && !z->stream_end && z->out_served == z->out_len && z->wrap != 0) {
+            /* the buffer is full exactly where a window ends: if that is the payload's end too and the trailer does not check
+             * out, inflate() has found that in this call (above) -- look */
+            const int32_t sr = stream_next(z);
+            if (sr < 0) {
+                z->error = sr;
+                return sr;
+            }
+        }
+        if (z->dev_status != 0 && (got < size || (z->trailer_err && z->stream_end && z->out_served == z->out_len))) {
             /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189) */
             z->error = (z->base_err != 0 && z->dev_status == MZHIP_STATUS_BUF_ERROR) ? z->base_err : z->dev_status;
             z->total_in = z->dev_in_used;
@@ -1066,8 +1083,10 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         return got;
     }
     int64_t avail = z->out_len - z->out_served;
-    if (z->dev_status != 0 && avail < size) {
-        /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189) */
+    if (z->dev_status != 0 && (avail < size || (z->trailer_err && avail == size))) {
+        /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189).  (A failed trailer check is met
+         * in the call that returns the payload's last byte even when that byte fills the buffer: behind it inflate() walks
+         * through the end-of-block code and the trailer without needing room -- round 5, tests/fuzz_wrappers.py) */
         z->error = (z->base_err != 0 && z->dev_status == MZHIP_STATUS_BUF_ERROR) ? z->base_err : z->dev_status;
         z->total_in = z->dev_in_used;
         z->total_out = z->out_len;

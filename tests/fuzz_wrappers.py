@@ -46,5 +46,6 @@ for libn in LIBS:
             diff={k:(a[k],b[k]) for k in KEYS if k!='out' and a[k]!=b[k]}
             if diff or a['out']!=b['out']:
                 bad+=1
+                if os.environ.get('MZ_FUZZ_DUMP'): open(os.path.join(os.environ['MZ_FUZZ_DUMP'],'wrap_bad_%d.bin'%bad),'wb').write(data)
                 if bad<15: print(libn,it,kind,name,'wb',wb,'chunk',chunk,'len',len(data),{k:((v[0][-2:],v[1][-2:]) if k=='rets' else v) for k,v in diff.items()},'out eq' if a['out']==b['out'] else 'OUT DIFF')
 print('wrapper fuzz cases',tot,'bad',bad)

@@ -153,6 +153,10 @@ def test_wrapper_error_parity(libs):
              # (cut inside ISIZE: a wrong CRC field has been judged by then -- -3 after it --, a right one waits for the rest: -5)
              ("gz bad crc, isize cut", flip(g, -8)[:-2], 31, {}), ("gz bad crc, no isize", flip(g, -5)[:-4], 31, {}),
              ("gz good crc, isize cut", g[:-2], 31, {}), ("gz crc cut", flip(g, -8)[:-5], 31, {}),
+             # (the payload's last byte fills the caller's buffer exactly: inflate() goes on through the end-of-block code and the
+             # trailer without needing room, so a failed check is reported by THAT call -- the bytes it would have returned are lost)
+             ("gz bad crc, exact read", flip(g, -8), 31, dict(chunk=len(d))), ("gz bad isize, exact reads", flip(g, -1), 31, dict(chunk=len(d) // 4)),
+             ("zl bad adler, exact read", flip(zl, -1), 15, dict(chunk=len(d))), ("zl bad adler, exact reads", flip(zl, -2), 15, dict(chunk=len(d) // 10)),
              ("zl bad adler", flip(zl, -1), 15, {}), ("zl bad adler hi", flip(zl, -4, 0x80), 15, {}),
              ("zl bad fcheck", flip(zl, 1), 15, {}), ("zl cm", flip(zl, 0, 1), 15, {}),
              ("zl cinfo 8", b"\x88" + bytes([31 - (0x8800 % 31)]) + zl[2:], 15, {}),
