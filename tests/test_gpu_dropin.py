@@ -126,134 +126,178 @@ def test_code_length_code_without_a_code(libs):
 def _crafted_deflate_corners():
     """Hand-made raw-DEFLATE streams around the corners of the format that no compressor writes (a small bit writer): a block
     of nothing but its end-of-block code (a one-bit code: the incomplete set zlib accepts) and the unused pattern of that code;
-    literals only with NO distance code; a single one-bit distance code, used and its unused pattern; a match where there is
-    no distance code; a distance in front of the stream; the fixed code's symbols 286 and distance 30; empty stored blocks, a
-    stored block whose lengths disagree, one cut inside its data; block type 3; 287 literal/length codes; a code-length code
-    that is over-subscribed, incomplete, a single one-bit code."""
-    import math  # noqa: F401
-    class BW:
-        def __init__(s): s.bits=[]
-        def put(s,v,n):
-            for i in range(n): s.bits.append((v>>i)&1)
-        def code(s,c,n):  # huffman code MSB first
-            for i in range(n-1,-1,-1): s.bits.append((c>>i)&1)
-        def bytes(s, pad=0):
-            b=s.bits+[0]*((-len(s.bits))%8); out=bytearray()
-            for i in range(0,len(b),8): out.append(sum(b[i+j]<<j for j in range(8)))
-            return bytes(out)+bytes(pad)
-    def canon(lens):
-        # returns {sym:(code,len)}
-        maxl=max(lens) if lens else 0; bl=[0]*(maxl+2)
-        for l in lens:
-            if l: bl[l]+=1
-        code=0; nxt=[0]*(maxl+2)
-        for b in range(1,maxl+1):
-            code=(code+bl[b-1])<<1; nxt[b]=code
-        out={}
-        for s,l in enumerate(lens):
-            if l: out[s]=(nxt[l],l); nxt[l]+=1
+    literals only with NO distance code; a single one-bit distance code, used, and its unused pattern; a match where there is
+    no distance code; a distance in front of the stream; the fixed code's length symbol 286 and distance code 30; empty stored
+    blocks, a stored block whose lengths disagree, one cut inside its data; block type 3; 287 literal/length codes; a
+    code-length code that is over-subscribed, incomplete, a single one-bit code.  -> [(name, stream)]"""
+    import math
+
+    class Bits:
+        def __init__(self):
+            self.bits = []
+
+        def put(self, value, n):  # a field, least significant bit first
+            self.bits += [(value >> i) & 1 for i in range(n)]
+
+        def code(self, code_len):  # a Huffman code, most significant bit first
+            code, n = code_len
+            self.bits += [(code >> i) & 1 for i in range(n - 1, -1, -1)]
+
+        def bytes(self, pad=0):
+            b = self.bits + [0] * (-len(self.bits) % 8)
+            return bytes(sum(b[i + j] << j for j in range(8)) for i in range(0, len(b), 8)) + bytes(pad)
+
+    def canonical(lens):  # -> {symbol: (code, length)}, appnote.txt:2139-2166
+        top = max(lens) if lens else 0
+        count = [0] * (top + 2)
+        for n in lens:
+            if n:
+                count[n] += 1
+        code, nxt = 0, [0] * (top + 2)
+        for n in range(1, top + 1):
+            code = (code + count[n - 1]) << 1
+            nxt[n] = code
+        out = {}
+        for sym, n in enumerate(lens):
+            if n:
+                out[sym] = (nxt[n], n)
+                nxt[n] += 1
         return out
-    ORDER=[16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15]
-    def dyn_header(bw, litlens, distlens, final=1, clens=None, rle=None):
-        """writes a dynamic header; litlens (>=257 entries), distlens (>=1); code-length code: all used lengths get a code"""
-        nlen=len(litlens); ndist=len(distlens)
-        seq=list(litlens)+list(distlens) if rle is None else rle
-        used=sorted(set(seq))
-        # code length code lengths: give each used symbol a length making a complete code
-        if clens is None:
-            k=len(used); clens=[0]*19
-            # simple: lengths from a complete code over k symbols
-            import math
-            if k==1: clens[used[0]]=1; # incomplete single -> add a dummy
-            else:
-                # assign lengths via building a balanced-ish complete code
-                ls=[]; 
-                n=k; l=math.ceil(math.log2(n)); short=(1<<l)-n
-                for i,s in enumerate(used): clens[s]=l-1 if i<short else l
-            if k==1:
-                other=(used[0]+1)%16; clens[other]=1
-        cc=canon(clens)
-        bw.put(final,1); bw.put(2,2); bw.put(nlen-257,5); bw.put(ndist-1,5)
-        hclen=19
-        while hclen>4 and clens[ORDER[hclen-1]]==0: hclen-=1
-        bw.put(hclen-4,4)
-        for i in range(hclen): bw.put(clens[ORDER[i]],3)
-        for item in seq:
-            if isinstance(item,tuple):
-                sym,extra,nb=item; c,l=cc[sym]; bw.code(c,l); bw.put(extra,nb)
-            else:
-                c,l=cc[item]; bw.code(c,l)
-        return canon(litlens), canon(distlens)
-    cases=[]
-    # 1: block with only EOB: lit set = {256: len 1}
-    bw=BW(); lit=[0]*257; lit[256]=1; lc,dc=dyn_header(bw,lit,[0]); bw.code(*lc[256]); cases.append(('only EOB, 1-bit code', bw.bytes(4)))
-    # 2: same but the stream uses the OTHER 1-bit pattern (invalid code)
-    bw=BW(); lc,dc=dyn_header(bw,lit,[0]); bw.code(1,1); cases.append(('unused pattern of a 1-bit lit code', bw.bytes(4)))
-    # 3: literals only, no distance codes (all zero)
-    bw=BW(); lit=[0]*257; lit[65]=2; lit[66]=2; lit[67]=2; lit[256]=2; lc,dc=dyn_header(bw,lit,[0]);
-    for ch in b'ABCABCCBA': bw.code(*lc[ch])
-    bw.code(*lc[256]); cases.append(('literals only, empty distance set', bw.bytes(4)))
-    # 4: one distance code of 1 bit, used
-    bw=BW(); lit=[0]*258; lit[65]=2; lit[66]=2; lit[256]=2; lit[257]=2; lc,dc=dyn_header(bw,lit,[1]);
-    for ch in b'ABAB': bw.code(*lc[ch])
-    bw.code(*lc[257]); bw.code(0,1)   # length 3, dist code 0 -> distance 1
-    bw.code(*lc[256]); cases.append(('single 1-bit distance code, used', bw.bytes(4)))
-    # 5: same, the other pattern (invalid distance code)
-    bw=BW(); lc,dc=dyn_header(bw,lit,[1]);
-    for ch in b'ABAB': bw.code(*lc[ch])
-    bw.code(*lc[257]); bw.code(1,1); bw.code(*lc[256]); cases.append(('unused pattern of a 1-bit distance code', bw.bytes(4)))
-    # 6: match with empty distance set
-    bw=BW(); lc,dc=dyn_header(bw,lit,[0]);
-    for ch in b'ABAB': bw.code(*lc[ch])
-    bw.code(*lc[257]); bw.put(0,1); bw.code(*lc[256]); cases.append(('a match with an empty distance set', bw.bytes(4)))
-    # 7: distance too far back
-    bw=BW(); lit=[0]*258; lit[65]=2; lit[66]=2; lit[256]=2; lit[257]=2; dist=[0]*30; dist[4]=1; dist[0]=1; lc,dc=dyn_header(bw,lit,dist)
-    for ch in b'AB': bw.code(*lc[ch])
-    bw.code(*lc[257]); bw.code(*dc[4]); bw.put(1,1)  # dist code 4: base 5 + extra 1 bit -> 6 > 2 bytes
-    bw.code(*lc[256]); cases.append(('distance too far back', bw.bytes(4)))
-    # 8: distance symbols 30 present in the set and used
-    dist=[0]*31
-    # ndist max 30 -> cannot declare 31; use fixed block for 30/31
-    bw=BW(); bw.put(1,1); bw.put(1,2)
-    def fixlit(bw,s):
-        if s<144: bw.code(0x30+s,8)
-        elif s<256: bw.code(0x190+s-144,9)
-        elif s<280: bw.code(s-256,7)
-        else: bw.code(0xC0+s-280,8)
-    for ch in b'ABCD': fixlit(bw,ch)
-    fixlit(bw,257); bw.code(30,5); fixlit(bw,256); cases.append(('fixed block, distance code 30', bw.bytes(4)))
-    bw=BW(); bw.put(1,1); bw.put(1,2)
-    for ch in b'ABCD': fixlit(bw,ch)
-    fixlit(bw,286); fixlit(bw,256); cases.append(('fixed block, length symbol 286', bw.bytes(4)))
-    # 9: stored blocks: empty, then data, LEN mismatch
-    bw=BW(); bw.put(0,1); bw.put(0,2); b=bw.bytes(); cases.append(('empty stored + final empty stored', b+b'\x00\x00\xff\xff'+b'\x01\x00\x00\xff\xff'))
-    cases.append(('stored LEN/NLEN mismatch', b'\x01\x05\x00\xfa\xfe'+b'hello'))
-    cases.append(('stored, data cut', b'\x01\x05\x00\xfa\xff'+b'hel'))
-    # 10: block type 3
-    cases.append(('block type 3', b'\x07\x00\x00\x00\x00'))
-    # 11: HLIT too large (nlen 287)
-    bw=BW(); bw.put(1,1); bw.put(2,2); bw.put(30,5); bw.put(0,5); bw.put(0,4); cases.append(('nlen 287', bw.bytes(40)))
-    # 12: repeat with nothing before it
-    bw=BW(); lit=[0]*257; lit[256]=1
-    try:
-        lc,dc=dyn_header(bw,lit,[0],rle=[(16,0,2)]+[0]*254+[1]+[0], clens=None)
-    except Exception as e: pass
-    # 13: code length code over-subscribed
-    bw=BW(); bw.put(1,1); bw.put(2,2); bw.put(0,5); bw.put(0,5); bw.put(15,4)
-    for i in range(19): bw.put(1,3)
-    cases.append(('code-length code over-subscribed', bw.bytes(40)))
-    # 14: code length code incomplete (one 2-bit code)
-    bw=BW(); bw.put(1,1); bw.put(2,2); bw.put(0,5); bw.put(0,5); bw.put(0,4); bw.put(2,3); bw.put(0,3); bw.put(0,3); bw.put(0,3)
-    cases.append(('code-length code incomplete', bw.bytes(40)))
-    # 15: code length code with a single 1-bit code (incomplete, max 1)
-    bw=BW(); bw.put(1,1); bw.put(2,2); bw.put(0,5); bw.put(0,5); bw.put(0,4); bw.put(0,3); bw.put(0,3); bw.put(0,3); bw.put(1,3)
-    cases.append(('code-length code: one 1-bit code', bw.bytes(60)))
+
+    order = (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15)
+
+    def dynamic_header(bw, lit, dist):
+        """BFINAL = 1, BTYPE = 2, the code-length code (a complete code over the lengths that occur; a second one-bit code
+        beside a single one) and the lengths themselves, one symbol each (no repeats) -> the two codes"""
+        seq = list(lit) + list(dist)
+        used = sorted(set(seq))
+        clens = [0] * 19
+        if len(used) == 1:
+            clens[used[0]] = clens[(used[0] + 1) % 16] = 1
+        else:
+            n = math.ceil(math.log2(len(used)))
+            short = (1 << n) - len(used)
+            for i, sym in enumerate(used):
+                clens[sym] = n - 1 if i < short else n
+        cc = canonical(clens)
+        bw.put(1, 1)
+        bw.put(2, 2)
+        bw.put(len(lit) - 257, 5)
+        bw.put(len(dist) - 1, 5)
+        hclen = 19
+        while hclen > 4 and clens[order[hclen - 1]] == 0:
+            hclen -= 1
+        bw.put(hclen - 4, 4)
+        for i in range(hclen):
+            bw.put(clens[order[i]], 3)
+        for n in seq:
+            bw.code(cc[n])
+        return canonical(lit), canonical(dist)
+
+    def fixed_lit(bw, sym):  # appnote.txt:2054-2059
+        if sym < 144:
+            bw.code((0x30 + sym, 8))
+        elif sym < 256:
+            bw.code((0x190 + sym - 144, 9))
+        elif sym < 280:
+            bw.code((sym - 256, 7))
+        else:
+            bw.code((0xC0 + sym - 280, 8))
+
+    cases = []
+    only_eob = [0] * 257
+    only_eob[256] = 1
+    bw = Bits()
+    lc, _ = dynamic_header(bw, only_eob, [0])
+    bw.code(lc[256])
+    cases.append(("only the end-of-block code, one bit", bw.bytes(4)))
+    bw = Bits()
+    dynamic_header(bw, only_eob, [0])
+    bw.code((1, 1))
+    cases.append(("the unused pattern of a one-bit literal/length code", bw.bytes(4)))
+
+    abc = [0] * 257
+    abc[65] = abc[66] = abc[67] = abc[256] = 2
+    bw = Bits()
+    lc, _ = dynamic_header(bw, abc, [0])
+    for ch in b"ABCABCCBA":
+        bw.code(lc[ch])
+    bw.code(lc[256])
+    cases.append(("literals only, no distance code", bw.bytes(4)))
+
+    ab = [0] * 258
+    ab[65] = ab[66] = ab[256] = ab[257] = 2  # 257 = a match of 3 bytes
+    for dist_bit, name in ((0, "a single one-bit distance code, used"), (1, "the unused pattern of a one-bit distance code")):
+        bw = Bits()
+        lc, _ = dynamic_header(bw, ab, [1])
+        for ch in b"ABAB":
+            bw.code(lc[ch])
+        bw.code(lc[257])
+        bw.code((dist_bit, 1))
+        bw.code(lc[256])
+        cases.append((name, bw.bytes(4)))
+    bw = Bits()
+    lc, _ = dynamic_header(bw, ab, [0])
+    for ch in b"ABAB":
+        bw.code(lc[ch])
+    bw.code(lc[257])
+    bw.put(0, 1)
+    bw.code(lc[256])
+    cases.append(("a match where there is no distance code", bw.bytes(4)))
+    dist = [0] * 30
+    dist[0] = dist[4] = 1
+    bw = Bits()
+    lc, dc = dynamic_header(bw, ab, dist)
+    for ch in b"AB":
+        bw.code(lc[ch])
+    bw.code(lc[257])
+    bw.code(dc[4])
+    bw.put(1, 1)  # distance code 4: 5 + one extra bit = 6, two bytes into the stream
+    bw.code(lc[256])
+    cases.append(("a distance in front of the stream", bw.bytes(4)))
+
+    for sym, name in ((None, "fixed block, distance code 30"), (286, "fixed block, length symbol 286")):
+        bw = Bits()
+        bw.put(1, 1)
+        bw.put(1, 2)
+        for ch in b"ABCD":
+            fixed_lit(bw, ch)
+        if sym is None:
+            fixed_lit(bw, 257)
+            bw.code((30, 5))
+        else:
+            fixed_lit(bw, sym)
+        fixed_lit(bw, 256)
+        cases.append((name, bw.bytes(4)))
+
+    cases.append(("an empty stored block, then an empty final one", b"\x00\x00\x00\xff\xff" + b"\x01\x00\x00\xff\xff"))
+    cases.append(("stored block, LEN and NLEN disagree", b"\x01\x05\x00\xfa\xfe" + b"hello"))
+    cases.append(("stored block, cut inside its data", b"\x01\x05\x00\xfa\xff" + b"hel"))
+    cases.append(("block type 3", b"\x07\x00\x00\x00\x00"))
+    bw = Bits()
+    bw.put(1, 1)
+    bw.put(2, 2)
+    bw.put(30, 5)
+    bw.put(0, 5)
+    bw.put(0, 4)
+    cases.append(("287 literal/length codes", bw.bytes(40)))
+    for clens, name in (([1] * 19, "code-length code over-subscribed"), ([2, 0, 0, 0], "code-length code incomplete"),
+                        ([0, 0, 0, 1], "code-length code of a single one-bit code")):
+        bw = Bits()
+        bw.put(1, 1)
+        bw.put(2, 2)
+        bw.put(0, 5)
+        bw.put(0, 5)
+        bw.put(len(clens) - 4, 4)
+        for n in clens:
+            bw.put(n, 3)
+        cases.append((name, bw.bytes(60)))
     return cases
 
 
 def test_crafted_deflate_corners(libs):
     """Every crafted corner stream, whole and cut 1 .. 11 bytes short, in 65 535-byte and 3-byte read() calls: every read() return
-    value, byte, TOTAL_IN / TOTAL_OUT, close() and error() as the all-reference build (16 streams x 12 lengths x 2 call sizes)."""
+    value, byte, TOTAL_IN / TOTAL_OUT, close() and error() as the all-reference build (17 streams x up to 12 lengths x 2 call sizes)."""
     hip, ref = libs
     n = 0
     for name, z in _crafted_deflate_corners():
