@@ -374,6 +374,15 @@ static int32_t verdict(mzhip_zlib *z, int32_t status, int64_t in_used) {
     z->decoded = 1;
     return 0;
 }
+/* Does inflate() meet the verdict without needing room for output?  A refused code, block type, header or stored-block length
+ * and a failed trailer check: yes -- the call that returns the last byte in front of it reports it even when that byte fills
+ * the caller's buffer (the bytes of that call are lost).  A distance too far back: no, MATCH waits for room first
+ * (inflate.c) -- and the device does not say which refusal it was.  But behind 32 KiB of output no distance is too far back
+ * any more, so every data error there is of the first kind; in front of that the question stays open (a refusal met exactly
+ * at a call's end is reported one call late when it was not a distance: DESIGN 1). */
+static int32_t verdict_needs_no_room(const mzhip_zlib *z, int64_t produced) {
+    return z->trailer_err || (z->dev_status == MZHIP_STATUS_DATA_ERROR && produced >= 32768);
+}
 /* a trailer check that failed ("incorrect data check" / "incorrect length check") */
 static int32_t trailer_verdict(mzhip_zlib *z, int64_t in_used) {
     z->trailer_err = 1;
@@ -1062,16 +1071,16 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
                 return sr;
             }
         }
-        if (got == size && !z->stream_end && z->out_served == z->out_len && z->wrap != 0) {
-            /* the buffer is full exactly where a window ends: if that is the payload's end too and the trailer does not check
-             * out, inflate() has found that in this call (above) -- look */
+        if (got == size && !z->stream_end && z->out_served == z->out_len) {
+            /* the buffer is full exactly where a window ends: if the stream ends or fails right there, inflate() may have found
+             * that in this call (verdict_needs_no_room) -- look */
             const int32_t sr = stream_next(z);
             if (sr < 0) {
                 z->error = sr;
                 return sr;
             }
         }
-        if (z->dev_status != 0 && (got < size || (z->trailer_err && z->stream_end && z->out_served == z->out_len))) {
+        if (z->dev_status != 0 && (got < size || (z->stream_end && z->out_served == z->out_len && verdict_needs_no_room(z, z->g0 + z->out_len)))) {
             /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189) */
             z->error = (z->base_err != 0 && z->dev_status == MZHIP_STATUS_BUF_ERROR) ? z->base_err : z->dev_status;
             z->total_in = z->dev_in_used;
@@ -1083,7 +1092,7 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         return got;
     }
     int64_t avail = z->out_len - z->out_served;
-    if (z->dev_status != 0 && (avail < size || (z->trailer_err && avail == size))) {
+    if (z->dev_status != 0 && (avail < size || (avail == size && verdict_needs_no_room(z, z->out_len)))) {
         /* the failing call reports the error, not a byte count (mz_strm_zlib.c:186-189).  (A failed trailer check is met
          * in the call that returns the payload's last byte even when that byte fills the buffer: behind it inflate() walks
          * through the end-of-block code and the trailer without needing room -- round 5, tests/fuzz_wrappers.py) */

@@ -32,8 +32,10 @@ for libn in LIBS:
             if rnd.random()<0.8: z+=co.flush(rnd.choice((zlib.Z_SYNC_FLUSH,zlib.Z_FULL_FLUSH,zlib.Z_BLOCK,zlib.Z_PARTIAL_FLUSH)))
         z+=co.flush()
         vs=[('whole',z),('cut',z[:rnd.randrange(0,len(z)+1)])]
-        for _ in range(2):
-            zz=bytearray(z); zz[rnd.randrange(len(zz))]^=1<<rnd.randrange(8); vs.append(('flip',bytes(zz)))
+        for _ in range(2):  # (no flips under a window below 15 bits: there inflate() refuses a distance by the history it holds PLUS what the current call
+            # has produced -- the caller's buffer size decides, INTEGRATION.md "One deviation" -- and a corrupted distance is where that shows)
+            zz=bytearray(z); zz[rnd.randrange(len(zz))]^=1<<rnd.randrange(8)
+            if wb in (-15,15,31): vs.append(('flip',bytes(zz)))
         for name,data in vs:
             chunk=rnd.choice((65535,7,1000,1<<20)); mi=rnd.choice((0,len(data)))
             a=hip.stream_decode(8,data,len(d)+70000,chunk=chunk,window_bits=wb,max_in=mi); b=ref.stream_decode(8,data,len(d)+70000,chunk=chunk,window_bits=wb,max_in=mi)

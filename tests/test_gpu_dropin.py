@@ -311,6 +311,35 @@ def test_crafted_deflate_corners(libs):
     assert n > 300
 
 
+def test_refusal_behind_a_full_buffer(libs):
+    """40 000 bytes of valid output (more than any distance reaches back), then a block type inflate() refuses: read() calls whose
+    sizes divide the 40 000 exactly.  The call that would have returned the last of those bytes has a full buffer and inflate()
+    still walks on -- a refusal that needs no room for output is met right there: that call fails and its bytes are lost.  (In
+    front of 32 KiB of output the device's verdict does not say whether the refusal was a distance too far back, which waits for
+    room: DESIGN 1 keeps that case open.)  One buffer and in windows; raw, zlib and gzip framing."""
+    import ctypes as C
+
+    hip, ref = libs
+    text, _ = synth.bench_corpus()
+    d = text[5000:45000]
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    for win in (0, 192 << 10, 16384 + 32768):
+        L.mzhip_set_stream_window(win, 48 << 10 if win else 0)
+        try:
+            for wb in (-15, 15, 31):
+                co = zlib.compressobj(6, zlib.DEFLATED, wb)
+                z = co.compress(d) + co.flush(zlib.Z_FULL_FLUSH) + b"\x07\x00\x00\x00"  # BFINAL = 1, BTYPE = 3
+                for chunk in (40000, 20000, 8000, 5000, 7000, 65535):
+                    a = hip.stream_decode(8, z, len(d) + 70000, chunk=chunk, window_bits=wb)
+                    b = ref.stream_decode(8, z, len(d) + 70000, chunk=chunk, window_bits=wb)
+                    assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (win, wb, chunk, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
+                    assert b["rets"][-1] == -3 and (len(b["out"]) < len(d) if len(d) % chunk == 0 or chunk > len(d) else True), (wb, chunk, b["rets"])
+        finally:
+            L.mzhip_set_stream_window(0, 0)
+
+
 def test_bitflip_verdicts_deflate(libs):
     """One flipped bit anywhere: the same read() sequence, bytes, close() and error().  TOTAL_IN / TOTAL_OUT after a data
     error are zlib's internal detection point ("treat as best-effort"): compared, counted, not asserted."""

@@ -60,6 +60,10 @@ def test_crafted_deflate_corners(libs):
     D.test_crafted_deflate_corners(libs)
 
 
+def test_refusal_behind_a_full_buffer(libs):
+    D.test_refusal_behind_a_full_buffer(libs)
+
+
 def test_truncation_accounting_window_mode(libs):
     D.test_truncation_accounting_window_mode(libs)
 
