@@ -854,6 +854,22 @@ static int32_t lz_stream_read(mzhip_lzma *z, void *buf, int32_t size) {
         z->total_out += k;
         got += k;
     }
+    if (z->streaming == 1 && got == size && z->out_served == z->out_len && !z->stream_end &&
+        (z->max_total_out < 0 || z->total_out < z->max_total_out)) {
+        /* method 14, the buffer full exactly where the decoded bytes end: liblzma has looked at the next packet in this call
+         * (above, the one-buffer path) -- is it one it refuses? */
+        if (z->s_err == 0) {
+            const int32_t rc = lz_stream_next(z);
+            if (rc != MZH_OK) {
+                z->error = 5; /* LZMA_MEM_ERROR */
+                return MZH_DATA_ERROR;
+            }
+            if (z->error != 0)
+                return MZH_DATA_ERROR;
+        }
+        if (z->s_err == MZHIP_STATUS_DATA_ERROR && z->out_served == z->out_len)
+            return lz_stream_fail(z);
+    }
     if (z->streaming == 2 && z->s_err != 0 && z->xz_err_eager && z->out_served == z->out_len)
         return lz_stream_fail(z); /* met on the walk behind the block whose last bytes this call would have returned */
     z->total_in = z->in_dropped; /* exact once the end marker has been decoded (what mz_zip.c:2116 needs) */
@@ -924,7 +940,13 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
             z->next_attempt = z->in_len * 2;
     }
     int64_t avail = z->out_len - z->out_served;
-    if (z->dev_status != 0 && avail < size) {
+    /* (method 14: liblzma is not told the entry's size, so with the caller's buffer full it still decodes the next packet to
+     * see whether it is the end marker (lzma_decoder.c, SEQ_IS_MATCH without no_eopm) -- and a packet it refuses is refused
+     * THERE: the call that returns the last bytes in front of a data error fails even when they fill the buffer.  LZMA2
+     * chunks know their size: method 95 stops at a full buffer.  Round 5, a fuzz with 7-byte read() calls) */
+    if (z->dev_status != 0 && (avail < size || (avail == size && z->method == MZH_COMPRESS_METHOD_LZMA &&
+                                                z->dev_status == MZHIP_STATUS_DATA_ERROR &&
+                                                (z->max_total_out < 0 || z->total_out + avail <= z->max_total_out)))) {
         z->error = z->dev_status == MZHIP_STATUS_BUF_ERROR ? 10 : 9; /* LZMA_BUF_ERROR : LZMA_DATA_ERROR */
         z->total_in = z->dev_in_used;
         z->total_out = z->out_len;

@@ -35,7 +35,7 @@ def run(n_streams, seed, lib):
     text = synth.bench_corpus()[0]
 
     def piece():
-        k, n = rnd.randrange(5), rnd.randrange(2000, 400000)
+        k, n = rnd.randrange(5), rnd.choice((rnd.randrange(1, 20000), rnd.randrange(2000, 400000)))
         if k == 0:
             o = rnd.randrange(len(text) - 1)
             return (text[o:] + text)[:n]
@@ -64,9 +64,12 @@ def run(n_streams, seed, lib):
         zz[rnd.randrange(len(zz))] ^= 1 << rnd.randrange(8)
         variants.append(("flip", bytes(zz)))
         for name, data in variants:
-            chunk = rnd.choice((65535, 65535, 1 << 20, 7777))
+            chunk = rnd.choice((65535, 65535, 1 << 20, 7777, 7, 100) if len(d) < 60000 else (65535, 65535, 1 << 20, 7777))  # (small entries also in tiny read() calls: which call reports a refusal)
             max_out = len(d) if eos else -1
             b = ref.stream_decode(14, data, len(d) + 70000, chunk=chunk, max_out=max_out)
+            if name == "flip" and max_out >= 0 and (b["total_out"] >= max_out or any(r < 0 and r != -3 for r in b["rets"])):
+                continue  # (a corrupted stream that reaches TOTAL_OUT_MAX: behind the limit the reference decodes on in read()-sized steps and its
+                          # byte counts go negative, e.g. -601 -- the case tests/test_gpu_dropin.py::test_lzma_window_mode leaves out)
             for win in (0, 1):
                 L.mzhip_set_stream_window(192 << 10 if win else 0, 48 << 10 if win else 0)
                 a = hip.stream_decode(14, data, len(d) + 70000, chunk=chunk, max_out=max_out)

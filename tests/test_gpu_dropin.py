@@ -494,6 +494,41 @@ def test_truncation_accounting_lzma(libs):
     print("lzma bit flips: %d of %d cases also agree in TOTAL_IN / TOTAL_OUT" % (same, n))
 
 
+def test_lzma_refusal_behind_a_full_buffer(libs):
+    """Method 14, corrupted streams read ONE byte (and seven) at a time, so that the bytes in front of the refusal always fill the
+    caller's buffer: liblzma is not told the entry's size and, with the buffer full, still decodes the next packet to see whether
+    it is the end marker -- a packet it refuses is refused in that call, which then fails instead of returning its byte(s).  The
+    same read() sequence, bytes, close() and error() as the all-reference build, one buffer and in windows."""
+    import ctypes as C
+    import random
+
+    hip, ref = libs
+    L = hip.L
+    L.mzhip_set_stream_window.argtypes = [C.c_int64, C.c_int64]
+    L.mzhip_set_stream_window.restype = None
+    text, _ = synth.bench_corpus()
+    d = text[20000:23000]
+    z = _zip_lzma(d, preset=3)
+    rnd = random.Random(5)
+    refused = 0
+    for win in (0, 4096):  # (4096: the smallest window the knob takes -- every entry is decoded in windows)
+        L.mzhip_set_stream_window(win, 4096 if win else 0)
+        try:
+            for k in range(14):
+                i = 30 + rnd.randrange(len(z) - 40)
+                bad = z[:i] + bytes([z[i] ^ (1 << rnd.randrange(8))]) + z[i + 1:]
+                for chunk in (1, 7):
+                    # (no TOTAL_OUT_MAX: a corrupted stream that runs past it is the case test_lzma_window_mode leaves out)
+                    a = hip.stream_decode(14, bad, len(d) + 70000, chunk=chunk)
+                    b = ref.stream_decode(14, bad, len(d) + 70000, chunk=chunk)
+                    assert (a["rets"], a["out"], a["close"], a["error"]) == (b["rets"], b["out"], b["close"], b["error"]), \
+                        (win, i, chunk, len(a["rets"]), len(b["rets"]), a["rets"][-2:], b["rets"][-2:], a["error"], b["error"])
+                    refused += b["error"] != 0
+        finally:
+            L.mzhip_set_stream_window(0, 0)
+    assert refused > 10, refused
+
+
 def test_lzma_window_mode(libs):
     """mz_stream_lzma READ in window mode (shim_lzma.c: the resumable build of K3, a 64-byte coder state and the adaptive
     model carried from launch to launch, out[] = dictionary so far + one window): entries of many windows -- presets whose

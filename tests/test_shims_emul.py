@@ -76,6 +76,10 @@ def test_lzma_window_mode(libs):
     D.test_lzma_window_mode(libs)
 
 
+def test_lzma_refusal_behind_a_full_buffer(libs):
+    D.test_lzma_refusal_behind_a_full_buffer(libs)
+
+
 def test_xz_window_mode(libs):
     D.test_xz_window_mode(libs)
 
