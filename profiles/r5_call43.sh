@@ -1,0 +1,6 @@
+#!/bin/bash
+# Round 5, call 43: test_lzma_refusal_behind_a_full_buffer on the device
+set -u
+root=$PWD; out=$root/gpurun_out/c43; mkdir -p $out
+( timeout 40 python -m pytest tests/test_gpu_dropin.py -x -q -k "lzma_refusal" 2>&1 | grep -v amdgpu.ids | tail -2 ) > $out/check.log 2>&1
+cat $out/check.log
