@@ -1073,7 +1073,8 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         }
         if (got == size && !z->stream_end && z->out_served == z->out_len) {
             /* the buffer is full exactly where a window ends: if the stream ends or fails right there, inflate() may have found
-             * that in this call (verdict_needs_no_room) -- look */
+             * that in this call (verdict_needs_no_room) -- look.  (The window slides: a CRC hint that points into it is withdrawn) */
+            mzhip_served_drop();
             const int32_t sr = stream_next(z);
             if (sr < 0) {
                 z->error = sr;
