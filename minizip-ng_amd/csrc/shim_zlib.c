@@ -89,6 +89,7 @@ typedef struct mzhip_zlib_s {
      * [history | the window's bytes]; the compressed bytes in front of the current block's header have been dropped */
     int8_t streaming;       /* window mode is on */
     int8_t stream_end;      /* the device has seen the end of the stream */
+    int8_t kind_known, kind_no_room; /* refusal_is_not_a_distance(): asked once per stream */
     int8_t trailer_err;     /* the verdict is a trailer check that failed: inflate() gets there without needing room for output, so the call
                              * that returns the payload's last byte reports it even when that byte fills the caller's buffer */
     mzhip_inflate_state sst; /* where the decode goes on (bit positions from in[0]) */
@@ -250,6 +251,7 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->decoded = 0;
     z->streaming = z->stream_end = 0;
     z->trailer_err = 0;
+    z->kind_known = z->kind_no_room = 0;
     z->t_par = z->t_serial = z->t_pull = 0.0;
     z->t_open = mzh_now();
     z->n_par = z->n_serial = 0;
@@ -377,11 +379,55 @@ static int32_t verdict(mzhip_zlib *z, int32_t status, int64_t in_used) {
 /* Does inflate() meet the verdict without needing room for output?  A refused code, block type, header or stored-block length
  * and a failed trailer check: yes -- the call that returns the last byte in front of it reports it even when that byte fills
  * the caller's buffer (the bytes of that call are lost).  A distance too far back: no, MATCH waits for room first
- * (inflate.c) -- and the device does not say which refusal it was.  But behind 32 KiB of output no distance is too far back
- * any more, so every data error there is of the first kind; in front of that the question stays open (a refusal met exactly
- * at a call's end is reported one call late when it was not a distance: DESIGN 1). */
-static int32_t verdict_needs_no_room(const mzhip_zlib *z, int64_t produced) {
-    return z->trailer_err || (z->dev_status == MZHIP_STATUS_DATA_ERROR && produced >= 32768);
+ * (inflate.c) -- and the device's verdict does not say which refusal it was.  Behind 32 KiB of output no distance is too far
+ * back any more, so every data error there is of the first kind.  In front of that the device is asked once more, the same
+ * payload behind 32 KiB of make-believe history: a distance that reached in front of the entry now lands in it and the decode
+ * goes on -- a refusal that stands where it stood was not a distance.  (One more launch for a stream that is refused in its
+ * first 32 KiB exactly at the end of a read() call, nothing otherwise.) */
+static int32_t refusal_is_not_a_distance(mzhip_zlib *z, const uint8_t *in, int64_t in_len, int64_t in_used, int64_t produced) {
+    if (z->kind_known)
+        return z->kind_no_room;
+    z->kind_known = 1;
+    z->kind_no_room = 0;
+    if (in_len <= 0 || in_len > 0x7FFFFFFF)
+        return 0;
+    const int64_t cap = 32768 + produced + 320;
+    uint8_t *tmp = (uint8_t *)calloc(1, (size_t)cap);
+    if (!tmp)
+        return 0;
+    mzhip_inflate_state sin;
+    memset(&sin, 0, sizeof(sin));
+    sin.out_pos = 32768;
+    sin.flags = 1;
+    uint32_t ol = 0, iu = 0, crc = 0;
+    mzhip_inflate_host_args a;
+    memset(&a, 0, sizeof(a));
+    a.size = (uint32_t)sizeof(a);
+    a.in = in;
+    a.in_len = (uint32_t)in_len;
+    a.buf = tmp;
+    a.buf_cap = (uint32_t)cap;
+    a.state_in = &sin;
+    a.out_len = &ol;
+    a.in_used = &iu;
+    a.crc = &crc;
+    const int32_t st = mzhip_inflate_host(&a);
+    free(tmp);
+    z->kind_no_room = st == MZHIP_STATUS_DATA_ERROR && (int64_t)iu == in_used && (int64_t)ol == 32768 + produced;
+    return z->kind_no_room;
+}
+static int32_t verdict_needs_no_room(mzhip_zlib *z, int64_t produced) {
+    if (z->trailer_err)
+        return 1;
+    if (z->dev_status != MZHIP_STATUS_DATA_ERROR)
+        return 0;
+    if (produced >= 32768)
+        return 1;
+    if (z->streaming) /* (the first window of an entry decoded in windows: nothing of its input has been given up yet) */
+        return z->g0 == 0 && z->in_dropped == 0 ? refusal_is_not_a_distance(z, z->in, z->in_len, z->dev_in_used, produced) : 0;
+    if (z->out_borrowed || z->dev_in_used < z->hdr_len)
+        return 0;
+    return refusal_is_not_a_distance(z, z->in + z->hdr_len, z->in_len - z->hdr_len, z->dev_in_used - z->hdr_len, produced);
 }
 /* a trailer check that failed ("incorrect data check" / "incorrect length check") */
 static int32_t trailer_verdict(mzhip_zlib *z, int64_t in_used) {

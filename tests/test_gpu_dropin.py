@@ -314,9 +314,10 @@ def test_crafted_deflate_corners(libs):
 def test_refusal_behind_a_full_buffer(libs):
     """40 000 bytes of valid output (more than any distance reaches back), then a block type inflate() refuses: read() calls whose
     sizes divide the 40 000 exactly.  The call that would have returned the last of those bytes has a full buffer and inflate()
-    still walks on -- a refusal that needs no room for output is met right there: that call fails and its bytes are lost.  (In
-    front of 32 KiB of output the device's verdict does not say whether the refusal was a distance too far back, which waits for
-    room: DESIGN 1 keeps that case open.)  One buffer and in windows; raw, zlib and gzip framing."""
+    still walks on -- a refusal that needs no room for output is met right there: that call fails and its bytes are lost.  In
+    front of 32 KiB of output the refusal may be a distance too far back, which waits for room; the device's verdict does not
+    say, so the shim asks it once more behind 32 KiB of make-believe history (shim_zlib.c refusal_is_not_a_distance): both kinds
+    are among the cases.  One buffer and in windows; raw, zlib and gzip framing."""
     import ctypes as C
 
     hip, ref = libs
@@ -336,6 +337,17 @@ def test_refusal_behind_a_full_buffer(libs):
                     b = ref.stream_decode(8, z, len(d) + 70000, chunk=chunk, window_bits=wb)
                     assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (win, wb, chunk, {k: (a[k], b[k]) for k in ALL if k != "out" and a[k] != b[k]})
                     assert b["rets"][-1] == -3 and (len(b["out"]) < len(d) if len(d) % chunk == 0 or chunk > len(d) else True), (wb, chunk, b["rets"])
+            # in front of 32 KiB of output the refusal may be a distance too far back -- the one kind that waits for room: 14 bytes,
+            # then block type 3 (met in the call that fills the buffer) against two literals, then a distance of 6 (met one call later)
+            early = [b"\x00\x0e\x00\xf1\xffABCDEFGHIJKLMN" + b"\x07\x00\x00\x00"]
+            early += [z for name, z in _crafted_deflate_corners() if name in ("a distance in front of the stream", "fixed block, length symbol 286",
+                                                                               "the unused pattern of a one-bit distance code")]
+            assert len(early) == 4
+            for z in early:
+                for chunk in (1, 2, 4, 7, 14):
+                    a = hip.stream_decode(8, z, 70000, chunk=chunk, window_bits=-15)
+                    b = ref.stream_decode(8, z, 70000, chunk=chunk, window_bits=-15)
+                    assert {k: a[k] for k in ALL} == {k: b[k] for k in ALL}, (win, z[:8], chunk, {k: (a[k], b[k]) for k in ALL if a[k] != b[k]})
         finally:
             L.mzhip_set_stream_window(0, 0)
 
