@@ -375,6 +375,17 @@ MZHIP_API int64_t mzhip_zip_index_mem(const uint8_t *zip, uint64_t zip_len, int6
  * digest + 64 * i.  Returns the number of entries that carry one. */
 MZHIP_API int64_t mzhip_zip_index_hash_mem(const uint8_t *zip, uint64_t zip_len, const int64_t *table, int64_t n,
                                            uint16_t *algorithm, uint16_t *digest_size, uint8_t *digest);
+/* The same two from the archive's TAIL alone (an archive too large to image: shim_autoprime.c rolls over it window by window):
+ * tail[0] = byte tail_off of a file of zip_len bytes; the tail must hold the end records and the whole central directory.
+ * MZHIP_INDEX_NEED_MORE = it does not yet: read the tail from *need_from and call again.  Rows come back with payload offset
+ * -1 (t[7]): the local headers lie in the body.  mzhip_zip_index_resolve fills in the rows whose local header and payload lie
+ * inside a window win[0 .. win_len) = bytes [win_off, win_off + win_len) of the file; returns the number resolved. */
+#define MZHIP_INDEX_NEED_MORE (-1000)
+MZHIP_API int64_t mzhip_zip_index_tail(const uint8_t *tail, uint64_t tail_off, uint64_t zip_len, int64_t *table, int64_t max_entries,
+                                       uint64_t *need_from);
+MZHIP_API int64_t mzhip_zip_index_hash_tail(const uint8_t *tail, uint64_t tail_off, uint64_t zip_len, const int64_t *table, int64_t n,
+                                            uint16_t *algorithm, uint16_t *digest_size, uint8_t *digest);
+MZHIP_API int64_t mzhip_zip_index_resolve(const uint8_t *win, uint64_t win_off, uint64_t win_len, int64_t *table, int64_t n);
 
 /* Prime (SURVEY 8b "Batching") ------------------------------------------------------------- */
 
@@ -398,6 +409,9 @@ MZHIP_API int64_t mzhip_prime_mem_begin(const uint8_t *zip, uint64_t zip_len);
 MZHIP_API int64_t mzhip_prime_wait(void);
 /* archives the READ streams primed on their own (shim_autoprime.c: on by default, MZHIP_AUTOPRIME=0 turns it off) */
 MZHIP_API uint64_t mzhip_autoprime_count(void);
+/* archives larger than the limit are rolled over window by window: windows primed / evicted so far, page-locked bytes the live
+ * windows hold now and held at most */
+MZHIP_API void mzhip_autoprime_stats(uint64_t *windows_primed, uint64_t *windows_evicted, uint64_t *live_bytes, uint64_t *peak_bytes);
 /* The same over several devices of the node (the host side of the sharded path in C): the entries are
  * independent (mz_zip.c:1682-1863 builds a fresh codec per entry), so the entry table is cut into ndev contiguous
  * slices balanced by compressed + uncompressed bytes (mzhip_shard_bounds) and ONE HOST THREAD PER SLICE decodes it on

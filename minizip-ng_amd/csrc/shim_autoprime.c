@@ -1,27 +1,46 @@
-/* shim_autoprime.c -- the UNMODIFIED reader loop primes itself (on by default since round 5).
+/* shim_autoprime.c -- the UNMODIFIED reader loop primes itself: archives of ANY size (round 6).
  *
  * mz_zip.c:1773 creates one codec stream per entry, so an application that is only re-linked against libmzhip.so pays one
  * launch and one PCIe round trip per entry: 33 MB/s on 64 KiB entries where one reference thread makes 350.
  * mzhip_prime_file() cures that with one line in the application; this file cures it with none: the first read() of an
  * entry walks down its base chain to the archive stream (compress stream -> crypt/raw stream -> zip->stream,
- * mz_zip.c:1765-1850), reads the archive through that stream's own vtbl (seek / tell / read, position restored afterwards),
- * hands the image to mzhip_prime_mem() -- every DEFLATE / LZMA / XZ entry decoded in one launch per codec -- and then looks
- * the entry up in the cache like any primed entry.  Everything else -- including every failure -- takes the ordinary
- * per-entry path with its exact error behaviour.
+ * mz_zip.c:1765-1850) and reads the archive through that stream's own vtbl (seek / tell / read, position restored
+ * afterwards).  The reference streams an archive of any size at a constant rate in constant memory (mz_zip.c:1757-1853,
+ * mz_strm_zlib.c:116-193); so does this:
  *
- * When it happens (all must hold; MZHIP_AUTOPRIME in the environment of the process: "0" = never, "<n>" = archives of up to
- * n MiB, unset = 512):
+ *   small archives (at most the limit: 512 MiB, or MZHIP_AUTOPRIME=<MiB>) are imaged whole and handed to mzhip_prime_mem()
+ *     -- every DEFLATE / LZMA / XZ entry decoded in one launch per codec, STORE entries' CRCs too;
+ *   larger ones are ROLLED OVER: the tail of the file (end records + central directory) is indexed once
+ *     (mzhip_zip_index_tail), the entries a codec stream would be opened for are cut -- in the order their local headers
+ *     lie in the file -- into windows of about 256 MiB of compressed + decoded bytes, and a window is imaged through the
+ *     reader's stream and decoded AHEAD of the reader: the window the entry at hand lies in (its first use), and the one
+ *     behind it right after (the look-ahead), each as a cache generation of its own on a worker thread's pipeline
+ *     (mzhip_prime_window_begin: H2D, launches, D2H of chunk i+1 / i / i-1 at once; the reader is served chunk by chunk).
+ *     Windows that have been read are evicted, least recently used first, to keep the page-locked bytes of all live windows
+ *     under 4 x the limit (2 GiB); readers of several threads -- one mz_zip_reader each over the same file, each in its own
+ *     part of it -- share the windows.
+ * Every failure, and every entry no window holds (encrypted, STORE, larger than a window), takes the ordinary per-entry path
+ * with its exact error behaviour.
+ *
+ * When it happens (all must hold; MZHIP_AUTOPRIME in the environment of the process: "0" = never, "<n>" = limit of n MiB
+ * ("<n>k": KiB, for tests), unset = 512):
  *   - the archive stream can seek, tell and read (a pipe cannot; the per-entry path serves it);
- *   - the archive is at most the limit, holds at least MZH_AUTOPRIME_MIN_ENTRIES entries a codec stream would be opened for
- *     (fewer: the per-entry path costs less than imaging the archive), and they decode to at most 4 x the limit (the cache
- *     is page-locked host memory; a bomb, or one entry of a huge archive, is not worth it);
- *   - this image (size + CRC of its last 64 KiB: the central directory) has not been primed already -- readers of several
- *     threads, one mz_zip_reader each over the same file, prime it once -- nor three times before (an application that
- *     alternates between archives entry by entry would otherwise re-image them for ever).
- * A new archive replaces the cache's previous generation (streams still reading from it keep it alive): one archive's
- * worth of decoded bytes at a time.  An application that calls mzhip_prime_* itself is left alone: while the cache holds
- * generations this file did not make, nothing is cleared or added. */
+ *   - the archive holds at least MZH_AUTOPRIME_MIN_ENTRIES entries a codec stream would be opened for (fewer: the per-entry
+ *     path costs less than imaging the archive); imaged whole, they decode to at most 4 x the limit (the cache is
+ *     page-locked host memory; a bomb is not worth it -- the sum is taken in unsigned arithmetic over exactly the rows
+ *     mzhip_prime_mem() would take and cut off at the bound);
+ *   - whole image: this image (size + CRC of its last 64 KiB: the central directory) has not been primed already --
+ *     readers of several threads prime it once -- nor three times before (an application that alternates between archives
+ *     entry by entry would otherwise re-image them for ever); rolled over: a window that was evicted three times in a row
+ *     before eight of its entries had been read is left to the per-entry path (the same guard, per window).
+ * Which archive a stream belongs to is asked on EVERY call, not remembered by stream address (the allocator hands a freed
+ * reader's address to the next one): its size and a hash of its last 4 KiB, read through the stream on every call.
+ * The cache's other generations are never touched: a new whole image replaces the previous one THIS FILE made (by identity,
+ * not mzhip_prime_clear()), windows are dropped one by one.  An application that calls mzhip_prime_* itself is left alone by
+ * the whole-image path (while the cache holds generations this file did not make, it adds nothing); rolling over an archive
+ * goes on beside them. */
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -34,26 +53,104 @@
 #endif
 #define MZH_AUTOPRIME_DEFAULT_MIB 512
 #define MZH_AUTOPRIME_SEEN 8
+#define MZH_ROLLS 4                       /* archives rolled over at the same time */
+#define MZH_ROLL_WINDOW ((uint64_t)256 << 20) /* compressed + decoded bytes of a window, at most (and at most 1/8 of the budget) */
+#define MZH_ROLL_GAP ((uint64_t)8 << 20)  /* bytes between two entries' local headers that a window does not image */
+#define MZH_ROLL_FRESH 256                /* calls: a window used this recently is not evicted for a look-ahead */
+#define MZH_ROLL_MAX_WINDOWS 20           /* live at once (the cache holds 32 generations) */
+#define MZH_TAIL4K 4096
+
+int64_t mzhip_prime_window_begin(uint8_t *img, size_t img_cap, uint64_t win_off, uint64_t win_len, const int64_t *rows, int64_t n,
+                                 const uint16_t *alg, const uint16_t *dsz, const uint8_t *dig, uint64_t zip_len, uint64_t ident,
+                                 uint64_t *out_bytes);
+void mzhip_prime_drop(uint64_t zip_len, uint64_t ident);
+int32_t mzhip_prime_has(uint64_t zip_len, uint64_t ident);
+void mzhip_prime_counts(int32_t *gens, int32_t *windows, uint64_t *clears);
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER; /* a window left the BUSY state */
+
+/* ---- whole images ---- */
 static struct {
     int64_t size;
-    uint32_t tail_crc;
+    uint64_t tail_crc;
     int32_t tries;
 } g_seen[MZH_AUTOPRIME_SEEN]; /* the images tried so far, newest first */
-static int64_t g_cur_size = -1; /* the image the cache holds now */
-static uint32_t g_cur_crc;
+static int64_t g_cur_size = -1; /* the whole image the cache holds now: size, CRC of its last 64 KiB, the generation's identity */
+static uint64_t g_cur_crc;
+static uint64_t g_cur_ident;
 static struct {
-    const void *arch;
     int64_t size;
+    uint64_t crc4; /* hash of the image's last 4 KiB */
     uint32_t era;
-    int32_t any; /* whether the cache held anything then */
-} g_done[16]; /* archive streams that have been dealt with (primed, in the cache already, or not worth it) while the cache
-                 was in the state it is in now: the call that every entry's first read() makes returns on these without I/O */
+    int32_t foreign; /* whether the cache held generations of the application's then */
+} g_done[16]; /* images that have been dealt with (primed, in the cache already, or not worth it) while the cache was in the
+                 state it is in now: the call that every entry's first read() makes returns on these after the 4 KiB tail read */
 static uint32_t g_done_next, g_era; /* era: moves on whenever the cache changes under this file's feet */
-int32_t mzhip_prime_any(void); /* mzhip_runtime.inc: the cache holds at least one generation */
-static uint64_t g_autoprimed; /* archives primed this way (tests) */
+static uint64_t g_clears_seen;
+static uint64_t g_autoprimed, g_windows_primed, g_windows_evicted, g_peak_bytes; /* (tests, reports) */
 MZHIP_API uint64_t mzhip_autoprime_count(void) { return __atomic_load_n(&g_autoprimed, __ATOMIC_RELAXED); }
+
+/* ---- archives that are rolled over ---- */
+enum { W_NONE = 0, W_BUSY, W_LIVE, W_DEAD };
+typedef struct {
+    uint64_t lo, hi;  /* the bytes of the file the window images */
+    int64_t r0, r1;   /* its rows */
+    uint64_t need;    /* bytes of the cache it will take: what its rows decode to, as the cache lays them out */
+    uint64_t held;    /* ... and holds while live */
+    uint64_t ident;
+    uint64_t stamp;   /* the call that used it last */
+    uint32_t hits;    /* calls that used it since it went live */
+    int32_t state, quick; /* quick: evictions in a row after fewer than 8 hits */
+} roll_win;
+typedef struct {
+    int64_t size;
+    uint64_t crc4, tail_crc; /* hashes of its last 4 / 64 KiB */
+    uint64_t ident, stamp;
+    int64_t n;
+    int64_t *rows; /* n x 8 (mzhip_zip_index_mem's columns), sorted by local header offset; payload offsets are filled in window by window */
+    uint16_t *alg, *dsz; /* Hash extra fields per row, or NULL: no row has one */
+    uint8_t *dig;
+    int32_t nwin, busy; /* busy: threads inside I/O for one of its windows */
+    roll_win *win;
+} roll;
+static roll *g_rolls[MZH_ROLLS];
+static uint64_t g_tick, g_live_bytes; /* page-locked bytes of the live windows of all rolls */
+
+MZHIP_API void mzhip_autoprime_stats(uint64_t *windows_primed, uint64_t *windows_evicted, uint64_t *live_bytes, uint64_t *peak_bytes) {
+    pthread_mutex_lock(&g_mu);
+    if (windows_primed)
+        *windows_primed = g_windows_primed;
+    if (windows_evicted)
+        *windows_evicted = g_windows_evicted;
+    if (live_bytes)
+        *live_bytes = g_live_bytes;
+    if (peak_bytes)
+        *peak_bytes = g_peak_bytes;
+    pthread_mutex_unlock(&g_mu);
+}
+
+static uint64_t fnv1a64(const uint8_t *p, uint64_t n, uint64_t h) {
+    for (uint64_t i = 0; i < n; i++)
+        h = (h ^ p[i]) * 0x100000001B3ull;
+    return h;
+}
+#define FNV0 0xCBF29CE484222325ull
+/* what names an image: a 64-bit hash of its last bytes, eight at a time, on the host (this runs on every entry's first read:
+ * mz_crypt_crc32_update's own arithmetic would send 4 KiB and more to the device) */
+static uint64_t tail_hash(const uint8_t *p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 29;
+    }
+    for (; i < n; i++)
+        h = (h ^ p[i]) * 0x100000001B3ull;
+    return h ^ (h >> 32);
+}
 
 static int32_t read_all(mzhip_stream *s, uint8_t *dst, int64_t n) {
     int64_t got = 0;
@@ -66,8 +163,318 @@ static int32_t read_all(mzhip_stream *s, uint8_t *dst, int64_t n) {
     }
     return 1;
 }
+static int32_t read_at(mzhip_stream *s, int64_t off, uint8_t *dst, int64_t n) {
+    return s->vtbl->seek(s, off, MZH_SEEK_SET) == MZH_OK && read_all(s, dst, n);
+}
 
-void mzhip_autoprime(mzhip_stream *codec_base) {
+/* is row t one that mzhip_prime_mem() / a window would decode?  (the conditions of prime_publish, mzhip_prime.inc) */
+static int row_codec(const int64_t *t) {
+    return (t[0] == 8 || t[0] == 14 || t[0] == 95) && !(t[1] & 1) && t[3] >= 0 && t[4] >= 0 && t[3] < ((int64_t)1 << 31) &&
+           t[4] < ((int64_t)1 << 31);
+}
+
+static int roll_trace(void) {
+    static int on = -1;
+    if (on < 0)
+        on = getenv("MZHIP_PRIME_TRACE") != NULL;
+    return on;
+}
+
+static void roll_free(roll *r) {
+    if (!r)
+        return;
+    for (int32_t w = 0; w < r->nwin; w++)
+        if (r->win[w].state == W_LIVE) {
+            mzhip_prime_drop((uint64_t)r->size, r->win[w].ident);
+            g_live_bytes -= r->win[w].held;
+        }
+    free(r->rows);
+    free(r->alg);
+    free(r->dsz);
+    free(r->dig);
+    free(r->win);
+    free(r);
+}
+
+static int cmp_rows_by_loff(const void *a, const void *b) {
+    const int64_t *x = (const int64_t *)a, *y = (const int64_t *)b;
+    return x[5] < y[5] ? -1 : x[5] > y[5] ? 1 : x[6] < y[6] ? -1 : x[6] > y[6];
+}
+
+/* index the archive from its tail and cut it into windows.  NULL: not worth it / not possible (the per-entry path serves it) */
+static roll *roll_new(mzhip_stream *arch, int64_t size, uint64_t crc4, uint64_t tail_crc, uint64_t budget) {
+    uint64_t from = size > (1 << 18) ? (uint64_t)size - (1 << 18) : 0;
+    uint8_t *tail = NULL;
+    int64_t *table = NULL;
+    roll *r = NULL;
+    int64_t n = 0;
+    for (int pass = 0; pass < 4; pass++) { /* (end record, ZIP64 end record, central directory: three reasons to go back further) */
+        const uint64_t len = (uint64_t)size - from;
+        if (len > ((uint64_t)1 << 31))
+            goto out; /* a central directory of 2 GiB: tens of millions of entries -- not this file's business */
+        free(tail);
+        tail = (uint8_t *)malloc((size_t)len);
+        if (!tail || !read_at(arch, (int64_t)from, tail, (int64_t)len))
+            goto out;
+        uint64_t need = 0;
+        n = mzhip_zip_index_tail(tail, from, (uint64_t)size, NULL, 0, &need);
+        if (n != MZHIP_INDEX_NEED_MORE)
+            break;
+        if (need >= from)
+            goto out;
+        from = need;
+    }
+    if (n < MZH_AUTOPRIME_MIN_ENTRIES || n > (1 << 26))
+        goto out;
+    table = (int64_t *)malloc((size_t)n * 8 * sizeof(int64_t));
+    if (!table || mzhip_zip_index_tail(tail, from, (uint64_t)size, table, n, NULL) != n)
+        goto out;
+    {
+        /* the rows a window can take: codec entries that fit one, in front of the central directory */
+        const uint64_t wmax = budget / 8 < MZH_ROLL_WINDOW ? budget / 8 : MZH_ROLL_WINDOW;
+        const int64_t cd0 = table[6];
+        uint16_t *alg = (uint16_t *)malloc((size_t)n * 2), *dsz = (uint16_t *)malloc((size_t)n * 2);
+        uint8_t *dig = (uint8_t *)malloc((size_t)n * 64);
+        int64_t nh = -1;
+        if (alg && dsz && dig)
+            nh = mzhip_zip_index_hash_tail(tail, from, (uint64_t)size, table, n, alg, dsz, dig);
+        /* (the Hash fields ride in column 2 -- the CRC, which a window does not need -- as the row's index, through the sort) */
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; i++) {
+            int64_t *t = table + 8 * i;
+            if (!row_codec(t) || t[5] < 0 || t[5] >= cd0 || (uint64_t)t[3] + (uint64_t)t[4] > wmax)
+                continue;
+            if (k != i)
+                memcpy(table + 8 * k, t, 8 * sizeof(int64_t));
+            table[8 * k + 2] = i;
+            table[8 * k + 7] = -1;
+            k++;
+        }
+        if (k < MZH_AUTOPRIME_MIN_ENTRIES) {
+            free(alg);
+            free(dsz);
+            free(dig);
+            goto out;
+        }
+        qsort(table, (size_t)k, 8 * sizeof(int64_t), cmp_rows_by_loff);
+        r = (roll *)calloc(1, sizeof(roll));
+        if (r && nh > 0) {
+            r->alg = (uint16_t *)malloc((size_t)k * 2);
+            r->dsz = (uint16_t *)malloc((size_t)k * 2);
+            r->dig = (uint8_t *)malloc((size_t)k * 64);
+            if (r->alg && r->dsz && r->dig) {
+                for (int64_t j = 0; j < k; j++) {
+                    const int64_t i = table[8 * j + 2];
+                    r->alg[j] = alg[i];
+                    r->dsz[j] = dsz[i];
+                    memcpy(r->dig + 64 * j, dig + 64 * i, 64);
+                }
+            } else {
+                free(r->alg);
+                free(r->dsz);
+                free(r->dig);
+                r->alg = r->dsz = NULL;
+                r->dig = NULL;
+            }
+        }
+        free(alg);
+        free(dsz);
+        free(dig);
+        if (!r)
+            goto out;
+        r->size = size;
+        r->crc4 = crc4;
+        r->tail_crc = tail_crc;
+        r->ident = fnv1a64(tail + ((uint64_t)cd0 - from), (uint64_t)size - (uint64_t)cd0, FNV0); /* as a whole image's generation */
+        r->n = k;
+        r->rows = table;
+        table = NULL;
+        /* windows: rows in file order until the budget of a window is reached or the file has a gap.  What a row occupies is
+         * not known before its local header has been read (30 + name + extra, which may differ from the central record's): a
+         * window images 128 KiB + the payload behind its last row's header, cut off at the central directory */
+        int32_t cap = 16, nw = 0;
+        roll_win *win = (roll_win *)calloc((size_t)cap, sizeof(roll_win));
+        uint64_t acc = 0, end = 0;
+        for (int64_t j = 0; win && j < k; j++) {
+            const int64_t *t = r->rows + 8 * j;
+            const uint64_t lo = (uint64_t)t[5], bytes = (uint64_t)t[3] + (uint64_t)t[4];
+            uint64_t hi = lo + 30 + 2 * 65535 + (uint64_t)t[3];
+            if (hi > (uint64_t)cd0)
+                hi = (uint64_t)cd0;
+            if (hi < end)
+                hi = end; /* (entries that overlap: the window only grows) */
+            const int fresh = nw == 0 || acc + bytes > wmax || lo + (uint64_t)t[3] - win[nw - 1].lo > wmax || lo > end + MZH_ROLL_GAP;
+            if (fresh) {
+                if (nw == cap) {
+                    roll_win *nwv = (roll_win *)realloc(win, (size_t)cap * 2 * sizeof(roll_win));
+                    if (!nwv) {
+                        free(win);
+                        win = NULL;
+                        break;
+                    }
+                    memset(nwv + cap, 0, (size_t)cap * sizeof(roll_win));
+                    win = nwv;
+                    cap *= 2;
+                }
+                if (nw && lo < win[nw - 1].hi)
+                    win[nw - 1].hi = lo > win[nw - 1].lo ? lo : win[nw - 1].lo; /* (windows do not overlap: a look-up finds one) */
+                win[nw].lo = lo;
+                win[nw].r0 = j;
+                win[nw].ident = fnv1a64((const uint8_t *)&lo, 8, r->ident ^ 0x9E3779B97F4A7C15ull);
+                nw++;
+                acc = 0;
+            }
+            acc += bytes;
+            end = hi;
+            win[nw - 1].hi = hi;
+            win[nw - 1].r1 = j + 1;
+            win[nw - 1].need += ((uint64_t)t[4] + 15) & ~(uint64_t)15;
+        }
+        if (!win) {
+            roll_free(r);
+            r = NULL;
+            goto out;
+        }
+        r->win = win;
+        r->nwin = nw;
+    }
+out:
+    free(tail);
+    free(table);
+    return r;
+}
+
+/* make room for `need` more page-locked bytes under `budget`: evict live windows, least recently used first, never `keep`
+ * (of roll rk); for a look-ahead only windows nobody used in the last MZH_ROLL_FRESH calls.  1 = there is room now. */
+static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_t keep, int lookahead) {
+    for (;;) {
+        int32_t live = 0;
+        roll *vr = NULL;
+        int32_t vw = -1;
+        for (int i = 0; i < MZH_ROLLS; i++) {
+            roll *r = g_rolls[i];
+            if (!r)
+                continue;
+            for (int32_t w = 0; w < r->nwin; w++) {
+                if (r->win[w].state != W_LIVE)
+                    continue;
+                live++;
+                if (r == rk && (w == keep || (lookahead && w == keep + 1)))
+                    continue;
+                if (lookahead && g_tick - r->win[w].stamp <= MZH_ROLL_FRESH)
+                    continue;
+                if (vw < 0 || r->win[w].stamp < vr->win[vw].stamp) {
+                    vr = r;
+                    vw = w;
+                }
+            }
+        }
+        if (g_live_bytes + need <= budget && live < MZH_ROLL_MAX_WINDOWS)
+            return 1;
+        if (vw < 0)
+            return 0;
+        roll_win *v = &vr->win[vw];
+        mzhip_prime_drop((uint64_t)vr->size, v->ident); /* (streams that still read from it keep it alive until they close) */
+        g_live_bytes -= v->held;
+        v->held = 0;
+        v->quick = v->hits < 8 ? v->quick + 1 : 0;
+        v->state = v->quick >= 3 ? W_DEAD : W_NONE;
+        g_windows_evicted++;
+        if (roll_trace())
+            fprintf(stderr, "[mzhip autoprime] window %d evicted after %u hits (%s); %llu bytes live\n", vw, v->hits, lookahead ? "look-ahead" : "needed",
+                    (unsigned long long)g_live_bytes);
+    }
+}
+
+/* window w of r must be live (or on its way): image it through `arch` and start its decode.  g_mu is held on entry and on
+ * exit, not while the stream is read.  lookahead: the window is not needed yet -- no eviction of windows in use, no waiting. */
+static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget, int lookahead) {
+    roll_win *W = &r->win[w];
+    for (;;) {
+        if (W->state == W_LIVE && !mzhip_prime_has((uint64_t)r->size, W->ident)) { /* (the cache let it go: 32 generations, a re-prime) */
+            g_live_bytes -= W->held;
+            W->held = 0;
+            W->state = W_NONE;
+        }
+        if (W->state == W_LIVE || W->state == W_DEAD)
+            return;
+        if (W->state == W_BUSY) {
+            if (lookahead)
+                return;
+            pthread_cond_wait(&g_cv, &g_mu);
+            continue;
+        }
+        break;
+    }
+    if (!roll_make_room(W->need, budget, r, lookahead ? w - 1 : w, lookahead) && lookahead)
+        return; /* (a window that is needed goes over the budget rather than without) */
+    W->state = W_BUSY;
+    r->busy++;
+    const uint64_t lo = W->lo, len = W->hi - W->lo;
+    const int64_t r0 = W->r0, nr = W->r1 - W->r0;
+    pthread_mutex_unlock(&g_mu);
+    size_t cap = 0;
+    uint8_t *img = (uint8_t *)mzhip_window_alloc((size_t)len + 16, &cap); /* page-locked: the H2D copies run at link speed */
+    if (!img) {
+        cap = 0;
+        img = (uint8_t *)malloc((size_t)len + 16);
+    }
+    int64_t k = -1;
+    uint64_t held = 0;
+    int64_t *rows = (int64_t *)malloc((size_t)nr * 8 * sizeof(int64_t));
+    if (img && rows && read_at(arch, (int64_t)lo, img, (int64_t)len)) {
+        memcpy(rows, r->rows + 8 * r0, (size_t)nr * 8 * sizeof(int64_t)); /* (r->rows itself is immutable: other threads read it) */
+        (void)mzhip_zip_index_resolve(img, lo, len, rows, nr);
+        k = mzhip_prime_window_begin(img, cap, lo, len, rows, nr, r->alg ? r->alg + r0 : NULL, r->dsz ? r->dsz + r0 : NULL,
+                                     r->dig ? r->dig + 64 * r0 : NULL, (uint64_t)r->size, W->ident, &held);
+        img = NULL; /* (the call took it over) */
+    }
+    if (img) {
+        if (cap)
+            mzhip_window_free(img, cap);
+        else
+            free(img);
+    }
+    free(rows);
+    pthread_mutex_lock(&g_mu);
+    r->busy--;
+    if (k > 0) {
+        W->state = W_LIVE;
+        W->held = held;
+        W->hits = 0;
+        W->stamp = g_tick;
+        g_live_bytes += held;
+        if (g_live_bytes > g_peak_bytes)
+            g_peak_bytes = g_live_bytes;
+        g_windows_primed++;
+        if (roll_trace())
+            fprintf(stderr, "[mzhip autoprime] window %d [%llu, %llu) %s: %lld entries, %llu bytes; %llu bytes live\n", w, (unsigned long long)lo,
+                    (unsigned long long)(lo + len), lookahead ? "ahead" : "needed", (long long)k, (unsigned long long)held, (unsigned long long)g_live_bytes);
+    } else {
+        W->state = W_DEAD; /* could not be read or decoded: its entries take the per-entry path */
+    }
+    pthread_cond_broadcast(&g_cv);
+}
+
+static void forget_everything(void) {
+    g_cur_size = -1;
+    g_era++;
+    for (int i = 0; i < MZH_AUTOPRIME_SEEN; i++)
+        g_seen[i].tries = 0; /* (the application manages the cache itself: only images that evict EACH OTHER count as thrashing) */
+    for (int i = 0; i < MZH_ROLLS; i++) {
+        roll *r = g_rolls[i];
+        if (!r)
+            continue;
+        for (int32_t w = 0; w < r->nwin; w++)
+            if (r->win[w].state == W_LIVE) {
+                r->win[w].state = W_NONE;
+                r->win[w].held = 0;
+            }
+    }
+    g_live_bytes = 0;
+}
+
+void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
     const char *env = getenv("MZHIP_AUTOPRIME");
     if (env && env[0] == '0')
         return;
@@ -77,14 +484,22 @@ void mzhip_autoprime(mzhip_stream *codec_base) {
     if (!arch->vtbl || !arch->vtbl->seek || !arch->vtbl->tell || !arch->vtbl->read || !arch->vtbl->is_open ||
         arch->vtbl->is_open(arch) != MZH_OK)
         return;
-    int64_t limit = env && *env ? strtoll(env, NULL, 10) : 0;
-    limit = (limit >= 1 ? limit : MZH_AUTOPRIME_DEFAULT_MIB) << 20;
+    /* "<n>": MiB; "<n>k": KiB (tests) */
+    char *endp = NULL;
+    int64_t limit = env && *env ? strtoll(env, &endp, 10) : 0;
+    const int kib = endp && (*endp == 'k' || *endp == 'K');
+    limit = (limit >= 1 ? (limit < (1 << 20) ? limit : (1 << 20)) : MZH_AUTOPRIME_DEFAULT_MIB) << (kib ? 10 : 20);
+    const uint64_t budget = 4 * (uint64_t)limit;
     pthread_mutex_lock(&g_mu);
-    if (g_cur_size >= 0 && !mzhip_prime_any()) { /* somebody cleared the cache: it holds nothing of ours any more */
-        g_cur_size = -1;
-        g_era++;
-        for (int i = 0; i < MZH_AUTOPRIME_SEEN; i++)
-            g_seen[i].tries = 0; /* (the application manages the cache itself: only images that evict EACH OTHER count as thrashing) */
+    g_tick++;
+    {
+        int32_t gens = 0, wins = 0;
+        uint64_t clears = 0;
+        mzhip_prime_counts(&gens, &wins, &clears);
+        if (clears != g_clears_seen) { /* somebody cleared the cache: it holds nothing of ours any more */
+            g_clears_seen = clears;
+            forget_everything();
+        }
     }
     const int64_t pos = arch->vtbl->tell(arch);
     if (pos >= 0 && arch->vtbl->seek(arch, 0, MZH_SEEK_END) == MZH_OK) {
@@ -92,27 +507,69 @@ void mzhip_autoprime(mzhip_stream *codec_base) {
         uint8_t *buf = NULL;
         int64_t *table = NULL;
         int dealt_with = 0;
-        const int32_t any_now = mzhip_prime_any();
-        for (int i = 0; i < 16; i++)
-            if (g_done[i].arch == (const void *)arch && g_done[i].size == size && g_done[i].era == g_era && g_done[i].any == any_now)
-                dealt_with = 1;
-        if (!dealt_with && g_cur_size < 0 && any_now) {
-            /* the cache holds generations this file did not make: the application primes for itself (mzhip_prime_file ...);
-             * nothing is cleared or added under its feet -- entries it did not prime take the per-entry path */
-            dealt_with = 2;
-        }
-        if (!dealt_with && size >= 22 && size <= limit) {
-            /* which image is this?  its size and the CRC of its tail (the end record and the central directory's end) */
+        /* which image is this?  its size and a hash of its last 4 KiB (the end record and the central directory's end) */
+        uint8_t t4[MZH_TAIL4K];
+        const int64_t n4 = size < MZH_TAIL4K ? size : MZH_TAIL4K;
+        uint64_t crc4 = 0;
+        roll *R = NULL;
+        if (size < 22 || !read_at(arch, size - n4, t4, n4))
+            goto done;
+        crc4 = tail_hash(t4, (size_t)n4);
+        for (int i = 0; i < MZH_ROLLS; i++)
+            if (g_rolls[i] && g_rolls[i]->size == size && g_rolls[i]->crc4 == crc4)
+                R = g_rolls[i];
+        if (R)
+            goto roll_on;
+        {
+            int32_t gens = 0, wins = 0;
+            mzhip_prime_counts(&gens, &wins, NULL);
+            if (g_cur_size >= 0 && !mzhip_prime_has((uint64_t)g_cur_size, g_cur_ident))
+                forget_everything(); /* (our whole image left the cache some other way) */
+            const int32_t foreign = gens - wins - (g_cur_size >= 0 ? 1 : 0) > 0;
+            for (int i = 0; i < 16; i++)
+                if (g_done[i].size == size && g_done[i].crc4 == crc4 && g_done[i].era == g_era && g_done[i].foreign == foreign)
+                    dealt_with = 1;
+            if (dealt_with)
+                goto done;
+            /* the image's full name: size + hash of its last 64 KiB */
             const int64_t tail = size < 65536 ? size : 65536;
             uint8_t *tb = (uint8_t *)malloc((size_t)tail);
-            uint32_t tcrc = 0;
-            int known = -1, ok = 0;
-            if (tb && arch->vtbl->seek(arch, size - tail, MZH_SEEK_SET) == MZH_OK && read_all(arch, tb, tail)) {
-                tcrc = mzhip_crc32_host(0, tb, (size_t)tail);
+            uint64_t tcrc = 0;
+            int ok = 0;
+            if (tb && read_at(arch, size - tail, tb, tail)) {
+                tcrc = tail_hash(tb, (size_t)tail);
                 ok = 1;
             }
             free(tb);
-            if (ok && !(size == g_cur_size && tcrc == g_cur_crc)) { /* (the cache holds it already: nothing to do) */
+            if (ok && size > limit && mzhip_prime_has((uint64_t)size, 0)) {
+                /* the application primed an archive of this length itself (mzhip_prime_file / _mem_begin): nothing to add */
+            } else if (ok && size > limit) {
+                /* too large to image: roll over it (beside whatever else the cache holds) */
+                R = roll_new(arch, size, crc4, tcrc, budget);
+                if (R) {
+                    int slot = -1;
+                    for (int i = 0; i < MZH_ROLLS; i++)
+                        if (!g_rolls[i])
+                            slot = i;
+                    for (int i = 0; slot < 0 && i < MZH_ROLLS; i++) /* the archive nobody has asked about for longest, if nobody is reading it now */
+                        if (g_rolls[i]->busy == 0 && (slot < 0 || g_rolls[i]->stamp < g_rolls[slot]->stamp))
+                            slot = i;
+                    if (slot < 0) {
+                        roll_free(R);
+                        R = NULL;
+                    } else {
+                        roll_free(g_rolls[slot]);
+                        g_rolls[slot] = R;
+                        (void)__atomic_add_fetch(&g_autoprimed, 1, __ATOMIC_RELAXED);
+                    }
+                }
+                if (R)
+                    goto roll_on;
+            } else if (ok && foreign && g_cur_size < 0) {
+                /* the cache holds generations this file did not make: the application primes for itself (mzhip_prime_file ...);
+                 * nothing is added under its feet -- entries it did not prime take the per-entry path */
+            } else if (ok && !(size == g_cur_size && tcrc == g_cur_crc)) { /* (the cache holds it already: nothing to do) */
+                int known = -1;
                 for (int i = 0; i < MZH_AUTOPRIME_SEEN; i++)
                     if (g_seen[i].size == size && g_seen[i].tail_crc == tcrc)
                         known = i;
@@ -125,26 +582,29 @@ void mzhip_autoprime(mzhip_stream *codec_base) {
                     g_seen[0].tail_crc = tcrc;
                     g_seen[0].tries = tries + 1;
                     buf = (uint8_t *)malloc((size_t)size);
-                    if (buf && arch->vtbl->seek(arch, 0, MZH_SEEK_SET) == MZH_OK && read_all(arch, buf, size)) {
+                    if (buf && read_at(arch, 0, buf, size)) {
                         /* worth it?  entries a codec stream would be opened for, and what they decode to */
                         const int64_t n = mzhip_zip_index_mem(buf, (uint64_t)size, NULL, 0);
                         if (n >= MZH_AUTOPRIME_MIN_ENTRIES && n <= (1 << 26) && (table = (int64_t *)malloc((size_t)n * 8 * sizeof(int64_t))) != NULL &&
                             mzhip_zip_index_mem(buf, (uint64_t)size, table, n) == n) {
-                            int64_t cnt = 0, usum = 0;
-                            for (int64_t i = 0; i < n; i++) {
-                                const int64_t m = table[8 * i];
-                                if ((m == 8 || m == 14 || m == 95) && table[8 * i + 7] >= 0 && !(table[8 * i + 1] & 1) /* not encrypted */) {
+                            int64_t cnt = 0;
+                            uint64_t usum = 0; /* unsigned, over the rows the prime takes, cut off at the bound: a crafted directory cannot wrap it */
+                            for (int64_t i = 0; i < n && usum <= budget; i++) {
+                                const int64_t *t = table + 8 * i;
+                                if (row_codec(t) && t[7] >= 0) {
                                     cnt++;
-                                    usum += table[8 * i + 4];
+                                    usum += (uint64_t)t[4];
                                 }
                             }
-                            if (cnt >= MZH_AUTOPRIME_MIN_ENTRIES && usum <= 4 * limit) {
-                                mzhip_prime_clear(); /* one archive's worth of cache at a time */
+                            if (cnt >= MZH_AUTOPRIME_MIN_ENTRIES && usum <= budget) {
+                                if (g_cur_size >= 0)
+                                    mzhip_prime_drop((uint64_t)g_cur_size, g_cur_ident); /* one whole image's worth of cache at a time -- ours, by name */
                                 g_cur_size = -1;
                                 g_era++;
                                 if (mzhip_prime_mem(buf, (uint64_t)size) > 0) {
                                     g_cur_size = size;
                                     g_cur_crc = tcrc;
+                                    g_cur_ident = fnv1a64(buf + table[6], (uint64_t)size - (uint64_t)table[6], FNV0); /* (prime_prepare's) */
                                     (void)__atomic_add_fetch(&g_autoprimed, 1, __ATOMIC_RELAXED);
                                 }
                             }
@@ -152,14 +612,40 @@ void mzhip_autoprime(mzhip_stream *codec_base) {
                     }
                 }
             }
+            {
+                int32_t g2 = 0, w2 = 0;
+                mzhip_prime_counts(&g2, &w2, NULL);
+                g_done[g_done_next % 16].size = size;
+                g_done[g_done_next % 16].crc4 = crc4;
+                g_done[g_done_next % 16].era = g_era;
+                g_done[g_done_next % 16].foreign = g2 - w2 - (g_cur_size >= 0 ? 1 : 0) > 0;
+                g_done_next++;
+            }
+            goto done;
         }
-        if (dealt_with != 1) {
-            g_done[g_done_next % 16].arch = arch;
-            g_done[g_done_next % 16].size = size;
-            g_done[g_done_next % 16].era = g_era;
-            g_done[g_done_next % 16].any = mzhip_prime_any();
-            g_done_next++;
+    roll_on:
+        R->stamp = g_tick;
+        if (payload_off >= 0) {
+            /* the window the entry at hand lies in; then the one behind it */
+            int32_t lo = 0, hi = R->nwin;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) / 2;
+                if (R->win[mid].lo <= (uint64_t)payload_off)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            const int32_t w = lo - 1;
+            if (w >= 0 && (uint64_t)payload_off < R->win[w].hi) {
+                const int first = R->win[w].state != W_LIVE || R->win[w].hits % 256 == 0; /* (a look-ahead that found no room is tried again) */
+                roll_ensure(R, w, arch, budget, 0);
+                R->win[w].stamp = g_tick;
+                R->win[w].hits++;
+                if (first && w + 1 < R->nwin)
+                    roll_ensure(R, w + 1, arch, budget, 1);
+            }
         }
+    done:
         free(table);
         free(buf);
         arch->vtbl->seek(arch, pos, MZH_SEEK_SET);

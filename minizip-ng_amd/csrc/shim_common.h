@@ -13,9 +13,10 @@ void mzhip_prime_unpin(void *pin);
 /* are these bytes one 65 535-byte reader chunk of a primed STORE entry?  1 = yes (*crc = its device-computed CRC-32;
  * equality was checked byte for byte against the primed payload) */
 int32_t mzhip_prime_store_crc(const uint8_t *buf, int32_t size, uint32_t *crc);
-/* MZHIP_AUTOPRIME: prime the archive behind a codec stream's base on first use (shim_autoprime.c); no-op otherwise */
+/* prime the archive behind a codec stream's base -- whole, or the window around the entry whose payload starts at payload_off --
+ * on an entry's first read (shim_autoprime.c; MZHIP_AUTOPRIME=0 turns it off) */
 struct mzhip_stream_s;
-void mzhip_autoprime(struct mzhip_stream_s *codec_base);
+void mzhip_autoprime(struct mzhip_stream_s *codec_base, int64_t payload_off);
 /* write-side prime (mzhip_prime_write): follow the bytes a WRITE stream is handed against the primed buffers */
 int32_t mzhip_wprime_track(int32_t method, int64_t *id, int64_t pos, const uint8_t *buf, int32_t size, uint32_t *chunk_crc,
                            int32_t *have_crc, const uint8_t **src);

@@ -910,7 +910,7 @@ int32_t mz_stream_lzma_read(void *stream, void *buf, int32_t size) {
         if (!z->tried_cache) {
             /* was this entry decoded by mzhip_prime_*()?  (payload offset + first payload bytes must agree) */
             z->tried_cache = 1;
-            mzhip_autoprime(z->stream.base); /* no-op unless MZHIP_AUTOPRIME is set */
+            mzhip_autoprime(z->stream.base, z->base_pos0); /* (shim_autoprime.c: on unless MZHIP_AUTOPRIME=0) */
             const uint8_t *data = NULL;
             int64_t usize = 0, csize = 0;
             uint32_t crc = 0;

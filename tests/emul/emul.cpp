@@ -16,13 +16,10 @@ extern "C" unsigned long long *emul_stats() { return mz_stats; }
 #endif
 
 static mzhip_crc_tables g_tabs;
-static int g_ready;
 
-static void ready() {
-    if (!g_ready) {
-        mzhip_crc_tables_init(&g_tabs);
-        g_ready = 1;
-    }
+static void ready() { /* (several host threads decode at once behind the prime cache: initialised exactly once) */
+    static const int once = (mzhip_crc_tables_init(&g_tabs), 1);
+    (void)once;
 }
 
 extern "C" int32_t emul_inflate(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t *out_len,

@@ -6,6 +6,8 @@
 // product has no CPU path, and a GPU box runs the same tests against the real device (tests/test_gpu_dropin.py,
 // test_gpu_wrappers.py).  What it cannot cover: the prime caches and the .xz writer, whose host code lives in
 // mzhip_kernels.hip.
+#include <atomic>
+
 #include "emul.cpp"
 
 #include "../../include/mzhip.h"
@@ -41,7 +43,7 @@ static int32_t mock_inflate_resume(const uint8_t *in, uint32_t in_len, uint8_t *
     return st;
 }
 // ... with the CRCs of the new bytes in the caller's pieces (the device does this with one k_crc32_batch launch)
-static int g_mock_seg_calls = 0;
+static std::atomic<int> g_mock_seg_calls{0};
 MOCK_API int mzmock_seg_calls(void) { return g_mock_seg_calls; }
 static int32_t mock_inflate_window(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                    const mzhip_inflate_state *state_in, mzhip_inflate_state *state_out, uint32_t *out_len,
@@ -138,11 +140,7 @@ struct MockParBackend {
     }
 };
 } // namespace
-MOCK_API void *mzhip_window_alloc(size_t bytes, size_t *cap) {
-    if (cap) *cap = bytes;
-    return getenv("MZMOCK_NO_PINNED") ? nullptr : malloc(bytes);
-}
-MOCK_API void mzhip_window_free(void *p, size_t) { free(p); }
+// (mzhip_window_alloc / _free: the product's pool over the stand-in's hipHostMalloc, which MZMOCK_NO_PINNED makes fail)
 // one large entry where it lies ("device-resident": the mock's device memory is host memory), inflate_parallel.inc's
 // mz_large_entry over the emulated device functions; MZMOCK_LARGE_WINDOW / _SHOW shrink the windows for the tests
 namespace {
@@ -188,7 +186,7 @@ MOCK_API int32_t mzhip_inflate_large(const void *d_in, uint32_t in_len, void *d_
     if (status) *status = r.status;
     return 0;
 }
-static int g_mock_par_blocks = 0, g_mock_par_calls = 0;
+static std::atomic<int> g_mock_par_blocks{0}, g_mock_par_calls{0};
 MOCK_API int mzmock_par_blocks(void) { return g_mock_par_blocks; }
 MOCK_API int mzmock_par_calls(void) { return g_mock_par_calls; }
 MOCK_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
@@ -287,7 +285,7 @@ MOCK_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *ou
 }
 MOCK_API uint32_t mzhip_lzma_model_bytes(void) { return emul_lzma_model_u16() * 2u; }
 MOCK_API uint32_t mzhip_lzma_encode_history_bytes(void) { return emul_lzma_encode_history_bytes(); }
-static int g_mock_lzma_windows = 0;
+static std::atomic<int> g_mock_lzma_windows{0};
 MOCK_API int mzmock_lzma_windows(void) { return g_mock_lzma_windows; }
 MOCK_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
                                         const mzhip_lzma_state *state_in, mzhip_lzma_state *state_out, void *model,
@@ -300,7 +298,7 @@ MOCK_API int32_t mzhip_lzma_resume_host(const uint8_t *in, uint32_t in_len, uint
     if (in_used) *in_used = iu;
     return st;
 }
-static int g_mock_lzma2_windows = 0;
+static std::atomic<int> g_mock_lzma2_windows{0};
 MOCK_API int mzmock_lzma2_windows(void) { return g_mock_lzma2_windows; }
 MOCK_API int32_t mzhip_lzma2_run_host(const mzhip_lzma2_run_args *ap) {
     if (!ap || ap->size < offsetof(mzhip_lzma2_run_args, in_used) + sizeof(void *)) return -102;
@@ -317,7 +315,7 @@ MOCK_API int32_t mzhip_lzma2_run_host(const mzhip_lzma2_run_args *ap) {
     if (a.in_used) *a.in_used = iu;
     return st;
 }
-static int g_mock_lzma_segments = 0;
+static std::atomic<int> g_mock_lzma_segments{0};
 MOCK_API int mzmock_lzma_segments(void) { return g_mock_lzma_segments; }
 MOCK_API int32_t mzhip_lzma_encode_resume_host(const uint8_t *in, uint32_t in_len, uint32_t skip_blocks, uint32_t last, int32_t preset,
                                                const mzhip_lzma_enc_state *state_in, mzhip_lzma_enc_state *state_out, void *model,
@@ -365,7 +363,7 @@ MOCK_API int32_t mzhip_xz_encode_finish_host(const uint64_t *, const uint64_t *,
     return MZHIP_STATUS_UNSUPPORTED;
 }
 
-static int g_mock_crc_calls = 0; // checksum calls that would have been a launch on the device
+static std::atomic<int> g_mock_crc_calls{0}; // checksum calls that would have been a launch on the device
 MOCK_API int mzmock_crc_host_calls(void) { return g_mock_crc_calls; }
 MOCK_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size) {
     uint32_t v = value;
@@ -377,32 +375,114 @@ MOCK_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t si
     }
     return v;
 }
-extern "C" uint32_t mzhip_crc32_combine(uint32_t a, uint32_t b, uint64_t len_b) { return mzhip_crc32_combine_host(a, b, len_b); }
 extern "C" uint32_t mzhip_adler32_combine(uint32_t a, uint32_t b, uint64_t len_b) { return mzhip_adler32_combine_host(a, b, len_b); }
 
-// prime caches: not available here (their host code lives in mzhip_kernels.hip); every lookup misses
-MOCK_API int64_t mzhip_prime_file(const char *) { return -109; }
-MOCK_API int64_t mzhip_prime_mem(const uint8_t *, uint64_t) { return -109; }
-MOCK_API void mzhip_prime_clear(void) {}
-MOCK_API int64_t mzhip_prime_file_multi(const char *, const int32_t *, int32_t) { return -109; }
-MOCK_API int64_t mzhip_prime_mem_multi(const uint8_t *, uint64_t, const int32_t *, int32_t) { return -109; }
-extern "C" int32_t mzhip_prime_lookup3(int32_t, int64_t, const uint8_t *, int32_t, int64_t, const uint8_t **, int64_t *, int64_t *,
-                                       uint32_t *, const uint32_t **, void **pin) {
-    *pin = nullptr;
+// ---- the READ-side prime cache: the PRODUCT's code (minizip-ng_amd/csrc/mzhip_prime.inc -- generations, the three-lane decode
+// pipeline, look-ups, the windows shim_autoprime.c rolls over large archives with) over a synchronous stand-in for the HIP
+// runtime: "device memory" is host memory, a "stream" completes every operation when it is queued, the batch launchers run the
+// emulated device cores entry by entry.  What the stand-in cannot show is overlap and device failures; what it does show is every
+// line of host logic between the unmodified zip layer and the kernels, in a container without a GPU and under the sanitizers.
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+namespace {
+typedef int hipError_t;
+typedef void *hipStream_t;
+enum { hipSuccess = 0, hipHostMallocDefault = 0, hipStreamNonBlocking = 1, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+thread_local int t_mock_dev = 0;
+std::atomic<long> g_mock_dev_allocs{0}, g_mock_host_allocs{0}; // outstanding (tests: nothing leaks)
+hipError_t hipGetDevice(int *d) { *d = t_mock_dev; return hipSuccess; }
+hipError_t hipSetDevice(int d) { t_mock_dev = d; return hipSuccess; }
+hipError_t hipGetLastError() { return hipSuccess; }
+const char *hipGetErrorString(hipError_t) { return "mock"; }
+hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); if (*p) g_mock_dev_allocs++; return *p ? hipSuccess : 2; }
+hipError_t hipFree(void *p) { if (p) g_mock_dev_allocs--; free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
+    if (getenv("MZMOCK_NO_PINNED")) { *p = nullptr; return 2; }
+    *p = malloc(n ? n : 1);
+    if (*p) g_mock_host_allocs++;
+    return *p ? hipSuccess : 2;
+}
+hipError_t hipHostFree(void *p) { if (p) g_mock_host_allocs--; free(p); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = malloc(1); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { if (n) memmove(d, s, n); return hipSuccess; }
+thread_local char g_err[256] = "";
+int32_t fail(const char *what, hipError_t) { snprintf(g_err, sizeof(g_err), "%s failed (mock)", what); return -104; }
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) return fail(#expr, _e); \
+    } while (0)
+struct DeviceCtx { int unused; };
+DeviceCtx g_mock_ctx;
+constexpr int kMaxDevices = 16;
+int32_t ctx_for_current(DeviceCtx **out) { *out = &g_mock_ctx; return 0; }
+struct Scratch {
+    void *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+};
+// one launch per codec = a loop over the emulated cores
+int32_t lzma_family_batch(int xz, const void *d_in, const uint64_t *in_off, const uint32_t *in_len, void *d_out, const uint64_t *out_off,
+                          const uint32_t *out_cap, const int64_t *max_out, uint32_t n, uint32_t *out_len, uint32_t *in_used, uint32_t *crc,
+                          int32_t *status, hipStream_t) {
+    for (uint32_t i = 0; i < n; i++)
+        status[i] = (xz ? emul_xz : emul_lzma)((const uint8_t *)d_in + in_off[i], in_len[i], (uint8_t *)d_out + out_off[i], out_cap[i],
+                                               max_out ? max_out[i] : -1, &out_len[i], &in_used[i], &crc[i]);
     return 0;
 }
-extern "C" void mzhip_prime_unpin(void *) {}
-extern "C" int32_t mzhip_prime_store_crc(const uint8_t *, int32_t, uint32_t *) { return 0; }
+} // namespace
+MOCK_API long mzmock_outstanding_allocs(void) { return g_mock_dev_allocs.load() + g_mock_host_allocs.load(); }
+MOCK_API int32_t mzhip_bind_thread_near_device(int32_t, int32_t) { return 0; }
+static std::atomic<int> g_mock_batch_launches{0};
+MOCK_API int mzmock_batch_launches(void) { return g_mock_batch_launches.load(); }
+MOCK_API int32_t mzhip_inflate_batch(const void *d_in, const uint64_t *in_off, const uint32_t *in_len, void *d_out, const uint64_t *out_off,
+                                     const uint32_t *out_cap, uint32_t n, uint32_t *out_len, uint32_t *in_used, uint32_t *crc,
+                                     int32_t *status, void *) {
+    g_mock_batch_launches++;
+    const uint8_t dummy = 0;
+    for (uint32_t i = 0; i < n; i++)
+        status[i] = emul_inflate(in_len[i] ? (const uint8_t *)d_in + in_off[i] : &dummy, in_len[i], (uint8_t *)d_out + out_off[i], out_cap[i],
+                                 &out_len[i], &in_used[i], &crc[i]);
+    return 0;
+}
+MOCK_API int32_t mzhip_crc32_batch(const void *d_buf, const uint64_t *off, const uint32_t *len, uint32_t n, const uint32_t *init, uint32_t *crc,
+                                   void *) {
+    for (uint32_t i = 0; i < n; i++) crc[i] = emul_crc32_super((const uint8_t *)d_buf + off[i], len[i], init ? init[i] : 0u);
+    return 0;
+}
+MOCK_API int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *off, const uint32_t *len, uint32_t n, uint32_t algorithm, void *d_digest,
+                                 void *) {
+    for (uint32_t i = 0; i < n; i++) {
+        uint8_t dg[64];
+        memset(dg, 0, sizeof(dg));
+        emul_sha((const uint8_t *)d_buf + off[i], len[i], (int)algorithm, dg);
+        memcpy((uint8_t *)d_digest + 32 * (size_t)i, dg, 32);
+    }
+    return 0;
+}
+#define mzhip_prime_any mzhip_prime_any_real
+#include "mzhip_prime.inc"
+#undef mzhip_prime_any
 extern "C" int32_t mzhip_take_crc_fault(void) { return 0; }
 extern "C" int32_t mzhip_wprime_track(int32_t, int64_t *, int64_t, const uint8_t *, int32_t, uint32_t *, int32_t *have_crc,
                                       const uint8_t **) {
     *have_crc = 0;
     return 0;
 }
-// "is any archive primed?": MZMOCK_PRIME_ANY=1 says yes (every lookup still misses), so that the streams' short first
-// pull and the ordinary decode behind it run on the CPU as well
+// "is any archive primed?": MZMOCK_PRIME_ANY=1 says yes even when nothing is, so that the streams' short first pull and the
+// ordinary decode behind it run on the CPU as well
 extern "C" int32_t mzhip_prime_any(void) {
     static const int on = getenv("MZMOCK_PRIME_ANY") != nullptr;
-    return on;
+    return on || mzhip_prime_any_real();
 }
 extern "C" int32_t mzhip_wprime_result(int32_t, int64_t, int64_t, const uint8_t **, const uint8_t **, uint32_t *) { return 0; }
