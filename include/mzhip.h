@@ -96,7 +96,10 @@ MZHIP_API int32_t mzhip_inflate_resume_batch(const void *d_in, const uint64_t *d
 /* ---- ONE raw-DEFLATE entry, or one window of it, through host buffers (H2D + kernel + D2H, synchronous): what the
  * mz_stream_zlib READ shim calls.  One entry point with an args struct: `size` = sizeof(mzhip_inflate_host_args) as the
  * caller was compiled, so fields can be appended without a new symbol.  (Round 5 folded mzhip_inflate_host, _host2,
- * _resume_host, _resume_host_seg and _resume_host_seg2 into this one.)
+ * _resume_host, _resume_host_seg and _resume_host_seg2 into this one; since round 6 it is NAMED for what it takes -- the
+ * positional mzhip_inflate_host / mzhip_deflate_host of rounds 1 - 4 are exported by no build, so a binary compiled against
+ * the old header fails to link instead of handing compressed bytes over as a struct.  A `size` that no build of the header
+ * can have produced -- below the first fields, above 4096, not a multiple of 4 -- is MZ_PARAM_ERROR.)
  *   whole entry   state_in = state_out = NULL: in[0 .. in_len) is the stream, buf[0 .. buf_cap) takes its bytes;
  *   one window    state_out != NULL (state_in = NULL or flags bit 0 clear: the start of the stream): buf[0 ..
  *                 state_in->out_pos) is the history the caller kept (the last 32 KiB it was given), the new bytes land
@@ -119,15 +122,15 @@ typedef struct mzhip_inflate_host_args {
     mzhip_inflate_state *state_out;
     uint32_t *out_len, *in_used, *crc, *adler, *seg_crc, *nseg;
 } mzhip_inflate_host_args;
-MZHIP_API int32_t mzhip_inflate_host(const mzhip_inflate_host_args *a);
+MZHIP_API int32_t mzhip_inflate_host_a(const mzhip_inflate_host_args *a);
 
 /* One window of ONE large entry decoded by as many waves as it holds blocks (replaces the single inflate() state the
  * reference streams an entry of any size through, mz_strm_zlib.c:116-193, where that state is the bottleneck): block
  * headers are searched for at every bit offset, every candidate is parsed by a wave of its own, the chain of blocks that
  * starts at state_in's header is believed, its bytes are produced as a source map and resolved by pointer jumping
- * (csrc/inflate_parallel.inc).  Same buffers as a window of mzhip_inflate_host; state_in must stand at a block header
+ * (csrc/inflate_parallel.inc).  Same buffers as a window of mzhip_inflate_host_a; state_in must stand at a block header
  * (bit == hdr_bit; NULL = the start of the stream).  Returns 0 with *blocks = blocks decoded (0: nothing a wave of its own
- * could take -- go on with mzhip_inflate_host, flags bit 1 makes it stop at the next block header), *out_len =
+ * could take -- go on with mzhip_inflate_host_a, flags bit 1 makes it stop at the next block header), *out_len =
  * bytes valid in buf, *ended = the final block was among them, state_out = the header of the first block not decoded;
  * *crc / *adler (either may be NULL) = CRC-32 / Adler-32 of the new bytes (what the gzip / zlib trailers run over). */
 MZHIP_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len, uint8_t *buf, uint32_t buf_cap,
@@ -247,7 +250,7 @@ MZHIP_API int32_t mzhip_lzma_encode_batch_preset(const void *d_in, const uint64_
                                                  uint32_t *d_out_len, uint32_t *d_crc, int32_t *d_status, void *stream);
 
 /* Host-buffer conveniences (H2D + kernel + D2H, synchronous); these are what the
- * vtbl shims use for one-entry-at-a-time callers (raw DEFLATE: mzhip_inflate_host / mzhip_deflate_host above / below). */
+ * vtbl shims use for one-entry-at-a-time callers (raw DEFLATE: mzhip_inflate_host_a / mzhip_deflate_host_a above / below). */
 MZHIP_API int32_t mzhip_lzma_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
                                   uint32_t *out_len, uint32_t *in_used, uint32_t *crc);
 MZHIP_API int32_t mzhip_xz_host(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, int64_t max_out,
@@ -345,7 +348,7 @@ MZHIP_API int32_t mzhip_xz_encode_host_preset(const uint8_t *in, uint32_t in_len
  * wave each, every piece but the last closed on a byte boundary, the last one final iff `final`; `level` / `window_log2` as
  * mzhip_deflate_batch_level (COMPRESS_LEVEL, mz_strm_zlib.c:87,339-343: levels 0 .. 3 are one class; window_log2 0 = 15); *crc / *adler (either
  * may be NULL) = CRC-32 / Adler-32 of `in`.  `size` = sizeof(mzhip_deflate_host_args) as the caller was compiled.  (Round 5
- * folded mzhip_deflate_host, _host2 and _host_level into this one.) */
+ * folded mzhip_deflate_host_a, _host2 and _host_level into this one.) */
 typedef struct mzhip_deflate_host_args {
     uint32_t size;
     uint32_t in_len, final, out_cap;
@@ -354,7 +357,7 @@ typedef struct mzhip_deflate_host_args {
     uint8_t *out;
     uint32_t *out_len, *crc, *adler;
 } mzhip_deflate_host_args;
-MZHIP_API int32_t mzhip_deflate_host(const mzhip_deflate_host_args *a);
+MZHIP_API int32_t mzhip_deflate_host_a(const mzhip_deflate_host_args *a);
 /* mz_crypt_crc32_update on a host buffer (mz_crypt.c:35-92: chaining value in, chaining value out).  Buffers of
  * MZHIP_CRC_HOST_BELOW bytes or more are reduced on the device (K2); smaller ones -- the reference calls the symbol
  * per byte from mz_strm_pkcrypt.c:79,86 -- are folded on the host with the same generated tables.  Never aborts: if

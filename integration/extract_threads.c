@@ -249,3 +249,137 @@ __attribute__((visibility("default"))) double mzdrop_extract_all(const char *pat
     if (getenv("MZDROP_TRACE")) fprintf(stderr, "[mzdrop] returning %.2f ms after the start\n", (xt_now() - t0) * 1e3);
     return xt_now() - t0;
 }
+
+/* ---- the re-linked application on an archive of any size: nothing but the reference's calls ----
+ * `minizip -x` without the file writes: every thread owns one mz_zip_reader opened with mz_zip_reader_open_file (the split,
+ * buffered and OS streams of mz_zip_rw.c:262-312 under it -- no mapping, no 2 GiB bound), walks its contiguous share of the
+ * entries and reads each through mz_zip_entry_read_open / _read (65 535-byte calls, mz_zip_rw.c:55) / _close, so that
+ * mz_zip.c:2116-2128 verifies every CRC-32.  No mzhip_prime_* call: whatever batching happens, happens behind the codec
+ * streams' first read() (shim_autoprime.c).  One thread walks with mz_zip_goto_first_entry / _next_entry exactly as minizip.c
+ * does; with several, each thread jumps to its first entry (mz_zip_goto_entry on a central-directory position from
+ * mzhip_zip_index_tail over the file's tail) and walks on from there.  Returns the seconds of the whole call. */
+typedef struct {
+    const char *path;
+    int64_t cd_first; /* < 0: start at the first entry */
+    int64_t count;
+    int64_t ok, bytes;
+    int32_t err, started;
+} xf_job;
+
+static void *xf_run(void *arg) {
+    xf_job *j = (xf_job *)arg;
+    void *reader = mz_zip_reader_create();
+    uint8_t *buf = (uint8_t *)malloc(UINT16_MAX);
+    void *zip = NULL;
+    if (!reader || !buf || mz_zip_reader_open_file(reader, j->path) != MZ_OK) {
+        j->err = MZ_OPEN_ERROR;
+        free(buf);
+        if (reader) mz_zip_reader_delete(&reader);
+        return NULL;
+    }
+    mz_zip_reader_get_zip_handle(reader, &zip);
+    int32_t err = j->cd_first < 0 ? mz_zip_goto_first_entry(zip) : mz_zip_goto_entry(zip, j->cd_first);
+    for (int64_t i = 0; err == MZ_OK && i < j->count; i++) {
+        int64_t total = 0;
+        mz_zip_file *fi = NULL;
+        err = mz_zip_entry_get_info(zip, &fi);
+        const int64_t want = err == MZ_OK ? fi->uncompressed_size : -1;
+        if (err == MZ_OK) err = mz_zip_entry_read_open(zip, 0, NULL);
+        if (err == MZ_OK) {
+            for (;;) {
+                const int32_t rd = mz_zip_entry_read(zip, buf, UINT16_MAX);
+                if (rd < 0) err = rd;
+                if (rd <= 0) break;
+                total += rd;
+            }
+            const int32_t cerr = mz_zip_entry_close(zip); /* MZ_CRC_ERROR when the bytes are not the archive's */
+            if (err == MZ_OK) err = cerr;
+        }
+        if (err == MZ_OK && total == want) {
+            j->ok++;
+            j->bytes += total;
+        } else if (j->err == MZ_OK) {
+            j->err = err != MZ_OK ? err : MZ_DATA_ERROR;
+        }
+        if (i + 1 < j->count) {
+            err = mz_zip_goto_next_entry(zip);
+            if (err == MZ_END_OF_LIST) {
+                err = MZ_OK;
+                break;
+            }
+        }
+    }
+    if (err != MZ_OK && j->err == MZ_OK) j->err = err;
+    mz_zip_reader_close(reader);
+    mz_zip_reader_delete(&reader);
+    free(buf);
+    return NULL;
+}
+
+__attribute__((visibility("default"))) double mzdrop_extract_file(const char *path, int32_t nthreads, int64_t *entries, int64_t *bytes,
+                                                                   int32_t *first_err) {
+    const double t0 = xt_now();
+    if (nthreads < 1) nthreads = 1;
+    int64_t n = INT64_MAX, *table = NULL;
+    if (nthreads > 1) { /* where the threads' shares start: the central directory, indexed from the file's tail */
+        const int fd = open(path, O_RDONLY);
+        struct stat sb;
+        if (fd < 0 || fstat(fd, &sb) != 0 || sb.st_size < 22) {
+            if (fd >= 0) close(fd);
+            return (double)MZ_OPEN_ERROR;
+        }
+        uint64_t from = sb.st_size > (1 << 18) ? (uint64_t)sb.st_size - (1 << 18) : 0, need = 0;
+        uint8_t *tail = NULL;
+        n = MZHIP_INDEX_NEED_MORE;
+        for (int pass = 0; pass < 4 && n == MZHIP_INDEX_NEED_MORE; pass++) {
+            free(tail);
+            const size_t len = (size_t)((uint64_t)sb.st_size - from);
+            tail = (uint8_t *)malloc(len);
+            if (!tail || pread(fd, tail, len, (off_t)from) != (ssize_t)len) {
+                n = MZ_READ_ERROR;
+                break;
+            }
+            n = mzhip_zip_index_tail(tail, from, (uint64_t)sb.st_size, NULL, 0, &need);
+            if (n == MZHIP_INDEX_NEED_MORE) from = need;
+        }
+        if (n > 0 && (table = (int64_t *)malloc((size_t)n * 8 * sizeof(int64_t))) != NULL)
+            n = mzhip_zip_index_tail(tail, from, (uint64_t)sb.st_size, table, n, NULL);
+        free(tail);
+        close(fd);
+        if (n <= 0 || !table) {
+            free(table);
+            return (double)(n < 0 ? n : MZ_FORMAT_ERROR);
+        }
+        if (nthreads > n) nthreads = (int32_t)n;
+    }
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    xf_job *jobs = (xf_job *)calloc((size_t)nthreads, sizeof(xf_job));
+    for (int32_t t = 0; t < nthreads; t++) {
+        jobs[t].path = path;
+        if (nthreads == 1) {
+            jobs[t].cd_first = -1;
+            jobs[t].count = INT64_MAX;
+        } else {
+            const int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+            jobs[t].cd_first = table[lo * 8 + 6];
+            jobs[t].count = hi - lo;
+        }
+        if (nthreads > 1 && pthread_create(&th[t], NULL, xf_run, &jobs[t]) == 0) jobs[t].started = 1;
+        else xf_run(&jobs[t]);
+    }
+    int64_t ok = 0, by = 0;
+    int32_t err = MZ_OK;
+    for (int32_t t = 0; t < nthreads; t++) {
+        if (jobs[t].started) pthread_join(th[t], NULL);
+        ok += jobs[t].ok;
+        by += jobs[t].bytes;
+        if (err == MZ_OK) err = jobs[t].err;
+    }
+    free(table);
+    free(th);
+    free(jobs);
+    if (entries) *entries = ok;
+    if (bytes) *bytes = by;
+    if (first_err) *first_err = err;
+    return xt_now() - t0;
+}

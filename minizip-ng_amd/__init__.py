@@ -179,7 +179,7 @@ def inflate_host(data, out_cap):
     ol, iu, crc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
     a = InflateHostArgs(size=C.sizeof(InflateHostArgs), in_len=len(data), buf_cap=out_cap, in_=C.addressof(src), buf=C.addressof(out),
                         out_len=C.addressof(ol), in_used=C.addressof(iu), crc=C.addressof(crc))
-    st = lib().mzhip_inflate_host(C.byref(a))
+    st = lib().mzhip_inflate_host_a(C.byref(a))
     return int(st), int(iu.value), out.raw[: ol.value], int(crc.value)
 
 

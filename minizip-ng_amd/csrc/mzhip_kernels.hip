@@ -92,7 +92,7 @@ struct InflateArgs {
 // Two instantiations: RESUMABLE = false is the batch as mzhip_inflate_batch launches it (no entry is taken up or left in the
 // middle: a.resume and a.stop are null, and the compiler drops the resume bookkeeping -- which block the cursor is in, where the
 // step loop's unwritten tokens start, whether to stop at the next header -- from a function that already holds more uniform state
-// than a wave has scalar registers); true is the window-by-window decode of the drop-in streams (mzhip_inflate_host with a state).
+// than a wave has scalar registers); true is the window-by-window decode of the drop-in streams (mzhip_inflate_host_a with a state).
 template <bool RESUMABLE>
 __global__ __launch_bounds__(MZ_WAVES_PER_WG * 64, MZ_MIN_WAVES_PER_SIMD) void k_inflate_batch(InflateArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

@@ -19,6 +19,10 @@
  *     Windows that have been read are evicted, least recently used first, to keep the page-locked bytes of all live windows
  *     under 4 x the limit (2 GiB); readers of several threads -- one mz_zip_reader each over the same file, each in its own
  *     part of it -- share the windows.
+ *     When the archive is a regular file of this process (one of /proc/self/fd has its size and its last 64 KiB), the file is
+ *     opened once more through that entry and the windows are imaged with pread() by a thread of this file's own -- the reader
+ *     never waits for a look-ahead, and never copies the archive through its 32 KiB stream buffer (mz_strm_buf.c:115-180) --;
+ *     otherwise (a memory stream, a custom stream) the reader's thread images a window through its stream when it first needs it.
  * Every failure, and every entry no window holds (encrypted, STORE, larger than a window), takes the ordinary per-entry path
  * with its exact error behaviour.
  *
@@ -39,10 +43,15 @@
  * not mzhip_prime_clear()), windows are dropped one by one.  An application that calls mzhip_prime_* itself is left alone by
  * the whole-image path (while the cache holds generations this file did not make, it adds nothing); rolling over an archive
  * goes on beside them. */
+#define _GNU_SOURCE
+#include <dirent.h>
+#include <fcntl.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "mz_strm_hip.h"
 #include "mzhip.h"
@@ -62,10 +71,12 @@
 
 int64_t mzhip_prime_window_begin(uint8_t *img, size_t img_cap, uint64_t win_off, uint64_t win_len, const int64_t *rows, int64_t n,
                                  const uint16_t *alg, const uint16_t *dsz, const uint8_t *dig, uint64_t zip_len, uint64_t ident,
-                                 uint64_t *out_bytes);
+                                 int32_t device, uint64_t *out_bytes);
 void mzhip_prime_drop(uint64_t zip_len, uint64_t ident);
 int32_t mzhip_prime_has(uint64_t zip_len, uint64_t ident);
 void mzhip_prime_counts(int32_t *gens, int32_t *windows, uint64_t *clears);
+uint64_t mzhip_prime_clears(void);
+int32_t mzhip_prime_current_device(void);
 
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_cv = PTHREAD_COND_INITIALIZER; /* a window left the BUSY state */
@@ -111,8 +122,9 @@ typedef struct {
     int64_t *rows; /* n x 8 (mzhip_zip_index_mem's columns), sorted by local header offset; payload offsets are filled in window by window */
     uint16_t *alg, *dsz; /* Hash extra fields per row, or NULL: no row has one */
     uint8_t *dig;
-    int32_t nwin, busy; /* busy: threads inside I/O for one of its windows */
+    int32_t nwin, busy; /* busy: threads inside I/O for one of its windows (and windows queued for the imaging thread) */
     roll_win *win;
+    int fd; /* the archive opened once more (>= 0): windows are imaged with pread() by the imaging thread */
 } roll;
 static roll *g_rolls[MZH_ROLLS];
 static uint64_t g_tick, g_live_bytes; /* page-locked bytes of the live windows of all rolls */
@@ -139,17 +151,21 @@ static uint64_t fnv1a64(const uint8_t *p, uint64_t n, uint64_t h) {
 /* what names an image: a 64-bit hash of its last bytes, eight at a time, on the host (this runs on every entry's first read:
  * mz_crypt_crc32_update's own arithmetic would send 4 KiB and more to the device) */
 static uint64_t tail_hash(const uint8_t *p, size_t n) {
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ n, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
     size_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t w;
-        memcpy(&w, p + i, 8);
-        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
-        h ^= h >> 29;
-    }
+    for (; i + 32 <= n; i += 32) /* four independent chains: the multiplies overlap */
+        for (int k = 0; k < 4; k++) {
+            uint64_t w;
+            memcpy(&w, p + i + 8 * k, 8);
+            h[k] = (h[k] ^ w) * 0xFF51AFD7ED558CCDull;
+            h[k] ^= h[k] >> 29;
+        }
+    uint64_t r = h[0];
+    for (int k = 1; k < 4; k++)
+        r = (r ^ h[k]) * 0xC4CEB9FE1A85EC53ull + k;
     for (; i < n; i++)
-        h = (h ^ p[i]) * 0x100000001B3ull;
-    return h ^ (h >> 32);
+        r = (r ^ p[i]) * 0x100000001B3ull;
+    return r ^ (r >> 32);
 }
 
 static int32_t read_all(mzhip_stream *s, uint8_t *dst, int64_t n) {
@@ -193,12 +209,42 @@ static void roll_free(roll *r) {
     free(r->dsz);
     free(r->dig);
     free(r->win);
+    if (r->fd >= 0)
+        close(r->fd);
     free(r);
 }
 
 static int cmp_rows_by_loff(const void *a, const void *b) {
     const int64_t *x = (const int64_t *)a, *y = (const int64_t *)b;
     return x[5] < y[5] ? -1 : x[5] > y[5] ? 1 : x[6] < y[6] ? -1 : x[6] > y[6];
+}
+
+/* Is the archive a regular file this process has open?  The descriptor table is looked through for a file of its size whose last
+ * bytes are the ones the stream delivered; that file is opened once more (a description of its own: pread() at any offset from
+ * any thread, whatever the application does with its descriptor).  -1: no (a memory stream, another kind of stream, no /proc). */
+static int own_descriptor(int64_t size, const uint8_t *tail, int64_t tail_len) {
+    DIR *d = opendir("/proc/self/fd");
+    if (!d)
+        return -1;
+    int found = -1;
+    uint8_t *probe = (uint8_t *)malloc((size_t)tail_len);
+    struct dirent *e;
+    while (probe && found < 0 && (e = readdir(d)) != NULL) {
+        if (e->d_name[0] < '0' || e->d_name[0] > '9')
+            continue;
+        const int fd = atoi(e->d_name);
+        struct stat sb;
+        if (fd == dirfd(d) || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (int64_t)sb.st_size != size)
+            continue;
+        if (pread(fd, probe, (size_t)tail_len, (off_t)(size - tail_len)) != (ssize_t)tail_len || memcmp(probe, tail, (size_t)tail_len) != 0)
+            continue;
+        char path[64];
+        snprintf(path, sizeof(path), "/proc/self/fd/%d", fd);
+        found = open(path, O_RDONLY | O_CLOEXEC);
+    }
+    free(probe);
+    closedir(d);
+    return found;
 }
 
 /* index the archive from its tail and cut it into windows.  NULL: not worth it / not possible (the per-entry path serves it) */
@@ -258,6 +304,8 @@ static roll *roll_new(mzhip_stream *arch, int64_t size, uint64_t crc4, uint64_t 
         }
         qsort(table, (size_t)k, 8 * sizeof(int64_t), cmp_rows_by_loff);
         r = (roll *)calloc(1, sizeof(roll));
+        if (r)
+            r->fd = -1;
         if (r && nh > 0) {
             r->alg = (uint16_t *)malloc((size_t)k * 2);
             r->dsz = (uint16_t *)malloc((size_t)k * 2);
@@ -337,6 +385,12 @@ static roll *roll_new(mzhip_stream *arch, int64_t size, uint64_t crc4, uint64_t 
         }
         r->win = win;
         r->nwin = nw;
+        {
+            const char *fenv = getenv("MZHIP_AUTOPRIME_FD"); /* "0": image through the reader's stream only (tests, comparison) */
+            const int64_t tl = (uint64_t)size - from < 65536 ? (int64_t)((uint64_t)size - from) : 65536;
+            if (!(fenv && fenv[0] == '0'))
+                r->fd = own_descriptor(size, tail + (((uint64_t)size - from) - (uint64_t)tl), tl);
+        }
     }
 out:
     free(tail);
@@ -386,33 +440,13 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
     }
 }
 
-/* window w of r must be live (or on its way): image it through `arch` and start its decode.  g_mu is held on entry and on
- * exit, not while the stream is read.  lookahead: the window is not needed yet -- no eviction of windows in use, no waiting. */
-static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget, int lookahead) {
+/* image window w of r -- through the reader's stream `arch`, or with pread() on the roll's own descriptor when arch is NULL --
+ * and start its decode on `device` (-1: the calling thread's).  The window is BUSY and r->busy counts it; g_mu is NOT held.  Ends with the lock taken, the window LIVE
+ * or DEAD and everybody who waits for it woken; returns with the lock HELD. */
+static void roll_image(roll *r, int32_t w, mzhip_stream *arch, int lookahead, int32_t device) {
     roll_win *W = &r->win[w];
-    for (;;) {
-        if (W->state == W_LIVE && !mzhip_prime_has((uint64_t)r->size, W->ident)) { /* (the cache let it go: 32 generations, a re-prime) */
-            g_live_bytes -= W->held;
-            W->held = 0;
-            W->state = W_NONE;
-        }
-        if (W->state == W_LIVE || W->state == W_DEAD)
-            return;
-        if (W->state == W_BUSY) {
-            if (lookahead)
-                return;
-            pthread_cond_wait(&g_cv, &g_mu);
-            continue;
-        }
-        break;
-    }
-    if (!roll_make_room(W->need, budget, r, lookahead ? w - 1 : w, lookahead) && lookahead)
-        return; /* (a window that is needed goes over the budget rather than without) */
-    W->state = W_BUSY;
-    r->busy++;
     const uint64_t lo = W->lo, len = W->hi - W->lo;
     const int64_t r0 = W->r0, nr = W->r1 - W->r0;
-    pthread_mutex_unlock(&g_mu);
     size_t cap = 0;
     uint8_t *img = (uint8_t *)mzhip_window_alloc((size_t)len + 16, &cap); /* page-locked: the H2D copies run at link speed */
     if (!img) {
@@ -422,11 +456,26 @@ static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget,
     int64_t k = -1;
     uint64_t held = 0;
     int64_t *rows = (int64_t *)malloc((size_t)nr * 8 * sizeof(int64_t));
-    if (img && rows && read_at(arch, (int64_t)lo, img, (int64_t)len)) {
+    int got = 0;
+    if (img && rows) {
+        if (arch) {
+            got = read_at(arch, (int64_t)lo, img, (int64_t)len);
+        } else {
+            uint64_t done = 0;
+            while (done < len) {
+                const ssize_t rd = pread(r->fd, img + done, (size_t)(len - done < ((uint64_t)1 << 30) ? len - done : ((uint64_t)1 << 30)), (off_t)(lo + done));
+                if (rd <= 0)
+                    break;
+                done += (uint64_t)rd;
+            }
+            got = done == len;
+        }
+    }
+    if (got) {
         memcpy(rows, r->rows + 8 * r0, (size_t)nr * 8 * sizeof(int64_t)); /* (r->rows itself is immutable: other threads read it) */
         (void)mzhip_zip_index_resolve(img, lo, len, rows, nr);
         k = mzhip_prime_window_begin(img, cap, lo, len, rows, nr, r->alg ? r->alg + r0 : NULL, r->dsz ? r->dsz + r0 : NULL,
-                                     r->dig ? r->dig + 64 * r0 : NULL, (uint64_t)r->size, W->ident, &held);
+                                     r->dig ? r->dig + 64 * r0 : NULL, (uint64_t)r->size, W->ident, device, &held);
         img = NULL; /* (the call took it over) */
     }
     if (img) {
@@ -448,12 +497,92 @@ static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget,
             g_peak_bytes = g_live_bytes;
         g_windows_primed++;
         if (roll_trace())
-            fprintf(stderr, "[mzhip autoprime] window %d [%llu, %llu) %s: %lld entries, %llu bytes; %llu bytes live\n", w, (unsigned long long)lo,
-                    (unsigned long long)(lo + len), lookahead ? "ahead" : "needed", (long long)k, (unsigned long long)held, (unsigned long long)g_live_bytes);
+            fprintf(stderr, "[mzhip autoprime] window %d [%llu, %llu) %s%s: %lld entries, %llu bytes; %llu bytes live\n", w, (unsigned long long)lo,
+                    (unsigned long long)(lo + len), lookahead ? "ahead" : "needed", arch ? "" : " (pread)", (long long)k, (unsigned long long)held,
+                    (unsigned long long)g_live_bytes);
     } else {
         W->state = W_DEAD; /* could not be read or decoded: its entries take the per-entry path */
     }
     pthread_cond_broadcast(&g_cv);
+}
+
+/* the imaging thread: windows of archives this process holds as files, one after the other, in the order they were asked for */
+typedef struct img_job_s {
+    roll *r;
+    int32_t w, lookahead, device; /* device: the one the reader that asked was on */
+    struct img_job_s *next;
+} img_job;
+static img_job *g_q_head, *g_q_tail;
+static pthread_cond_t g_q_cv = PTHREAD_COND_INITIALIZER;
+static int g_img_thread; /* 0 not started, 1 running, -1 could not be started */
+
+static void *img_thread(void *arg) {
+    (void)arg;
+    pthread_mutex_lock(&g_mu);
+    for (;;) {
+        while (!g_q_head)
+            pthread_cond_wait(&g_q_cv, &g_mu);
+        img_job *j = g_q_head;
+        g_q_head = j->next;
+        if (!g_q_head)
+            g_q_tail = NULL;
+        pthread_mutex_unlock(&g_mu);
+        roll_image(j->r, j->w, NULL, j->lookahead, j->device); /* (takes the lock again) */
+        free(j);
+    }
+    return NULL;
+}
+
+/* window w of r must be live (or on its way).  g_mu is held on entry and on exit, not while the archive is read.
+ * lookahead: the window is not needed yet -- no eviction of windows in use, no waiting. */
+static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget, int lookahead) {
+    roll_win *W = &r->win[w];
+    for (;;) {
+        if (W->state == W_LIVE && !mzhip_prime_has((uint64_t)r->size, W->ident)) { /* (the cache let it go: 32 generations, a re-prime) */
+            g_live_bytes -= W->held;
+            W->held = 0;
+            W->state = W_NONE;
+        }
+        if (W->state == W_LIVE || W->state == W_DEAD)
+            return;
+        if (W->state == W_BUSY) {
+            if (lookahead)
+                return;
+            pthread_cond_wait(&g_cv, &g_mu);
+            continue;
+        }
+        /* W_NONE */
+        if (!roll_make_room(W->need, budget, r, lookahead ? w - 1 : w, lookahead) && lookahead)
+            return; /* (a window that is needed goes over the budget rather than without) */
+        W->state = W_BUSY;
+        r->busy++;
+        if (r->fd >= 0 && g_img_thread >= 0) { /* the imaging thread reads it; a needed window is waited for above */
+            if (g_img_thread == 0) {
+                pthread_t t;
+                g_img_thread = pthread_create(&t, NULL, img_thread, NULL) == 0 ? 1 : -1;
+                if (g_img_thread > 0)
+                    pthread_detach(t);
+            }
+            img_job *j = g_img_thread > 0 ? (img_job *)malloc(sizeof(img_job)) : NULL;
+            if (j) {
+                j->r = r;
+                j->w = w;
+                j->lookahead = lookahead;
+                j->device = mzhip_prime_current_device();
+                j->next = NULL;
+                if (g_q_tail)
+                    g_q_tail->next = j;
+                else
+                    g_q_head = j;
+                g_q_tail = j;
+                pthread_cond_signal(&g_q_cv);
+                continue;
+            }
+        }
+        pthread_mutex_unlock(&g_mu);
+        roll_image(r, w, arch, lookahead, -1);
+        return;
+    }
 }
 
 static void forget_everything(void) {
@@ -493,17 +622,26 @@ void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
     pthread_mutex_lock(&g_mu);
     g_tick++;
     {
-        int32_t gens = 0, wins = 0;
-        uint64_t clears = 0;
-        mzhip_prime_counts(&gens, &wins, &clears);
+        const uint64_t clears = mzhip_prime_clears();
         if (clears != g_clears_seen) { /* somebody cleared the cache: it holds nothing of ours any more */
             g_clears_seen = clears;
             forget_everything();
         }
     }
+    /* where the stream stands; how long the archive is (one seek to where the tail starts, or to the end of a shorter one) */
     const int64_t pos = arch->vtbl->tell(arch);
-    if (pos >= 0 && arch->vtbl->seek(arch, 0, MZH_SEEK_END) == MZH_OK) {
-        const int64_t size = arch->vtbl->tell(arch);
+    int64_t size = -1;
+    if (pos >= 0) {
+        if (arch->vtbl->seek(arch, -(int64_t)MZH_TAIL4K, MZH_SEEK_END) == MZH_OK) {
+            const int64_t at = arch->vtbl->tell(arch);
+            size = at >= 0 ? at + MZH_TAIL4K : -1;
+        } else if (arch->vtbl->seek(arch, 0, MZH_SEEK_END) == MZH_OK) {
+            size = arch->vtbl->tell(arch);
+            if (size >= MZH_TAIL4K || (size > 0 && arch->vtbl->seek(arch, 0, MZH_SEEK_SET) != MZH_OK))
+                size = -1; /* (a stream that cannot do the first seek but is that long: not one to read through) */
+        }
+    }
+    if (pos >= 0 && size >= 0) {
         uint8_t *buf = NULL;
         int64_t *table = NULL;
         int dealt_with = 0;
@@ -512,7 +650,7 @@ void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
         const int64_t n4 = size < MZH_TAIL4K ? size : MZH_TAIL4K;
         uint64_t crc4 = 0;
         roll *R = NULL;
-        if (size < 22 || !read_at(arch, size - n4, t4, n4))
+        if (size < 22 || !read_all(arch, t4, n4)) /* (the stream stands where the tail starts) */
             goto done;
         crc4 = tail_hash(t4, (size_t)n4);
         for (int i = 0; i < MZH_ROLLS; i++)

@@ -498,6 +498,13 @@ static void xz_fresh_block(mzhip_lzma *z, uint32_t dict) {
 static int32_t xz_stream_start(mzhip_lzma *z) {
     static const uint8_t magic[6] = {0xFD, '7', 'z', 'X', 'Z', 0x00};
     z->xz_no_stream = 1;
+    if (z->in_len < 13 && !z->base_eof) {
+        /* a short first read (the 256-byte probe pull, a pipe, a stream that hands back less than it was asked for) says
+         * nothing about the header yet: more input first -- only a header that IS malformed or unsupported locks the stream
+         * out of window mode (a large .xz entry then ran the one-buffer path into MEM_ERROR past 2 GiB) */
+        z->xz_no_stream = 0;
+        return 1;
+    }
     if (z->in_len < 13 || memcmp(z->in, magic, 6) != 0 || z->in[6] != 0 || (z->in[7] != 0 && z->in[7] != 1 && z->in[7] != 4) ||
         mzhip_crc32_host(0, z->in + 6, 2) != xz_le32(z->in + 8) || z->in[12] == 0)
         return 0;

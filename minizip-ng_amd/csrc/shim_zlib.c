@@ -2,7 +2,7 @@
  *
  * Drop-in for the reference's mz_strm_zlib.c (same 13 exported symbols,
  * mz_strm_zlib.h:20-35).  Host side stays C; the DEFLATE arithmetic runs in the
- * gfx950 kernels behind mzhip_inflate_host() (include/mzhip.h).  There is no
+ * gfx950 kernels behind mzhip_inflate_host_a() (include/mzhip.h).  There is no
  * CPU codec in here: if the device is unusable, read() fails with an MZ error.
  *
  * Contract mirrored from the reference (file:line = mz_strm_zlib.c):
@@ -411,7 +411,7 @@ static int32_t refusal_is_not_a_distance(mzhip_zlib *z, const uint8_t *in, int64
     a.out_len = &ol;
     a.in_used = &iu;
     a.crc = &crc;
-    const int32_t st = mzhip_inflate_host(&a);
+    const int32_t st = mzhip_inflate_host_a(&a);
     free(tmp);
     z->kind_no_room = st == MZHIP_STATUS_DATA_ERROR && (int64_t)iu == in_used && (int64_t)ol == 32768 + produced;
     return z->kind_no_room;
@@ -571,14 +571,16 @@ int64_t mzh_stream_gulp(void) {
 #ifndef MZH_STREAM_EARLY_OUT
 #define MZH_STREAM_EARLY_OUT (4 << 20) /* ... or decoded bytes */
 #endif
-static int8_t mzh_par_mode = -1;
-MZHIP_API void mzhip_set_stream_parallel(int32_t on) { mzh_par_mode = on ? 1 : 0; }
+static int8_t mzh_par_mode = -1; /* (read and set with atomics: streams of several threads ask, tests/test_autoprime_emul.py under TSan) */
+MZHIP_API void mzhip_set_stream_parallel(int32_t on) { __atomic_store_n(&mzh_par_mode, (int8_t)(on ? 1 : 0), __ATOMIC_RELAXED); }
 static int32_t mzh_stream_parallel(void) {
-    if (mzh_par_mode < 0) {
+    int8_t m = __atomic_load_n(&mzh_par_mode, __ATOMIC_RELAXED);
+    if (m < 0) {
         const char *e = getenv("MZHIP_STREAM_PARALLEL");
-        mzh_par_mode = (e && e[0] == '0') ? 0 : 1;
+        m = (e && e[0] == '0') ? 0 : 1;
+        __atomic_store_n(&mzh_par_mode, m, __ATOMIC_RELAXED);
     }
-    return mzh_par_mode;
+    return m;
 }
 
 static int32_t stream_drop_input(mzhip_zlib *z) {
@@ -594,7 +596,7 @@ static int32_t stream_drop_input(mzhip_zlib *z) {
     return 0;
 }
 
-/* the pieces of one decode call: the same cut as a window of mzhip_inflate_host makes (first, stride ..., rest) */
+/* the pieces of one decode call: the same cut as a window of mzhip_inflate_host_a makes (first, stride ..., rest) */
 static void stream_pieces_add(mzhip_zlib *z, int64_t g, int64_t nbytes, uint32_t first, uint32_t stride, uint32_t nseg) {
     if (nbytes <= 0 || !stride)
         return;
@@ -829,7 +831,7 @@ static int32_t stream_next(mzhip_zlib *z) {
         wa.seg_crc = z->pc_tmp;
         wa.seg_cap = (uint32_t)z->pc_tmp_cap;
         wa.nseg = &nseg;
-        int32_t st = mzhip_inflate_host(&wa);
+        int32_t st = mzhip_inflate_host_a(&wa);
         z->t_serial += mzh_now() - ts0;
         z->n_serial++;
         if (out_len > (uint32_t)z->out_len) {
@@ -853,7 +855,7 @@ static int32_t stream_next(mzhip_zlib *z) {
             wa.state_out = NULL;
             wa.seg_first = wa.seg_stride = wa.seg_cap = 0;
             wa.seg_crc = wa.nseg = NULL;
-            st = mzhip_inflate_host(&wa);
+            st = mzhip_inflate_host_a(&wa);
             if (st == MZHIP_STATUS_OK || st == MZHIP_STATUS_BUF_ERROR || st == MZHIP_STATUS_DATA_ERROR) {
                 stream_sum(z, (int64_t)out_len - z->out_len, crc, adler);
                 z->out_len = out_len;
@@ -937,7 +939,7 @@ static int32_t attempt_decode(mzhip_zlib *z) {
         ea.in_used = &in_used;
         ea.crc = &z->out_crc;
         ea.adler = z->wrap == 1 ? &z->out_adler : NULL;
-        int32_t st = mzhip_inflate_host(&ea);
+        int32_t st = mzhip_inflate_host_a(&ea);
         int32_t early = 0;
         const int64_t early_out = MZH_STREAM_EARLY_OUT < mzh_stream_window() ? MZH_STREAM_EARLY_OUT : mzh_stream_window();
         if (mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
@@ -1237,7 +1239,7 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
     da.out_len = &out_len;
     da.crc = &crc;
     da.adler = z->wrap == 1 ? &adler : NULL;
-    int32_t st = mzhip_deflate_host(&da);
+    int32_t st = mzhip_deflate_host_a(&da);
     if (st != 0) {
         free(out);
         z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */

@@ -76,8 +76,8 @@ static int32_t mock_inflate_window(const uint8_t *in, uint32_t in_len, uint8_t *
     return st;
 }
 // include/mzhip.h: a whole entry (no states) or one window of it, one entry point
-MOCK_API int32_t mzhip_inflate_host(const mzhip_inflate_host_args *ap) {
-    if (!ap || ap->size < offsetof(mzhip_inflate_host_args, buf) + sizeof(void *)) return -102;
+MOCK_API int32_t mzhip_inflate_host_a(const mzhip_inflate_host_args *ap) {
+    if (!ap || ap->size < offsetof(mzhip_inflate_host_args, buf) + sizeof(void *) || ap->size > 4096u || (ap->size & 3u)) return -102;
     mzhip_inflate_host_args a;
     memset(&a, 0, sizeof(a));
     memcpy(&a, ap, ap->size < sizeof(a) ? ap->size : sizeof(a));
@@ -244,7 +244,7 @@ MOCK_API int32_t mzhip_inflate_parallel_host(const uint8_t *in, uint32_t in_len,
     return 0;
 }
 
-// one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host does)
+// one stream segment = 64 KiB pieces, every piece but the last closed on a byte boundary (as mzhip_deflate_host_a does)
 static int32_t mock_deflate_segment(const uint8_t *in, uint32_t in_len, uint32_t final, int32_t level, int32_t window_log2,
                                     uint8_t *out, uint32_t out_cap, uint32_t *out_len, uint32_t *crc, uint32_t *adler) {
     const uint32_t piece = 64u << 10;
@@ -266,8 +266,8 @@ static int32_t mock_deflate_segment(const uint8_t *in, uint32_t in_len, uint32_t
     if (adler) *adler = ad;
     return 0;
 }
-MOCK_API int32_t mzhip_deflate_host(const mzhip_deflate_host_args *ap) {
-    if (!ap || ap->size < offsetof(mzhip_deflate_host_args, out) + sizeof(void *)) return -102;
+MOCK_API int32_t mzhip_deflate_host_a(const mzhip_deflate_host_args *ap) {
+    if (!ap || ap->size < offsetof(mzhip_deflate_host_args, out) + sizeof(void *) || ap->size > 4096u || (ap->size & 3u)) return -102;
     mzhip_deflate_host_args a;
     memset(&a, 0, sizeof(a));
     memcpy(&a, ap, ap->size < sizeof(a) ? ap->size : sizeof(a));

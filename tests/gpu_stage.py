@@ -24,7 +24,7 @@ def inflate(name, extra=b""):
     ol, iu, crc = C.c_uint32(), C.c_uint32(), C.c_uint32()
     a = mz.InflateHostArgs(size=C.sizeof(mz.InflateHostArgs), in_len=len(z) + len(extra), buf_cap=len(d) + 8, in_=C.addressof(src),
                            buf=C.addressof(out), out_len=C.addressof(ol), in_used=C.addressof(iu), crc=C.addressof(crc))
-    st = L.mzhip_inflate_host(C.byref(a))
+    st = L.mzhip_inflate_host_a(C.byref(a))
     ok = st == 0 and out.raw[:ol.value] == d and crc.value == zlib.crc32(d) and iu.value == len(z)
     print(name, "status", st, "out", ol.value, "/", len(d), "used", iu.value, "/", len(z), "crc_ok",
           crc.value == zlib.crc32(d), "OK" if ok else "FAIL", "err=", L.mzhip_last_error(), flush=True)

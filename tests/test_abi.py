@@ -67,8 +67,13 @@ def test_ctypes_signatures_come_from_the_header(lib):
         got = [(n.rstrip("_"), t is C.c_void_p) for n, t in cls._fields_]
         assert got == fields, (cname, got, fields)
     for gone in ("mzhip_inflate_host2", "mzhip_inflate_resume_host", "mzhip_inflate_resume_host_seg", "mzhip_inflate_resume_host_seg2",
-                 "mzhip_deflate_host2", "mzhip_deflate_host_level"):
+                 "mzhip_deflate_host2", "mzhip_deflate_host_level",
+                 # the names that took positional arguments until round 4 are exported by NO build any more -- a binary
+                 # compiled against the old header must fail to link, not pass its input buffer as the args struct
+                 "mzhip_inflate_host", "mzhip_deflate_host"):
         assert not hasattr(lib, gone), gone
+    assert hasattr(lib, "mzhip_inflate_host_a") and hasattr(lib, "mzhip_deflate_host_a")
+    assert b"0.6" in lib.mzhip_version()
 
 
 def test_dropin_symbol_set_matches_reference_headers(lib):

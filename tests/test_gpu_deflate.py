@@ -1,5 +1,5 @@
 """GPU parity tests for K4 (DEFLATE encode, fixed-Huffman blocks, fused CRC-32 of the input) through the C ABI
-(mzhip_deflate_batch / mzhip_deflate_host) and through the drop-in mz_stream_zlib WRITE path.  Compressor
+(mzhip_deflate_batch / mzhip_deflate_host_a) and through the drop-in mz_stream_zlib WRITE path.  Compressor
 output is not a format property, so parity = the reference side (oracle restatement, zlib 1.2.11, the compiled
 reference's mz_stream_zlib READ) inflates the bytes back to the input and every CRC agrees."""
 import ctypes as C

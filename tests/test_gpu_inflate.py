@@ -1,5 +1,5 @@
 """GPU parity tests for K1+K2 (raw-DEFLATE decode + fused CRC-32) through the C ABI
-(mzhip_inflate_batch / mzhip_inflate_host), checked against the oracle (oracle/*.c), zlib-made
+(mzhip_inflate_batch / mzhip_inflate_host_a), checked against the oracle (oracle/*.c), zlib-made
 expected bytes, the golden fixtures, and -- where oracle/_ref travelled -- the compiled reference."""
 import zlib
 
