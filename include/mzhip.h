@@ -364,6 +364,10 @@ MZHIP_API int32_t mzhip_deflate_host_a(const mzhip_deflate_host_args *a);
  * the device is unusable the value is still exact and the failure is reported by the next codec-stream call. */
 #define MZHIP_CRC_HOST_BELOW 4096u
 MZHIP_API uint32_t mzhip_crc32_host(uint32_t value, const uint8_t *buf, size_t size);
+/* Device failures met under mz_crypt_crc32_update since the process started.  The symbol has no error channel (mz_crypt.h:20), so
+ * the checksum of such a call is folded on the host by this library's own tables; the failure is reported by mzhip_last_error()
+ * on the calling thread, by the thread's next codec-stream call (MZ_STREAM_ERROR), once on stderr -- and counted here. */
+MZHIP_API uint64_t mzhip_crc_faults(void);
 
 /* Archive index (host, C) --------------------------------------------------------------- */
 

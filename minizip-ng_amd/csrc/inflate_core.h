@@ -110,6 +110,9 @@ extern __device__ unsigned long long mz_prof_buf[32];
                                                                      reads fall 7 - 11 %, its writes grow 40 - 60 %, the probe is 0.3 - 7 % slower: profiles/r5/call4_probe.log) */
 #define MZ_CRING_DW 16u /* a power of two: the slot of a stream dword is its index & 15, nothing to keep track of */
 #define MZ_CRING_RS 19u /* row stride: 16 + 2 mirrored, odd */
+#ifndef MZ_PF_GROUPS
+#define MZ_PF_GROUPS 2 /* groups of four stream dwords a lane loads at a time (inflate_walk.inc): 1 or 2 */
+#endif
 #ifndef MZ_EMIT_GROUP
 #define MZ_EMIT_GROUP 8u /* records one lane turns into bytes per emit round (4 or 8: records are stored in quads) */
 #endif

@@ -36,7 +36,8 @@
  *   - whole image: this image (size + CRC of its last 64 KiB: the central directory) has not been primed already --
  *     readers of several threads prime it once -- nor three times before (an application that alternates between archives
  *     entry by entry would otherwise re-image them for ever); rolled over: a window that was evicted three times in a row
- *     before eight of its entries had been read is left to the per-entry path (the same guard, per window).
+ *     before eight of its entries (or all it has) had been read is left to the per-entry path for the next 4096 entries
+ *     (the same guard, per window).
  * Which archive a stream belongs to is asked on EVERY call, not remembered by stream address (the allocator hands a freed
  * reader's address to the next one): its size and a hash of its last 4 KiB, read through the stream on every call.
  * The cache's other generations are never touched: a new whole image replaces the previous one THIS FILE made (by identity,
@@ -67,6 +68,7 @@
 #define MZH_ROLL_GAP ((uint64_t)8 << 20)  /* bytes between two entries' local headers that a window does not image */
 #define MZH_ROLL_FRESH 256                /* calls: a window used this recently is not evicted for a look-ahead */
 #define MZH_ROLL_MAX_WINDOWS 20           /* live at once (the cache holds 32 generations) */
+#define MZH_ROLL_DEAD_FOR 4096             /* calls a window that was given up stays with the per-entry path */
 #define MZH_TAIL4K 4096
 
 int64_t mzhip_prime_window_begin(uint8_t *img, size_t img_cap, uint64_t win_off, uint64_t win_len, const int64_t *rows, int64_t n,
@@ -431,8 +433,15 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
         mzhip_prime_drop((uint64_t)vr->size, v->ident); /* (streams that still read from it keep it alive until they close) */
         g_live_bytes -= v->held;
         v->held = 0;
-        v->quick = v->hits < 8 ? v->quick + 1 : 0;
+        {
+            /* the thrash guard: priming a window pays after about eight entries have been read from it (or all it has) */
+            const int64_t all = v->r1 - v->r0;
+            v->quick = (int64_t)v->hits < (all < 8 ? all : 8) ? v->quick + 1 : 0;
+        }
         v->state = v->quick >= 3 ? W_DEAD : W_NONE;
+        v->stamp = g_tick; /* (a dead window comes back after MZH_ROLL_DEAD_FOR calls: the access pattern may have changed) */
+        if (v->state == W_DEAD && roll_trace())
+            fprintf(stderr, "[mzhip autoprime] window %d evicted three times in a row after fewer than eight hits: left to the per-entry path\n", vw);
         g_windows_evicted++;
         if (roll_trace())
             fprintf(stderr, "[mzhip autoprime] window %d evicted after %u hits (%s); %llu bytes live\n", vw, v->hits, lookahead ? "look-ahead" : "needed",
@@ -502,6 +511,9 @@ static void roll_image(roll *r, int32_t w, mzhip_stream *arch, int lookahead, in
                     (unsigned long long)g_live_bytes);
     } else {
         W->state = W_DEAD; /* could not be read or decoded: its entries take the per-entry path */
+        if (roll_trace())
+            fprintf(stderr, "[mzhip autoprime] window %d [%llu, %llu) could not be primed (read %d, result %lld)\n", w, (unsigned long long)lo,
+                    (unsigned long long)(lo + len), got, (long long)k);
     }
     pthread_cond_broadcast(&g_cv);
 }
@@ -541,6 +553,10 @@ static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget,
         if (W->state == W_LIVE && !mzhip_prime_has((uint64_t)r->size, W->ident)) { /* (the cache let it go: 32 generations, a re-prime) */
             g_live_bytes -= W->held;
             W->held = 0;
+            W->state = W_NONE;
+        }
+        if (W->state == W_DEAD && W->quick >= 3 && g_tick - W->stamp > MZH_ROLL_DEAD_FOR) { /* given up for thrashing, long ago: once more */
+            W->quick = 0;
             W->state = W_NONE;
         }
         if (W->state == W_LIVE || W->state == W_DEAD)

@@ -216,3 +216,51 @@ def test_differential_fuzz_batch(gpu):
             assert gpu.entry_bytes(batch, h_out, i, len(oo)) == oo, i
             n_ok += 1
     assert n_ok > 100
+
+
+def test_crc32_device_fault_is_loud():
+    """mz_crypt_crc32_update has no error channel (mz_crypt.h:20) and used to degrade silently when the device
+    failed under it.  With a failure injected into the first device checksum of a fresh process (MZHIP_FAULT_INJECT=crc): the
+    value is still the right CRC-32 (the library's own host fold), mzhip_last_error() of the thread names the symbol,
+    mzhip_crc_faults() counts it, stderr carries one line, and the thread's next codec-stream read fails with MZ_STREAM_ERROR
+    instead of carrying on behind a device that does not answer."""
+    import os
+    import subprocess
+    import sys
+
+    from tests import gpu_util
+
+    gpu_util.mz.require_gpu()
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drop = os.path.join(ROOT, "integration", "_build", "libmzhipdrop.so")
+    if not os.path.exists(drop):
+        pytest.skip("drop-in library missing (built where /root/reference exists)")
+    code = r"""
+import ctypes as C, sys, zlib
+sys.path.insert(0, %r)
+import numpy as np
+import oracle
+from tests import synth
+hip = oracle.MzDriver(%r)
+L = C.CDLL(%r)
+L.mzhip_last_error.restype = C.c_char_p
+L.mzhip_crc_faults.restype = C.c_uint64
+data = synth.corpus()[:200000]
+assert L.mzhip_crc_faults() == 0
+got = hip.crc32(data)
+assert got == zlib.crc32(data), (got, zlib.crc32(data))
+assert L.mzhip_crc_faults() == 1
+msg = L.mzhip_last_error().decode()
+assert "mz_crypt_crc32_update" in msg and "host" in msg, msg
+z = synth.deflate_raw(data[:70000])
+r = hip.stream_decode(8, z, 70000)
+assert r["rets"][0] == -1, r["rets"]            # MZ_STREAM_ERROR: the fault the checksum call could not report
+r = hip.stream_decode(8, z, 70000)              # ... reported once; the device answers again
+assert r["out"] == data[:70000] and r["close"] == 0
+assert hip.crc32(data) == zlib.crc32(data) and L.mzhip_crc_faults() == 1
+print("fault path ok")
+""" % (ROOT, drop, gpu_util.mz.LIB_PATH)
+    env = dict(os.environ, MZHIP_FAULT_INJECT="crc")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert "fault path ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "mzhip: mz_crypt_crc32_update: device failure" in r.stderr

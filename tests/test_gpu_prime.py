@@ -582,3 +582,24 @@ print(json.dumps(res))
         _, crc_h, _, st_h = oracle.MzDriver(DROP).zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_hip, out_off=out_off)
         assert (st_r == 0).all() and (st_h == 0).all() and (crc_r == crc_h).all() and (o_ref == o_hip).all()
         mz.lib().mzhip_prime_clear()
+
+
+def test_concurrent_window_primes_keep_the_runtime_sane():
+    """Round 6 regression: a rolled archive makes two primes at once the normal case (the window at hand and the look-ahead),
+    and the second one's lane set -- three streams -- used to be destroyed when it finished.  The runtime's scratch and
+    work-queue caches still held events recorded on those streams, and this HIP runtime answers a query of such an event with
+    "operation not permitted when stream is capturing": launches of other threads failed at random, entries went unserved.
+    Lane sets are never destroyed now.  Twelve passes over a rolled archive with one and two reader threads, clears in between,
+    through the archive's own descriptor and through the readers' streams: every pass clean (statuses, bytes, no miss)."""
+    import subprocess
+    import sys
+
+    mz = importlib.import_module("minizip-ng_amd")
+    mz.require_gpu()
+    if not (os.path.exists(DROP) and oracle.have_ref()):
+        pytest.skip("drop-in / reference libraries missing (built where /root/reference exists)")
+    for fd in ("1", "0"):
+        env = dict(os.environ, MZHIP_AUTOPRIME_FD=fd)
+        env.pop("MZHIP_PRIME_TRACE", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag_roll.py"), "12", "2"], capture_output=True, text=True, env=env, timeout=600)
+        assert "diag_roll: 0 of 12 passes were not clean" in r.stdout, (fd, r.stdout[-3000:], r.stderr[-1500:])
