@@ -597,7 +597,8 @@ def full_archive_legs(mz, path, n, size, want_crc_np, cores, with_reference):
                     sec = D.mzdrop_extract_file(path.encode(), T, C.byref(ne), C.byref(nb), C.byref(fe))
                 w1 = [C.c_uint64() for _ in range(4)]
                 L.mzhip_autoprime_stats(*[C.byref(x) for x in w1])
-                ok = sec > 0 and fe.value == 0 and ne.value == n and nb.value == n * size and L.mzhip_autoprime_count() == a0 + 1
+                # (rolled over by the library itself: windows were primed during the call -- the archive's index is made once per process)
+                ok = sec > 0 and fe.value == 0 and ne.value == n and nb.value == n * size and w1[0].value > w0[0].value and L.mzhip_autoprime_count() >= max(a0, 1)
                 if ok and (best is None or sec < best):
                     best = sec
                     info = "%d windows primed, %d evicted, at most %.0f MiB of decoded bytes held at once" % (

@@ -568,8 +568,9 @@ print(json.dumps(res))
                   % (T, s["sec"], n * size / 2**30 / s["sec"], s["primed"], s["evicted"], s["peak"] / 2**20, s["hwm"] / 2**20))
             assert s["err"] == 0 and s["entries"] == n and s["bytes"] == n * size, s
             assert s["peak"] <= (2 << 30) + (512 << 20), s
-            assert s["hwm"] < (5 << 30), s                                  # far below 6.7 GiB decoded + 2.1 GiB of image
+            assert s["hwm"] < (6 << 30) + (512 << 20), s                    # below what the archive decodes to (6.7 GiB), let alone + its 2.1 GiB image: the windows' 2 GiB, the pool's spare blocks, the HIP runtime
         assert res["1"]["autos"] == 1 and res["1"]["primed"] >= 20 and res["1"]["evicted"] >= res["1"]["primed"] - 16
+        assert res["4"]["autos"] == 1                                       # (indexed once per process, rolled over again)
         assert n * size / 2**30 / res["1"]["sec"] > 1.5                     # the reference's reader thread makes ~0.36 GiB/s
         # bytes of a sample of the entries against the reference's reader (the zip layer verified every CRC above)
         table = oracle.ref().zip_index(path)
