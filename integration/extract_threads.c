@@ -264,6 +264,7 @@ typedef struct {
     int64_t count;
     int64_t ok, bytes;
     int32_t err, started;
+    double t_goto, t_open, t_read, t_close; /* MZDROP_TRACE: where the thread's time goes */
 } xf_job;
 
 static void *xf_run(void *arg) {
@@ -278,13 +279,17 @@ static void *xf_run(void *arg) {
         return NULL;
     }
     mz_zip_reader_get_zip_handle(reader, &zip);
+    const int trace = getenv("MZDROP_TRACE") != NULL;
+    double a = trace ? xt_now() : 0.0, b;
     int32_t err = j->cd_first < 0 ? mz_zip_goto_first_entry(zip) : mz_zip_goto_entry(zip, j->cd_first);
     for (int64_t i = 0; err == MZ_OK && i < j->count; i++) {
         int64_t total = 0;
         mz_zip_file *fi = NULL;
         err = mz_zip_entry_get_info(zip, &fi);
         const int64_t want = err == MZ_OK ? fi->uncompressed_size : -1;
+        if (trace) { b = xt_now(); j->t_goto += b - a; a = b; }
         if (err == MZ_OK) err = mz_zip_entry_read_open(zip, 0, NULL);
+        if (trace) { b = xt_now(); j->t_open += b - a; a = b; }
         if (err == MZ_OK) {
             for (;;) {
                 const int32_t rd = mz_zip_entry_read(zip, buf, UINT16_MAX);
@@ -292,8 +297,10 @@ static void *xf_run(void *arg) {
                 if (rd <= 0) break;
                 total += rd;
             }
+            if (trace) { b = xt_now(); j->t_read += b - a; a = b; }
             const int32_t cerr = mz_zip_entry_close(zip); /* MZ_CRC_ERROR when the bytes are not the archive's */
             if (err == MZ_OK) err = cerr;
+            if (trace) { b = xt_now(); j->t_close += b - a; a = b; }
         }
         if (err == MZ_OK && total == want) {
             j->ok++;
@@ -374,6 +381,9 @@ __attribute__((visibility("default"))) double mzdrop_extract_file(const char *pa
         ok += jobs[t].ok;
         by += jobs[t].bytes;
         if (err == MZ_OK) err = jobs[t].err;
+        if (getenv("MZDROP_TRACE"))
+            fprintf(stderr, "[mzdrop] thread %d: %lld entries: goto + info %.1f ms, read_open %.1f ms, read %.1f ms, close %.1f ms\n", t, (long long)jobs[t].ok,
+                    jobs[t].t_goto * 1e3, jobs[t].t_open * 1e3, jobs[t].t_read * 1e3, jobs[t].t_close * 1e3);
     }
     free(table);
     free(th);

@@ -11,6 +11,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* study hooks (tests/study/lzma_lockstep.c counts decisions by kind and packet); nothing in an ordinary build */
+#ifndef ORC_TRACE_BIT
+#define ORC_TRACE_BIT(p_) ((void)0)
+#define ORC_TRACE_DIRECT(n_) ((void)0)
+#define ORC_TRACE_PACKET() ((void)0)
+#endif
+
 #define K_TOP (1u << 24)
 #define K_BITS 11
 #define K_MOVE 5
@@ -39,6 +46,7 @@ static void rc_norm(rc_t *rc) {
 }
 
 static unsigned rc_bit(rc_t *rc, uint16_t *p) {
+    ORC_TRACE_BIT(p);
     rc_norm(rc); /* liblzma normalises before, not after, each bit */
     uint32_t bound = (rc->range >> K_BITS) * *p;
     if (rc->code < bound) {
@@ -54,6 +62,7 @@ static unsigned rc_bit(rc_t *rc, uint16_t *p) {
 
 static uint32_t rc_direct(rc_t *rc, int n) {
     uint32_t r = 0;
+    ORC_TRACE_DIRECT(n);
     while (n--) {
         rc_norm(rc);
         rc->range >>= 1;
@@ -144,6 +153,7 @@ static int32_t lz_run(lz_t *z, size_t limit, int lzma2) {
     uint8_t *out = z->out;
     const unsigned pb_mask = (1u << z->pb) - 1, lp_mask = (1u << z->lp) - 1, lc = z->lc;
     for (;;) {
+        ORC_TRACE_PACKET();
         if (rc->eof)
             return ORC_DATA_ERROR; /* truncated */
         if (lzma2 && z->opos == limit)

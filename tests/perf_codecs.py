@@ -8,7 +8,9 @@ import zlib
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from tests import gpu_util, synth  # noqa: E402
 from tests.test_oracle import _zip_lzma  # noqa: E402
 
@@ -72,7 +74,7 @@ if which in ("lzma", "both", "all"):
     print("LZMA decode: %d x %d B, ratio %.3f: %.1f ms  %.2f GiB/s out  ok=%s" % (
         n_total, size, ratio, ms, n_total * size / 2**30 / (ms / 1e3), ok), flush=True)
 
-if which in ("deflate", "both", "all"):
+if which in ("deflate", "deflate_only", "both", "all"):
     n_unique, n_total, size = 512, 20000, 65536
     datas = synth.slices(n_unique, size, 1234)
     idx = np.arange(n_total) % n_unique
