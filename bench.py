@@ -92,15 +92,24 @@ def measured_traffic(cfg, n, size):
     every read request of K1 is 128 bytes and FETCH_SIZE tallies those at 64, so the derived counters under-report by the
     read half (profiles/r4/pmc_calibration.json); `traffic_raw` keeps what they say."""
     name = "hbm_traffic.json" if cfg == 2 else "hbm_traffic_cfg%d.json" % cfg
-    for rnd in ("r5", "r4", "r3", "r2"):
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    try:
+        from req_harvest import kernel_src_hash
+        mine = kernel_src_hash()
+    except Exception:  # noqa: BLE001
+        mine = None
+    for rnd in ("r6", "r5", "r4", "r3", "r2"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, name)) as f:
                 t = json.load(f)
             if n == t.get("entries", 100000) and size == t.get("entry_bytes", 65536):
                 if "read_bytes_per_launch" in t:
+                    theirs = t.get("kernel_src_hash")
+                    same = ("taken on EXACTLY the device sources this run was built from (hash %s)" % mine if theirs and theirs == mine else
+                            "taken on OTHER device sources than this run's (%s against %s)" % (theirs, mine) if theirs else "device sources of the measurement not recorded")
                     return (t["read_bytes_per_launch"] + t["write_bytes_per_launch"], t.get("traffic_raw"),
-                            "static: profiles/%s/%s (rocprofv3 --pmc passes of the L2's memory-side requests by size, bytes = size x count, commit %s), "
-                            "not measured by this run" % (rnd, name, t.get("commit", "unknown")))
+                            "static: profiles/%s/%s (rocprofv3 --pmc passes of the L2's memory-side requests by size, bytes = size x count, commit %s; %s; "
+                            "regenerate with `bash profiles/gpu.sh evidence <name>`), not measured by this run" % (rnd, name, t.get("commit", "unknown"), same))
                 raw = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
                 return (raw + t["fetch_bytes_per_launch"], raw,
                         "static: profiles/%s/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit %s; traffic = 2 x FETCH + WRITE, the "

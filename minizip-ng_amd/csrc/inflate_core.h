@@ -61,7 +61,7 @@ extern unsigned long long mz_stats[24], mz_stat_max;
 
 #include "crc32_core.h"
 #include "wave.h"
-/* MZ_PROF (measurement builds of the device code only, profiles/ab_k1.sh): every wave adds the shader-clock cycles it
+/* MZ_PROF (measurement builds of the device code only, profiles/gpu.sh build "prof PROF=1"): every wave adds the shader-clock cycles it
  * spent in each section of mz_inflate_entry to mz_prof_buf[]; mzhip_prof_read() hands the sums to tests/perf_probe.py */
 #if defined(MZ_PROF) && !defined(MZHIP_HOST_EMUL)
 extern __device__ unsigned long long mz_prof_buf[32];

@@ -28,7 +28,7 @@
 #include "wave.h"
 
 #ifndef MZ_LZMA_MAX_LCLP
-#define MZ_LZMA_MAX_LCLP 3 /* literal contexts held in LDS: 0x300 << 3 probabilities (measurement builds: 0, profiles/ab_k3.sh) */
+#define MZ_LZMA_MAX_LCLP 3 /* literal contexts held in LDS: 0x300 << 3 probabilities (measurement builds: 0, profiles/r3/scripts/ab_k3.sh) */
 #endif
 #define MZ_LZMA_LIT_PROBS (0x300u << MZ_LZMA_MAX_LCLP)
 #define MZ_LZMA_XPROBS MZ_LZMA_LIT_PROBS /* lc + lp = 4: as many again, in a per-wave scratch in HBM */

@@ -209,7 +209,7 @@ struct LzmaArgs {
 };
 
 // K3: one wave per workgroup, the wave's whole probability model (15.6 KiB) in LDS -> 10 waves per CU.
-#ifdef MZ_LZMA_WAVES /* measurement builds (profiles/ab_k3.sh): waves per SIMD the register allocation is held to */
+#ifdef MZ_LZMA_WAVES /* measurement builds (profiles/r3/scripts/ab_k3.sh): waves per SIMD the register allocation is held to */
 __global__ __launch_bounds__(64, MZ_LZMA_WAVES) void k_lzma_batch(LzmaArgs a) {
 #else
 __global__ __launch_bounds__(64) void k_lzma_batch(LzmaArgs a) {

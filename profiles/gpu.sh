@@ -101,10 +101,25 @@ evidence)
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $out/stats -o k --output-format csv -- python $root/bench.py --steps 20 --warmup 5 --no-legs --no-cpu-baseline --no-other-configs > $out/bench_under_rocprof.json 2> $out/stats.err )
   find $out/stats -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
   rm -rf $out/stats
+  export HARVEST_OUT=$out HARVEST_COMMIT=$(cat $root/.commit 2>/dev/null || echo unknown)
   for cfg in 2 3 4 5; do
-    case $cfg in 2|3) kern=k_inflate_batch;; 4) kern=k_lzma;; 5) kern=k_deflate_batch;; esac
+    case $cfg in 2|3) kern=k_inflate_batch; hk=k_inflate_batch;; 4) kern=k_lzma; hk=k_lzma+;; 5) kern=k_deflate_batch; hk=k_deflate_batch;; esac
     req $out cfg$cfg $kern python $root/bench.py --config $cfg --steps 3 --warmup 1 --no-legs --no-cpu-baseline --no-other-configs
     summary $out cfg$cfg $kern 0
+    # hbm_traffic*.json of this very build: entries, entry size and algorithmic bytes from the JSON line the run printed
+    python3 - $out cfg$cfg $cfg "$hk" <<'PY'
+import json, subprocess, sys, os
+out, tag, cfg, hk = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+line = None
+for ln in open(os.path.join(out, "req_%s_1.log" % tag), errors="replace"):
+    if ln.startswith("{") and '"roofline"' in ln:
+        line = json.loads(ln)
+if line:
+    c = line["config"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(out)))
+    subprocess.run([sys.executable, os.path.join(root, "profiles", "req_harvest.py"), "r6", out, tag, str(cfg), str(c.get("entries_total", 0)), str(c.get("entry_bytes", 0)),
+                    str(line["roofline"]["algorithmic_bytes_per_launch"]), hk])
+PY
   done | tee $out/req_summary.txt
   head -c 1500 $out/bench.json ;;
 *)

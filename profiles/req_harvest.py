@@ -4,7 +4,7 @@
     python profiles/req_harvest.py <round> <dir with req_<tag>_{1,2}.csv> <tag> <config> <entries> <entry_bytes> <algorithmic_bytes> [kernel] [ablation tags ...]
 
 req_<tag>_1.csv: TCC_EA0_RDREQ_{sum,32B_sum,64B_sum,128B_sum}; req_<tag>_2.csv: TCC_EA0_WRREQ_{sum,64B_sum}, TCC_HIT_sum,
-TCC_MISS_sum -- separate rocprofv3 --pmc passes of the same command (profiles/r5_call*.sh), rows of the named kernel only.
+TCC_MISS_sum -- separate rocprofv3 --pmc passes of the same command (profiles/gpu.sh req / probe / evidence; round 5: profiles/r5/scripts/), rows of the named kernel only.
 Bytes read = 32 n32 + 64 n64 + 128 n128 (what FETCH_SIZE is derived from, with the 128-byte requests counted as 128 and not
 as 64: the guide's "FETCH_SIZE is half the bytes" and profiles/r4/pmc_calibration.json are this); bytes written = 32 (n -
 n64) + 64 n64 (= WRITE_SIZE).  `traffic_raw` keeps what the two derived counters would have said.  Ablation tags (builds
@@ -41,6 +41,19 @@ def load(d, tag, kernel):
                 traffic_raw=int(fetch_raw + wr), launches=out["launches"], kernel_ms_under_pmc=out["kernel_ms_under_pmc"])
 
 
+def kernel_src_hash():
+    """what names the kernels a measurement was taken on: a hash of every device source (minizip-ng_amd/csrc/*.h, *.inc, *.hip).  bench.py
+    computes the same and says in `traffic_source` whether the counters belong to the build it is timing."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "minizip-ng_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     rnd, d, tag, cfg, entries, entry_bytes, alg = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     kernel = sys.argv[8] if len(sys.argv) > 8 else "k_inflate_batch"
@@ -49,7 +62,8 @@ def main():
              traffic_over_algorithmic=round((t["read_bytes_per_launch"] + t["write_bytes_per_launch"]) / alg, 2),
              source="rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_{sum,32B,64B,128B}_sum | TCC_EA0_WRREQ_{sum,64B}_sum TCC_HIT_sum TCC_MISS_sum in two passes "
                     "of one command on one binary; bytes = sum of size x count, mean of the kernel's launches",
-             commit=subprocess.run(["git", "log", "-1", "--format=%h"], capture_output=True, text=True, cwd=ROOT).stdout.strip())
+             commit=subprocess.run(["git", "log", "-1", "--format=%h"], capture_output=True, text=True, cwd=ROOT).stdout.strip() or os.environ.get("HARVEST_COMMIT", "unknown"),
+             kernel_src_hash=kernel_src_hash())
     sections = {}
     for ab in sys.argv[9:]:
         name, atag = ab.split("=")
@@ -61,7 +75,7 @@ def main():
         t["bytes_by_section_note"] = ("HEAD minus a build with that stage removed (MZ_ABLATE / MZ_CHASE_X: wrong output, traffic and time only); the stages "
                                       "share the L2, so the differences overlap and do not add up to the total")
     name = "hbm_traffic.json" if cfg == 2 and entries == 100000 else "hbm_traffic_cfg%d_%dx%d.json" % (cfg, entries, entry_bytes) if cfg == 2 else "hbm_traffic_cfg%d.json" % cfg
-    path = os.path.join(ROOT, "profiles", rnd, name)
+    path = os.path.join(os.environ.get("HARVEST_OUT") or os.path.join(ROOT, "profiles", rnd), name)  # (HARVEST_OUT: on the GPU box only gpurun_out/ comes back)
     json.dump(t, open(path, "w"), indent=1)
     print(path, "read %.2f GB write %.2f GB = %.2f x algorithmic (raw counters: %.2f x)" % (t["read_bytes_per_launch"] / 1e9, t["write_bytes_per_launch"] / 1e9,
           t["traffic_over_algorithmic"], t["traffic_raw"] / alg))
