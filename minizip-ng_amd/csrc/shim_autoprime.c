@@ -66,7 +66,7 @@
 #define MZH_ROLLS 4                       /* archives rolled over at the same time */
 #define MZH_ROLL_WINDOW ((uint64_t)256 << 20) /* compressed + decoded bytes of a window, at most (and at most 1/8 of the budget) */
 #define MZH_ROLL_GAP ((uint64_t)8 << 20)  /* bytes between two entries' local headers that a window does not image */
-#define MZH_ROLL_FRESH 256                /* calls: a window used this recently is not evicted for a look-ahead */
+#define MZH_ROLL_FRESH 64                 /* calls (of all readers together): a window used this recently is some reader's; it is not evicted for a look-ahead, and for a needed window only past twice the budget */
 #define MZH_ROLL_MAX_WINDOWS 20           /* live at once (the cache holds 32 generations) */
 #define MZH_ROLL_DEAD_FOR 4096             /* calls a window that was given up stays with the per-entry path */
 #define MZH_TAIL4K 4096
@@ -405,8 +405,8 @@ out:
 static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_t keep, int lookahead) {
     for (;;) {
         int32_t live = 0;
-        roll *vr = NULL;
-        int32_t vw = -1;
+        roll *vr = NULL, *fr = NULL;
+        int32_t vw = -1, fw = -1; /* the least recently used window nobody has used lately / of those in use */
         for (int i = 0; i < MZH_ROLLS; i++) {
             roll *r = g_rolls[i];
             if (!r)
@@ -417,8 +417,13 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
                 live++;
                 if (r == rk && (w == keep || (lookahead && w == keep + 1)))
                     continue;
-                if (lookahead && g_tick - r->win[w].stamp <= MZH_ROLL_FRESH)
+                if (g_tick - r->win[w].stamp <= MZH_ROLL_FRESH) { /* some reader is in it: several threads, a part of the archive each */
+                    if (fw < 0 || r->win[w].stamp < fr->win[fw].stamp) {
+                        fr = r;
+                        fw = w;
+                    }
                     continue;
+                }
                 if (vw < 0 || r->win[w].stamp < vr->win[vw].stamp) {
                     vr = r;
                     vw = w;
@@ -427,8 +432,17 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
         }
         if (g_live_bytes + need <= budget && live < MZH_ROLL_MAX_WINDOWS)
             return 1;
-        if (vw < 0)
-            return 0;
+        if (vw < 0) {
+            /* nothing but windows in use is left.  A look-ahead does without; a window that is needed goes over the budget -- up
+             * to twice: T readers hold T windows -- rather than take the bytes another reader is being served from (it would
+             * prime them again a moment later: measured, 62 windows primed for an archive of 32) */
+            if (lookahead)
+                return 0;
+            if (fw < 0 || (g_live_bytes + need <= 2 * budget && live < MZH_ROLL_MAX_WINDOWS))
+                return 1;
+            vr = fr;
+            vw = fw;
+        }
         roll_win *v = &vr->win[vw];
         mzhip_prime_drop((uint64_t)vr->size, v->ident); /* (streams that still read from it keep it alive until they close) */
         g_live_bytes -= v->held;
@@ -518,7 +532,8 @@ static void roll_image(roll *r, int32_t w, mzhip_stream *arch, int lookahead, in
     pthread_cond_broadcast(&g_cv);
 }
 
-/* the imaging thread: windows of archives this process holds as files, one after the other, in the order they were asked for */
+/* the imaging threads (up to MZH_IMG_THREADS, started as they are needed): windows of archives this process holds as files, in the
+ * order they were asked for */
 typedef struct img_job_s {
     roll *r;
     int32_t w, lookahead, device; /* device: the one the reader that asked was on */
@@ -526,14 +541,17 @@ typedef struct img_job_s {
 } img_job;
 static img_job *g_q_head, *g_q_tail;
 static pthread_cond_t g_q_cv = PTHREAD_COND_INITIALIZER;
-static int g_img_thread; /* 0 not started, 1 running, -1 could not be started */
+static int g_img_threads, g_img_idle, g_img_failed; /* imaging threads started / waiting for work; one could not be started */
+#define MZH_IMG_THREADS 3 /* windows imaged at once: readers of several threads need their first windows at the same moment */
 
 static void *img_thread(void *arg) {
     (void)arg;
     pthread_mutex_lock(&g_mu);
     for (;;) {
+        g_img_idle++;
         while (!g_q_head)
             pthread_cond_wait(&g_q_cv, &g_mu);
+        g_img_idle--;
         img_job *j = g_q_head;
         g_q_head = j->next;
         if (!g_q_head)
@@ -572,14 +590,17 @@ static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget,
             return; /* (a window that is needed goes over the budget rather than without) */
         W->state = W_BUSY;
         r->busy++;
-        if (r->fd >= 0 && g_img_thread >= 0) { /* the imaging thread reads it; a needed window is waited for above */
-            if (g_img_thread == 0) {
+        if (r->fd >= 0 && !(g_img_failed && g_img_threads == 0)) { /* an imaging thread reads it; a needed window is waited for above */
+            if (g_img_idle == 0 && g_img_threads < MZH_IMG_THREADS && !g_img_failed) {
                 pthread_t t;
-                g_img_thread = pthread_create(&t, NULL, img_thread, NULL) == 0 ? 1 : -1;
-                if (g_img_thread > 0)
+                if (pthread_create(&t, NULL, img_thread, NULL) == 0) {
                     pthread_detach(t);
+                    g_img_threads++;
+                } else {
+                    g_img_failed = 1;
+                }
             }
-            img_job *j = g_img_thread > 0 ? (img_job *)malloc(sizeof(img_job)) : NULL;
+            img_job *j = g_img_threads > 0 ? (img_job *)malloc(sizeof(img_job)) : NULL;
             if (j) {
                 j->r = r;
                 j->w = w;
@@ -635,16 +656,9 @@ void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
     const int kib = endp && (*endp == 'k' || *endp == 'K');
     limit = (limit >= 1 ? (limit < (1 << 20) ? limit : (1 << 20)) : MZH_AUTOPRIME_DEFAULT_MIB) << (kib ? 10 : 20);
     const uint64_t budget = 4 * (uint64_t)limit;
-    pthread_mutex_lock(&g_mu);
-    g_tick++;
-    {
-        const uint64_t clears = mzhip_prime_clears();
-        if (clears != g_clears_seen) { /* somebody cleared the cache: it holds nothing of ours any more */
-            g_clears_seen = clears;
-            forget_everything();
-        }
-    }
-    /* where the stream stands; how long the archive is (one seek to where the tail starts, or to the end of a shorter one) */
+    /* where the stream stands; how long the archive is (one seek to where the tail starts, or to the end of a shorter one); which
+     * image it is: its size and a hash of its last 4 KiB (the end record and the central directory's end).  The stream is this
+     * thread's own: none of this is done under the lock the readers of other threads wait for. */
     const int64_t pos = arch->vtbl->tell(arch);
     int64_t size = -1;
     if (pos >= 0) {
@@ -657,18 +671,29 @@ void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
                 size = -1; /* (a stream that cannot do the first seek but is that long: not one to read through) */
         }
     }
-    if (pos >= 0 && size >= 0) {
+    if (pos < 0)
+        return;
+    uint8_t t4[MZH_TAIL4K];
+    const int64_t n4 = size < MZH_TAIL4K ? size : MZH_TAIL4K;
+    if (size < 22 || !read_all(arch, t4, n4)) { /* (the stream stands where the tail starts) */
+        arch->vtbl->seek(arch, pos, MZH_SEEK_SET);
+        return;
+    }
+    const uint64_t crc4 = tail_hash(t4, (size_t)n4);
+    pthread_mutex_lock(&g_mu);
+    g_tick++;
+    {
+        const uint64_t clears = mzhip_prime_clears();
+        if (clears != g_clears_seen) { /* somebody cleared the cache: it holds nothing of ours any more */
+            g_clears_seen = clears;
+            forget_everything();
+        }
+    }
+    {
         uint8_t *buf = NULL;
         int64_t *table = NULL;
         int dealt_with = 0;
-        /* which image is this?  its size and a hash of its last 4 KiB (the end record and the central directory's end) */
-        uint8_t t4[MZH_TAIL4K];
-        const int64_t n4 = size < MZH_TAIL4K ? size : MZH_TAIL4K;
-        uint64_t crc4 = 0;
         roll *R = NULL;
-        if (size < 22 || !read_all(arch, t4, n4)) /* (the stream stands where the tail starts) */
-            goto done;
-        crc4 = tail_hash(t4, (size_t)n4);
         for (int i = 0; i < MZH_ROLLS; i++)
             if (g_rolls[i] && g_rolls[i]->size == size && g_rolls[i]->crc4 == crc4)
                 R = g_rolls[i];
@@ -802,7 +827,7 @@ void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
     done:
         free(table);
         free(buf);
-        arch->vtbl->seek(arch, pos, MZH_SEEK_SET);
     }
     pthread_mutex_unlock(&g_mu);
+    arch->vtbl->seek(arch, pos, MZH_SEEK_SET);
 }
