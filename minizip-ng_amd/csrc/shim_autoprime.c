@@ -115,6 +115,7 @@ typedef struct {
     uint64_t stamp;   /* the call that used it last */
     uint32_t hits;    /* calls that used it since it went live */
     int32_t state, quick; /* quick: evictions in a row after fewer than 8 hits */
+    int32_t ahead;    /* primed as a look-ahead and not asked for yet: nobody's window so far */
 } roll_win;
 typedef struct {
     int64_t size;
@@ -417,7 +418,9 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
                 live++;
                 if (r == rk && (w == keep || (lookahead && w == keep + 1)))
                     continue;
-                if (g_tick - r->win[w].stamp <= MZH_ROLL_FRESH) { /* some reader is in it: several threads, a part of the archive each */
+                if (g_tick - r->win[w].stamp <= MZH_ROLL_FRESH || (r->win[w].ahead && r->win[w].hits == 0)) {
+                    /* some reader is in it (several threads, a part of the archive each) -- or some reader is about to be: a
+                     * look-ahead that has not been reached yet (its stamp is as old as its reader's window is long) */
                     if (fw < 0 || r->win[w].stamp < fr->win[fw].stamp) {
                         fr = r;
                         fw = w;
@@ -450,7 +453,8 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
         {
             /* the thrash guard: priming a window pays after about eight entries have been read from it (or all it has) */
             const int64_t all = v->r1 - v->r0;
-            v->quick = (int64_t)v->hits < (all < 8 ? all : 8) ? v->quick + 1 : 0;
+            if (!(v->ahead && v->hits == 0)) /* (a look-ahead nobody reached says nothing about the readers' pattern) */
+                v->quick = (int64_t)v->hits < (all < 8 ? all : 8) ? v->quick + 1 : 0;
         }
         v->state = v->quick >= 3 ? W_DEAD : W_NONE;
         v->stamp = g_tick; /* (a dead window comes back after MZH_ROLL_DEAD_FOR calls: the access pattern may have changed) */
@@ -514,6 +518,7 @@ static void roll_image(roll *r, int32_t w, mzhip_stream *arch, int lookahead, in
         W->state = W_LIVE;
         W->held = held;
         W->hits = 0;
+        W->ahead = lookahead;
         W->stamp = g_tick;
         g_live_bytes += held;
         if (g_live_bytes > g_peak_bytes)
