@@ -34,7 +34,9 @@ def _run(n, extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n,cfg,entries,unique", [(2, 2, 3001, 256), (4, 2, 5003, 256), (3, 3, 20000, 512), (4, 3, 30001, 512), (2, 4, 48, 6), (2, 5, 2000, 256)])
+# (8, ...): the rank count of the driver's SCALE run, as a dry run on one device
+@pytest.mark.parametrize("n,cfg,entries,unique", [(2, 2, 3001, 256), (4, 2, 5003, 256), (8, 2, 10007, 256), (3, 3, 20000, 512), (4, 3, 30001, 512), (8, 3, 40009, 512),
+                                                  (2, 4, 48, 6), (2, 5, 2000, 256)])
 def test_strong_scaling_line_accounts_for_every_entry(n, cfg, entries, unique):
     line = _run(n, ["--config", str(cfg), "--entries", str(entries), "--unique", str(unique)])
     assert line["n_gpus"] == n and line["scaling"] == "strong"
