@@ -23,14 +23,19 @@ def load(d, tag, kernel):
     kernel = kernel.rstrip("+")
     for i in (1, 2):
         rows = [r for r in csv.DictReader(open(os.path.join(d, "req_%s_%d.csv" % (tag, i)))) if kernel in r["Kernel_Name"]]  # (a substring: k_inflate_batch is "void k_inflate_batch<false>(InflateArgs)" since it became a template)
-        acc, dur = collections.defaultdict(list), {}
+        acc, dur, per_kernel = collections.defaultdict(list), {}, collections.Counter()
         for r in rows:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Dispatch_Id"] not in dur:
+                per_kernel[r["Kernel_Name"]] += 1
             dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        # '+': one STEP of the workload is one launch of each matching kernel; the command ran `steps` of them (the kernel launched
+        # most often says how many) -- the sums are per step
+        steps = max(per_kernel.values()) if (add and per_kernel) else 1
         for k, v in acc.items():
-            out[k] = sum(v) if add else sum(v) / len(v)
-        out["launches"] = 1 if add else len(dur)
-        out["kernel_ms_under_pmc"] = round(sum(dur.values()) / (1 if add else max(1, len(dur))), 3)
+            out[k] = sum(v) / steps if add else sum(v) / len(v)
+        out["launches"] = steps if add else len(dur)
+        out["kernel_ms_under_pmc"] = round(sum(dur.values()) / (steps if add else max(1, len(dur))), 3)
     n32, n64, n128 = out.get("TCC_EA0_RDREQ_32B_sum", 0), out.get("TCC_EA0_RDREQ_64B_sum", 0), out.get("TCC_EA0_RDREQ_128B_sum", 0)
     w, w64 = out.get("TCC_EA0_WRREQ_sum", 0), out.get("TCC_EA0_WRREQ_64B_sum", 0)
     rd = 32 * n32 + 64 * n64 + 128 * n128
