@@ -283,3 +283,65 @@ print("tsan run done")
     assert "tsan run done" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     mine = [ln for ln in r.stderr.split("WARNING: ThreadSanitizer") if "mzhip" in ln or "shim_" in ln or "roll_" in ln]
     assert not mine, mine[0][:3000]
+
+
+def test_rolling_over_archives_other_tools_wrote(libs, monkeypatch):
+    """The rolling prime takes its entry table from the central directory alone and a window's payload offsets from the local
+    headers it images: archives laid out by another writer (Python's zipfile) -- entries with data descriptors (flag bit 3: the
+    local headers hold no sizes), ZIP64 extended information on every entry, an archive comment, 5 KiB of foreign bytes in front
+    of the first local header -- are rolled over with every entry a cache hit and the all-reference reader's results."""
+    import io
+    import zipfile
+
+    hip, ref, L = libs
+    c = synth.corpus()
+    rnd = np.random.RandomState(11)
+
+    def members(n, size):
+        return [c[o:o + k] for o, k in zip(rnd.randint(0, len(c) - size, size=n), rnd.randint(1, size + 1, size=n))]
+
+    class NoSeek(io.RawIOBase):  # zipfile then writes data descriptors behind every payload
+        def __init__(self):
+            self.b = io.BytesIO()
+
+        def writable(self):
+            return True
+
+        def write(self, d):
+            return self.b.write(d)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        cases = []
+        ms = members(160, 12000)
+        ns = NoSeek()
+        with zipfile.ZipFile(ns, "w", zipfile.ZIP_DEFLATED) as z:
+            for i, m in enumerate(ms):
+                z.writestr("dd/%04d" % i, m)
+            z.comment = b"written through a stream that cannot seek " * 8
+        p = os.path.join(tmp, "dd.zip")
+        open(p, "wb").write(ns.b.getvalue())
+        cases.append((p, ms))
+        ms = members(160, 12000)
+        p = os.path.join(tmp, "z64.zip")
+        with zipfile.ZipFile(p, "w", zipfile.ZIP_DEFLATED) as z:
+            for i, m in enumerate(ms):
+                with z.open("z64/%04d" % i, "w", force_zip64=True) as f:
+                    f.write(m)
+        cases.append((p, ms))
+        ms = members(160, 12000)
+        p = os.path.join(tmp, "prefixed.zip")
+        open(p, "wb").write(bytes(rnd.bytes(5000)))
+        with zipfile.ZipFile(p, "a", zipfile.ZIP_DEFLATED) as z:
+            for i, m in enumerate(ms):
+                z.writestr("sfx/%04d" % i, m)
+        cases.append((p, ms))
+        monkeypatch.setenv("MZHIP_AUTOPRIME", "128k")
+        for p, ms in cases:
+            assert os.path.getsize(p) > (128 << 10)
+            lens = np.array([len(m) for m in ms], dtype=np.int32)
+            L.mzhip_prime_clear()
+            a0 = stats(L)
+            read_both(hip, ref, p, lens)
+            s = stats(L)
+            assert s["primed"] > a0["primed"] and s["hits"] >= len(ms) and s["misses"] == 0, (p, s)
+        L.mzhip_prime_clear()
