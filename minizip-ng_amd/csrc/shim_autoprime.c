@@ -35,9 +35,9 @@
  *     mzhip_prime_mem() would take and cut off at the bound);
  *   - whole image: this image (size + CRC of its last 64 KiB: the central directory) has not been primed already --
  *     readers of several threads prime it once -- nor three times before (an application that alternates between archives
- *     entry by entry would otherwise re-image them for ever); rolled over: a window that was evicted three times in a row
- *     before eight of its entries (or all it has) had been read is left to the per-entry path for the next 4096 entries
- *     (the same guard, per window).
+ *     entry by entry would otherwise re-image them for ever); rolled over: a window that was evicted four times in a row
+ *     before eight of its entries (a quarter of a small window's) had been read is left to the per-entry path for the next
+ *     4096 entries (the same guard, per window).
  * Which archive a stream belongs to is asked on EVERY call, not remembered by stream address (the allocator hands a freed
  * reader's address to the next one): its size and a hash of its last 4 KiB, read through the stream on every call.
  * The cache's other generations are never touched: a new whole image replaces the previous one THIS FILE made (by identity,
@@ -401,8 +401,9 @@ out:
     return r;
 }
 
-/* make room for `need` more page-locked bytes under `budget`: evict live windows, least recently used first, never `keep`
- * (of roll rk); for a look-ahead only windows nobody used in the last MZH_ROLL_FRESH calls.  1 = there is room now. */
+/* make room for `need` more bytes of cache under `budget`: evict live windows, least recently used first -- never `keep` (of
+ * roll rk), and windows some reader is in (used in the last MZH_ROLL_FRESH calls) or is about to be in (a look-ahead nobody
+ * has reached) only for a window that is NEEDED and would take the cache past twice the budget.  1 = go ahead. */
 static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_t keep, int lookahead) {
     for (;;) {
         int32_t live = 0;
@@ -451,15 +452,16 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
         g_live_bytes -= v->held;
         v->held = 0;
         {
-            /* the thrash guard: priming a window pays after about eight entries have been read from it (or all it has) */
-            const int64_t all = v->r1 - v->r0;
+            /* the thrash guard: priming a window pays after about eight entries have been read from it (a quarter of a small
+             * window's: readers of several threads meet in the windows where their shares touch) */
+            const int64_t all = v->r1 - v->r0, pays = all >= 32 ? 8 : (all >= 4 ? all / 4 : 1);
             if (!(v->ahead && v->hits == 0)) /* (a look-ahead nobody reached says nothing about the readers' pattern) */
-                v->quick = (int64_t)v->hits < (all < 8 ? all : 8) ? v->quick + 1 : 0;
+                v->quick = (int64_t)v->hits < pays ? v->quick + 1 : 0;
         }
-        v->state = v->quick >= 3 ? W_DEAD : W_NONE;
+        v->state = v->quick >= 4 ? W_DEAD : W_NONE;
         v->stamp = g_tick; /* (a dead window comes back after MZH_ROLL_DEAD_FOR calls: the access pattern may have changed) */
         if (v->state == W_DEAD && roll_trace())
-            fprintf(stderr, "[mzhip autoprime] window %d evicted three times in a row after fewer than eight hits: left to the per-entry path\n", vw);
+            fprintf(stderr, "[mzhip autoprime] window %d evicted four times in a row before it had paid for itself: left to the per-entry path\n", vw);
         g_windows_evicted++;
         if (roll_trace())
             fprintf(stderr, "[mzhip autoprime] window %d evicted after %u hits (%s); %llu bytes live\n", vw, v->hits, lookahead ? "look-ahead" : "needed",
@@ -549,14 +551,28 @@ static pthread_cond_t g_q_cv = PTHREAD_COND_INITIALIZER;
 static int g_img_threads, g_img_idle, g_img_failed; /* imaging threads started / waiting for work; one could not be started */
 #define MZH_IMG_THREADS 3 /* windows imaged at once: readers of several threads need their first windows at the same moment */
 
+static int g_quiesce, g_img_running; /* the process is exiting: no new window is taken up / windows being imaged right now */
+static pthread_cond_t g_quiet_cv = PTHREAD_COND_INITIALIZER;
+
+/* at exit (mzhip_prime.inc prime_at_exit): the imaging threads finish the window they are reading and take no other; windows
+ * still queued stay BUSY for ever -- nobody is going to ask */
+void mzhip_autoprime_quiesce(void) {
+    pthread_mutex_lock(&g_mu);
+    g_quiesce = 1;
+    while (g_img_running > 0)
+        pthread_cond_wait(&g_quiet_cv, &g_mu);
+    pthread_mutex_unlock(&g_mu);
+}
+
 static void *img_thread(void *arg) {
     (void)arg;
     pthread_mutex_lock(&g_mu);
     for (;;) {
         g_img_idle++;
-        while (!g_q_head)
+        while (!g_q_head || g_quiesce)
             pthread_cond_wait(&g_q_cv, &g_mu);
         g_img_idle--;
+        g_img_running++;
         img_job *j = g_q_head;
         g_q_head = j->next;
         if (!g_q_head)
@@ -564,6 +580,8 @@ static void *img_thread(void *arg) {
         pthread_mutex_unlock(&g_mu);
         roll_image(j->r, j->w, NULL, j->lookahead, j->device); /* (takes the lock again) */
         free(j);
+        g_img_running--;
+        pthread_cond_broadcast(&g_quiet_cv);
     }
     return NULL;
 }
@@ -578,7 +596,7 @@ static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget,
             W->held = 0;
             W->state = W_NONE;
         }
-        if (W->state == W_DEAD && W->quick >= 3 && g_tick - W->stamp > MZH_ROLL_DEAD_FOR) { /* given up for thrashing, long ago: once more */
+        if (W->state == W_DEAD && W->quick >= 4 && g_tick - W->stamp > MZH_ROLL_DEAD_FOR) { /* given up for thrashing, long ago: once more */
             W->quick = 0;
             W->state = W_NONE;
         }

@@ -50,7 +50,7 @@ with tempfile.TemporaryDirectory() as tmp:
     for it in range(cases):
         method = rnd.choice((8, 8, 8, 8, 14, 95))
         n = rnd.randint(3, 120 if method != 8 else 400 * scale)
-        top = rnd.choice((300, 3000, 20000, 70000 if method == 8 else 30000)) * (scale if method == 8 else 1)
+        top = min(rnd.choice((300, 3000, 20000, 70000 if method == 8 else 30000)) * (scale if method == 8 else 1), len(c) // 2)
         lens = np.array([rnd.choice((0, 1, rnd.randint(0, top), rnd.randint(0, top))) for _ in range(n)], dtype=np.int32)
         offs = np.array([rnd.randint(0, len(c) - int(top) - 1) for _ in range(n)], dtype=np.int64)
         path = os.path.join(tmp, "f%d.zip" % it)
