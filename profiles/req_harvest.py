@@ -54,6 +54,8 @@ def kernel_src_hash():
     h = hashlib.sha1()
     d = os.path.join(ROOT, "minizip-ng_amd", "csrc")
     for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.hip"))):
+        if os.path.basename(f) in ("mzhip_prime.inc", "shim_common.h"):  # the host-side prime cache and the shims' glue: nothing a kernel or its launch sees
+            continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
