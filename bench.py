@@ -567,7 +567,8 @@ def full_archive_legs(mz, path, n, size, want_crc_np, cores, with_reference):
                                      limit, so it is rolled over window by window ahead of the reader (shim_autoprime.c, round 6);
                                      peak page-locked bytes of the windows beside it
       vtbl_unprimed_cfg2_archive_T   the same with T reader threads, a contiguous share of the entries each
-      vtbl_unprimed_cfg2_mapped      one thread, the reader on mz_stream_mem over a mapping (mzdrop_extract_all without a prime)
+      vtbl_unprimed_cfg2_mapped      one thread, the reader on mz_stream_mem over a mapping (mzdrop_extract_all without a prime; the
+                                     windows are imaged through the readers' memory streams); _mapped_T: T such readers
     and, with_reference, the CPU baseline of record as BASELINE.md 3 defines it: the reference's reader over the same file,
     whole archive, cores threads, median of 3 (+ one thread on a slice)."""
     out, cb = {}, None
@@ -590,7 +591,7 @@ def full_archive_legs(mz, path, n, size, want_crc_np, cores, with_reference):
     had = os.environ.pop("MZHIP_AUTOPRIME", None)
     try:
         for key, T, mapped in (("vtbl_unprimed_cfg2_archive", 1, False), ("vtbl_unprimed_cfg2_archive_T", max(2, min(8, cores // 2)), False),
-                               ("vtbl_unprimed_cfg2_mapped", 1, True)):
+                               ("vtbl_unprimed_cfg2_mapped", 1, True), ("vtbl_unprimed_cfg2_mapped_T", max(2, min(8, cores // 2)), True)):
             if mapped and fsize > 0x7FFFFFFF:
                 continue
             best, info = None, ""
