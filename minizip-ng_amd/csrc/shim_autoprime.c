@@ -273,7 +273,7 @@ static roll *roll_new(mzhip_stream *arch, int64_t size, uint64_t crc4, uint64_t 
             goto out;
         from = need;
     }
-    if (n < MZH_AUTOPRIME_MIN_ENTRIES || n > (1 << 26))
+    if (n < MZH_AUTOPRIME_MIN_ENTRIES || n > (1 << 23)) /* (eight million entries: the table and the Hash fields are ~130 bytes a row) */
         goto out;
     table = (int64_t *)malloc((size_t)n * 8 * sizeof(int64_t));
     if (!table || mzhip_zip_index_tail(tail, from, (uint64_t)size, table, n, NULL) != n)
