@@ -60,7 +60,8 @@ case "$mode" in
 build)
   for v in "$@"; do
     set -- $v; tag=$1; shift
-    ( make -s -C "$B/csrc" OUT=../_build_ab_$tag "$@" > /tmp/ab_build_$tag.log 2>&1 && echo "built $tag ($*)" || { echo "FAILED $tag"; tail -5 /tmp/ab_build_$tag.log; } ) &
+    args=(); for a in "$@"; do args+=("${a//%/ }"); done   # (a % inside a variable's value stands for a space: EXTRA=-DA=1%-DB=2)
+    ( make -s -C "$B/csrc" OUT=../_build_ab_$tag "${args[@]}" > /tmp/ab_build_$tag.log 2>&1 && echo "built $tag ($*)" || { echo "FAILED $tag"; tail -5 /tmp/ab_build_$tag.log; } ) &
     while [ $(jobs -r | wc -l) -ge ${AB_JOBS:-6} ]; do sleep 1; done
   done
   wait ;;

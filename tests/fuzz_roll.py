@@ -1,7 +1,7 @@
 """Differential fuzz of the auto-prime (not a pytest): random archives through the unmodified reader loop on the drop-in against the
 all-reference reader -- sizes, entry counts, methods, reader threads, whole-image limit (so that some archives are imaged whole, most
 are rolled over in windows of many sizes), imaging through the archive's own descriptor or through the readers' streams, a
-clear now and then, sometimes one flipped payload byte (that entry must fail on both sides, every other one must not).
+clear now and then, entries read front to back, back to front or in a random order, sometimes one flipped payload byte (that entry must fail on both sides, every other one must not).
 
     python tests/fuzz_roll.py [cases=200] [seed=1] [library]
 
@@ -56,18 +56,32 @@ with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "f%d.zip" % it)
         ref.zip_write(path, c, offs, lens, method=method, level=rnd.choice((1, 6, 9)))
         table = ref.zip_index(path)
-        victim = -1
+        victim, cd_victim = -1, -1
         if rnd.random() < 0.25:
             cand = [i for i in range(n) if table[i, 3] > 24]
             if cand:
                 victim = rnd.choice(cand)
+                cd_victim = int(table[victim, 6])
                 raw = bytearray(open(path, "rb").read())
                 raw[int(table[victim, 7]) + rnd.randint(8, int(table[victim, 3]) - 8)] ^= 1 << rnd.randrange(8)
                 open(path, "wb").write(raw)
         cd = table[:, 6].copy()
+        if rnd.random() < 0.3:
+            # not front to back: a random order (windows are primed, evicted and primed again; the thrash guard may give some up:
+            # slower, never different), or back to front
+            perm = np.array(rnd.sample(range(n), n)) if rnd.random() < 0.6 else np.arange(n)[::-1]
+            cd, lens, table = cd[perm], lens[perm], table[perm]
         out_off = np.concatenate(([0], np.cumsum(lens[:-1].astype(np.int64))))
-        o_ref = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
-        o_hip = np.zeros(int(lens.sum()) + 1, dtype=np.uint8)
+        pad = 1
+        if victim >= 0:
+            # a stream with a flipped bit may decode to MORE than its declared size before it is refused (nothing bounds a DEFLATE
+            # stream's output, mz_strm_zlib.c:116-193), and the driver copies what it is handed: the victim's bytes go behind
+            # everybody else's, with room to spare, so that they cannot land in a neighbour's slot
+            where = int(np.nonzero(table[:, 6] == cd_victim)[0][0])
+            out_off[where] = int(lens.sum())
+            pad = int(lens[where]) + (16 << 20)
+        o_ref = np.zeros(int(lens.sum()) + pad, dtype=np.uint8)
+        o_hip = np.zeros(int(lens.sum()) + pad, dtype=np.uint8)
         _, crc_r, ulen_r, st_r = ref.zip_read_all(path, cd, nthreads=1, own_crc=False, out=o_ref, out_off=out_off)
         limit = rnd.choice(("32k", "64k", "128k", "512k", "2", "512"))
         os.environ["MZHIP_AUTOPRIME"] = limit
@@ -90,6 +104,9 @@ with tempfile.TemporaryDirectory() as tmp:
                 pass  # (the flip fell where the stream does not care: both sides decode it)
             if not same:
                 bad += 1
+                why = "statuses" if not ((st_h == 0) == good).all() else "crc" if not (crc_h[good] == crc_r[good]).all() else "sizes" if not (ulen_h[good] == ulen_r[good]).all() else "bytes"
+                idx = [int(i) for i in np.nonzero(good)[0] if not np.array_equal(o_hip[int(out_off[i]):int(out_off[i]) + int(lens[i])], o_ref[int(out_off[i]):int(out_off[i]) + int(lens[i])])][:5]
+                print("  differs in: %s; entries with other bytes %s; the failed entries ref %s hip %s; sizes there %s" % (why, idx, np.nonzero(st_r)[0][:5], np.nonzero(st_h)[0][:5], lens[idx] if idx else ""), flush=True)
                 print("case %d pass %d: method %d, %d entries, limit %s, %d threads, mapped %s, fd %s: statuses ref %s hip %s, last error %r" % (
                     it, p, method, n, limit, threads, mapped, os.environ["MZHIP_AUTOPRIME_FD"], st_r[st_r != 0][:5], st_h[st_h != 0][:5], L.mzhip_last_error()), flush=True)
         w = [C.c_uint64() for _ in range(4)]
