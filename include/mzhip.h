@@ -452,6 +452,12 @@ MZHIP_API void mzhip_set_write_segment(int64_t segment_bytes);
 /* Window mode of mz_stream_zlib READ offers every window that starts at a block header to mzhip_inflate_parallel_host first
  * (a wave per DEFLATE block); 0 turns that off (MZHIP_STREAM_PARALLEL=0 in the environment does the same). */
 MZHIP_API void mzhip_set_stream_parallel(int32_t on);
+/* ... and while the caller is served one such window, a thread of the stream's own has the device decode the next one (the two
+ * buffers swap when the caller has used the first up); 0 turns that off (MZHIP_STREAM_LOOKAHEAD=0 does the same): the device
+ * call and the serving then take turns.  What the caller sees -- bytes, return values, totals, errors -- is the same either way.
+ * mzhip_stream_lookahead_windows(): windows taken over from such a thread so far, all streams of the process. */
+MZHIP_API void mzhip_set_stream_lookahead(int32_t on);
+MZHIP_API uint64_t mzhip_stream_lookahead_windows(void);
 /* page-locked host memory for a READ stream's window buffer, from the library's pool (next to the current device; NULL when
  * there is none to be had -- the caller then uses plain memory); *cap = what to hand back to mzhip_window_free */
 MZHIP_API void *mzhip_window_alloc(size_t bytes, size_t *cap);

@@ -43,6 +43,7 @@
 #define _POSIX_C_SOURCE 200112L /* clock_gettime */
 #endif
 #include <stdio.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -123,6 +124,38 @@ typedef struct mzhip_zlib_s {
     int64_t par_bytes, serial_bytes;
     int32_t par_miss;       /* windows in a row the many-wave decode got (next to) nothing out of */
     int32_t par_rest;       /* serial windows to go before it is tried again */
+    /* ... and AHEAD of the caller (round 6): while read() calls are served from the window in out[], a thread of the stream's own
+     * runs the next many-wave window into out2[] = [the last 96 KiB of out[] | room]; stream_next() then swaps the two.  The
+     * decode call and its arguments are the ones stream_next() would have made a moment later: what a caller can observe
+     * (bytes, return values, verdicts and the call that reports them) does not know the difference; the base stream is pulled
+     * one gulp earlier.  The device call and the serving of a window used to take turns: half of a large entry's time each. */
+    uint8_t *out2;
+    int8_t out2_pinned;
+    size_t out2_pin_cap;
+    uint32_t *pc_tmp2;
+    int32_t pc_tmp2_cap;
+    pthread_t la_thread;    /* the stream's look-ahead thread: started with the first window that is decoded ahead, joined at close (a
+                             * thread per window paid the HIP runtime's per-thread set-up every 64 MiB: 7 ms of a window's 13) */
+    pthread_mutex_t la_mu;
+    pthread_cond_t la_cv;
+    int8_t la_started;      /* the thread exists */
+    int8_t la_job;          /* 0 none, 1 posted / running, 2 done, 3 the thread is to exit */
+    int8_t la_active;       /* a window is on its way (or done and not taken over): nothing touches in[], out2[], pc_tmp2 or la but the thread */
+    struct {
+        mzhip_inflate_state st_in, st_out;
+        uint32_t show, hist, pol, pb, pended, wcrc, wadler, nseg, seg_first, stride;
+        int32_t pr, device;
+        int64_t gnew, bit0;
+        double t;
+    } la;
+    double t_wait;          /* (MZHIP_STREAM_STATS) seconds stream_next() waited for that thread */
+    int32_t n_ahead;        /* windows decoded ahead */
+    int32_t n_attempts;     /* (stats) whole-entry decodes asked of the device before window mode */
+    int64_t gulp_ramp;      /* window mode: compressed bytes pulled ahead of the next window; grows fourfold per window up to mzh_stream_gulp() */
+    double t_begin;         /* (stats) when window mode began */
+    double t_attempts;      /* (stats) seconds inside those decodes */
+    double t_posted, t_overlap, t_book; /* (stats) when the last one was posted; reader time between a post and the next wait; the
+                                         * reader's own work between a wait's end and the next post (take-over, input pull, history copy) */
     /* write side */
     uint8_t *wbuf;
     int64_t wlen, wcap;
@@ -216,7 +249,9 @@ static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
     return base->vtbl->read(base, buf, size);
 }
 
+static void lookahead_cancel(mzhip_zlib *z);
 static void free_buffers(mzhip_zlib *z) {
+    lookahead_cancel(z); /* (the look-ahead thread reads in[] and writes out2[]: it is joined before either goes) */
     in_release(z);
     free(z->pc);
     free(z->pc_tmp);
@@ -252,7 +287,10 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->streaming = z->stream_end = 0;
     z->trailer_err = 0;
     z->kind_known = z->kind_no_room = 0;
-    z->t_par = z->t_serial = z->t_pull = 0.0;
+    z->t_par = z->t_serial = z->t_pull = z->t_wait = z->t_overlap = z->t_book = z->t_posted = 0.0;
+    z->n_ahead = 0;
+    z->n_attempts = 0;
+    z->t_attempts = 0.0;
     z->t_open = mzh_now();
     z->n_par = z->n_serial = 0;
     z->par_bytes = z->serial_bytes = 0;
@@ -566,7 +604,7 @@ int64_t mzh_stream_gulp(void) {
 #define MZH_PAR_MIN_ROOM (1 << 20) /* room in the window below which it is not offered; output below which an offer counts as a miss */
 #endif
 #ifndef MZH_STREAM_EARLY
-#define MZH_STREAM_EARLY (1 << 20) /* compressed bytes pulled, entry not over: window mode from here on */
+#define MZH_STREAM_EARLY (256 << 10) /* compressed bytes pulled, entry not over: window mode from here on */
 #endif
 #ifndef MZH_STREAM_EARLY_OUT
 #define MZH_STREAM_EARLY_OUT (4 << 20) /* ... or decoded bytes */
@@ -581,6 +619,18 @@ static int32_t mzh_stream_parallel(void) {
         __atomic_store_n(&mzh_par_mode, m, __ATOMIC_RELAXED);
     }
     return m;
+}
+
+/* How far window mode pulls ahead of a window.  The entry's compressed size is not known here (mz_zip.c:1815-1830 sets
+ * MZ_STREAM_PROP_TOTAL_IN_MAX for raw, stored and encrypted entries only), and what is pulled behind the entry's end is
+ * read for nothing: 1 MiB in front of the first window, four times as much per window after it, up to the gulp. */
+static int64_t gulp_now(const mzhip_zlib *z) {
+    const int64_t g = mzh_stream_gulp();
+    return z->gulp_ramp > 0 && z->gulp_ramp < g ? z->gulp_ramp : g;
+}
+static void gulp_grow(mzhip_zlib *z) {
+    if (z->gulp_ramp > 0 && z->gulp_ramp < mzh_stream_gulp())
+        z->gulp_ramp *= 4;
 }
 
 static int32_t stream_drop_input(mzhip_zlib *z) {
@@ -706,9 +756,263 @@ static int32_t stream_finish(mzhip_zlib *z, int64_t used) {
     return want == z->run_adler ? verdict(z, MZHIP_STATUS_OK, used + 4) : trailer_verdict(z, used + 4);
 }
 
+/* ---- window mode, one window ahead (see the struct) ---- */
+#define MZH_LA_HIST 98304 /* bytes of out[] that go in front of the next window: the 32 KiB of history and what may not have been served yet */
+int32_t mzhip_prime_current_device(void);   /* (mzhip_prime.inc) the calling thread's device */
+void mzhip_thread_use_device(int32_t dev);  /* (mzhip_runtime.inc) ... and making it another thread's */
+static int8_t mzh_la_mode = -1;
+static uint64_t mzh_la_windows; /* windows taken over from a look-ahead thread, all streams (tests, reports) */
+MZHIP_API void mzhip_set_stream_lookahead(int32_t on) { __atomic_store_n(&mzh_la_mode, (int8_t)(on ? 1 : 0), __ATOMIC_RELAXED); }
+MZHIP_API uint64_t mzhip_stream_lookahead_windows(void) { return __atomic_load_n(&mzh_la_windows, __ATOMIC_RELAXED); }
+static int32_t mzh_stream_lookahead(void) {
+    int8_t m = __atomic_load_n(&mzh_la_mode, __ATOMIC_RELAXED);
+    if (m < 0) {
+        const char *e = getenv("MZHIP_STREAM_LOOKAHEAD"); /* "0": the device call and the serving take turns, as before round 6 */
+        m = (e && e[0] == '0') ? 0 : 1;
+        __atomic_store_n(&mzh_la_mode, m, __ATOMIC_RELAXED);
+    }
+    return m;
+}
+static void *lookahead_run(void *arg) {
+    mzhip_zlib *z = (mzhip_zlib *)arg;
+    int32_t dev = -2;
+    pthread_mutex_lock(&z->la_mu);
+    for (;;) {
+        while (z->la_job != 1 && z->la_job != 3)
+            pthread_cond_wait(&z->la_cv, &z->la_mu);
+        if (z->la_job == 3)
+            break;
+        pthread_mutex_unlock(&z->la_mu);
+        if (z->la.device >= 0 && z->la.device != dev) {
+            dev = z->la.device;
+            mzhip_thread_use_device(dev);
+        }
+        const double t0 = mzh_now();
+        z->la.pr = mzhip_inflate_parallel_host(z->in, z->la.show, z->out2, (uint32_t)z->out_cap, &z->la.st_in, &z->la.st_out, &z->la.pol, &z->la.pb,
+                                               &z->la.pended, z->wrap == 2 ? &z->la.wcrc : NULL, z->wrap == 1 ? &z->la.wadler : NULL, z->la.seg_first,
+                                               z->pc_tmp2_cap ? z->la.stride : 0u, z->pc_tmp2, (uint32_t)z->pc_tmp2_cap, &z->la.nseg);
+        z->la.t = mzh_now() - t0;
+        pthread_mutex_lock(&z->la_mu);
+        z->la_job = 2;
+        pthread_cond_broadcast(&z->la_cv);
+    }
+    pthread_mutex_unlock(&z->la_mu);
+    return NULL;
+}
+/* wait for the window that is on its way (if one is) */
+static void lookahead_wait(mzhip_zlib *z) {
+    if (!z->la_active)
+        return;
+    pthread_mutex_lock(&z->la_mu);
+    while (z->la_job == 1)
+        pthread_cond_wait(&z->la_cv, &z->la_mu);
+    z->la_job = 0;
+    pthread_mutex_unlock(&z->la_mu);
+    z->la_active = 0;
+}
+static void lookahead_cancel(mzhip_zlib *z) {
+    lookahead_wait(z);
+    if (z->la_started) {
+        pthread_mutex_lock(&z->la_mu);
+        z->la_job = 3;
+        pthread_cond_broadcast(&z->la_cv);
+        pthread_mutex_unlock(&z->la_mu);
+        pthread_join(z->la_thread, NULL);
+        pthread_mutex_destroy(&z->la_mu);
+        pthread_cond_destroy(&z->la_cv);
+        z->la_started = 0;
+        z->la_job = 0;
+    }
+    if (z->out2) {
+        if (z->out2_pinned)
+            mzhip_window_free(z->out2, z->out2_pin_cap);
+        else
+            free(z->out2);
+    }
+    z->out2 = NULL;
+    z->out2_pinned = 0;
+    free(z->pc_tmp2);
+    z->pc_tmp2 = NULL;
+    z->pc_tmp2_cap = 0;
+}
+/* the many-wave decode has just delivered a window and stands at a block header: start the next one.  Nothing happens when
+ * anything is not as the steady state of a large entry has it -- stream_next() then does what it always did. */
+static void lookahead_start(mzhip_zlib *z, int32_t par_on) {
+    if (!mzh_stream_lookahead() || !par_on || z->la_active || z->stream_end || z->par_rest > 0 || z->par_miss > 0 || z->sst.bit != z->sst.hdr_bit ||
+        !(z->sst.flags & 1u) || z->out_len < 32768)
+        return;
+    const int64_t gulp = gulp_now(z);
+    while (!z->base_eof && z->in_len < gulp) { /* the gulp the next window would have pulled */
+        const double tp0 = mzh_now();
+        const int32_t rd = pull_chunk(z);
+        z->t_pull += mzh_now() - tp0;
+        if (rd < 0) {
+            if (z->in_len == 0)
+                return;
+            z->base_err = rd;
+            z->base_eof = 1;
+        }
+    }
+    gulp_grow(z);
+    const int64_t hist = z->out_len < MZH_LA_HIST ? z->out_len : MZH_LA_HIST;
+    if (z->in_len < MZH_PAR_MIN_IN || z->out_cap - hist < MZH_PAR_MIN_ROOM)
+        return;
+    if (!z->out2) {
+        size_t cap = 0;
+        z->out2 = (uint8_t *)mzhip_window_alloc((size_t)z->out_cap, &cap);
+        z->out2_pinned = z->out2 != NULL;
+        z->out2_pin_cap = cap;
+        if (!z->out2)
+            z->out2 = (uint8_t *)malloc((size_t)z->out_cap);
+        if (!z->out2)
+            return;
+    }
+    const uint32_t stride = (uint32_t)z->read_stride;
+    if (stride) {
+        const int32_t want = (int32_t)(z->out_cap / stride) + 4;
+        if (want > z->pc_tmp2_cap) {
+            free(z->pc_tmp2);
+            z->pc_tmp2 = (uint32_t *)malloc((size_t)want * sizeof(uint32_t));
+            z->pc_tmp2_cap = z->pc_tmp2 ? want : 0;
+        }
+    }
+    memcpy(z->out2, z->out + (z->out_len - hist), (size_t)hist);
+    z->la.st_in = z->sst;
+    z->la.st_in.out_pos = (uint32_t)hist;
+    z->la.st_in.flags = 1;
+    z->la.hist = (uint32_t)hist;
+    z->la.gnew = z->g0 + z->out_len;
+    z->la.stride = stride;
+    z->la.seg_first = stride ? (uint32_t)((stride - z->la.gnew % stride) % stride) : 0u;
+    int64_t show = z->in_len;
+    if (z->par_in_q16 > 0) {
+        const int64_t est = (int64_t)(z->sst.hdr_bit >> 3) + (((z->out_cap - hist) * z->par_in_q16) >> 15) + (256 << 10);
+        if (est < show)
+            show = est;
+    }
+    z->la.show = (uint32_t)show;
+    z->la.bit0 = z->sst.hdr_bit;
+    z->la.pol = z->la.pb = z->la.pended = z->la.nseg = 0;
+    z->la.wcrc = 0;
+    z->la.wadler = 1;
+    z->la.pr = 0;
+    z->la.device = mzhip_prime_current_device();
+    if (!z->la_started) {
+        if (pthread_mutex_init(&z->la_mu, NULL) != 0)
+            return;
+        if (pthread_cond_init(&z->la_cv, NULL) != 0) {
+            pthread_mutex_destroy(&z->la_mu);
+            return;
+        }
+        z->la_job = 0;
+        if (pthread_create(&z->la_thread, NULL, lookahead_run, z) != 0) {
+            pthread_mutex_destroy(&z->la_mu);
+            pthread_cond_destroy(&z->la_cv);
+            return;
+        }
+        z->la_started = 1;
+    }
+    pthread_mutex_lock(&z->la_mu);
+    z->la_job = 1;
+    pthread_cond_broadcast(&z->la_cv);
+    pthread_mutex_unlock(&z->la_mu);
+    z->la_active = 1;
+    z->t_posted = mzh_now();
+}
+/* stream_next(): is a window there that was decoded ahead?  1 = taken over (*ret is stream_next's answer), 0 = no: go on as ever
+ * (*skip_par: the many-wave decode has just been asked at this very header and had nothing) */
+static int32_t lookahead_adopt(mzhip_zlib *z, int32_t *ret, int32_t *skip_par) {
+    if (!z->la_active)
+        return 0;
+    const double tw0 = mzh_now();
+    z->t_overlap += tw0 - z->t_posted;
+    lookahead_wait(z);
+    z->t_wait += mzh_now() - tw0;
+    z->t_par += z->la.t;
+    z->n_par++;
+    if (z->la.pr < 0) {
+        z->stream_end = 1;
+        *ret = verdict(z, MZH_STREAM_ERROR, z->in_dropped); /* device / runtime failure */
+        return 1;
+    }
+    if (!z->la.pb) { /* (next to) nothing for a wave of its own at this header: as if stream_next() had asked */
+        z->par_miss++;
+        *skip_par = 1;
+        return 0;
+    }
+    /* out2[] = [hist bytes of out[]'s end | the new window]: it becomes out[] */
+    const int64_t unserved = z->out_len - z->out_served, hist = z->la.hist;
+    if (unserved > hist) { /* (cannot be: stream_next() is called with less than 64 KiB unserved) */
+        *skip_par = 0;
+        return 0;
+    }
+    mzhip_served_drop();
+    {
+        uint8_t *t = z->out;
+        const int8_t tp = z->out_pinned;
+        const size_t tc = z->out_pin_cap;
+        z->out = z->out2;
+        z->out_pinned = z->out2_pinned;
+        z->out_pin_cap = z->out2_pin_cap;
+        z->out2 = t;
+        z->out2_pinned = tp;
+        z->out2_pin_cap = tc;
+        uint32_t *q = z->pc_tmp;
+        const int32_t qc = z->pc_tmp_cap;
+        z->pc_tmp = z->pc_tmp2;
+        z->pc_tmp_cap = z->pc_tmp2_cap;
+        z->pc_tmp2 = q;
+        z->pc_tmp2_cap = qc;
+    }
+    z->g0 += z->out_len - hist;
+    z->out_served = hist - unserved;
+    z->out_len = hist;
+    const int64_t made = (int64_t)z->la.pol - hist;
+    z->par_bytes += made;
+    z->n_ahead++;
+    __atomic_fetch_add(&mzh_la_windows, 1, __ATOMIC_RELAXED);
+    if (z->la.nseg)
+        stream_pieces_add(z, z->la.gnew, made, z->la.seg_first, z->la.stride, z->la.nseg);
+    if (made > 0)
+        z->par_in_q16 = ((((int64_t)z->la.st_out.hdr_bit - z->la.bit0) >> 3) << 16) / made + 1;
+    stream_sum(z, made, z->la.wcrc, z->la.wadler);
+    z->out_len = z->la.pol;
+    z->sst = z->la.st_out;
+    if (z->la.pended) {
+        z->stream_end = 1;
+        *ret = stream_finish(z, z->in_dropped + (((int64_t)z->la.st_out.bit + 7) >> 3));
+        return 1;
+    }
+    stream_drop_input(z);
+    z->par_miss = made >= MZH_PAR_MIN_ROOM ? 0 : z->par_miss + 1;
+    if (z->par_miss >= 3) {
+        z->par_miss = 2;
+        z->par_rest = 8;
+    }
+    if (z->out_len > z->out_served) {
+        *ret = 0;
+        return 1;
+    }
+    return 0; /* (nothing new to serve: the loop of stream_next() goes on from the new state) */
+}
+
 /* window mode: make more decoded bytes available behind out_served.  Returns 0 (bytes, the stream end or a verdict are
  * there) or a negative MZ error. */
 static int32_t stream_next(mzhip_zlib *z) {
+    int32_t skip_par = 0;
+    {
+        int32_t ret = 0;
+        const double tb0 = mzh_now(), tw = z->t_wait;
+        if (lookahead_adopt(z, &ret, &skip_par)) {
+            if (ret == 0 && !z->stream_end) { /* (the same test the synchronous window makes below) */
+                const int32_t par_on = mzh_stream_parallel() && z->in_len < ((int64_t)1 << 28) && mzh_stream_gulp() >= MZH_PAR_MIN_IN &&
+                                       z->out_cap >= 2 * (int64_t)MZH_PAR_MIN_ROOM;
+                lookahead_start(z, par_on);
+            }
+            z->t_book += (mzh_now() - tb0) - (z->t_wait - tw);
+            return ret;
+        }
+    }
     /* little left to serve: slide.  What stays is what has not been served yet and, in any case, the last 32 KiB that
      * were produced (the history back-references may reach); the rest of the buffer is room for the next window */
     if (z->out_len - z->out_served < 65536) {
@@ -725,7 +1029,8 @@ static int32_t stream_next(mzhip_zlib *z) {
     for (;;) {
         /* compressed bytes for about a window: pull ahead (each pull <= 32767 bytes like the reference's) */
         const double tp0 = mzh_now();
-        while (!z->base_eof && z->in_len < mzh_stream_gulp()) {
+        const int64_t gulp = gulp_now(z);
+        while (!z->base_eof && z->in_len < gulp) {
             const int32_t rd = pull_chunk(z);
             if (rd < 0) {
                 if (z->in_len == 0)
@@ -734,6 +1039,7 @@ static int32_t stream_next(mzhip_zlib *z) {
                 z->base_eof = 1;
             }
         }
+        gulp_grow(z);
         z->t_pull += mzh_now() - tp0;
         z->sst.out_pos = (uint32_t)z->out_len;
         z->sst.flags = 1;
@@ -754,7 +1060,13 @@ static int32_t stream_next(mzhip_zlib *z) {
         /* (windows and gulps too small to be offered -- the tests' -- never ask the serial kernel for block boundaries either) */
         const int32_t par_on = mzh_stream_parallel() && z->in_len < ((int64_t)1 << 28) && mzh_stream_gulp() >= MZH_PAR_MIN_IN &&
                                z->out_cap >= 2 * (int64_t)MZH_PAR_MIN_ROOM;
-        if (par_on && z->par_rest > 0)
+        if (par_on && skip_par) {
+            skip_par = 0; /* (asked ahead of time, at this header: nothing for it) */
+            if (z->par_miss >= 3) {
+                z->par_miss = 2;
+                z->par_rest = 8;
+            }
+        } else if (par_on && z->par_rest > 0)
             z->par_rest--;
         else if (par_on && z->sst.bit == z->sst.hdr_bit && z->in_len >= MZH_PAR_MIN_IN && z->out_cap - z->out_len >= MZH_PAR_MIN_ROOM) {
             uint32_t pb = 0, pended = 0, pol = 0;
@@ -803,8 +1115,10 @@ static int32_t stream_next(mzhip_zlib *z) {
                 z->par_rest = 8;
             }
             if (pb) {
-                if (z->out_len > z->out_served)
+                if (z->out_len > z->out_served) {
+                    lookahead_start(z, par_on); /* the next window, while this one is served */
                     return 0;
+                }
                 continue;
             }
             nseg = 0;
@@ -895,7 +1209,7 @@ static int32_t stream_next(mzhip_zlib *z) {
             continue;
         }
         /* input ended inside the window and the base stream has more: go on with it (what was decoded so far stays) */
-        if (z->in_len >= mzh_stream_gulp()) { /* a single block larger than the gulp: let the input buffer grow */
+        if (z->in_len >= gulp_now(z)) { /* a single block larger than the gulp: let the input buffer grow */
             int tries = 0;
             while (!z->base_eof && tries++ < 512) {
                 const int32_t rd = pull_chunk(z);
@@ -910,6 +1224,35 @@ static int32_t stream_next(mzhip_zlib *z) {
     }
 }
 
+/* from here on the entry is decoded window by window (out[] is a window already) */
+static int32_t window_mode_begin(mzhip_zlib *z) {
+    z->streaming = 1;
+    z->t_begin = mzh_now();
+    z->gulp_ramp = 4 * (int64_t)MZH_STREAM_EARLY;
+    if (!z->in_pinned) { /* (room for a gulp and the pull that crosses it; grows like any in[] if a block needs more) */
+        int64_t want = mzh_stream_gulp() + 2 * MZH_STAGING_BYTES;
+        if (want < z->in_cap)
+            want = z->in_cap;
+        (void)in_grow(z, want);
+    }
+    z->in_dropped = 0;
+    if (z->hdr_len > 0) { /* the wrapper's header is done with: positions stay those of the whole stream */
+        memmove(z->in, z->in + z->hdr_len, (size_t)(z->in_len - z->hdr_len));
+        z->in_len -= z->hdr_len;
+        z->in_dropped = z->hdr_len;
+    }
+    z->run_crc = 0;
+    z->run_adler = 1;
+    z->run_n = 0;
+    memset(&z->sst, 0, sizeof(z->sst));
+    z->out_len = z->out_served = 0;
+    const int32_t sr = stream_next(z);
+    if (sr < 0)
+        return sr;
+    z->decoded = 1; /* (bytes are there; the verdict comes with the last window) */
+    return 0;
+}
+
 static int32_t attempt_decode(mzhip_zlib *z) {
     if (z->wrap != 0 && z->hdr_len == 0) {
         const int32_t h = parse_wrapper_header(z);
@@ -920,9 +1263,24 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             return 1;
         }
     }
+    if (!z->payload_done && !z->streaming && mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
+        (z->max_total_in >= (int64_t)MZH_STREAM_EARLY + z->hdr_len || (!z->base_eof && z->in_len - z->hdr_len >= MZH_STREAM_EARLY - (MZH_STREAM_EARLY >> 6)))) { /* (pulls are 32 767 bytes: 8 of them are 262 136) */
+        /* the stream is long enough for window mode -- the caller has said so (MZ_STREAM_PROP_TOTAL_IN_MAX: mz_zip.c sets it for
+         * raw, stored and encrypted entries), or that much has been pulled and the attempts on the first 32, 64 and 128 KiB all
+         * ran out of input: straight there.  (Up to round 6 the attempts went on to 1 MiB, each from the first byte, on one wave:
+         * 10 of them, 0.16 of the 0.38 s a 1 GiB entry took, profiles/r6/large_entry_lookahead.log.) */
+        if (z->out_cap < mzh_stream_window()) {
+            out_release(z);
+            z->out = out_window_alloc(z, mzh_stream_window());
+            z->out_cap = z->out ? mzh_stream_window() : 0;
+            if (!z->out)
+                return MZH_MEM_ERROR;
+        }
+        return window_mode_begin(z);
+    }
     while (!z->payload_done) {
         if (z->out_cap == 0) {
-            z->out_cap = z->in_len * 4 + 65536;
+            z->out_cap = z->in_len * 8 + 65536; /* (a decode that runs out of room starts over in four times as much) */
             z->out = (uint8_t *)malloc((size_t)z->out_cap);
             if (!z->out)
                 return MZH_MEM_ERROR;
@@ -939,7 +1297,10 @@ static int32_t attempt_decode(mzhip_zlib *z) {
         ea.in_used = &in_used;
         ea.crc = &z->out_crc;
         ea.adler = z->wrap == 1 ? &z->out_adler : NULL;
+        const double ta0 = mzh_now();
         int32_t st = mzhip_inflate_host_a(&ea);
+        z->t_attempts += mzh_now() - ta0;
+        z->n_attempts++;
         int32_t early = 0;
         const int64_t early_out = MZH_STREAM_EARLY_OUT < mzh_stream_window() ? MZH_STREAM_EARLY_OUT : mzh_stream_window();
         if (mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
@@ -958,33 +1319,8 @@ static int32_t attempt_decode(mzhip_zlib *z) {
             }
             early = z->out_cap >= mzh_stream_window();
         }
-        if (early || (st == MZHIP_STATUS_OUT_FULL && z->out_cap >= mzh_stream_window())) {
-            /* more than a window of output: from here on the entry is decoded window by window.  The first window once
-             * more, this time asking where it stops */
-            z->streaming = 1;
-            if (!z->in_pinned) { /* (room for a gulp and the pull that crosses it; grows like any in[] if a block needs more) */
-                int64_t want = mzh_stream_gulp() + 2 * MZH_STAGING_BYTES;
-                if (want < z->in_cap)
-                    want = z->in_cap;
-                (void)in_grow(z, want);
-            }
-            z->in_dropped = 0;
-            if (z->hdr_len > 0) { /* the wrapper's header is done with: positions stay those of the whole stream */
-                memmove(z->in, z->in + z->hdr_len, (size_t)(z->in_len - z->hdr_len));
-                z->in_len -= z->hdr_len;
-                z->in_dropped = z->hdr_len;
-            }
-            z->run_crc = 0;
-            z->run_adler = 1;
-            z->run_n = 0;
-            memset(&z->sst, 0, sizeof(z->sst));
-            z->out_len = z->out_served = 0;
-            const int32_t sr = stream_next(z);
-            if (sr < 0)
-                return sr;
-            z->decoded = 1; /* (bytes are there; the verdict comes with the last window) */
-            return 0;
-        }
+        if (early || (st == MZHIP_STATUS_OUT_FULL && z->out_cap >= mzh_stream_window()))
+            return window_mode_begin(z); /* more than a window of output: the first window once more, this time asking where it stops */
         if (st == MZHIP_STATUS_OUT_FULL) {
             if (z->out_cap >= 0x7FFFFFFF)
                 return MZH_MEM_ERROR;
@@ -1068,6 +1404,10 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
         if (!z->tried_cache) {
             /* was this entry decoded by mzhip_prime_*()?  (payload offset + first payload bytes must agree) */
             z->tried_cache = 1;
+            /* the caller has said how long the stream is: the first attempt waits for all of it (or for what sends it to window
+             * mode) instead of asking the device at 32 KiB, 64 KiB, 128 KiB ... from the first byte each time */
+            if (z->max_total_in > 0 && z->next_attempt == 0)
+                z->next_attempt = z->max_total_in < (int64_t)MZH_STREAM_EARLY + 1024 ? z->max_total_in : (int64_t)MZH_STREAM_EARLY + 1024;
             mzhip_autoprime(z->stream.base, z->base_pos0); /* (shim_autoprime.c: on unless MZHIP_AUTOPRIME=0) */
             const uint8_t *data = NULL;
             int64_t usize = 0, csize = 0;
@@ -1375,12 +1715,14 @@ int32_t mz_stream_zlib_close(void *stream) {
         const char *e = getenv("MZHIP_STREAM_STATS");
         if (e && e[0] == '1')
             fprintf(stderr,
-                    "mzhip window mode: %.3f s open to close, %lld bytes out; many-wave windows %d (%.3f s, %lld bytes), serial windows %d "
-                    "(%.3f s, %lld bytes), pulling input %.3f s\n",
-                    mzh_now() - z->t_open, (long long)z->total_out, z->n_par, z->t_par, (long long)z->par_bytes, z->n_serial, z->t_serial,
-                    (long long)z->serial_bytes, z->t_pull);
+                    "mzhip window mode: %.3f s open to close (window mode from %.3f s on, after %d whole-entry attempts that took %.3f s), %lld bytes out; many-wave windows %d (%.3f s, %lld bytes), serial windows %d "
+                    "(%.3f s, %lld bytes), pulling input %.3f s; %d windows decoded ahead of the reader, which waited %.3f s for them (%.3f s of its own "
+                    "between a window's start and that wait, %.3f s taking windows over and starting the next)\n",
+                    mzh_now() - z->t_open, z->t_begin - z->t_open, z->n_attempts, z->t_attempts, (long long)z->total_out, z->n_par, z->t_par, (long long)z->par_bytes, z->n_serial, z->t_serial,
+                    (long long)z->serial_bytes, z->t_pull, z->n_ahead, z->t_wait, z->t_overlap, z->t_book);
     }
     z->initialized = 0;
+    lookahead_cancel(z); /* (a window may still be on its way: its thread reads in[]) */
     in_release(z);
     free(z->pc);
     free(z->pc_tmp);

@@ -474,6 +474,7 @@ MOCK_API int32_t mzhip_sha_batch(const void *d_buf, const uint64_t *off, const u
 #include "mzhip_prime.inc"
 #undef mzhip_prime_any
 extern "C" int32_t mzhip_take_crc_fault(void) { return 0; }
+extern "C" void mzhip_thread_use_device(int32_t) {}
 MOCK_API uint64_t mzhip_crc_faults(void) { return 0; }
 extern "C" int32_t mzhip_wprime_track(int32_t, int64_t *, int64_t, const uint8_t *, int32_t, uint32_t *, int32_t *have_crc,
                                       const uint8_t **) {

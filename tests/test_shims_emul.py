@@ -289,6 +289,21 @@ def test_window_mode_many_waves():
             # (where the base stream stands after a data error is not compared: window mode pulls up to a gulp ahead of the decode)
             a.pop("base_pos"), b.pop("base_pos")
             assert a == b, (name, "flip", where)
+    # one window ahead: while a window is served, a thread of the stream decodes the next one (the default; everything above ran
+    # that way) -- and with that off the device call and the serving take turns, as up to round 5: the same answers
+    L.mzhip_stream_lookahead_windows.restype = C.c_uint64
+    assert L.mzhip_stream_lookahead_windows() >= 20
+    L.mzhip_set_stream_lookahead(0)
+    w0 = L.mzhip_stream_lookahead_windows()
+    for name, d, z in cases[:3]:
+        d = d if d is not None else zlib.decompress(z, -15)
+        for chunk in (65535, 300000, 7777):
+            assert ref.stream_decode(8, z, len(d) + 10, chunk=chunk) == hip.stream_decode(8, z, len(d) + 10, chunk=chunk), (name, chunk, "no look-ahead")
+    assert L.mzhip_stream_lookahead_windows() == w0
+    L.mzhip_set_stream_lookahead(1)
+    name, d, z = cases[0]
+    assert ref.stream_decode(8, z, len(d) + 10, chunk=7777) == hip.stream_decode(8, z, len(d) + 10, chunk=7777)
+    assert L.mzhip_stream_lookahead_windows() > w0
     # the switch: the same streams with the many-wave decode off take the serial windows only
     L.mzhip_set_stream_parallel(0)
     b0 = L.mzmock_par_blocks()
