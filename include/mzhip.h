@@ -457,6 +457,11 @@ MZHIP_API void mzhip_set_stream_parallel(int32_t on);
  * call and the serving then take turns.  What the caller sees -- bytes, return values, totals, errors -- is the same either way.
  * mzhip_stream_lookahead_windows(): windows taken over from such a thread so far, all streams of the process. */
 MZHIP_API void mzhip_set_stream_lookahead(int32_t on);
+/* mz_stream_zlib WRITE collects 8 MiB per device launch; a full segment is coded by a thread of the stream while the caller
+ * fills the next one (its bytes reach the base stream, from the caller's thread, when the segment after it is full or at
+ * close).  0 turns that off (MZHIP_WRITE_OVERLAP=0 does the same): the segment is coded before write() returns.  The
+ * stream that is written is the same either way. */
+MZHIP_API void mzhip_set_write_overlap(int32_t on);
 MZHIP_API uint64_t mzhip_stream_lookahead_windows(void);
 /* page-locked host memory for a READ stream's window buffer, from the library's pool (next to the current device; NULL when
  * there is none to be had -- the caller then uses plain memory); *cap = what to hand back to mzhip_window_free */

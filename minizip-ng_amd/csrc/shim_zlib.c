@@ -159,6 +159,18 @@ typedef struct mzhip_zlib_s {
     /* write side */
     uint8_t *wbuf;
     int64_t wlen, wcap;
+    /* a full segment is coded by a thread of the stream while the caller fills the next one (wbuf and wjob.in swap) */
+    pthread_t w_thread;
+    pthread_mutex_t w_mu;
+    pthread_cond_t w_cv;
+    int8_t w_started, w_state; /* w_state: 0 none, 1 posted / running, 2 done, 3 the thread is to exit */
+    int8_t w_pending;          /* a segment is on its way (or done and not pushed to the base stream yet) */
+    struct {
+        uint8_t *in, *out;     /* in: the other segment buffer */
+        int64_t in_len;
+        uint32_t out_cap, out_len, crc, adler;
+        int32_t st, device;
+    } wjob;
     uint32_t w_crc, w_adler;
     int64_t w_total;   /* uncompressed bytes already handed to the device */
     int8_t w_header_done;
@@ -250,7 +262,9 @@ static int32_t base_read(mzhip_stream *base, void *buf, int32_t size) {
 }
 
 static void lookahead_cancel(mzhip_zlib *z);
+static void write_ahead_stop(mzhip_zlib *z);
 static void free_buffers(mzhip_zlib *z) {
+    write_ahead_stop(z); /* (... and the write side's reads wjob.in) */
     lookahead_cancel(z); /* (the look-ahead thread reads in[] and writes out2[]: it is joined before either goes) */
     in_release(z);
     free(z->pc);
@@ -1539,8 +1553,161 @@ static int32_t push_to_base(mzhip_zlib *z, const uint8_t *out, uint32_t out_len)
     return MZH_OK;
 }
 
+#ifndef MZH_WRITE_SEGMENT
+#define MZH_WRITE_SEGMENT (8 << 20) /* bytes collected per device launch (128 pieces of 64 KiB) */
+#endif
+static int8_t mzh_wo_mode = -1;
+MZHIP_API void mzhip_set_write_overlap(int32_t on) { __atomic_store_n(&mzh_wo_mode, (int8_t)(on ? 1 : 0), __ATOMIC_RELAXED); }
+static int32_t mzh_write_overlap(void) {
+    int8_t m = __atomic_load_n(&mzh_wo_mode, __ATOMIC_RELAXED);
+    if (m < 0) {
+        const char *e = getenv("MZHIP_WRITE_OVERLAP"); /* "0": a full segment is coded before write() returns, as before round 6 */
+        m = (e && e[0] == '0') ? 0 : 1;
+        __atomic_store_n(&mzh_wo_mode, m, __ATOMIC_RELAXED);
+    }
+    return m;
+}
+
+/* one segment through the device: in[0 .. in_len) -> out */
+static int32_t segment_encode(const mzhip_zlib *z, const uint8_t *in, int64_t in_len, int32_t final, uint8_t *out, uint32_t cap, uint32_t *out_len,
+                              uint32_t *crc, uint32_t *adler) {
+    mzhip_deflate_host_args da; /* level and window as mz_strm_zlib.c:87 hands them on */
+    memset(&da, 0, sizeof(da));
+    da.size = (uint32_t)sizeof(da);
+    da.in = in;
+    da.in_len = (uint32_t)in_len;
+    da.final = (uint32_t)final;
+    da.level = z->level;
+    da.window_log2 = z->wlog;
+    da.out = out;
+    da.out_cap = cap;
+    da.out_len = out_len;
+    da.crc = crc;
+    da.adler = z->wrap == 1 ? adler : NULL;
+    return mzhip_deflate_host_a(&da);
+}
+static uint32_t segment_cap(int64_t n) { return (uint32_t)(n + n / 8 + 128 + (n / 65536 + 1) * 80); }
+/* ... and what follows it: the running wrapper checksums (arithmetic on the device-computed segment checksums only), the bytes to the base stream */
+static int32_t segment_done(mzhip_zlib *z, int32_t st, int64_t in_len, const uint8_t *out, uint32_t out_len, uint32_t crc, uint32_t adler) {
+    if (st != 0) {
+        z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */
+        return MZH_DATA_ERROR;       /* mz_strm_zlib.c:233-236 */
+    }
+    z->w_crc = z->w_total == 0 ? crc : mzhip_crc32_combine(z->w_crc, crc, (uint64_t)in_len);
+    if (z->wrap == 1)
+        z->w_adler = mzhip_adler32_combine(z->w_adler, adler, (uint64_t)in_len);
+    z->w_total += in_len;
+    return push_to_base(z, out, out_len);
+}
+
+static void *write_ahead_run(void *arg) {
+    mzhip_zlib *z = (mzhip_zlib *)arg;
+    int32_t dev = -2;
+    pthread_mutex_lock(&z->w_mu);
+    for (;;) {
+        while (z->w_state != 1 && z->w_state != 3)
+            pthread_cond_wait(&z->w_cv, &z->w_mu);
+        if (z->w_state == 3)
+            break;
+        pthread_mutex_unlock(&z->w_mu);
+        if (z->wjob.device >= 0 && z->wjob.device != dev) {
+            dev = z->wjob.device;
+            mzhip_thread_use_device(dev);
+        }
+        z->wjob.st = segment_encode(z, z->wjob.in, z->wjob.in_len, 0, z->wjob.out, z->wjob.out_cap, &z->wjob.out_len, &z->wjob.crc, &z->wjob.adler);
+        pthread_mutex_lock(&z->w_mu);
+        z->w_state = 2;
+        pthread_cond_broadcast(&z->w_cv);
+    }
+    pthread_mutex_unlock(&z->w_mu);
+    return NULL;
+}
+/* the segment that is on its way: wait for it, hand its bytes on */
+static int32_t write_ahead_finish(mzhip_zlib *z) {
+    if (!z->w_pending)
+        return MZH_OK;
+    pthread_mutex_lock(&z->w_mu);
+    while (z->w_state == 1)
+        pthread_cond_wait(&z->w_cv, &z->w_mu);
+    z->w_state = 0;
+    pthread_mutex_unlock(&z->w_mu);
+    z->w_pending = 0;
+    return segment_done(z, z->wjob.st, z->wjob.in_len, z->wjob.out, z->wjob.out_len, z->wjob.crc, z->wjob.adler);
+}
+/* (close, delete, re-open: a segment that is still on its way reads wjob.in and writes wjob.out) */
+static void write_ahead_stop(mzhip_zlib *z) {
+    if (z->w_pending) {
+        pthread_mutex_lock(&z->w_mu);
+        while (z->w_state == 1)
+            pthread_cond_wait(&z->w_cv, &z->w_mu);
+        z->w_state = 0;
+        pthread_mutex_unlock(&z->w_mu);
+        z->w_pending = 0;
+    }
+    if (z->w_started) {
+        pthread_mutex_lock(&z->w_mu);
+        z->w_state = 3;
+        pthread_cond_broadcast(&z->w_cv);
+        pthread_mutex_unlock(&z->w_mu);
+        pthread_join(z->w_thread, NULL);
+        pthread_mutex_destroy(&z->w_mu);
+        pthread_cond_destroy(&z->w_cv);
+        z->w_started = 0;
+        z->w_state = 0;
+    }
+    free(z->wjob.in);
+    free(z->wjob.out);
+    z->wjob.in = z->wjob.out = NULL;
+    z->wjob.out_cap = 0;
+}
+/* the full segment in wbuf goes to the stream's thread, the caller gets the other buffer: 1 = done, 0 = not possible (the caller codes it itself) */
+static int32_t write_ahead_post(mzhip_zlib *z) {
+    if (!mzh_write_overlap() || z->wlen < (int64_t)MZH_WRITE_SEGMENT)
+        return 0;
+    if (!z->wjob.in)
+        z->wjob.in = (uint8_t *)malloc(MZH_WRITE_SEGMENT);
+    const uint32_t cap = segment_cap(MZH_WRITE_SEGMENT);
+    if (!z->wjob.out) {
+        z->wjob.out = (uint8_t *)malloc(cap);
+        z->wjob.out_cap = z->wjob.out ? cap : 0;
+    }
+    if (!z->wjob.in || !z->wjob.out)
+        return 0;
+    if (!z->w_started) {
+        if (pthread_mutex_init(&z->w_mu, NULL) != 0)
+            return 0;
+        if (pthread_cond_init(&z->w_cv, NULL) != 0) {
+            pthread_mutex_destroy(&z->w_mu);
+            return 0;
+        }
+        z->w_state = 0;
+        if (pthread_create(&z->w_thread, NULL, write_ahead_run, z) != 0) {
+            pthread_mutex_destroy(&z->w_mu);
+            pthread_cond_destroy(&z->w_cv);
+            return 0;
+        }
+        z->w_started = 1;
+    }
+    uint8_t *t = z->wbuf;
+    z->wbuf = z->wjob.in;
+    z->wjob.in = t;
+    z->wjob.in_len = z->wlen;
+    z->wjob.out_len = 0;
+    z->wjob.crc = 0;
+    z->wjob.adler = 1;
+    z->wjob.st = 0;
+    z->wjob.device = mzhip_prime_current_device();
+    z->wlen = 0;
+    pthread_mutex_lock(&z->w_mu);
+    z->w_state = 1;
+    pthread_cond_broadcast(&z->w_cv);
+    pthread_mutex_unlock(&z->w_mu);
+    z->w_pending = 1;
+    return 1;
+}
+
 static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
-    if (z->wlen == 0 && !final)
+    if (z->wlen == 0 && !final && !z->w_pending)
         return MZH_OK;
     if (z->wrap != 0 && !z->w_header_done) {
         /* the header deflate() emits when no gz_header was set: gzip = magic, CM 8, no flags, no mtime, XFL from
@@ -1561,36 +1728,21 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
         if (push_to_base(z, h, hl) != MZH_OK)
             return MZH_WRITE_ERROR;
     }
-    uint32_t cap = (uint32_t)(z->wlen + z->wlen / 8 + 128 + (z->wlen / 65536 + 1) * 80);
+    /* the segment before this one first: its bytes go out in front of this one's */
+    int32_t err = write_ahead_finish(z);
+    if (err != MZH_OK)
+        return err;
+    if (z->wlen == 0 && !final)
+        return MZH_OK;
+    if (!final && write_ahead_post(z))
+        return MZH_OK; /* (coded while the caller fills the next segment; handed on by the next flush) */
+    const uint32_t cap = segment_cap(z->wlen);
     uint8_t *out = (uint8_t *)malloc(cap);
     if (!out)
         return MZH_MEM_ERROR;
     uint32_t out_len = 0, crc = 0, adler = 1;
-    mzhip_deflate_host_args da; /* level and window as mz_strm_zlib.c:87 hands them on */
-    memset(&da, 0, sizeof(da));
-    da.size = (uint32_t)sizeof(da);
-    da.in = z->wbuf;
-    da.in_len = (uint32_t)z->wlen;
-    da.final = (uint32_t)final;
-    da.level = z->level;
-    da.window_log2 = z->wlog;
-    da.out = out;
-    da.out_cap = cap;
-    da.out_len = &out_len;
-    da.crc = &crc;
-    da.adler = z->wrap == 1 ? &adler : NULL;
-    int32_t st = mzhip_deflate_host_a(&da);
-    if (st != 0) {
-        free(out);
-        z->error = MZH_STREAM_ERROR; /* device failure: never substitute a CPU result */
-        return MZH_DATA_ERROR;       /* mz_strm_zlib.c:233-236 */
-    }
-    /* running wrapper checksums: arithmetic on the device-computed segment checksums only */
-    z->w_crc = z->w_total == 0 ? crc : mzhip_crc32_combine(z->w_crc, crc, (uint64_t)z->wlen);
-    if (z->wrap == 1)
-        z->w_adler = mzhip_adler32_combine(z->w_adler, adler, (uint64_t)z->wlen);
-    z->w_total += z->wlen;
-    int32_t err = push_to_base(z, out, out_len);
+    const int32_t st = segment_encode(z, z->wbuf, z->wlen, final, out, cap, &out_len, &crc, &adler);
+    err = segment_done(z, st, z->wlen, out, out_len, crc, adler);
     free(out);
     if (err != MZH_OK)
         return err;
@@ -1608,8 +1760,6 @@ static int32_t flush_segment(mzhip_zlib *z, int32_t final) {
     }
     return MZH_OK;
 }
-
-#define MZH_WRITE_SEGMENT (8 << 20) /* bytes collected per device launch (128 pieces of 64 KiB) */
 
 /* bytes into the segment buffer, launching whenever it is full */
 static int32_t collect(mzhip_zlib *z, const uint8_t *p, int64_t left) {
@@ -1734,6 +1884,7 @@ int32_t mz_stream_zlib_close(void *stream) {
     mzhip_prime_unpin(z->prime_pin);
     z->prime_pin = NULL;
     z->out_borrowed = 0;
+    write_ahead_stop(z); /* (flush_segment(final) has waited for the last segment; this ends the thread) */
     free(z->wbuf);
     z->in = z->out = z->wbuf = NULL;
     z->in_cap = z->out_cap = z->wcap = 0;

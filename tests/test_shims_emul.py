@@ -374,3 +374,41 @@ def test_large_entry_where_it_lies():
             assert st == 0 and got == want and crc == zlib.crc32(want), name
         except zlib.error:
             assert st == -3, (name, st)
+
+
+def test_write_segments_coded_ahead():
+    """mz_stream_zlib WRITE hands a full segment to a thread of the stream and goes on collecting the next one
+    (shim_zlib.c write_ahead_*; 8 MiB segments in the product, 256 KiB in this build so that a few MB cross many): the
+    stream that reaches the base is byte for byte the one the synchronous path writes (mzhip_set_write_overlap(0)), with the
+    same totals and close() / error() results, raw, zlib- and gzip-wrapped, for writes of 65 535, 1 000 and 700 000 bytes;
+    the reference inflates it to the input."""
+    import ctypes as C
+    import zlib
+
+    from tests import synth
+
+    if not os.path.isdir("/root/reference") or not oracle.have_ref():
+        pytest.skip("needs the reference sources at build time")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul"), "B=_build_wseg", 'SHIM_DEFS=-DMZH_WRITE_SEGMENT="(256<<10)"'],
+                   check=True, capture_output=True)
+    so = os.path.join(ROOT, "tests", "emul", "_build_wseg", "libmockdrop.so")
+    hip = oracle.MzDriver(so)
+    L = C.CDLL(so)
+    text, _ = synth.bench_corpus()
+    data = text[:900000] * 2 + bytes(300000) + text[5000:400000]
+    for level in (1, 6):
+        for wb, inflate_bits in ((0, -15), (15, 15), (31, 31)):
+            for chunk in (65535, 1000, 700000):
+                L.mzhip_set_write_overlap(1)
+                a = hip.stream_encode(8, data, level=level, chunk=chunk, window_bits=wb)
+                L.mzhip_set_write_overlap(0)
+                b = hip.stream_encode(8, data, level=level, chunk=chunk, window_bits=wb)
+                L.mzhip_set_write_overlap(1)
+                assert a == b, (level, wb, chunk)
+                assert zlib.decompress(a[0], inflate_bits) == data, (level, wb, chunk)
+                assert a[1]["total_in"] == len(data) and a[1]["close"] == 0 and a[1]["error"] == 0
+    # a stream that ends exactly where a segment ends, and one byte either side of it
+    for n in (4 * (256 << 10) - 1, 4 * (256 << 10), 4 * (256 << 10) + 1, 256 << 10):
+        d = (text * 4)[:n]
+        a = hip.stream_encode(8, d, level=1, chunk=65535)
+        assert zlib.decompress(a[0], -15) == d, n
