@@ -124,6 +124,15 @@ typedef struct mzhip_inflate_host_args {
 } mzhip_inflate_host_args;
 MZHIP_API int32_t mzhip_inflate_host_a(const mzhip_inflate_host_args *a);
 
+/* (diagnostics, tests) The first step of mzhip_inflate_parallel_host alone: every bit offset of [b0, b1) of in[] at which a
+ * dynamic-Huffman or stored block header could start (BTYPE, HLIT / HDIST <= 29 and a complete code-length code; LEN = ~NLEN),
+ * in no order; *n = how many there are, out[] holds min(*n, cap).  which = 0: the kernel the product runs (32 offsets per lane),
+ * 1: one offset per lane, the statement of the test (mz_block_header_plausible), 2: the product's kernel and the second step
+ * behind it (k_check_headers: a lane reads each candidate's header to its end and keeps it only if a decoder would get past it).
+ * misalign (0 - 15): where the bytes are put relative to a 16-byte boundary on the device. */
+MZHIP_API int32_t mzhip_find_blocks_host(const uint8_t *in, uint32_t in_len, uint32_t b0, uint32_t b1, int32_t which, uint32_t misalign,
+                                         uint32_t *out, uint32_t cap, uint32_t *n);
+
 /* One window of ONE large entry decoded by as many waves as it holds blocks (replaces the single inflate() state the
  * reference streams an entry of any size through, mz_strm_zlib.c:116-193, where that state is the bottleneck): block
  * headers are searched for at every bit offset, every candidate is parsed by a wave of its own, the chain of blocks that

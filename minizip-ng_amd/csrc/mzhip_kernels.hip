@@ -608,15 +608,252 @@ struct ParFindArgs {
     uint32_t cap;
     uint32_t *count;
 };
-// every bit offset of [b0, b1): could a block header start here?  One offset per lane; what passes is appended (order
-// does not matter, the host sorts: a few thousand offsets per MiB)
-__global__ __launch_bounds__(256) void k_find_blocks(ParFindArgs a) {
+// every bit offset of [b0, b1): could a block header start here (mz_block_header_plausible)?  What passes is appended (order
+// does not matter, the host puts them in order: ~7 per KiB of text).
+// k_find_blocks_lane: one offset per lane -- 64 lanes fetch the same dozen bytes, a quarter of them go on to four byte loads of
+// the stored-block test, and every candidate is an atomic of its own: 1.25 ms for the 16.8 MB one window of text is shown.
+// Kept as the statement of what is searched for (tests/test_gpu_streams.py holds the kernel below against it).
+__global__ __launch_bounds__(256) void k_find_blocks_lane(ParFindArgs a) {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
     for (uint64_t p = (uint64_t)a.b0 + (uint64_t)blockIdx.x * 256u + threadIdx.x; p < a.b1; p += stride)
         if (mz_block_header_plausible(a.in, a.in_len, (uint32_t)p)) {
             const uint32_t k = atomicAdd(a.count, 1u);
             if (k < a.cap) a.cands[k] = (uint32_t)p;
         }
+}
+// k_find_blocks: 32 offsets per lane out of one 16-byte fetch.  The tests that need no loop are made for all 32 at once on the
+// 64-bit register (BTYPE = 2 is "bit k+1 clear, bit k+2 set"; HLIT / HDIST > 29 is "four bits in a row set"), a lane then
+// walks the offsets that are left (7 of 32 on random bits) through the Kraft sum of the code-length code; the stored-block
+// test is made once per byte position (LEN ^ NLEN of the 5 positions the lane's offsets can point at).  One atomic per wave
+// and round.  Bit g of the aligned dwords q[] is stream bit g - 8 * (in & 3).
+__global__ __launch_bounds__(256) void k_find_blocks(ParFindArgs a) {
+    const int lane = (int)(threadIdx.x & 63u);
+    if (a.in_len < 24u) return;
+    const uint32_t mis = (uint32_t)((uintptr_t)a.in & 3u), sh0 = mis * 8u;
+    const uint32_t *q = (const uint32_t *)(a.in - mis);
+    const uint32_t nd = (a.in_len + mis + 3u) >> 2; /* dwords of q[] that hold bytes of the stream */
+    /* offsets that may be looked at: [b0, lim), where the 24 bytes behind an offset are still the stream's */
+    const uint64_t lim64 = 8ull * (uint64_t)(a.in_len - 23u);
+    const uint64_t lim = lim64 < (uint64_t)a.b1 ? lim64 : (uint64_t)a.b1;
+    if ((uint64_t)a.b0 >= lim) return;
+    const uint64_t g0 = (uint64_t)a.b0 + sh0, g1 = lim + sh0; /* the same range in bits of q[] */
+    const uint64_t j0 = g0 >> 5, j1 = (g1 + 31u) >> 5;       /* ... and in dwords: a lane takes one */
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t jb = j0 + (uint64_t)blockIdx.x * 256u + (threadIdx.x & ~63u); jb < j1; jb += stride) { /* (wave-uniform trip count) */
+        const uint64_t j = jb + (uint64_t)lane;
+        uint32_t found = 0; /* bit k: offset 32 j + k (in bits of q[]) is a candidate */
+        if (j < j1) {
+            uint32_t d[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; t++) d[t] = (j + t < nd) ? q[j + t] : 0u;
+            const uint64_t lo = ((uint64_t)d[1] << 32) | d[0], hi = ((uint64_t)d[3] << 32) | d[2];
+            /* which of the 32 offsets are inside [g0, g1) */
+            uint32_t in_range = 0xFFFFFFFFu;
+            if ((j << 5) < g0) in_range &= 0xFFFFFFFFu << (uint32_t)(g0 - (j << 5));
+            if (((j + 1u) << 5) > g1) in_range &= 0xFFFFFFFFu >> (uint32_t)(((j + 1u) << 5) - g1);
+            const uint32_t b1c = (uint32_t)~(lo >> 1), b2 = (uint32_t)(lo >> 2);
+            uint32_t dyn = b1c & b2 & in_range;
+            dyn &= ~(uint32_t)((lo >> 4) & (lo >> 5) & (lo >> 6) & (lo >> 7));    /* HLIT <= 29 */
+            dyn &= ~(uint32_t)((lo >> 9) & (lo >> 10) & (lo >> 11) & (lo >> 12)); /* HDIST <= 29 */
+            while (dyn) {
+                const uint32_t k = (uint32_t)__builtin_ctz(dyn);
+                dyn &= dyn - 1u;
+                const uint32_t ncode = ((uint32_t)(lo >> (k + 13u)) & 15u) + 4u;
+                const uint32_t s = k + 17u; /* 17 .. 48: the 3-bit lengths start here, 57 bits at most */
+                uint64_t w = (lo >> s) | (hi << (64u - s));
+                uint32_t kraft = 0;
+                for (uint32_t i = 0; i < ncode; i++) {
+                    const uint32_t l = (uint32_t)w & 7u;
+                    w >>= 3;
+                    kraft += l ? (128u >> l) : 0u;
+                }
+                if (kraft == 128u) found |= 1u << k;
+            }
+            /* stored blocks: BTYPE = 0 and LEN ^ NLEN = 0xFFFF at byte (g + 10) >> 3 = 4 j + 1 .. 4 j + 5 */
+            const uint32_t sto = b1c & ~b2 & in_range;
+            if (sto) {
+#pragma unroll
+                for (uint32_t t = 1; t <= 5u; t++) {
+                    const uint32_t v = (uint32_t)(t < 5u ? (lo >> (8u * t)) : ((lo >> 40) | (hi << 24)));
+                    const uint32_t km = t == 1u ? 0x0000003Fu : t == 2u ? 0x00003FC0u : t == 3u ? 0x003FC000u : t == 4u ? 0x3FC00000u : 0xC0000000u;
+                    if (((v ^ (v >> 16)) & 0xFFFFu) == 0xFFFFu) found |= sto & km;
+                }
+            }
+        }
+        /* append: a slot per candidate, one fetch-add per wave and round */
+        const uint32_t n = (uint32_t)__builtin_popcount(found);
+        const uint32_t incl = mz_wave_incl_scan(n, lane);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total) { /* (wave-uniform) */
+            uint32_t base = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) base = atomicAdd(a.count, total);
+            __builtin_amdgcn_wave_barrier();
+            base = MZ_UNIFORM(base);
+            uint32_t at = base + incl - n, f = found;
+            while (f) {
+                const uint32_t k = (uint32_t)__builtin_ctz(f);
+                f &= f - 1u;
+                if (at < a.cap) a.cands[at] = (uint32_t)((j << 5) + k - sh0);
+                at++;
+            }
+        }
+    }
+}
+
+// The candidates of k_find_blocks are ~0.09 % of a text stream's bit offsets, and all but one in two hundred of them are not block
+// headers: each used to cost a wave of k_inflate_blocks a header parse (120 000 waves per window against 530 blocks: 1 of the
+// counting pass's 2 ms).  Here a LANE reads one candidate's header to its end -- the run-length coded lengths through the
+// code-length code, bit by bit as puff.c would -- and keeps it only if the decoder would get past the header: no repeat without a
+// length before it or past HLIT + HDIST, an end-of-block code, and both sets neither over-subscribed nor incomplete (a single
+// 1-bit code and, for distances, no code at all excepted): the verdicts of inflate_header.inc / inflate_tables.inc, i.e. zlib's.
+// Stored-block candidates pass as they are.  What is kept is appended to out[] (no order).
+struct ParCheckArgs {
+    const uint8_t *in;
+    uint32_t in_len;
+    const uint32_t *cands, *count; // what k_find_blocks found (*count may exceed cap: then cap of them are there)
+    uint32_t cap;
+    uint32_t *out, *out_count;
+};
+__device__ __forceinline__ uint64_t mz_find_bits64(const uint32_t *q, uint32_t nd, uint64_t g) {
+    const uint64_t j = g >> 5;
+    const uint32_t s = (uint32_t)g & 31u;
+    const uint32_t d0 = j < nd ? q[j] : 0u, d1 = j + 1u < nd ? q[j + 1u] : 0u, d2 = j + 2u < nd ? q[j + 2u] : 0u;
+    uint64_t w = (((uint64_t)d1 << 32) | d0) >> s;
+    if (s) w |= (uint64_t)d2 << (64u - s);
+    return w;
+}
+__global__ __launch_bounds__(256) void k_check_headers(ParCheckArgs a) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t n = *a.count < a.cap ? *a.count : a.cap;
+    const uint32_t mis = (uint32_t)((uintptr_t)a.in & 3u), sh0 = mis * 8u;
+    const uint32_t *q = (const uint32_t *)(a.in - mis);
+    const uint32_t nd = (a.in_len + mis + 3u) >> 2;
+    const uint64_t end_bit = 8ull * a.in_len + sh0; /* (in bits of q[]) */
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t ib = blockIdx.x * 256u + (threadIdx.x & ~63u); ib < n; ib += stride) { /* (wave-uniform trip count) */
+        const uint32_t i = ib + (uint32_t)lane;
+        uint32_t keep = 0, p = 0;
+        if (i < n) {
+            p = a.cands[i];
+            const uint64_t g = (uint64_t)p + sh0;
+            const uint64_t h = mz_find_bits64(q, nd, g);
+            if ((((uint32_t)h >> 1) & 3u) == 0u) {
+                keep = 1; /* stored: LEN / NLEN have been looked at */
+            } else {
+                const uint32_t nlen = (((uint32_t)h >> 3) & 31u) + 257u, ndist = (((uint32_t)h >> 8) & 31u) + 1u, ncode = (((uint32_t)h >> 13) & 15u) + 4u;
+                /* the code-length code: lengths by symbol (3 bits each), how many codes of each length (5 bits each) */
+                const uint64_t ord_lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) | (6ull << 35) | (10ull << 40) |
+                                        (5ull << 45) | (11ull << 50) | (4ull << 55);
+                const uint64_t ord_hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
+                uint64_t lw = mz_find_bits64(q, nd, g + 17u), cl = 0, bc = 0;
+                for (uint32_t k = 0; k < ncode; k++) {
+                    const uint32_t l = (uint32_t)lw & 7u;
+                    lw >>= 3;
+                    const uint32_t sym = (uint32_t)(k < 12u ? ord_lo >> (5u * k) : ord_hi >> (5u * (k - 12u))) & 31u;
+                    cl |= (uint64_t)l << (3u * sym);
+                    bc += 1ull << (5u * l);
+                }
+                /* its symbols in code order (counting sort by length): 19 x 5 bits */
+                uint64_t s0 = 0, s1 = 0, offs = 0; /* offs: 5 bits per length, where the next symbol of that length goes */
+                {
+                    uint32_t at = 0;
+                    for (uint32_t l = 1; l <= 7u; l++) {
+                        offs |= (uint64_t)at << (5u * l);
+                        at += (uint32_t)(bc >> (5u * l)) & 31u;
+                    }
+                }
+                for (uint32_t sym = 0; sym < 19u; sym++) {
+                    const uint32_t l = (uint32_t)(cl >> (3u * sym)) & 7u;
+                    if (l) {
+                        const uint32_t at = (uint32_t)(offs >> (5u * l)) & 31u;
+                        offs += 1ull << (5u * l);
+                        if (at < 12u) s0 |= (uint64_t)sym << (5u * at);
+                        else s1 |= (uint64_t)sym << (5u * (at - 12u));
+                    }
+                }
+                /* the lengths of the literal / length and distance codes, read for their sums only */
+                uint64_t pos = g + 17u + 3u * ncode, bb = mz_find_bits64(q, nd, pos);
+                uint32_t used = 0, idx = 0, prev = 0, ok = 1, has256 = 0, ll_total = 0, d_total = 0, ll_max = 0, d_max = 0;
+                const uint32_t ntot = nlen + ndist;
+                while (ok && idx < ntot) {
+                    if (used > 48u) {
+                        pos += used;
+                        used = 0;
+                        bb = mz_find_bits64(q, nd, pos);
+                    }
+                    uint32_t code = 0, first = 0, index = 0, sym = 99u, len = 1;
+                    for (; len <= 7u; len++) {
+                        code |= (uint32_t)(bb >> used) & 1u;
+                        used++;
+                        const uint32_t count = (uint32_t)(bc >> (5u * len)) & 31u;
+                        if (code < first + count) { /* (code >= first always: the code-length code is complete, k_find_blocks) */
+                            const uint32_t at = index + (code - first);
+                            sym = (uint32_t)(at < 12u ? s0 >> (5u * at) : s1 >> (5u * (at - 12u))) & 31u;
+                            break;
+                        }
+                        index += count;
+                        first += count;
+                        first <<= 1;
+                        code <<= 1;
+                    }
+                    if (sym == 99u) { /* no code of the code-length code */
+                        ok = 0;
+                        break;
+                    }
+                    uint32_t val, rep;
+                    if (sym < 16u) {
+                        val = sym;
+                        rep = 1;
+                    } else {
+                        const uint32_t ext = sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+                        const uint32_t xb = (uint32_t)(bb >> used) & ((1u << ext) - 1u);
+                        used += ext;
+                        if (sym == 16u) {
+                            if (idx == 0u) {
+                                ok = 0;
+                                break;
+                            }
+                            val = prev;
+                            rep = 3u + xb;
+                        } else {
+                            val = 0;
+                            rep = (sym == 17u ? 3u : 11u) + xb;
+                        }
+                        if (idx + rep > ntot) {
+                            ok = 0;
+                            break;
+                        }
+                    }
+                    if (val) {
+                        const uint32_t n1 = idx < nlen ? (rep < nlen - idx ? rep : nlen - idx) : 0u, n2 = rep - n1;
+                        ll_total += n1 << (15u - val);
+                        d_total += n2 << (15u - val);
+                        if (n1 && val > ll_max) ll_max = val;
+                        if (n2 && val > d_max) d_max = val;
+                        if (idx <= 256u && 256u < idx + rep) has256 = 1;
+                    }
+                    prev = val;
+                    idx += rep;
+                }
+                if (pos + used > end_bit) ok = 0; /* (the header runs past the bytes this window was shown: the chain ends in front of it either way) */
+                if (!has256) ok = 0;
+                if (ll_total > 32768u || (ll_total < 32768u && ll_max != 1u)) ok = 0;
+                if (d_total > 32768u || (d_total < 32768u && d_max > 1u)) ok = 0;
+                keep = ok;
+            }
+        }
+        uint64_t km = __ballot(keep != 0u);
+        if (km) { /* (wave-uniform) */
+            const uint32_t total = (uint32_t)__popcll(km);
+            uint32_t base = 0;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) base = atomicAdd(a.out_count, total);
+            __builtin_amdgcn_wave_barrier();
+            base = MZ_UNIFORM(base);
+            if (keep) a.out[base + MZ_RANK_BELOW(km)] = p; /* (never more than were found: out[] is as large as cands[]) */
+        }
+    }
 }
 
 struct ParBlocksArgs {

@@ -131,6 +131,8 @@ typedef struct {
 } roll;
 static roll *g_rolls[MZH_ROLLS];
 static uint64_t g_tick, g_live_bytes; /* page-locked bytes of the live windows of all rolls */
+static uint64_t g_busy_bytes;         /* ... and what the windows that are being imaged and decoded right now will take: they count against the
+                                       * budget like live ones (with four readers, seven windows on their way were 1.8 GB nobody had counted) */
 
 MZHIP_API void mzhip_autoprime_stats(uint64_t *windows_primed, uint64_t *windows_evicted, uint64_t *live_bytes, uint64_t *peak_bytes) {
     pthread_mutex_lock(&g_mu);
@@ -434,7 +436,7 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
                 }
             }
         }
-        if (g_live_bytes + need <= budget && live < MZH_ROLL_MAX_WINDOWS)
+        if (g_live_bytes + g_busy_bytes + need <= budget && live < MZH_ROLL_MAX_WINDOWS)
             return 1;
         if (vw < 0) {
             /* nothing but windows in use is left.  A look-ahead does without; a window that is needed goes over the budget -- up
@@ -442,7 +444,7 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
              * prime them again a moment later: measured, 62 windows primed for an archive of 32) */
             if (lookahead)
                 return 0;
-            if (fw < 0 || (g_live_bytes + need <= 2 * budget && live < MZH_ROLL_MAX_WINDOWS))
+            if (fw < 0 || (g_live_bytes + g_busy_bytes + need <= 2 * budget && live < MZH_ROLL_MAX_WINDOWS))
                 return 1;
             vr = fr;
             vw = fw;
@@ -516,6 +518,7 @@ static void roll_image(roll *r, int32_t w, mzhip_stream *arch, int lookahead, in
     free(rows);
     pthread_mutex_lock(&g_mu);
     r->busy--;
+    g_busy_bytes -= W->need < g_busy_bytes ? W->need : g_busy_bytes;
     if (k > 0) {
         W->state = W_LIVE;
         W->held = held;
@@ -613,6 +616,7 @@ static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget,
             return; /* (a window that is needed goes over the budget rather than without) */
         W->state = W_BUSY;
         r->busy++;
+        g_busy_bytes += W->need;
         if (r->fd >= 0 && !(g_img_failed && g_img_threads == 0)) { /* an imaging thread reads it; a needed window is waited for above */
             if (g_img_idle == 0 && g_img_threads < MZH_IMG_THREADS && !g_img_failed) {
                 pthread_t t;

@@ -120,7 +120,9 @@ def test_rolling_autoprime_any_size_bounded_memory(libs, monkeypatch, nthreads):
         s = stats(L)
         n_codec = int((lens > 0).sum())
         assert s["autos"] == a0["autos"] + 1, s
-        assert s["hits"] >= n_codec and s["misses"] == 0, s
+        # (one reader: every entry is a hit.  Several: a window can be evicted under the reader that was about to use it -- the
+        # entry then takes the per-entry path, same bytes -- which happens to one entry in a few hundred on a device)
+        assert s["hits"] + s["misses"] >= n_codec and s["misses"] <= (0 if nthreads == 1 else 4), s
         windows = s["primed"] - a0["primed"]
         assert windows >= 25 and s["evicted"] - a0["evicted"] >= windows - 12, s   # ~36 windows of 128 KiB; at most ~11 fit the budget
         budget, window = 4 * (256 << 10), (256 << 10) // 2
@@ -129,7 +131,7 @@ def test_rolling_autoprime_any_size_bounded_memory(libs, monkeypatch, nthreads):
         # a second pass over the same archive (a new reader, windows long evicted) rolls again, from the same index
         read_both(hip, ref, path, lens, nthreads=1)
         s2 = stats(L)
-        assert s2["autos"] == s["autos"] and s2["misses"] == 0 and s2["primed"] > s["primed"], s2
+        assert s2["autos"] == s["autos"] and s2["misses"] == s["misses"] and s2["primed"] > s["primed"], s2
         L.mzhip_prime_clear()
         assert stats(L)["entries"] == 0
 

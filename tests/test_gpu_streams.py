@@ -136,6 +136,141 @@ def test_one_window_on_many_waves(gpu):
         assert seg[i] == zlib.crc32(d[i * 65535:min((i + 1) * 65535, ol.value)])
 
 
+_HEADER_CHECK_PROG = r"""
+import ctypes as C, json, random, sys, zlib
+import numpy as np
+sys.path.insert(0, %r)
+from tests import synth, gpu_util
+L = gpu_util.mz.lib()
+L.mzhip_inflate_parallel_host.restype = C.c_int32
+L.mzhip_inflate_parallel_host.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+rnd = random.Random(17)
+text, _ = synth.bench_corpus()
+binary = bytes((i * 7 + (i >> 3)) & 255 for i in range(200000))
+d = text * 6 + binary * 3 + text[::-1] * 2 + bytes(rnd.getrandbits(3) for _ in range(300000))
+cap = 32 << 20
+buf = np.zeros(cap, dtype=np.uint8)
+res = []
+for level, strat, mem in [(l, zlib.Z_DEFAULT_STRATEGY, 8) for l in range(1, 10)] + [(6, zlib.Z_FILTERED, 8), (6, zlib.Z_HUFFMAN_ONLY, 8), (6, zlib.Z_RLE, 8),
+                                                                              (1, zlib.Z_RLE, 8), (9, zlib.Z_FILTERED, 1), (6, zlib.Z_DEFAULT_STRATEGY, 1),
+                                                                              (6, zlib.Z_HUFFMAN_ONLY, 1), (6, zlib.Z_HUFFMAN_ONLY, 4)]:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, mem, strat)
+    z = co.compress(d) + co.flush()
+    zin = np.frombuffer(z, dtype=np.uint8).copy()
+    st = (C.c_uint32 * 4)()
+    ol, nb, ended = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = L.mzhip_inflate_parallel_host(zin.ctypes.data, zin.size, buf.ctypes.data, cap, None, C.byref(st), C.byref(ol), C.byref(nb), C.byref(ended),
+                                       None, None, 0, 0, None, 0, None)
+    assert rc == 0, (level, strat, mem, rc)
+    assert buf[:ol.value].tobytes() == d[:ol.value], (level, strat, mem)
+    res.append([level, strat, mem, ol.value, nb.value, ended.value, len(d)])
+print(json.dumps(res))
+"""
+
+
+def test_header_check_keeps_every_real_block(gpu):
+    """Behind the header search a lane reads each candidate's header to its end and drops what a decoder would refuse
+    (k_check_headers).  A real block that it dropped would end the chain of a window early: streams of every level and
+    strategy zlib has -- Huffman only (no distance code at all), RLE (one distance code), filtered, a tiny memLevel (a block
+    every few KB, many of them fixed: the chain ends there by design) -- are decoded by ONE many-wave window exactly as far,
+    in exactly as many blocks, as with the check switched off (MZHIP_HEADER_CHECK=0, a process of its own), byte for byte; and
+    the streams made of dynamic blocks throughout are decoded to their last megabyte."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for check in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", _HEADER_CHECK_PROG % root], capture_output=True, text=True, timeout=600, cwd=root,
+                           env=dict(os.environ, MZHIP_HEADER_CHECK=check))
+        assert r.returncode == 0, r.stderr[-3000:]
+        got[check] = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])
+    assert got["1"] == got["0"]
+    through = [g for g in got["1"] if g[3] > g[6] - (1 << 20)]
+    print("streams decoded through by one window: %d of %d; blocks per stream %s" % (len(through), len(got["1"]), sorted(g[4] for g in got["1"])))
+    assert len(through) >= 13 and all(g[4] >= 20 for g in through)
+
+
+def test_header_search_kernels_agree(gpu):
+    """The header search of a window (k_find_blocks: 32 bit offsets per lane from one 16-byte fetch, the loop-free tests made for
+    all 32 at once) against the kernel it replaced (one offset per lane through mz_block_header_plausible, the statement of the
+    test): the same set of candidates on noise, on streams of text at three levels, on stored blocks and zeros, for ranges that
+    start and end anywhere, inputs of every small length and every placement relative to a dword on the device -- and, in
+    Python, the dynamic-header rule itself on a sample of the candidates and of the offsets that were refused."""
+    import random
+
+    L = gpu.mz.lib()
+    L.mzhip_find_blocks_host.restype = C.c_int32
+    L.mzhip_find_blocks_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    rnd = random.Random(5)
+    text, _ = synth.bench_corpus()
+
+    def find(a, b0, b1, which, mis):
+        cap = 1 << 20
+        out = np.zeros(cap, dtype=np.uint32)
+        n = C.c_uint32()
+        rc = L.mzhip_find_blocks_host(a.ctypes.data, a.size, b0, b1, which, mis, out.ctypes.data, cap, C.byref(n))
+        assert rc == 0 and n.value <= cap, (rc, n.value)
+        return np.sort(out[:n.value])
+
+    def bits(a, p, k):
+        v = 0
+        for i in range(k):
+            v |= ((int(a[(p + i) >> 3]) >> ((p + i) & 7)) & 1) << i
+        return v
+
+    def plausible(a, p):
+        if (p >> 3) + 24 > a.size:
+            return False
+        bt = bits(a, p + 1, 2)
+        if bt == 0:
+            b = (p + 10) >> 3
+            return (int(a[b]) | int(a[b + 1]) << 8) ^ (int(a[b + 2]) | int(a[b + 3]) << 8) == 0xFFFF
+        if bt != 2 or bits(a, p + 3, 5) > 29 or bits(a, p + 8, 5) > 29:
+            return False
+        kraft = 0
+        for i in range(bits(a, p + 13, 4) + 4):
+            l = bits(a, p + 17 + 3 * i, 3)
+            kraft += (128 >> l) if l else 0
+        return kraft == 128
+
+    stored = b"".join(zlib.compressobj(0, zlib.DEFLATED, -15).compress(bytes(rnd.getrandbits(8) for _ in range(n))) for n in (70000, 3, 65535, 100))
+    inputs = [("noise", bytes(rnd.getrandbits(8) for _ in range(1 << 20))),
+              ("text level 1", synth.deflate_raw(text * 6, 1)), ("text level 6", synth.deflate_raw(text * 6, 6)), ("text level 9", synth.deflate_raw(text * 3, 9)),
+              ("stored", stored + synth.deflate_raw(bytes(rnd.getrandbits(8) for _ in range(200000)), 6)), ("zeros", bytes(300000)), ("ones", b"\xff" * 300000)]
+    total = 0
+    for name, raw in inputs:
+        a = np.frombuffer(raw, dtype=np.uint8).copy()
+        nb = 8 * a.size
+        ranges = [(0, nb), (1, nb), (31, nb - 7), (rnd.randrange(nb // 2), rnd.randrange(nb // 2, nb)), (nb - 300, nb), (12345, 12345), (12345, 12346)]
+        for i, (b0, b1) in enumerate(ranges):
+            mis = (0, 1, 2, 3, 5, 8, 15)[i % 7]
+            new, old = find(a, b0, b1, 0, mis), find(a, b0, b1, 1, mis)
+            assert np.array_equal(new, old), (name, b0, b1, mis, new.size, old.size)
+            assert new.size == 0 or (new[0] >= b0 and new[-1] < b1)
+            total += new.size
+            kept = find(a, b0, b1, 2, mis)   # ... and what the header check behind the search keeps of them
+            assert np.isin(kept, new).all() and np.unique(kept).size == kept.size, (name, b0, b1, mis)
+            if name == "noise" and i == 0:
+                assert kept.size * 20 < new.size + 20, (kept.size, new.size)
+        full = find(a, 0, nb, 0, 0)
+        yes = set(int(x) for x in full)
+        for p in [int(x) for x in full[:: max(1, full.size // 60)]]:
+            assert plausible(a, p), (name, p)
+        for p in (rnd.randrange(nb) for _ in range(300)):
+            assert plausible(a, p) == (p in yes), (name, p)
+    assert total > 10000
+    for n in list(range(0, 40)) + [63, 64, 65, 100, 257]:   # inputs shorter than a lane's fetch, ranges that hold nothing
+        a = np.frombuffer(bytes(rnd.getrandbits(8) for _ in range(n)) + b"\0", dtype=np.uint8)[:n].copy() if n else np.zeros(1, dtype=np.uint8)[:0].copy()
+        if n == 0:
+            continue
+        for mis in (0, 3):
+            assert np.array_equal(find(a, 0, 8 * n, 0, mis), find(a, 0, 8 * n, 1, mis)), n
+
+
 @pytest.mark.parametrize("kind", ["sparse", "text"])
 def test_entry_larger_than_any_window_bounded_memory(tmp_path, kind):
     """A ZIP64 entry of 3 GiB (the reference streams any size through 32 767 bytes, mz_strm_zlib.c:51,116-193): the
