@@ -104,6 +104,9 @@ static uint64_t g_clears_seen;
 static uint64_t g_autoprimed, g_windows_primed, g_windows_evicted, g_peak_bytes; /* (tests, reports) */
 MZHIP_API uint64_t mzhip_autoprime_count(void) { return __atomic_load_n(&g_autoprimed, __ATOMIC_RELAXED); }
 
+#ifndef MZH_ROLL_WINDOW_DIV
+#define MZH_ROLL_WINDOW_DIV 16 /* a window is at most the budget / this: 128 MiB of compressed + decoded bytes by default.  (8 until the end of round 6: eight readers, a window and a look-ahead each, are twice the budget in 256 MiB windows -- windows in use were evicted, one in three passes left a window to the per-entry path: 2 GiB/s instead of 6 - 8, tests/diag_roll_T.py) */
+#endif
 /* ---- archives that are rolled over ---- */
 enum { W_NONE = 0, W_BUSY, W_LIVE, W_DEAD };
 typedef struct {
@@ -282,7 +285,13 @@ static roll *roll_new(mzhip_stream *arch, int64_t size, uint64_t crc4, uint64_t 
         goto out;
     {
         /* the rows a window can take: codec entries that fit one, in front of the central directory */
-        const uint64_t wmax = budget / 8 < MZH_ROLL_WINDOW ? budget / 8 : MZH_ROLL_WINDOW;
+        static int wdiv = 0;
+        if (!wdiv) {
+            const char *e = getenv("MZHIP_ROLL_WINDOW_DIV"); /* (A/B) windows of budget / this */
+            const int v = e ? atoi(e) : 0;
+            wdiv = v >= 4 && v <= 256 ? v : MZH_ROLL_WINDOW_DIV;
+        }
+        const uint64_t wmax = budget / (uint64_t)wdiv < MZH_ROLL_WINDOW ? budget / (uint64_t)wdiv : MZH_ROLL_WINDOW;
         const int64_t cd0 = table[6];
         uint16_t *alg = (uint16_t *)malloc((size_t)n * 2), *dsz = (uint16_t *)malloc((size_t)n * 2);
         uint8_t *dig = (uint8_t *)malloc((size_t)n * 64);
@@ -407,6 +416,14 @@ out:
  * roll rk), and windows some reader is in (used in the last MZH_ROLL_FRESH calls) or is about to be in (a look-ahead nobody
  * has reached) only for a window that is NEEDED and would take the cache past twice the budget.  1 = go ahead. */
 static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_t keep, int lookahead) {
+    static int count_busy = -1;
+    if (count_busy < 0) {
+        /* "1": windows on their way count against the budget like live ones.  Measured with 8 file readers on the config-2 archive
+         * (tests/diag_roll_T.py): the look-aheads that then go without make every pass ~2 GiB/s instead of 5 - 8 -- off */
+        const char *e = getenv("MZHIP_ROLL_BUSY");
+        count_busy = (e && e[0] == '1') ? 1 : 0;
+    }
+    const uint64_t busy_bytes = count_busy ? g_busy_bytes : 0;
     for (;;) {
         int32_t live = 0;
         roll *vr = NULL, *fr = NULL;
@@ -436,7 +453,7 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
                 }
             }
         }
-        if (g_live_bytes + g_busy_bytes + need <= budget && live < MZH_ROLL_MAX_WINDOWS)
+        if (g_live_bytes + busy_bytes + need <= budget && live < MZH_ROLL_MAX_WINDOWS)
             return 1;
         if (vw < 0) {
             /* nothing but windows in use is left.  A look-ahead does without; a window that is needed goes over the budget -- up
@@ -444,7 +461,7 @@ static int roll_make_room(uint64_t need, uint64_t budget, const roll *rk, int32_
              * prime them again a moment later: measured, 62 windows primed for an archive of 32) */
             if (lookahead)
                 return 0;
-            if (fw < 0 || (g_live_bytes + g_busy_bytes + need <= 2 * budget && live < MZH_ROLL_MAX_WINDOWS))
+            if (fw < 0 || (g_live_bytes + busy_bytes + need <= 2 * budget && live < MZH_ROLL_MAX_WINDOWS))
                 return 1;
             vr = fr;
             vw = fw;

@@ -576,7 +576,7 @@ print(json.dumps(res))
             # output; the peak varies by 1 - 2 GB from run to run with what the four readers happen to wait for at once.)
             assert s["pinned_peak"] <= (5 << 30) + (512 << 20), s
             assert s["hwm"] < (8 << 30), s
-        assert res["1"]["autos"] == 1 and res["1"]["primed"] >= 20 and res["1"]["evicted"] >= res["1"]["primed"] - 16
+        assert res["1"]["autos"] == 1 and res["1"]["primed"] >= 40 and res["1"]["evicted"] >= res["1"]["primed"] - 24
         assert res["4"]["autos"] == 1                                       # (indexed once per process, rolled over again)
         assert n * size / 2**30 / res["1"]["sec"] > 1.5                     # the reference's reader thread makes ~0.36 GiB/s
         # bytes of a sample of the entries against the reference's reader (the zip layer verified every CRC above)
