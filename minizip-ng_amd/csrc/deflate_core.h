@@ -310,8 +310,11 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
         }                                                                  \
     } while (0)
 
-/* Encode in[0..in_len) as one raw-DEFLATE piece.  final != 0: a complete stream (last block BFINAL, padded to a
- * byte).  final == 0: non-final blocks followed by an empty stored block, so that pieces of one stream can be
+/* Encode in[warm..in_len) as one raw-DEFLATE piece.  final != 0: a complete stream (last block BFINAL, padded to a
+ * byte).  warm (a multiple of 64, 0 for a piece that stands alone): in[0..warm) are the bytes in front of the piece in the
+ * SAME stream -- they are hashed into the buckets before the first position is coded and matches may reach back into them
+ * (DEFLATE's window spans blocks), so a stream can be cut into pieces for as many waves without paying for it in matches
+ * that end at the cut; in_len - warm <= MZ_DEF_BLOCK then (one block: positions are 16 bits wide).  final == 0: non-final blocks followed by an empty stored block, so that pieces of one stream can be
  * concatenated on byte boundaries.  tok = this wave's token scratch (MZ_DEF_BLOCK words).  All arguments
  * wave-uniform. */
 /* ways / xhead: the match finder keeps the `ways` most recent positions of every hash bucket (1 = the fast class: zlib
@@ -327,7 +330,7 @@ MZ_DEV void mz_huff_build(mz_deflate_lds *L, uint32_t base, uint32_t n, uint32_t
  * is worth 3.3 % of the output on the bench corpus with the same match finder (tests/study/enc_parse.c). */
 #define MZ_DEF_WAYS_BEST 4u
 template <uint32_t parse> /* (a template argument: the cost parse needs 160 registers, the other classes run four waves per SIMD on 128) */
-MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
+MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint32_t warm, uint8_t *out, uint32_t out_cap, uint32_t final,
                              uint32_t *tok, mz_deflate_lds *L, const uint32_t *crc_tab, const mzhip_crc_tables *tabs,
                              uint32_t ways, uint16_t *xhead, uint32_t max_dist, mz_deflate_result *res) {
     MZ_LANE_DECL
@@ -341,8 +344,10 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
     MZ_LANES { P(crc_acc) = (lane == 0) ? 0xFFFFFFFFu : 0u; }
     MZ_DPROF_DECL
 
-    for (uint32_t blk = 0; blk < in_len || blk == 0u; blk += MZ_DEF_BLOCK) {
+    const uint8_t *const cin = in + warm; /* the piece's own bytes: what the CRC runs over */
+    for (uint32_t blk = warm; blk < in_len || blk == warm; blk += MZ_DEF_BLOCK) {
         const uint32_t blk_end = (in_len - blk < MZ_DEF_BLOCK) ? in_len : blk + MZ_DEF_BLOCK;
+        const uint32_t lo = (blk == warm) ? 0u : blk; /* the oldest position a match of this block may start at */
         const uint32_t bfinal = (final && blk_end == in_len) ? 1u : 0u;
         /* ================= pass 1: tokens and histograms ================= */
         MZ_LANES {
@@ -351,6 +356,35 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             for (uint32_t i = (uint32_t)lane; i <= MZ_DEF_NSYM; i += 64u) L->freq[i] = 0u;
         }
         MZ_WAVE_SYNC();
+        if (blk == warm && warm) {
+            /* the bytes in front of the piece into the buckets, 64 positions a step, nothing else: what the coded steps below do
+             * with a position's bucket, without the look at its candidates */
+            for (uint32_t p = 0; ways == 1u && p < warm; p += 64u) { /* one way: the bucket is the newest position, nothing moves down */
+                MZ_LANES {
+                    const uint32_t pos = p + (uint32_t)lane;
+                    L->u.head[(mz_load_u32(in + pos) * 2654435761u) >> (32 - MZ_DEF_HBITS)] = (uint16_t)pos;
+                }
+            }
+            if (ways == 1u) MZ_WAVE_SYNC();
+            for (uint32_t p = 0; ways > 1u && p < warm; p += 64u) {
+                PV(uint32_t, wh);
+                PV(uint32_t, wc);
+                PV2(uint32_t, wcx, MZ_DEF_WAYS_BEST - 1u);
+                MZ_LANES {
+                    const uint32_t pos = p + (uint32_t)lane;
+                    P(wh) = (mz_load_u32(in + pos) * 2654435761u) >> (32 - MZ_DEF_HBITS); /* (pos + 4 <= warm + 3 < in_len or the piece is empty: below) */
+                    P(wc) = (uint32_t)L->u.head[P(wh)];
+                    for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++) P(wcx)[w - 1u] = (w < ways) ? (uint32_t)xhead[((w - 1u) << MZ_DEF_HBITS) | P(wh)] : 0u;
+                }
+                MZ_WAVE_SYNC();
+                MZ_LANES {
+                    for (uint32_t w = MZ_DEF_WAYS_BEST - 1u; w >= 1u; w--)
+                        if (w < ways) xhead[((w - 1u) << MZ_DEF_HBITS) | P(wh)] = (uint16_t)(w == 1u ? P(wc) : P(wcx)[w - 2u]);
+                    L->u.head[P(wh)] = (uint16_t)(p + (uint32_t)lane);
+                }
+                MZ_WAVE_SYNC();
+            }
+        }
         uint32_t ntokens = 0, skip = 0;
         PV(uint32_t, xbits); /* extra bits of this lane's tokens */
         MZ_LANES { P(xbits) = 0; }
@@ -383,7 +417,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
             for (uint32_t w = 1; w < MZ_DEF_WAYS_BEST; w++)                                                            \
                 P(candx_n)[w - 1u] = (have4 && w < ways) ? (uint32_t)xhead[((w - 1u) << MZ_DEF_HBITS) | h] : 0u;       \
             const uint32_t d = (pos - P(cand_n)) & 0xFFFFu;                                                            \
-            uint32_t ok = (have4 && pos + 16u <= blk_end && d >= 1u && d <= max_dist && d <= pos - blk) ? 1u : 0u;     \
+            uint32_t ok = (have4 && pos + 16u <= blk_end && d >= 1u && d <= max_dist && d <= pos - lo) ? 1u : 0u;      \
             P(pre_n) = ok;                                                                                             \
             if (ok) {                                                                                                  \
                 for (uint32_t k = 0; k < 4u; k++) {                                                                    \
@@ -438,7 +472,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
                         if (w >= ways) break;
                         const uint32_t d = (pos - (w ? P(candx)[w - 1u] : P(cand))) & 0xFFFFu;
                         /* the head table is cleared per block, so a candidate never precedes the block */
-                        if (d >= 1u && d <= max_dist && d <= pos - blk && d != dist) {
+                        if (d >= 1u && d <= max_dist && d <= pos - lo && d != dist) {
                             uint32_t l;
                             if (w == 0u && P(pre)) { /* the first 16 bytes are here already */
                                 const uint32_t x0 = P(pa)[0] ^ P(pb)[0], x1 = P(pa)[1] ^ P(pb)[1], x2 = P(pa)[2] ^ P(pb)[2],
@@ -502,7 +536,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint8_t *out, u
 #include "deflate_select.inc"
 #undef MZ_DEF_STORE_TOKENS
             MZ_DPROF_MARK(20); /* tokens out, histograms */
-            MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, (p + nv), crc_tab, tabs->kx);
+            MZ_CRC_FOLD_TILES(crc_acc, crc_done, cin, (p + nv) - warm, crc_tab, tabs->kx);
             MZ_DPROF_MARK(21); /* CRC of the input */
         }
 #undef MZ_DEF_LOOKUP
@@ -922,8 +956,8 @@ finish:
     res->out_len = obyte;
     {
         uint32_t crc;
-        MZ_CRC_FOLD_TILES(crc_acc, crc_done, in, in_len, crc_tab, tabs->kx);
-        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, in, in_len, crc_tab, tabs);
+        MZ_CRC_FOLD_TILES(crc_acc, crc_done, cin, in_len - warm, crc_tab, tabs->kx);
+        MZ_CRC_FINISH(crc, crc_acc, crc_tmp, crc_done, cin, in_len - warm, crc_tab, tabs);
         res->crc = crc;
     }
     MZ_DPROF_FLUSH

@@ -403,6 +403,7 @@ struct DeflateArgs {
     const uint64_t *out_off;
     const uint32_t *out_cap;
     const uint8_t *final_flag; // may be null: every piece is a complete stream
+    const uint32_t *warm;      // may be null (0): bytes in front of a piece, in the same blob, that it may match into (mz_deflate_piece)
     uint32_t n;
     uint32_t *out_len;
     uint32_t *crc;
@@ -440,8 +441,9 @@ __device__ __forceinline__ void deflate_batch_body(const DeflateArgs &a) {
         const uint8_t *in = a.in + (((uint64_t)MZ_UNIFORM((uint32_t)(io >> 32)) << 32) | MZ_UNIFORM((uint32_t)io));
         uint8_t *out = a.out + (((uint64_t)MZ_UNIFORM((uint32_t)(oo >> 32)) << 32) | MZ_UNIFORM((uint32_t)oo));
         const uint32_t fin = a.final_flag ? MZ_UNIFORM((uint32_t)a.final_flag[e]) : 1u;
+        const uint32_t warm = a.warm ? MZ_UNIFORM(a.warm[e]) : 0u;
         mz_deflate_result r;
-        mz_deflate_piece<kParse>(in, MZ_UNIFORM(a.in_len[e]), out, MZ_UNIFORM(a.out_cap[e]), fin,
+        mz_deflate_piece<kParse>(in - warm, MZ_UNIFORM(a.in_len[e]) + warm, warm, out, MZ_UNIFORM(a.out_cap[e]), fin,
                          a.tok + (size_t)(blockIdx.x * MZ_WAVES_PER_WG + wave) * MZ_DEF_BLOCK, L, crc_tab, a.tabs,
                          MZ_UNIFORM(a.ways), xhead, MZ_UNIFORM(a.max_dist), &r);
         a.out_len[e] = r.out_len;

@@ -432,6 +432,8 @@ extern "C" uint32_t emul_lzma_lds_bytes(void) { return (uint32_t)sizeof(mz_lzma_
 
 static uint32_t g_def_max_dist = 32768u - 262u;
 extern "C" void emul_deflate_window(uint32_t window_log2) { g_def_max_dist = (1u << window_log2) - 262u; }
+static uint32_t g_def_warm = 0; /* the next calls' in[] starts this many bytes in front of the piece (emul_deflate_warm) */
+extern "C" void emul_deflate_warm(uint32_t warm) { g_def_warm = warm; }
 static int32_t emul_deflate_ways(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_cap, uint32_t final,
                                  uint32_t ways, uint32_t parse, uint32_t *out_len, uint32_t *crc) {
     ready();
@@ -441,8 +443,8 @@ static int32_t emul_deflate_ways(const uint8_t *in, uint32_t in_len, uint8_t *ou
     memset(xh, 0x5A, (MZ_DEF_WAYS_BEST - 1u) * sizeof(uint16_t) << MZ_DEF_HBITS);
     mz_deflate_result r;
     uint32_t *tok = (uint32_t *)malloc(MZ_DEF_BLOCK * sizeof(uint32_t));
-    if (parse) mz_deflate_piece<1u>(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, &r);
-    else mz_deflate_piece<0u>(in, in_len, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, &r);
+    if (parse) mz_deflate_piece<1u>(in, in_len, g_def_warm, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, &r);
+    else mz_deflate_piece<0u>(in, in_len, g_def_warm, out, out_cap, final, tok, L, g_tabs.byte_tab, &g_tabs, ways, xh, g_def_max_dist, &r);
     free(tok);
     free(xh);
     free(L);

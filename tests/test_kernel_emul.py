@@ -987,3 +987,56 @@ def test_parallel_window_candidate_order(tmp_path):
     subprocess.run(["g++", "-O2", os.path.join(ROOT, "tests", "unit_par_order.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "0 of 300 differ" in r.stdout, r.stdout + r.stderr
+
+
+def test_deflate_pieces_with_history(emu):
+    """K4 cuts ONE stream into pieces of 16 KiB for as many waves (the WRITE shim's segments, mzhip_prime_write's entries); every
+    piece but the first is handed the 32 KiB in front of it (`warm`): they are hashed into the buckets before its first position
+    is coded and its matches may reach back into them.  The pieces' bytes, concatenated, are one stream zlib inflates to the
+    input; each piece's CRC covers its own bytes only; and the stream is SMALLER than with pieces of 64 KiB that do not see each
+    other (what rounds 2 - 5 wrote), far smaller than 16 KiB pieces without the history."""
+    import random
+    import zlib
+
+    from tests import synth
+
+    emu.emul_deflate_lazy.argtypes = emu.emul_deflate.argtypes
+    emu.emul_deflate_best.argtypes = emu.emul_deflate.argtypes
+    text, _ = synth.bench_corpus()
+    rnd = random.Random(3)
+
+    def encode(data, piece, fn, history):
+        a = np.frombuffer(data, dtype=np.uint8).copy() if data else np.zeros(1, dtype=np.uint8)
+        out, pos, n = b"", 0, len(data)
+        while True:
+            k = min(piece, n - pos)
+            warm = (min(pos, 32768) // 64) * 64 if history else 0
+            cap = k + k // 8 + 128
+            o = np.zeros(cap, dtype=np.uint8)
+            ol, cr = C.c_uint32(), C.c_uint32()
+            emu.emul_deflate_warm(warm)
+            try:
+                st = fn(a[pos - warm:].ctypes.data_as(_u8p), k + warm, o.ctypes.data_as(_u8p), cap, 1 if pos + k >= n else 0, C.byref(ol), C.byref(cr))
+            finally:
+                emu.emul_deflate_warm(0)
+            assert st == 0 and cr.value == zlib.crc32(data[pos:pos + k]), (pos, k, st)
+            out += o[:ol.value].tobytes()
+            pos += k
+            if pos >= n:
+                return out
+
+    cases = [("text", (text * 2)[:400000]), ("binary + text", bytes((i * 7 + (i >> 3)) & 255 for i in range(150000)) + text[:100000]),
+             ("one piece and a bit", text[:16384 + 70]), ("exactly four", text[:65536]), ("short", text[:100]), ("empty", b""),
+             ("noise", bytes(rnd.getrandbits(8) for _ in range(70000))), ("zeros", bytes(200000))]
+    for name, data in cases:
+        for cls, fn in (("fast", emu.emul_deflate), ("lazy", emu.emul_deflate_lazy), ("best", emu.emul_deflate_best)):
+            if cls == "best" and len(data) > 200000:
+                continue
+            z16 = encode(data, 16384, fn, True)
+            assert zlib.decompress(z16, -15) == data, (name, cls)
+            if name == "text" and cls != "best":
+                z64_blind, z16_blind = encode(data, 65536, fn, False), encode(data, 16384, fn, False)
+                assert zlib.decompress(z64_blind, -15) == data
+                print("%s, %s: 16 KiB pieces with history %.4f, 64 KiB pieces without %.4f, 16 KiB without %.4f" % (
+                    name, cls, len(z16) / len(data), len(z64_blind) / len(data), len(z16_blind) / len(data)))
+                assert len(z16) < len(z64_blind) < len(z16_blind)
