@@ -684,6 +684,155 @@ static void forget_everything(void) {
     g_live_bytes = 0;
 }
 
+/* ... from the central directory, for the entry whose local header stands at loff: the directory of the archive that was asked
+ * about last is kept as (local header offset, compressed size) pairs in offset order (16 bytes an entry, archives of up to a
+ * million entries; another archive replaces it).  Which archive: its size and a hash of its last 4 KiB, as everywhere in this
+ * file.  The stream is the calling thread's own; the lock covers the pairs only. */
+static pthread_mutex_t g_hint_mu = PTHREAD_MUTEX_INITIALIZER;
+static struct {
+    int64_t size, n;
+    uint64_t crc4;
+    int64_t *pairs;
+} g_hint;
+static int cmp_pairs(const void *a, const void *b) {
+    const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return x < y ? -1 : x > y;
+}
+static int64_t cd_csize_hint(mzhip_stream *arch, int64_t loff) {
+    const int64_t pos = arch->vtbl->tell(arch);
+    if (pos < 0 || arch->vtbl->seek(arch, 0, MZH_SEEK_END) != MZH_OK)
+        return 0;
+    const int64_t size = arch->vtbl->tell(arch);
+    uint8_t t4[MZH_TAIL4K];
+    const int64_t n4 = size < MZH_TAIL4K ? size : MZH_TAIL4K;
+    int64_t found = 0;
+    if (size >= 22 && read_at(arch, size - n4, t4, n4)) {
+        const uint64_t crc4 = tail_hash(t4, (size_t)n4);
+        int have = 0;
+        pthread_mutex_lock(&g_hint_mu);
+        have = g_hint.pairs && g_hint.size == size && g_hint.crc4 == crc4;
+        pthread_mutex_unlock(&g_hint_mu);
+        if (!have) { /* read the directory (outside the lock: this thread's stream), then put it in place */
+            uint64_t from = size > (1 << 18) ? (uint64_t)size - (1 << 18) : 0;
+            uint8_t *tail = NULL;
+            int64_t n = 0, *table = NULL, *pairs = NULL;
+            int ok = 1;
+            for (int pass = 0; ok && pass < 4; pass++) {
+                const uint64_t len = (uint64_t)size - from;
+                free(tail);
+                tail = len <= ((uint64_t)256 << 20) ? (uint8_t *)malloc((size_t)len) : NULL;
+                if (!tail || !read_at(arch, (int64_t)from, tail, (int64_t)len)) {
+                    ok = 0;
+                    break;
+                }
+                uint64_t need = 0;
+                n = mzhip_zip_index_tail(tail, from, (uint64_t)size, NULL, 0, &need);
+                if (n != MZHIP_INDEX_NEED_MORE)
+                    break;
+                if (need >= from)
+                    ok = 0;
+                from = need;
+            }
+            if (ok && n > 0 && n <= (1 << 20) && (table = (int64_t *)malloc((size_t)n * 8 * sizeof(int64_t))) != NULL &&
+                mzhip_zip_index_tail(tail, from, (uint64_t)size, table, n, NULL) == n && (pairs = (int64_t *)malloc((size_t)n * 2 * sizeof(int64_t))) != NULL) {
+                for (int64_t k = 0; k < n; k++) {
+                    pairs[2 * k] = table[8 * k + 5];
+                    pairs[2 * k + 1] = table[8 * k + 3];
+                }
+                qsort(pairs, (size_t)n, 2 * sizeof(int64_t), cmp_pairs);
+                pthread_mutex_lock(&g_hint_mu);
+                free(g_hint.pairs);
+                g_hint.pairs = pairs;
+                g_hint.n = n;
+                g_hint.size = size;
+                g_hint.crc4 = crc4;
+                pthread_mutex_unlock(&g_hint_mu);
+                pairs = NULL;
+                have = 1;
+            }
+            free(pairs);
+            free(table);
+            free(tail);
+        }
+        if (have) {
+            pthread_mutex_lock(&g_hint_mu);
+            if (g_hint.pairs && g_hint.size == size && g_hint.crc4 == crc4) {
+                int64_t lo = 0, hi = g_hint.n - 1;
+                while (lo <= hi) {
+                    const int64_t mid = (lo + hi) / 2, v = g_hint.pairs[2 * mid];
+                    if (v == loff) {
+                        found = g_hint.pairs[2 * mid + 1];
+                        break;
+                    }
+                    if (v < loff)
+                        lo = mid + 1;
+                    else
+                        hi = mid - 1;
+                }
+            }
+            pthread_mutex_unlock(&g_hint_mu);
+        }
+    }
+    (void)arch->vtbl->seek(arch, pos, MZH_SEEK_SET);
+    return found > 0 ? found : 0;
+}
+
+/* How many compressed bytes the entry holds whose payload starts at payload_off of the archive under codec_base, read off the
+ * local header in front of it (appnote.txt 4.3.7: signature, flags at +6, compressed size at +18, name and extra lengths at
+ * +26 / +28; the ZIP64 extra field when the size says 0xFFFFFFFF) -- or, when the header leaves the sizes to a data descriptor, off
+ * the central directory (cd_csize_hint).  0 = not to be had: no header where one should be, a stream that cannot seek.  The codec stream is not told the size (mz_zip.c:1815-1830 sets
+ * MZ_STREAM_PROP_TOTAL_IN_MAX for raw, stored and encrypted entries only); the READ shim uses this as a HINT for when to ask the
+ * device -- once, with all of the entry, instead of at 32, 64, 128 KiB from the first byte each time -- never for what it reads
+ * or returns: a wrong hint costs an attempt, nothing else.  The stream's position is restored. */
+int64_t mzhip_lfh_csize_hint(mzhip_stream *codec_base, int64_t payload_off) {
+    if (!codec_base || !codec_base->vtbl || payload_off < 30)
+        return 0;
+    mzhip_stream *arch = codec_base->base ? codec_base->base : codec_base;
+    if (!arch->vtbl || !arch->vtbl->seek || !arch->vtbl->tell || !arch->vtbl->read || !arch->vtbl->is_open ||
+        arch->vtbl->is_open(arch) != MZH_OK)
+        return 0;
+    const int64_t pos = arch->vtbl->tell(arch);
+    if (pos < 0)
+        return 0;
+    uint8_t buf[2048];
+    const int64_t back = payload_off < (int64_t)sizeof(buf) ? payload_off : (int64_t)sizeof(buf);
+    const int got = read_at(arch, payload_off - back, buf, back);
+    if (arch->vtbl->seek(arch, pos, MZH_SEEK_SET) != MZH_OK || !got)
+        return 0;
+    for (int64_t i = back - 30; i >= 0; i--) {
+        if (buf[i] != 0x50 || buf[i + 1] != 0x4B || buf[i + 2] != 0x03 || buf[i + 3] != 0x04)
+            continue;
+        const int64_t n = (int64_t)buf[i + 26] | ((int64_t)buf[i + 27] << 8), m = (int64_t)buf[i + 28] | ((int64_t)buf[i + 29] << 8);
+        if (i + 30 + n + m != back)
+            continue; /* (these four bytes inside a name or an extra field) */
+        const uint32_t flags = (uint32_t)buf[i + 6] | ((uint32_t)buf[i + 7] << 8);
+        if (flags & 8u) /* sizes follow the payload (the reference's own writer does that): the central directory has them */
+            return cd_csize_hint(arch, payload_off - back + i);
+        const uint32_t c32 = (uint32_t)buf[i + 18] | ((uint32_t)buf[i + 19] << 8) | ((uint32_t)buf[i + 20] << 16) | ((uint32_t)buf[i + 21] << 24);
+        const uint32_t u32 = (uint32_t)buf[i + 22] | ((uint32_t)buf[i + 23] << 8) | ((uint32_t)buf[i + 24] << 16) | ((uint32_t)buf[i + 25] << 24);
+        if (c32 != 0xFFFFFFFFu)
+            return (int64_t)c32;
+        const uint8_t *x = buf + i + 30 + n, *xe = x + m;
+        while (xe - x >= 4) {
+            const uint32_t id = (uint32_t)x[0] | ((uint32_t)x[1] << 8), len = (uint32_t)x[2] | ((uint32_t)x[3] << 8);
+            if ((int64_t)len > xe - x - 4)
+                return 0;
+            if (id == 1u) {
+                const uint32_t skip = u32 == 0xFFFFFFFFu ? 8u : 0u;
+                if (len < skip + 8u)
+                    return 0;
+                uint64_t c = 0;
+                for (int k = 7; k >= 0; k--)
+                    c = (c << 8) | x[4 + skip + k];
+                return c <= (uint64_t)INT64_MAX ? (int64_t)c : 0;
+            }
+            x += 4 + len;
+        }
+        return 0;
+    }
+    return 0;
+}
+
 void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
     const char *env = getenv("MZHIP_AUTOPRIME");
     if (env && env[0] == '0')

@@ -17,6 +17,7 @@ int32_t mzhip_prime_store_crc(const uint8_t *buf, int32_t size, uint32_t *crc);
  * on an entry's first read (shim_autoprime.c; MZHIP_AUTOPRIME=0 turns it off) */
 struct mzhip_stream_s;
 void mzhip_autoprime(struct mzhip_stream_s *codec_base, int64_t payload_off);
+int64_t mzhip_lfh_csize_hint(struct mzhip_stream_s *codec_base, int64_t payload_off); /* (shim_autoprime.c) the entry's compressed size off its local header, or 0 */
 /* write-side prime (mzhip_prime_write): follow the bytes a WRITE stream is handed against the primed buffers */
 int32_t mzhip_wprime_track(int32_t method, int64_t *id, int64_t pos, const uint8_t *buf, int32_t size, uint32_t *chunk_crc,
                            int32_t *have_crc, const uint8_t **src);

@@ -73,6 +73,7 @@ typedef struct mzhip_zlib_s {
     int32_t dev_status;
     int64_t dev_in_used;
     int64_t next_attempt; /* try the device again once in_len reaches this */
+    int64_t csize_hint;   /* the entry's compressed size as its local header has it (0: unknown): when to ask the device, nothing else */
     /* write side, mzhip_prime_write: the entry so far equals bytes [0, wp_pos) of primed buffer wp_id */
     int64_t wp_id, wp_pos;
     int8_t wp_off; /* this entry is not (or no longer) following a primed buffer */
@@ -314,6 +315,7 @@ int32_t mz_stream_zlib_open(void *stream, const char *path, int32_t mode) {
     z->dev_status = 0;
     z->dev_in_used = 0;
     z->next_attempt = 0;
+    z->csize_hint = 0;
     z->tried_cache = 0;
     z->hash_alg = 0;
     z->hash_digest = NULL;
@@ -1278,7 +1280,8 @@ static int32_t attempt_decode(mzhip_zlib *z) {
         }
     }
     if (!z->payload_done && !z->streaming && mzh_stream_parallel() && z->in_len < mzh_stream_window() &&
-        (z->max_total_in >= (int64_t)MZH_STREAM_EARLY + z->hdr_len || (!z->base_eof && z->in_len - z->hdr_len >= MZH_STREAM_EARLY - (MZH_STREAM_EARLY >> 6)))) { /* (pulls are 32 767 bytes: 8 of them are 262 136) */
+        (z->max_total_in >= (int64_t)MZH_STREAM_EARLY + z->hdr_len || z->csize_hint >= (int64_t)MZH_STREAM_EARLY ||
+         (!z->base_eof && z->in_len - z->hdr_len >= MZH_STREAM_EARLY - (MZH_STREAM_EARLY >> 6)))) { /* (pulls are 32 767 bytes: 8 of them are 262 136) */
         /* the stream is long enough for window mode -- the caller has said so (MZ_STREAM_PROP_TOTAL_IN_MAX: mz_zip.c sets it for
          * raw, stored and encrypted entries), or that much has been pulled and the attempts on the first 32, 64 and 128 KiB all
          * ran out of input: straight there.  (Up to round 6 the attempts went on to 1 MiB, each from the first byte, on one wave:
@@ -1420,8 +1423,12 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
             z->tried_cache = 1;
             /* the caller has said how long the stream is: the first attempt waits for all of it (or for what sends it to window
              * mode) instead of asking the device at 32 KiB, 64 KiB, 128 KiB ... from the first byte each time */
+            /* (... and never for more than half a window: an entry that has pulled a window's worth is not offered window mode) */
+            int64_t first_at = (int64_t)MZH_STREAM_EARLY + 1024;
+            if (first_at > mzh_stream_window() / 2)
+                first_at = mzh_stream_window() / 2;
             if (z->max_total_in > 0 && z->next_attempt == 0)
-                z->next_attempt = z->max_total_in < (int64_t)MZH_STREAM_EARLY + 1024 ? z->max_total_in : (int64_t)MZH_STREAM_EARLY + 1024;
+                z->next_attempt = z->max_total_in < first_at ? z->max_total_in : first_at;
             mzhip_autoprime(z->stream.base, z->base_pos0); /* (shim_autoprime.c: on unless MZHIP_AUTOPRIME=0) */
             const uint8_t *data = NULL;
             int64_t usize = 0, csize = 0;
@@ -1436,6 +1443,12 @@ int32_t mz_stream_zlib_read(void *stream, void *buf, int32_t size) {
                 z->dev_status = 0;
                 z->decoded = 1;
                 break;
+            }
+            /* not primed, and the caller has not said how long the stream is: the local header in front of the payload may */
+            if (z->max_total_in <= 0 && z->wrap == 0 && z->base_pos0 >= 30 && z->next_attempt == 0) {
+                z->csize_hint = mzhip_lfh_csize_hint(z->stream.base, z->base_pos0);
+                if (z->csize_hint > 0)
+                    z->next_attempt = z->csize_hint < first_at ? z->csize_hint : first_at;
             }
         }
         if (!z->base_eof && z->in_len < z->next_attempt)

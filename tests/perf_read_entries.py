@@ -1,5 +1,6 @@
 """Entries READ one by one through the unmodified mz_zip reader on the drop-in with nothing primed (MZHIP_AUTOPRIME=0: the per-entry
-path every look-up that misses takes) and on the all-reference build.   python tests/perf_read_entries.py [n size [drop-in only]]"""
+path every look-up that misses takes) and on the all-reference build.   python tests/perf_read_entries.py [n size [drop-in only]]
+MZ_PERF_PYZIP=1: the archive is written by Python's zipfile (sizes in the local headers) instead of the reference's writer."""
 import os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
@@ -16,7 +17,13 @@ for n, size in shapes:
     lens = np.full(n, size, dtype=np.int32)
     with tempfile.TemporaryDirectory() as tmp:
         p = os.path.join(tmp, "r.zip")
-        ref.zip_write(p, blob, offs, lens, method=8, level=6)
+        if os.environ.get("MZ_PERF_PYZIP") == "1":  # sizes in the local headers (Info-ZIP, 7-Zip, Python ... on a seekable output); the reference's writer leaves them to a data descriptor
+            import zipfile
+            with zipfile.ZipFile(p, "w", zipfile.ZIP_DEFLATED, compresslevel=6) as zf:
+                for i in range(n):
+                    zf.writestr("e/%06d" % i, blob[int(offs[i]):int(offs[i]) + size].tobytes())
+        else:
+            ref.zip_write(p, blob, offs, lens, method=8, level=6)
         cd = ref.zip_index(p)[:, 6].copy()
         for name, drv in ((("drop-in", hip),) if len(sys.argv) > 3 else (("drop-in", hip), ("reference", ref))):
             sec, crc, ulen, st = drv.zip_read_all(p, cd, nthreads=1, own_crc=False)
