@@ -67,7 +67,7 @@
 #define MZH_ROLL_WINDOW ((uint64_t)256 << 20) /* compressed + decoded bytes of a window, at most (and at most 1/8 of the budget) */
 #define MZH_ROLL_GAP ((uint64_t)8 << 20)  /* bytes between two entries' local headers that a window does not image */
 #define MZH_ROLL_FRESH 64                 /* calls (of all readers together): a window used this recently is some reader's; it is not evicted for a look-ahead, and for a needed window only past twice the budget */
-#define MZH_ROLL_MAX_WINDOWS 20           /* live at once (the cache holds 32 generations) */
+#define MZH_ROLL_MAX_WINDOWS 48           /* live at once (the cache holds 64 generations) */
 #define MZH_ROLL_DEAD_FOR 4096             /* calls a window that was given up stays with the per-entry path */
 #define MZH_TAIL4K 4096
 
@@ -131,6 +131,7 @@ typedef struct {
     int32_t nwin, busy; /* busy: threads inside I/O for one of its windows (and windows queued for the imaging thread) */
     roll_win *win;
     int fd; /* the archive opened once more (>= 0): windows are imaged with pread() by the imaging thread */
+    uint64_t wmax; /* what a window of this archive holds at most (compressed + decoded bytes) */
 } roll;
 static roll *g_rolls[MZH_ROLLS];
 static uint64_t g_tick, g_live_bytes; /* page-locked bytes of the live windows of all rolls */
@@ -345,6 +346,7 @@ static roll *roll_new(mzhip_stream *arch, int64_t size, uint64_t crc4, uint64_t 
         if (!r)
             goto out;
         r->size = size;
+        r->wmax = wmax;
         r->crc4 = crc4;
         r->tail_crc = tail_crc;
         r->ident = fnv1a64(tail + ((uint64_t)cd0 - from), (uint64_t)size - (uint64_t)cd0, FNV0); /* as a whole image's generation */
@@ -611,7 +613,7 @@ static void *img_thread(void *arg) {
 static void roll_ensure(roll *r, int32_t w, mzhip_stream *arch, uint64_t budget, int lookahead) {
     roll_win *W = &r->win[w];
     for (;;) {
-        if (W->state == W_LIVE && !mzhip_prime_has((uint64_t)r->size, W->ident)) { /* (the cache let it go: 32 generations, a re-prime) */
+        if (W->state == W_LIVE && !mzhip_prime_has((uint64_t)r->size, W->ident)) { /* (the cache let it go: 64 generations, a re-prime) */
             g_live_bytes -= W->held;
             W->held = 0;
             W->state = W_NONE;
@@ -997,6 +999,40 @@ void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
         }
     roll_on:
         R->stamp = g_tick;
+        /* Every reader that is at work wants the window it is in and the one behind it.  The budget (4 x the limit) holds that
+         * for eight readers; more of them -- sixteen threads over one archive -- used to evict each other's windows (3 - 6 GiB/s,
+         * thousands of look-ups on the per-entry path).  The budget grows with the readers seen lately: 2 windows each and 2 to
+         * spare, never past four times what was asked for. */
+        uint64_t budget_now = budget;
+        {
+            static struct {
+                pthread_t t;
+                uint64_t tick;
+                int used;
+            } seen[64];
+            const pthread_t me = pthread_self();
+            int mine = -1, spare = -1, readers = 0;
+            for (int i = 0; i < 64; i++) {
+                if (seen[i].used && pthread_equal(seen[i].t, me))
+                    mine = i;
+                else if (!seen[i].used) {
+                    if (spare < 0 || seen[spare].used)
+                        spare = i;
+                } else if (spare < 0 || (seen[spare].used && seen[i].tick < seen[spare].tick))
+                    spare = i; /* (no free slot so far: the one that has not been seen for longest) */
+            }
+            if (mine < 0)
+                mine = spare;
+            seen[mine].t = me;
+            seen[mine].tick = g_tick;
+            seen[mine].used = 1;
+            for (int i = 0; i < 64; i++)
+                if (seen[i].used && g_tick - seen[i].tick <= 4096)
+                    readers++;
+            const uint64_t want = (uint64_t)(2 * readers + 2) * R->wmax;
+            if (want > budget_now)
+                budget_now = want < 4 * budget ? want : 4 * budget;
+        }
         if (payload_off >= 0) {
             /* the window the entry at hand lies in; then the one behind it */
             int32_t lo = 0, hi = R->nwin;
@@ -1010,11 +1046,11 @@ void mzhip_autoprime(mzhip_stream *codec_base, int64_t payload_off) {
             const int32_t w = lo - 1;
             if (w >= 0 && (uint64_t)payload_off < R->win[w].hi) {
                 const int first = R->win[w].state != W_LIVE || R->win[w].hits % 256 == 0; /* (a look-ahead that found no room is tried again) */
-                roll_ensure(R, w, arch, budget, 0);
+                roll_ensure(R, w, arch, budget_now, 0);
                 R->win[w].stamp = g_tick;
                 R->win[w].hits++;
                 if (first && w + 1 < R->nwin)
-                    roll_ensure(R, w + 1, arch, budget, 1);
+                    roll_ensure(R, w + 1, arch, budget_now, 1);
             }
         }
     done:

@@ -124,7 +124,7 @@ def test_rolling_autoprime_any_size_bounded_memory(libs, monkeypatch, nthreads):
         # entry then takes the per-entry path, same bytes -- which happens to one entry in a few hundred on a device)
         assert s["hits"] + s["misses"] >= n_codec and s["misses"] <= (0 if nthreads == 1 else 4), s
         windows = s["primed"] - a0["primed"]
-        assert windows >= 50 and s["evicted"] - a0["evicted"] >= windows - 24, s   # ~80 windows of 64 KiB (the budget / 16); at most ~20 fit the budget
+        assert windows >= 50 and s["evicted"] - a0["evicted"] >= windows - 32, s   # ~80 windows of at most 64 KiB (the budget / 16); ~25 of them fit the budget (the bytes are what is bounded, below)
         budget, window = 4 * (256 << 10), (256 << 10) // 4
         assert s["peak"] <= budget + nthreads * window, s
         assert s["live"] <= budget + nthreads * window, s
