@@ -41,8 +41,20 @@
 #define MZ_DPROF_FLUSH if (lane >= 16 && lane < 32) atomicAdd(&mz_prof_buf[lane], (unsigned long long)prof_acc);
 #else
 #define MZ_DPROF_DECL
-#define MZ_DPROF_MARK(i) ((void)0)
+#define MZ_DPROF_MARK(i) MZ_DPRIO_AT(i)
 #define MZ_DPROF_FLUSH
+#endif
+/* the wave's issue priority by section, as in inflate_core.h (MZ_PRIO_MAP): two bits per mark i - 16 = the priority of what
+ * runs BEHIND mark i (28: behind the step loop: code construction).  Everything at 2 except the match measurement (0: its
+ * loads are in flight, the wave has little to issue): 20 000 x 64 KiB at level 1 15.25 -> 14.8 ms (+3 %); the measurement
+ * alone on top +1 %, codes and pass 2 alone on top +1 % (profiles/r6/ab_setprio_k3_k4.log).  -DMZ_DPRIO_MAP=0: without. */
+#ifndef MZ_DPRIO_MAP
+#define MZ_DPRIO_MAP 0x200aa22ull
+#endif
+#if MZ_DPRIO_MAP && !defined(MZHIP_HOST_EMUL) && !defined(MZ_PROF)
+#define MZ_DPRIO_AT(i) __builtin_amdgcn_s_setprio((int)(((MZ_DPRIO_MAP) >> (2 * ((i) - 16))) & 3ull))
+#else
+#define MZ_DPRIO_AT(i) ((void)0)
 #endif
 #ifndef MZ_DEF_HBITS
 #define MZ_DEF_HBITS 12
@@ -539,6 +551,7 @@ MZ_DEV void mz_deflate_piece(const uint8_t *in, uint32_t in_len, uint32_t warm, 
             MZ_CRC_FOLD_TILES(crc_acc, crc_done, cin, (p + nv) - warm, crc_tab, tabs->kx);
             MZ_DPROF_MARK(21); /* CRC of the input */
         }
+        MZ_DPRIO_AT(28);
 #undef MZ_DEF_LOOKUP
         if (parse && blk_end > blk) {
             /* ================= cost parse (see the comment above mz_deflate_piece) ================= */

@@ -78,8 +78,23 @@ extern __device__ unsigned long long mz_prof_buf[32];
     if (lane < 32) atomicAdd(&mz_prof_buf[lane], (unsigned long long)prof_acc);
 #else
 #define MZ_PROF_DECL
-#define MZ_PROF_MARK(i) ((void)0)
+#define MZ_PROF_MARK(i) MZ_PRIO_AT(i)
 #define MZ_PROF_FLUSH
+#endif
+/* The wave's issue priority by section (s_setprio; round 6, profiles/r6/ab_k1_setprio.log).  The four waves of a SIMD stand in
+ * different sections of different entries; the arbiter's default (oldest first) lets a wave in a dependent chain of LDS
+ * look-ups (the walks) wait behind waves that only have loads and stores to issue.  Two bits per section mark i =
+ * the priority of what runs BEHIND mark i (14: the start of pass 1, 15: a block header): the walks 3, near copies 2, far
+ * copies / store / CRC 1, the rest 0.  64 KiB entries 3.91 -> 3.69 ms per 20 000 (+5.6 %), 8 KiB entries 7.27 -> 7.13 ms per
+ * 200 000 (+2 %); any split that puts the walks on top is within 1 % of this one, one section alone on top gives +2 - 3 %.
+ * -DMZ_PRIO_MAP=0 is the build without. */
+#ifndef MZ_PRIO_MAP
+#define MZ_PRIO_MAP 0x34016330ull
+#endif
+#if MZ_PRIO_MAP && !defined(MZHIP_HOST_EMUL) && !defined(MZ_PROF)
+#define MZ_PRIO_AT(i) __builtin_amdgcn_s_setprio((int)(((MZ_PRIO_MAP) >> (2 * (i))) & 3ull))
+#else
+#define MZ_PRIO_AT(i) ((void)0)
 #endif
 
 #ifndef MZ_LROOT

@@ -84,6 +84,20 @@ typedef struct mz_lzma_state {
 
 /* the packet loop's stop test: nothing in the one-shot builds */
 #define LZ_RESUME_CHECK() ((void)0)
+/* the wave's issue priority (s_setprio): the chain of decisions against the work all lanes do between packets (CRC tiles,
+ * match copies).  MZ_LZPRIO = chain << 2 | bulk; 0 = no priorities, the default: what pays in K1 and K4 loses here -- one
+ * round of 4096 x 1 MiB streams 431 ms without, 440 with the chain on top (3 | 0, 2 | 1), 448 with the bulk work on top: every
+ * wave is in its chain nearly all the time, a priority only reorders equals (profiles/r6/ab_setprio_k3_k4.log) */
+#ifndef MZ_LZPRIO
+#define MZ_LZPRIO 0
+#endif
+#if MZ_LZPRIO && !defined(MZHIP_HOST_EMUL)
+#define LZ_PRIO_CHAIN() __builtin_amdgcn_s_setprio(((MZ_LZPRIO) >> 2) & 3)
+#define LZ_PRIO_BULK() __builtin_amdgcn_s_setprio((MZ_LZPRIO) & 3)
+#else
+#define LZ_PRIO_CHAIN() ((void)0)
+#define LZ_PRIO_BULK() ((void)0)
+#endif
 
 typedef struct mz_lzma_result {
     int32_t status;
@@ -437,6 +451,7 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
  * model and output locals of its caller by name; leaves through `goto finish` with `status` on any failure. */
 #define LZ_PACKET_LOOP()                                                                                              \
     for (;;) {                                                                                                        \
+        LZ_PRIO_CHAIN();                                                                                              \
         if (eof) goto finish; /* truncated input */                                                                   \
         if (lzma2 && opos == chunk_end) break; /* LZMA2: the chunk's uncompressed size has been produced */           \
         LZ_RESUME_CHECK();                                                                                            \
@@ -457,7 +472,7 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
             prev_byte = sym & 0xFFu;                                                                                  \
             opos++;                                                                                                   \
             state = state < 4 ? 0 : (state < 10 ? state - 3 : state - 6);                                             \
-            if ((opos & (MZ_CRC_TILE - 1)) == 0) MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx);  \
+            if ((opos & (MZ_CRC_TILE - 1)) == 0) { LZ_PRIO_BULK(); MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx); LZ_PRIO_CHAIN(); }  \
             continue;                                                                                                 \
         }                                                                                                             \
         uint32_t len;                                                                                                 \
@@ -483,7 +498,7 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
                     match_byte = LZ_U(out[opos - rep0 - 1]);                                                          \
                     state = state < 7 ? 9 : 11;                                                                       \
                     if ((opos & (MZ_CRC_TILE - 1)) == 0)                                                              \
-                        MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx);                           \
+                        { LZ_PRIO_BULK(); MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx); LZ_PRIO_CHAIN(); }                           \
                     continue;                                                                                         \
                 }                                                                                                     \
             } else {                                                                                                  \
@@ -559,6 +574,7 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
                 n = out_cap - opos;                                                                                   \
                 full = 1;                                                                                             \
             }                                                                                                         \
+            LZ_PRIO_BULK();                                                                                           \
             const uint32_t dist = rep0 + 1;                                                                           \
             const uint8_t *src = out + (opos - dist);                                                                 \
             if (dist >= n) {                                                                                          \
@@ -578,7 +594,7 @@ MZ_DEV uint32_t mz_prob_half(uint32_t pair, uint32_t b) { return (pair >> (b << 
             }                                                                                                         \
             prev_byte = LZ_U(out[opos - 1]);                                                                          \
             match_byte = LZ_U(out[opos - dist]);                                                                      \
-            MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx);                                       \
+            { LZ_PRIO_BULK(); MZ_CRC_FOLD_TILES(crc_acc, crc_done, out, LZ_CRC_LIMIT(opos), crc_tab, tabs->kx); LZ_PRIO_CHAIN(); }                                       \
         }                                                                                                             \
     }
 
