@@ -47,7 +47,8 @@
 /* the wave's issue priority by section, as in inflate_core.h (MZ_PRIO_MAP): two bits per mark i - 16 = the priority of what
  * runs BEHIND mark i (28: behind the step loop: code construction).  Everything at 2 except the match measurement (0: its
  * loads are in flight, the wave has little to issue): 20 000 x 64 KiB at level 1 15.25 -> 14.8 ms (+3 %); the measurement
- * alone on top +1 %, codes and pass 2 alone on top +1 % (profiles/r6/ab_setprio_k3_k4.log).  -DMZ_DPRIO_MAP=0: without. */
+ * alone on top +1 %, codes and pass 2 alone on top +1 % (profiles/r6/ab_setprio_k3_k4.log); as in K1 it is the start of a
+ * launch that gains, config 5's 100 000 pieces run as before (69.1 ms).  -DMZ_DPRIO_MAP=0: without. */
 #ifndef MZ_DPRIO_MAP
 #define MZ_DPRIO_MAP 0x200aa22ull
 #endif

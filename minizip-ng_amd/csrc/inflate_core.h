@@ -81,13 +81,15 @@ extern __device__ unsigned long long mz_prof_buf[32];
 #define MZ_PROF_MARK(i) MZ_PRIO_AT(i)
 #define MZ_PROF_FLUSH
 #endif
-/* The wave's issue priority by section (s_setprio; round 6, profiles/r6/ab_k1_setprio.log).  The four waves of a SIMD stand in
- * different sections of different entries; the arbiter's default (oldest first) lets a wave in a dependent chain of LDS
- * look-ups (the walks) wait behind waves that only have loads and stores to issue.  Two bits per section mark i =
+/* The wave's issue priority by section (s_setprio; round 6, profiles/r6/ab_k1_setprio.log).  Two bits per section mark i =
  * the priority of what runs BEHIND mark i (14: the start of pass 1, 15: a block header): the walks 3, near copies 2, far
- * copies / store / CRC 1, the rest 0.  64 KiB entries 3.91 -> 3.69 ms per 20 000 (+5.6 %), 8 KiB entries 7.27 -> 7.13 ms per
- * 200 000 (+2 %); any split that puts the walks on top is within 1 % of this one, one section alone on top gives +2 - 3 %.
- * -DMZ_PRIO_MAP=0 is the build without. */
+ * copies / store / CRC 1, the rest 0.  What it buys is the START of a launch: the four waves of a SIMD begin their entries
+ * together and stand in the same section at the same time, a chain of dependent LDS look-ups queueing behind three others
+ * like it; with priorities the waves fall out of step at once.  20 000 x 64 KiB entries (five rounds of the resident waves)
+ * 3.91 -> 3.69 ms (+5.6 %), 200 000 x 8 KiB 7.27 -> 7.13 ms (+2 %); any split with the walks on top is within 1 % of this
+ * one.  Over the 24 rounds of config 2 the waves have drifted apart by themselves: 16.04 -> 15.96 ms (+0.5 %), config 3
+ * +1.3 %.  It is the short launches that gain: a chunk of a prime, a window of a large entry, a rank's share of a table cut
+ * eight ways.  -DMZ_PRIO_MAP=0 is the build without. */
 #ifndef MZ_PRIO_MAP
 #define MZ_PRIO_MAP 0x34016330ull
 #endif
