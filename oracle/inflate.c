@@ -46,6 +46,7 @@ typedef struct {
 typedef struct {
     uint16_t count[MAXBITS + 1];
     uint16_t symbol[FIXLCODES];
+    int maxlen; /* longest code of the set (0: the set is empty) */
 } huff_t;
 
 static uint32_t getbits(st_t *s, int need) {
@@ -74,12 +75,18 @@ static int decode_sym(st_t *s, const huff_t *h) {
         int count = h->count[len];
         if (code - count < first)
             return h->symbol[index + (code - first)];
+        if (len >= h->maxlen)
+            return -2; /* an unused code of an incomplete set.  zlib 1.2.11 only lets a set be incomplete when its longest
+                        * code has one bit (inflate_table(): "max != 1"), or empty, and marks the unused one-bit entries
+                        * invalid: inflate() refuses the stream on that ONE bit -- it does not ask for the fourteen a
+                        * bit-by-bit walk would still want, which is Z_BUF_ERROR instead of Z_DATA_ERROR when the input ends
+                        * right there (tests/fuzz_gpu.py seed 606: two of 200 000 streams; tests/test_oracle.py) */
         index += count;
         first += count;
         first <<= 1;
         code <<= 1;
     }
-    return -2; /* ran out of codes: an unused code of an incomplete set */
+    return -2;
 }
 
 /* returns 0 complete, >0 incomplete (bits left), <0 over-subscribed */
@@ -88,6 +95,10 @@ static int build(huff_t *h, const uint8_t *length, int n) {
     memset(h->count, 0, sizeof(h->count));
     for (int i = 0; i < n; i++)
         h->count[length[i]]++;
+    h->maxlen = 0;
+    for (int len = 1; len <= MAXBITS; len++)
+        if (h->count[len])
+            h->maxlen = len;
     int left = 1;
     for (int len = 1; len <= MAXBITS; len++) {
         left <<= 1;

@@ -65,6 +65,14 @@ def test_status_parity_malformed(gpu):
             names.append((name, cname))
             pays.append(bad)
             caps.append(len(data) + 70000)
+    # an unused code of an incomplete distance set, the input ending right behind it: Z_DATA_ERROR on its one bit, at every cut
+    # (tests/test_oracle.py INCOMPLETE_DISTANCE_SET: the two streams of the device fuzz on which the restatement was wrong)
+    from tests.test_oracle import INCOMPLETE_DISTANCE_SET
+    for k, z in enumerate(INCOMPLETE_DISTANCE_SET):
+        for n in range(1, len(z) + 1):
+            names.append(("incomplete distance set %d" % k, "cut %d" % n))
+            pays.append(z[:n])
+            caps.append(100000)
     batch = gpu.make_batch(pays, caps)
     out_len, in_used, crc, status = gpu.run_inflate(batch)
     h_out = batch["d_out"].cpu().numpy()

@@ -94,6 +94,51 @@ def test_inflate_status_parity_with_reference():
     assert n > 100
 
 
+INCOMPLETE_DISTANCE_SET = (  # tests/fuzz_gpu.py 40000 606, streams 35526 and 137369: a block whose distance set is ONE code of one
+    # bit (what zlib writes when a block uses one distance), a flipped bit makes a match take the unused code, and the input
+    # ends within the fourteen bits behind it
+    bytes.fromhex("edc10109000000c32058ffd0cf71040b00000000002e0c"),
+    bytes.fromhex("edc1010d000000c2a0bd7f6983088b0000000000000000000000000000000000000000000000007067"),
+)
+
+
+def _zlib_status(z, wbits=-15):
+    d = zlib.decompressobj(wbits)
+    try:
+        out = d.decompress(z)
+    except zlib.error:
+        return -3, None
+    return (0 if d.eof else -5), out
+
+
+def test_unused_code_of_an_incomplete_set_is_refused_on_its_one_bit():
+    """zlib only accepts an incomplete Huffman set whose longest code has one bit and refuses the unused one-bit code as soon
+    as it sees it (Z_DATA_ERROR) -- also when the input ends right behind it, where a bit-by-bit canonical walk would still ask
+    for more bits (Z_BUF_ERROR).  The restatement against the zlib of this interpreter at every cut of the two streams the
+    device fuzz found (the device agreed with the reference, the restatement did not)."""
+    for z in INCOMPLETE_DISTANCE_SET:
+        for n in range(1, len(z) + 1):
+            want, out = _zlib_status(z[:n])
+            st, used, got = oracle.inflate_raw(z[:n], 100000)
+            assert st == want, (z.hex(), n, st, want)
+            if st == 0:
+                assert got == out
+        assert oracle.inflate_raw(z, 100000)[0] == -3
+
+
+@needs_ref
+def test_incomplete_set_status_with_reference():
+    ref = oracle.ref()
+    for z in INCOMPLETE_DISTANCE_SET:
+        for n in range(1, len(z) + 1):
+            r = ref.stream_decode(8, z[:n], 100000)
+            st, used, out = oracle.inflate_raw(z[:n], 100000)
+            last = r["rets"][-1] if r["rets"] else 0
+            assert st == (last if last < 0 else 0), (z.hex(), n, st, r["rets"])
+            if st == -3:
+                assert len(out) == r["total_out"], (n, len(out), r["total_out"])
+
+
 @needs_ref
 def test_empty_code_length_code_status_with_reference():
     """A dynamic block whose code-length code has no code at all: inflate() reads the nlen + ndist lengths as zeros of one bit
