@@ -46,6 +46,14 @@ int32_t orc_lzma_zip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size
     d /= 9;
     z->lp = d % 5;
     z->pb = d / 5;
+    if (z->lc + z->lp > 4) {
+        /* liblzma 5.2.5 lzma_lzma_lclppb_decode(): lc + lp > LZMA_LCLP_MAX is refused with the header (LZMA_FORMAT_ERROR from
+         * the alone decoder -> MZ_DATA_ERROR, mz_strm_lzma.c:236), although the LZMA specification allows lc up to 8.  The
+         * device refused it all along (lzma_entry.inc); the restatement did not until tests/fuzz_oracle_lzma.py, round 6. */
+        free(z);
+        if (in_used) *in_used = 9;
+        return ORC_DATA_ERROR;
+    }
     uint64_t dict = in[5] | ((uint32_t)in[6] << 8) | ((uint32_t)in[7] << 16) | ((uint32_t)in[8] << 24);
     if (dict < 4096)
         dict = 4096;

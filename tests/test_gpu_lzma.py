@@ -119,3 +119,33 @@ def test_lzma_every_lc_lp_pb(gpu):
     if oracle.have_ref():
         r = oracle.ref().stream_decode(14, pays[0], len(d) + 8, max_in=len(pays[0]), max_out=len(d))
         assert r["out"] == d and r["error"] == 0
+
+
+def test_lzma_every_properties_byte(gpu):
+    """All 256 values of the properties byte in front of two streams (a run of one byte: decodes to the same bytes under any
+    lc / lp; text): refused with the header where liblzma refuses it (>= 225, lc + lp > 4: lzma_lzma_lclppb_decode), decoded
+    or refused like the oracle everywhere else -- the oracle itself is pinned to the compiled reference on the same 256
+    headers (tests/test_oracle.py::test_lzma_properties_byte_rules)."""
+    import lzma as pylzma
+
+    pays, datas = [], []
+    for d in (b"q" * 5000, synth.corpus()[:20000]):
+        raw = pylzma.compress(d, format=pylzma.FORMAT_ALONE, filters=[dict(id=pylzma.FILTER_LZMA1, preset=6)])
+        z = bytes([5, 2, 5, 0]) + raw[:5] + raw[13:]
+        for props in range(256):
+            pays.append(z[:4] + bytes([props]) + z[5:])
+            datas.append(d)
+    caps = [len(d) + 70000 for d in datas]
+    b, h_out, out_len, in_used, crc, status = run_lzma(gpu, pays, caps, [-1] * len(pays))
+    refused = 0
+    for i, z in enumerate(pays):
+        props = z[4]
+        st, used, out = oracle.lzma_zip_decode(z, caps[i], -1)
+        if props >= 225 or props % 9 + (props // 9) % 5 > 4:
+            assert st == -3 and status[i] != 0, (i, props, st, status[i])
+            refused += 1
+            continue
+        assert (status[i] == 0) == (st == 0), (i, props, status[i], st)
+        if st == 0:
+            assert out_len[i] == len(out) and gpu.entry_bytes(b, h_out, i, len(out)) == out and crc[i] == zlib.crc32(out), (i, props)
+    assert refused > 200
